@@ -1,0 +1,221 @@
+/* iseg_hip.h -- C ABI of libiseg_hip.so, the MI355X (gfx950) compute library behind iseg_amd.
+ *
+ * The reference (edwardyehuang/iSeg) has no native boundary: its "kernels" are TensorFlow/Keras ops reached
+ * through Python call signatures.  Each entry point below therefore cites the reference Python call site(s)
+ * whose per-step arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - C linkage, plain pointers and sizes; no torch / C++ types.
+ *   - Pointers are DEVICE pointers unless the name ends in _h. Tensors are dense NHWC / row-major.
+ *   - dtype: ISEG_F32 (0) or ISEG_BF16 (1) storage; arithmetic is fp32 (MFMA accumulates in fp32).
+ *   - Returns ISEG_OK (0) or a negative iseg status; iseg_last_error() holds a per-thread message.
+ *   - Nothing allocates or frees device memory: the caller owns inputs, outputs and workspace
+ *     (query iseg_*_workspace_bytes first).  All work is enqueued on `stream`; entry points never
+ *     synchronise, so they can be captured into a hipGraph.
+ *   - Keras weight layouts are consumed as they are: Dense [in,out], Conv2D [kh,kw,Cin,Cout],
+ *     DepthwiseConv2D [kh,kw,C,1].
+ */
+#ifndef ISEG_HIP_H
+#define ISEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef ISEG_HIP_STREAM_T
+#define ISEG_HIP_STREAM_T
+typedef struct ihipStream_t* iseg_stream_t; /* == hipStream_t */
+#endif
+
+#define ISEG_STATUS_OK 0
+#define ISEG_STATUS_ARG (-1)
+#define ISEG_STATUS_HIP (-2)
+#define ISEG_STATUS_UNSUPPORTED (-3)
+#define ISEG_STATUS_WORKSPACE (-4)
+
+#define ISEG_DTYPE_F32 0
+#define ISEG_DTYPE_BF16 1
+
+/* epilogue activations of iseg_gemm */
+#define ISEG_ACT_NONE 0
+#define ISEG_ACT_RELU 1      /* keras.activations.relu   (layers/model_builder.py:66,92-93) */
+#define ISEG_ACT_GELU 2      /* keras.activations.gelu, exact erf (backbones/convnext.py:53) */
+#define ISEG_ACT_GELU_GRAD 3 /* v *= gelu'(aux)  : backward of ISEG_ACT_GELU, aux = saved pre-activation */
+#define ISEG_ACT_RELU_GRAD 4 /* v  = aux > 0 ? v : 0 */
+
+int iseg_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf_h; returns its length */
+size_t iseg_last_error(char* buf_h, size_t n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Dense contraction  D[M,N] = epilogue( alpha * sum_k A(m,k) B(k,n) )
+ * Replaces: keras.layers.Dense (backbones/convnext.py:29-30,51-54; backbones/swin.py Mlp/qkv/proj;
+ * backbones/vit.py MLPBlock), 1x1 keras.layers.Conv2D (layers/model_builder.py:54-64; layers/core_model_ext.py:129)
+ * and, after iseg_im2col, every spatial Conv2D (layers/aspp.py:41-52; backbones/convnext.py:72-75), plus their
+ * autodiff transposes (dgrad: a_kcontig=1,b_kcontig=1 on the Keras kernel as stored; wgrad: a_kcontig=0,b_kcontig=0).
+ *   a_kcontig=1: A(m,k) = A[m*lda + k]      a_kcontig=0: A(m,k) = A[k*lda + m]
+ *   b_kcontig=1: B(k,n) = B[n*ldb + k]      b_kcontig=0: B(k,n) = B[k*ldb + n]   (Keras [in,out])
+ * Epilogue, in this order:  v = alpha*acc ; v += bias[n] ; pre_out[m,n] = v ; act ; v *= colscale[n] ;
+ *   v *= rowscale[m / rows_per_group] ; v += residual[m,n] ; v += D[m,n] if accumulate ; D[m,n] = v.
+ * residual / aux / pre_out have the OUTPUT dtype.  in_dtype bf16 -> MFMA path; f32 -> fp32 FMA (parity) path.
+ * split_k: 0 = automatic (skinny outputs with a long reduction are split and reduced in slab order:
+ * deterministic), n>0 = forced.  Workspace: iseg_gemm_workspace_bytes().
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct iseg_gemm_args {
+    const void* A;
+    int64_t lda;
+    int a_kcontig;
+    const void* B;
+    int64_t ldb;
+    int b_kcontig;
+    void* D;
+    int64_t ldd;
+    int64_t M, N, K;
+    int in_dtype, out_dtype;
+    const float* bias;     /* [N] or NULL */
+    const float* colscale; /* [N] or NULL  (ConvNeXt layer scale gamma, backbones/convnext.py:56-57) */
+    const float* rowscale; /* [ceil(M/rows_per_group)] or NULL (drop_path per-sample factor, utils/drops.py:8-22) */
+    int64_t rows_per_group;
+    const void* residual; /* [M, ldr] or NULL */
+    int64_t ldr;
+    const void* aux; /* [M, ldaux], needed by ISEG_ACT_*_GRAD */
+    int64_t ldaux;
+    void* pre_out; /* [M, ldp] or NULL: pre-activation saved for backward */
+    int64_t ldp;
+    int act;
+    float alpha;
+    int accumulate;
+    int split_k;
+} iseg_gemm_args;
+
+int iseg_gemm_splits(const iseg_gemm_args* args_h);
+size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
+int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last axis: keras.layers.LayerNormalization(axis=-1, epsilon)
+ * (backbones/convnext.py:27,71; backbones/swin.py norm1/norm2; backbones/vit.py). x,y: [rows, C], C % 8 == 0.
+ * mean/rstd [rows] are saved for the backward.  bwd: dx (= dx_add + LN^T dy), dgamma, dbeta.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                       int C, float eps, int dtype, iseg_stream_t stream);
+size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
+int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                       const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
+                       int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Depthwise KxK conv, stride 1, dilation `dil`, explicit top/left padding (TF "same": pad = (K-1)*dil/2):
+ * keras.layers.DepthwiseConv2D (backbones/convnext.py:25,50; build_dilated_convnext :245-266).
+ * w: [K*K, C] fp32 (the Keras [K,K,C,1] kernel), bias [C] or NULL.  y = conv(x) + bias (+ add).
+ * flip=1 turns it into the data gradient: call with dy as x, pad' = (K-1)*dil - pad, bias NULL, and
+ * `add` = gradient arriving through the residual branch.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C,
+                      int K, int dil, int pad_t, int pad_l, int flip, int dtype, iseg_stream_t stream);
+size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int C, int K);
+int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W, int C,
+                             int K, int dil, int pad_t, int pad_l, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (Sync)BatchNorm, training mode: keras BatchNormalization(synchronized=True) as wired by
+ * layers/normalizations.py:14-23,39-132; moments as layers/keras3/bn.py:10-73 / layers/syncbn.py:70-119.
+ *   1. iseg_bn_stats       packed[0:C]=sum x, [C:2C]=sum x^2, [2C]=local count   (one message for RCCL all-reduce)
+ *   2. (caller) all-reduce(sum) of packed over ranks
+ *   3. iseg_bn_finalize    mean, rstd=rsqrt(var_biased+eps); moving <- moving*momentum + batch*(1-momentum)
+ *   4. iseg_bn_apply_fwd   y = act((x-mean)*rstd*gamma+beta); y may be a channel slice (ldy) of a concat buffer
+ *  bwd: iseg_bn_bwd_reduce sums[0:C]=sum dz, [C:2C]=sum dz*xhat (dz = dy*relu'(y)); (caller) all-reduce;
+ *       iseg_bn_bwd_apply  dx = gamma*rstd*(dz - sums0/n - xhat*sums1/n);  dgamma = sums[C:2C], dbeta = sums[0:C].
+ * x: [rows, C] with row stride ldx (elements); C, ld* multiples of 8.
+ * --------------------------------------------------------------------------------------------------------- */
+size_t iseg_bn_workspace_bytes(int64_t rows, int C);
+int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes,
+                  iseg_stream_t stream);
+int iseg_bn_finalize(const float* packed, int C, float eps, float momentum, float* mean, float* rstd, float* moving_mean,
+                     float* moving_var, iseg_stream_t stream);
+int iseg_bn_apply_fwd(const void* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                      void* y, int64_t ldy, int64_t rows, int C, int relu, int dtype, iseg_stream_t stream);
+int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                       const float* rstd, float* sums, int64_t rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
+                       iseg_stream_t stream);
+int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                      const float* rstd, const float* gamma, const float* sums, float inv_n, void* dx, int64_t lddx, int64_t rows,
+                      int C, int relu, int dtype, iseg_stream_t stream);
+int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t stream); /* inference: rstd of moving var */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Layout / elementwise
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, iseg_stream_t stream);
+/* dst[k][n] = src[k][n]*colscale[n]: layer-scale folded Dense kernel for the dgrad of backbones/convnext.py:54-57 */
+int iseg_scale_cols_cast(const float* src, const float* colscale, void* dst, int64_t rows, int cols, int dst_dtype,
+                         iseg_stream_t stream);
+/* patches of keras.layers.Conv2D(padding="same"/"valid", strides, dilation_rate): col[m][(i*KW+j)*C+c], row stride ldc */
+int iseg_im2col(const void* x, int in_dtype, void* col, int out_dtype, int N, int H, int W, int C, int KH, int KW, int sh, int sw,
+                int dh, int dw, int pt, int pl, int Ho, int Wo, int64_t ldc, iseg_stream_t stream);
+int iseg_col2im(const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int sh, int sw, int dh, int dw, int pt,
+                int pl, int Ho, int Wo, int64_t ldc, int dtype, iseg_stream_t stream);
+/* out[b][c] (+)= scale * sum_r x[b][r][c]: bias gradients; tf.reduce_mean over H,W (layers/model_builder.py:266) */
+size_t iseg_colsum_workspace_bytes(int batch, int64_t rows, int C);
+int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int batch, int64_t rows, int C, float* out, float scale,
+                int accumulate, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* y[b][r][:] (+)= scale*v[b][:]: ImageLevelBlock broadcast (layers/model_builder.py:268) and the pooling gradient */
+int iseg_broadcast_rows(const void* v, int v_dtype, void* y, int64_t ldy, int64_t batch_stride, int batch, int64_t rows, int C,
+                        float scale, int accumulate, int dtype, iseg_stream_t stream);
+int iseg_axpby(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, int dtype, iseg_stream_t stream);
+int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,
+                  iseg_stream_t stream);
+/* keras.layers.Dropout: y = x*mask/(1-rate); mask = f(seed, index) so backward = same call on dy */
+int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, int dtype, iseg_stream_t stream);
+/* utils/drops.py:14-20: s[n] = floor(keep + u_n)/keep */
+int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, iseg_stream_t stream);
+int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
+/* ConvNeXt layer-scale parameter gradients from Z = g^T dout (see iseg_amd/blocks.py) */
+size_t iseg_layerscale_grads_workspace_bytes(int K, int N);
+int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S, float* dW2,
+                          float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                          iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * tf.image.resize (half-pixel, no antialias): utils/common.py:107-134 resize_image
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, int out_dtype, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                             iseg_stream_t stream);
+size_t iseg_resize_bilinear_bwd_workspace_bytes(int N, int Hi, int Wi, int Ho, int Wo, int C);
+int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, const void* dx_add, int N, int Hi, int Wi,
+                             int Ho, int Wo, int C, void* ws, size_t ws_bytes, iseg_stream_t stream);
+int iseg_resize_nearest_i32(const int32_t* x, int32_t* y, int N, int Hi, int Wi, int Ho, int Wo, int C, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * losses/catecrossentropy_ignore_label.py:44-88 weighted_loss (CategoricalCrossentropy(from_logits), NONE) and
+ * metrics/seg_metric_wrapper.py:89-102 + metrics/confusion_matrix.py:65-143.
+ * logits [P,C] fp32, labels [P] int32.  loss_px [P] (optional), loss_sum[0] = loss_sum_scale * sum_p loss_p,
+ * dlogits = grad_scale * w_p * (softmax - onehot) (optional).
+ * --------------------------------------------------------------------------------------------------------- */
+size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C);
+int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C, int ignore_label,
+                           float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits, float grad_scale, void* ws,
+                           size_t ws_bytes, iseg_stream_t stream);
+/* pred_out [P] int32 (optional) = first argmax; cm [C*C] uint64 counts += (label != ignore) at [label][pred] */
+int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P, int C, int ignore_label, int32_t* pred_out,
+                          unsigned long long* cm, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * optimizers/modern/adamw.py:13-74, optimizers/modern/sgd.py:12-51 over the flat parameter buffer.
+ * Every tensor is padded to a multiple of 256 elements; seg_of_block[b] = tensor index of 256-element block b
+ * (-1 = padding).  hp (device): [lr, sqrt(1-b2^t)/(1-b1^t), grad_scale, clipvalue(<=0 off)].
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, const int32_t* seg_of_block,
+                    const float* seg_lr_mult, const float* seg_wd, const float* hp, float beta1, float beta2, float eps,
+                    int64_t nblocks, iseg_stream_t stream);
+int iseg_sgd_momentum_step(float* w, const float* g, float* m, void* w_bf16, const int32_t* seg_of_block,
+                           const float* seg_lr_mult, const float* seg_l2, const float* hp, float momentum, int64_t nblocks,
+                           iseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISEG_HIP_H */

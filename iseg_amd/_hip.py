@@ -1,0 +1,119 @@
+"""ctypes binding of libiseg_hip.so (the C ABI declared in include/iseg_hip.h).
+
+This is the only place Python touches the native library.  There is deliberately NO fallback: if the shared
+object is missing or a call fails, an exception is raised (HipLibraryMissing / HipCallError) -- the product
+path never silently routes through torch ops or the oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libiseg_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD = 0, 1, 2, 3, 4
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64), ("a_kcontig", C.c_int),
+        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_kcontig", C.c_int),
+        ("D", C.c_void_p), ("ldd", C.c_int64),
+        ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64),
+        ("in_dtype", C.c_int), ("out_dtype", C.c_int),
+        ("bias", C.c_void_p), ("colscale", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_group", C.c_int64),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("aux", C.c_void_p), ("ldaux", C.c_int64),
+        ("pre_out", C.c_void_p), ("ldp", C.c_int64),
+        ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int),
+    ]
+
+
+_p, _i, _l, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> (restype, argtypes); must list every symbol include/iseg_hip.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    "iseg_version": (_i, []),
+    "iseg_last_error": (_z, [C.c_char_p, _z]),
+    "iseg_gemm_splits": (_i, [C.POINTER(GemmArgs)]),
+    "iseg_gemm_workspace_bytes": (_z, [C.POINTER(GemmArgs)]),
+    "iseg_gemm": (_i, [C.POINTER(GemmArgs), _p, _z, _p]),
+    "iseg_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "iseg_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
+    "iseg_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_dwconv2d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "iseg_dwconv2d_bwd_weight_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "iseg_dwconv2d_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "iseg_bn_workspace_bytes": (_z, [_l, _i]),
+    "iseg_bn_stats": (_i, [_p, _l, _p, _l, _i, _i, _p, _z, _p]),
+    "iseg_bn_finalize": (_i, [_p, _i, _f, _f, _p, _p, _p, _p, _p]),
+    "iseg_bn_apply_fwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _l, _i, _i, _i, _p]),
+    "iseg_bn_bwd_reduce": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _p, _z, _p]),
+    "iseg_bn_bwd_apply": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _f, _p, _l, _l, _i, _i, _i, _p]),
+    "iseg_rsqrt_eps": (_i, [_p, _f, _p, _i, _p]),
+    "iseg_cast": (_i, [_p, _i, _p, _i, _l, _p]),
+    "iseg_scale_cols_cast": (_i, [_p, _p, _p, _l, _i, _i, _p]),
+    "iseg_im2col": (_i, [_p, _i, _p, _i] + [_i] * 14 + [_l, _p]),
+    "iseg_col2im": (_i, [_p, _p] + [_i] * 14 + [_l, _i, _p]),
+    "iseg_colsum_workspace_bytes": (_z, [_i, _l, _i]),
+    "iseg_colsum": (_i, [_p, _l, _l, _i, _l, _i, _p, _f, _i, _i, _p, _z, _p]),
+    "iseg_broadcast_rows": (_i, [_p, _i, _p, _l, _l, _i, _l, _i, _f, _i, _i, _p]),
+    "iseg_axpby": (_i, [_p, _p, _p, _f, _f, _l, _i, _p]),
+    "iseg_rowscale": (_i, [_p, _p, _p, _l, _i, _l, _i, _p]),
+    "iseg_dropout": (_i, [_p, _p, _l, _f, _u64, _i, _p]),
+    "iseg_drop_path_mask": (_i, [_p, _i, _f, _u64, _p]),
+    "iseg_fill_f32": (_i, [_p, _f, _l, _p]),
+    "iseg_layerscale_grads_workspace_bytes": (_z, [_i, _i]),
+    "iseg_layerscale_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "iseg_resize_bilinear_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "iseg_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "iseg_resize_nearest_i32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "iseg_softmax_ce_workspace_bytes": (_z, [_l, _i]),
+    "iseg_softmax_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _z, _p]),
+    "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
+    "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
+    "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _l, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the CDLL; raises HipLibraryMissing when the .so is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m iseg_amd.build` (hipcc --offload-arch=gfx950). "
+                "iseg_amd has no CPU or torch fallback.")
+        dll = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(dll, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = dll
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    lib().iseg_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(status, what):
+    if status != 0:
+        raise HipCallError(f"{what} failed with status {status}: {last_error()}")
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,102 @@
+// Shared device/host helpers for the iseg_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define ISEG_OK 0
+#define ISEG_ERR_ARG (-1)
+#define ISEG_ERR_HIP (-2)
+#define ISEG_ERR_UNSUPPORTED (-3)
+#define ISEG_ERR_WORKSPACE (-4)
+
+#define ISEG_F32 0
+#define ISEG_BF16 1
+
+typedef __bf16 bf16_t;
+
+// ---- error plumbing (api.cpp) ----------------------------------------------------------
+extern "C" void iseg_set_error(const char* fmt, ...);
+int iseg_check_launch(const char* what);
+
+#define ISEG_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            iseg_set_error(__VA_ARGS__);        \
+            return ISEG_ERR_ARG;                \
+        }                                       \
+    } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t dtype_size(int dtype) { return dtype == ISEG_BF16 ? 2 : 4; }
+
+// ---- device helpers ---------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <class T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector access: VecN<T>::N elements per 16 B.
+template <class T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ __forceinline__ static void load(const float* p, float* out) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    }
+    __device__ __forceinline__ static void store(float* p, const float* in) {
+        *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    __device__ __forceinline__ static void load(const bf16_t* p, float* out) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) out[i] = (float)v[i];
+    }
+    __device__ __forceinline__ static void store(bf16_t* p, const float* in) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16_t)in[i];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+
+// 8 consecutive elements (used where bf16 and f32 kernels share a "8 channels per lane" shape).
+template <class T> __device__ __forceinline__ void load8(const T* p, float* out);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* out) {
+    Vec16<float>::load(p, out);
+    Vec16<float>::load(p + 4, out + 4);
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float* out) { Vec16<bf16_t>::load(p, out); }
+template <class T> __device__ __forceinline__ void store8(T* p, const float* in);
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* in) {
+    Vec16<float>::store(p, in);
+    Vec16<float>::store(p + 4, in + 4);
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float* in) { Vec16<bf16_t>::store(p, in); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over aligned groups of `width` lanes (width power of two <= 64)
+__device__ __forceinline__ float group_sum(float v, int width) {
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// exact-erf GELU, as keras.activations.gelu(approximate=False)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

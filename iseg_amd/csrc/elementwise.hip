@@ -1,0 +1,549 @@
+// HBM-bound data-movement and elementwise kernels: dtype casts, im2col / col2im for the few real spatial
+// convolutions (stem 4x4/s4, downsample 2x2/s2, ASPP 3x3 dilated: backbones/convnext.py:72-75, layers/aspp.py:41-52),
+// column sums (bias / broadcast gradients), global average pooling + broadcast (layers/model_builder.py:260-273
+// ImageLevelBlock), drop-path / dropout masks (utils/drops.py:8-22, keras.layers.Dropout), residual adds.
+// All of them are one pass over the data with 16-B lanes and grid-stride loops capped at 8 blocks per CU.
+#include "common.h"
+#include "iseg_hip.h"
+
+namespace {
+
+static inline unsigned cap_blocks(int64_t work_items, int per_block = 256) {
+    int64_t b = ceil_div64(work_items, per_block);
+    if (b > 256 * 8) b = 256 * 8;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+template <class TI, class TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8<TI>(src + i * 8, v);
+        store8<TO>(dst + i * 8, v);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TO>(to_f32(src[i]));
+}
+
+// dst[k][n] = src[k][n] * colscale[n]  (f32 master -> compute dtype), used for the layer-scale folded weights
+template <class TO>
+__global__ void scale_cols_cast_kernel(const float* __restrict__ src, const float* __restrict__ colscale, TO* __restrict__ dst,
+                                       int64_t rows, int cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TO>(src[i] * colscale[i % cols]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// im2col: col[m][ (i*KW + j)*C + c ] = x[n, oh*sh + i*dh - pt, ow*sw + j*dw - pl, c]   (0 outside)
+// ---------------------------------------------------------------------------------------------
+template <class TI, class TO, int V>
+__global__ void im2col_kernel(const TI* __restrict__ x, TO* __restrict__ col, int N, int H, int W, int C, int KH, int KW, int sh,
+                              int sw, int dh, int dw, int pt, int pl, int Ho, int Wo, int64_t ldc) {
+    const int cv = C / V;
+    const int64_t kk = (int64_t)KH * KW * cv;
+    const int64_t M = (int64_t)N * Ho * Wo;
+    const int64_t total = M * kk;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * V;
+        int64_t r = idx / cv;
+        const int j = (int)(r % KW);
+        r /= KW;
+        const int i = (int)(r % KH);
+        const int64_t m = r / KH;
+        const int ow = (int)(m % Wo);
+        const int oh = (int)((m / Wo) % Ho);
+        const int n = (int)(m / ((int64_t)Wo * Ho));
+        const int ih = oh * sh + i * dh - pt, iw = ow * sw + j * dw - pl;
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = 0.f;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+            const TI* p = x + (((int64_t)n * H + ih) * W + iw) * C + c;
+            if (V == 8) load8<TI>(p, v);
+            else v[0] = to_f32(p[0]);
+        }
+        TO* q = col + m * ldc + ((int64_t)i * KW + j) * C + c;
+        if (V == 8) store8<TO>(q, v);
+        else q[0] = from_f32<TO>(v[0]);
+    }
+}
+
+// zero the padding columns [K, ldc) of every row
+template <class TO>
+__global__ void zero_pad_cols_kernel(TO* __restrict__ col, int64_t M, int64_t K, int64_t ldc) {
+    const int64_t padw = ldc - K;
+    const int64_t total = M * padw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        col[(i / padw) * ldc + K + (i % padw)] = from_f32<TO>(0.f);
+}
+
+// col2im (gather form, deterministic): dx[n,ih,iw,c] = sum over taps (i,j) and outputs (oh,ow) that read it
+template <class T, int V>
+__global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int H, int W, int C, int KH, int KW, int sh,
+                              int sw, int dh, int dw, int pt, int pl, int Ho, int Wo, int64_t ldc) {
+    const int cv = C / V;
+    const int64_t total = (int64_t)N * H * W * cv;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv) * V;
+        int64_t r = idx / cv;
+        const int iw = (int)(r % W);
+        r /= W;
+        const int ih = (int)(r % H);
+        const int n = (int)(r / H);
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        for (int i = 0; i < KH; ++i) {
+            const int th = ih + pt - i * dh;
+            if (th < 0 || th % sh != 0) continue;
+            const int oh = th / sh;
+            if (oh >= Ho) continue;
+            for (int j = 0; j < KW; ++j) {
+                const int tw = iw + pl - j * dw;
+                if (tw < 0 || tw % sw != 0) continue;
+                const int ow = tw / sw;
+                if (ow >= Wo) continue;
+                const T* p = dcol + (((int64_t)n * Ho + oh) * Wo + ow) * ldc + ((int64_t)i * KW + j) * C + c;
+                if (V == 8) {
+                    float v[8];
+                    load8<T>(p, v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[u] += v[u];
+                } else {
+                    acc[0] += to_f32(p[0]);
+                }
+            }
+        }
+        T* q = dx + idx / cv * C + c;
+        if (V == 8) store8<T>(q, acc);
+        else q[0] = from_f32<T>(acc[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched column sums: out[b][c] = scale * sum_r x[b][r][c]   (x row stride ldx, batch stride bsx)
+// ---------------------------------------------------------------------------------------------
+template <class T, int V>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t bsx,
+                                                             float* __restrict__ partials, int64_t rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [C]
+    const int b = blockIdx.y;
+    const int nch = C / V;
+    for (int i = threadIdx.x; i < C; i += 256) lds_s[i] = 0.f;
+    __syncthreads();
+    const int tpc = nch < 256 ? nch : 256;
+    const int rpi = 256 / tpc;
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const T* xb = x + (int64_t)b * bsx;
+    if (tr < rpi) {
+        for (int c = tc; c < nch; c += tpc) {
+            float s[8] = {};
+            for (int64_t r = (int64_t)blockIdx.x * rpi + tr; r < rows; r += (int64_t)gridDim.x * rpi) {
+                if (V == 8) {
+                    float v[8];
+                    load8<T>(xb + r * ldx + c * 8, v);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s[u] += v[u];
+                } else {
+                    s[0] += to_f32(xb[r * ldx + c]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < V; ++u) atomicAdd(&lds_s[c * V + u], s[u]);
+        }
+    }
+    __syncthreads();
+    float* out = partials + ((int64_t)b * gridDim.x + blockIdx.x) * C;
+    for (int i = threadIdx.x; i < C; i += 256) out[i] = lds_s[i];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partials, int P, int C, float* __restrict__ out, float scale,
+                                    int accumulate) {
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partials[((int64_t)b * P + p) * C + j];
+    s *= scale;
+    float* dst = out + (int64_t)b * C + j;
+    if (accumulate) s += *dst;
+    *dst = s;
+}
+
+static int colsum_blocks(int64_t rows, int C, int V) {
+    const int nch = C / V;
+    const int tpc = nch < 256 ? nch : 256;
+    const int rpi = 256 / tpc;
+    int64_t b = ceil_div64(rows, (int64_t)rpi * 8);
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// y[b][r][c] (+)= scale * v[b][c]     (broadcast a per-sample vector over R rows; y row stride ldy, batch stride bsy)
+template <class T, class TV>
+__global__ void broadcast_rows_kernel(const TV* __restrict__ v, T* __restrict__ y, int64_t ldy, int64_t bsy, int B, int64_t R,
+                                      int C, float scale, int accumulate) {
+    const int cv = C / 8;
+    const int64_t total = (int64_t)B * R * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * 8;
+        const int64_t r = (i / cv) % R;
+        const int b = (int)(i / (cv * R));
+        float a[8];
+        load8<TV>(v + (int64_t)b * C + c, a);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] *= scale;
+        T* p = y + (int64_t)b * bsy + r * ldy + c;
+        if (accumulate) {
+            float o[8];
+            load8<T>(p, o);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += o[u];
+        }
+        store8<T>(p, a);
+    }
+}
+
+// y = alpha*a + beta*b   (b may be null)
+template <class T>
+__global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, float alpha, float beta,
+                             int64_t n) {
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float va[8], vb[8];
+        load8<T>(a + i * 8, va);
+        if (b) {
+            load8<T>(b + i * 8, vb);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) va[u] = alpha * va[u] + beta * vb[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) va[u] = alpha * va[u];
+        }
+        store8<T>(y + i * 8, va);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(alpha * to_f32(a[i]) + (b ? beta * to_f32(b[i]) : 0.f));
+}
+
+// y[m][:] = x[m][:] * s[m / rows_per_group]
+template <class T>
+__global__ void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int64_t rows, int C,
+                                int64_t rows_per_group) {
+    const int cv = C / 8;
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / cv;
+        const float f = s[m / rows_per_group];
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] *= f;
+        store8<T>(y + i * 8, v);
+    }
+}
+
+// counter-based uniform in [0,1): splitmix64 of (seed, index)
+__device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+// y = x * (u >= rate) / (1-rate); the mask is a pure function of (seed, element index): backward re-derives it
+template <class T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float rate, uint64_t seed) {
+    const float inv_keep = 1.0f / (1.0f - rate);
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = uniform01(seed, (uint64_t)(i * 8 + u)) >= rate ? v[u] * inv_keep : 0.f;
+        store8<T>(y + i * 8, v);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(uniform01(seed, (uint64_t)i) >= rate ? to_f32(x[i]) * inv_keep : 0.f);
+}
+
+// per-sample drop-path factors: s[n] = floor(keep + u_n) / keep   (utils/drops.py:14-20)
+__global__ void drop_path_mask_kernel(float* __restrict__ s, int n, float keep, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) s[i] = floorf(keep + uniform01(seed, (uint64_t)i)) / keep;
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void rsqrt_eps_kernel(const float* __restrict__ var, float eps, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rsqrtf(var[i] + eps);
+}
+
+// layer-scale bookkeeping for one ConvNeXt block (backbones/convnext.py:56-57), from Z = g^T @ dout (unscaled):
+//   dW2[k][n] = Z[k][n]*gamma[n] ; dgamma[n] = sum_k W2[k][n]*Z[k][n] + b2[n]*S[n] ; db2[n] = gamma[n]*S[n], S = colsum(dout)
+// stage 1: elementwise dW2 and per-block partial column dots (block = 64 columns x 4 k-lanes, strip of k rows)
+__global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __restrict__ Z, const float* __restrict__ W2,
+                                                                const float* __restrict__ gamma, float* __restrict__ dW2,
+                                                                float* __restrict__ partials, int Kdim, int Ndim, int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (n < Ndim) {
+        const float g = gamma[n];
+        for (int k = blockIdx.y * 4 + ty; k < Kdim; k += gridDim.y * 4) {
+            const int64_t o = (int64_t)k * Ndim + n;
+            const float z = Z[o];
+            s += W2[o] * z;
+            const float v = z * g;
+            if (accumulate) dW2[o] += v;
+            else dW2[o] = v;
+        }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < Ndim) partials[(int64_t)blockIdx.y * Ndim + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+__global__ void layerscale_stage2_kernel(const float* __restrict__ partials, int P, const float* __restrict__ b2,
+                                         const float* __restrict__ gamma, const float* __restrict__ S, float* __restrict__ dgamma,
+                                         float* __restrict__ db2, int Ndim, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= Ndim) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * Ndim + n];
+    const float dg = s + b2[n] * S[n], dbv = gamma[n] * S[n];
+    if (accumulate) {
+        dgamma[n] += dg;
+        db2[n] += dbv;
+    } else {
+        dgamma[n] = dg;
+        db2[n] = dbv;
+    }
+}
+
+static int layerscale_ksplits(int K) {
+    int p = K / 32;
+    if (p > 64) p = 64;
+    if (p < 1) p = 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int iseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t stream) {
+    ISEG_REQUIRE(src && dst && n >= 0, "iseg_cast: bad arguments");
+    if (n == 0) return ISEG_OK;
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (src_dtype == ISEG_F32 && dst_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == ISEG_BF16 && dst_dtype == ISEG_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == ISEG_F32 && dst_dtype == ISEG_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, stream, (const float*)src, (float*)dst, n);
+    else if (src_dtype == ISEG_BF16 && dst_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, n);
+    else {
+        iseg_set_error("iseg_cast: bad dtypes %d -> %d", src_dtype, dst_dtype);
+        return ISEG_ERR_ARG;
+    }
+    return iseg_check_launch("iseg_cast");
+}
+
+extern "C" int iseg_scale_cols_cast(const float* src, const float* colscale, void* dst, int64_t rows, int cols, int dst_dtype,
+                                    hipStream_t stream) {
+    ISEG_REQUIRE(src && colscale && dst && rows > 0 && cols > 0, "iseg_scale_cols_cast: bad arguments");
+    const unsigned blocks = cap_blocks(rows * cols);
+    if (dst_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((scale_cols_cast_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, src, colscale, (bf16_t*)dst, rows,
+                           cols);
+    else
+        hipLaunchKernelGGL((scale_cols_cast_kernel<float>), dim3(blocks), dim3(256), 0, stream, src, colscale, (float*)dst, rows,
+                           cols);
+    return iseg_check_launch("iseg_scale_cols_cast");
+}
+
+extern "C" int iseg_im2col(const void* x, int in_dtype, void* col, int out_dtype, int N, int H, int W, int C, int KH, int KW,
+                           int sh, int sw, int dh, int dw, int pt, int pl, int Ho, int Wo, int64_t ldc, hipStream_t stream) {
+    ISEG_REQUIRE(x && col, "iseg_im2col: null pointer");
+    const int64_t K = (int64_t)KH * KW * C;
+    ISEG_REQUIRE(ldc >= K, "iseg_im2col: ldc=%lld < KH*KW*C=%lld", (long long)ldc, (long long)K);
+    ISEG_REQUIRE(!(in_dtype == ISEG_BF16 && out_dtype == ISEG_F32), "iseg_im2col: bf16 -> f32 unsupported");
+    const int64_t M = (int64_t)N * Ho * Wo;
+    const bool vec = (C % 8 == 0) && (ldc % 8 == 0);
+    const unsigned blocks = cap_blocks(M * KH * KW * (vec ? C / 8 : C));
+#define IM2COL(TI, TO)                                                                                                        \
+    do {                                                                                                                      \
+        if (vec)                                                                                                              \
+            hipLaunchKernelGGL((im2col_kernel<TI, TO, 8>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, (TO*)col, N, H, W, C, \
+                               KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc);                                                  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((im2col_kernel<TI, TO, 1>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, (TO*)col, N, H, W, C, \
+                               KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc);                                                  \
+        if (ldc > K)                                                                                                          \
+            hipLaunchKernelGGL((zero_pad_cols_kernel<TO>), dim3(cap_blocks(M * (ldc - K))), dim3(256), 0, stream, (TO*)col, M, K, \
+                               ldc);                                                                                          \
+    } while (0)
+    if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) IM2COL(float, float);
+    else if (in_dtype == ISEG_F32 && out_dtype == ISEG_BF16) IM2COL(float, bf16_t);
+    else IM2COL(bf16_t, bf16_t);
+#undef IM2COL
+    return iseg_check_launch("iseg_im2col");
+}
+
+extern "C" int iseg_col2im(const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int sh, int sw, int dh, int dw,
+                           int pt, int pl, int Ho, int Wo, int64_t ldc, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dcol && dx, "iseg_col2im: null pointer");
+    const bool vec = (C % 8 == 0) && (ldc % 8 == 0);
+    const unsigned blocks = cap_blocks((int64_t)N * H * W * (vec ? C / 8 : C));
+#define COL2IM(T)                                                                                                              \
+    do {                                                                                                                       \
+        if (vec)                                                                                                               \
+            hipLaunchKernelGGL((col2im_kernel<T, 8>), dim3(blocks), dim3(256), 0, stream, (const T*)dcol, (T*)dx, N, H, W, C, KH, \
+                               KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc);                                                       \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((col2im_kernel<T, 1>), dim3(blocks), dim3(256), 0, stream, (const T*)dcol, (T*)dx, N, H, W, C, KH, \
+                               KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc);                                                       \
+    } while (0)
+    if (dtype == ISEG_BF16) COL2IM(bf16_t);
+    else COL2IM(float);
+#undef COL2IM
+    return iseg_check_launch("iseg_col2im");
+}
+
+extern "C" size_t iseg_colsum_workspace_bytes(int batch, int64_t rows, int C) {
+    const int V = C % 8 == 0 ? 8 : 1;
+    return (size_t)batch * colsum_blocks(rows, C, V) * C * sizeof(float);
+}
+
+extern "C" int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int batch, int64_t rows, int C, float* out,
+                           float scale, int accumulate, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(x && out && batch > 0 && rows > 0 && C > 0, "iseg_colsum: bad arguments");
+    const bool vec = (C % 8 == 0) && (ldx % 8 == 0) && (batch_stride % 8 == 0) && ((uintptr_t)x % 16 == 0);
+    const int V = vec ? 8 : 1;
+    const int P = colsum_blocks(rows, C, V);
+    const size_t need = (size_t)batch * P * C * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_colsum: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const size_t lds = (size_t)C * sizeof(float);
+#define COLSUM(T, VV)                                                                                                  \
+    hipLaunchKernelGGL((colsum_partial_kernel<T, VV>), dim3(P, batch), dim3(256), lds, stream, (const T*)x, ldx, batch_stride, \
+                       (float*)ws, rows, C)
+    if (dtype == ISEG_BF16) {
+        if (vec) COLSUM(bf16_t, 8);
+        else COLSUM(bf16_t, 1);
+    } else {
+        if (vec) COLSUM(float, 8);
+        else COLSUM(float, 1);
+    }
+#undef COLSUM
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, P, C, out, scale,
+                       accumulate);
+    return iseg_check_launch("iseg_colsum");
+}
+
+extern "C" int iseg_broadcast_rows(const void* v, int v_dtype, void* y, int64_t ldy, int64_t batch_stride, int batch, int64_t rows,
+                                   int C, float scale, int accumulate, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(v && y && C % 8 == 0 && ldy % 8 == 0 && batch_stride % 8 == 0, "iseg_broadcast_rows: bad arguments");
+    const unsigned blocks = cap_blocks((int64_t)batch * rows * (C / 8));
+#define BC(T, TV)                                                                                                           \
+    hipLaunchKernelGGL((broadcast_rows_kernel<T, TV>), dim3(blocks), dim3(256), 0, stream, (const TV*)v, (T*)y, ldy, batch_stride, \
+                       batch, rows, C, scale, accumulate)
+    if (dtype == ISEG_BF16) {
+        if (v_dtype == ISEG_BF16) BC(bf16_t, bf16_t);
+        else BC(bf16_t, float);
+    } else {
+        ISEG_REQUIRE(v_dtype == ISEG_F32, "iseg_broadcast_rows: f32 output needs f32 vector");
+        BC(float, float);
+    }
+#undef BC
+    return iseg_check_launch("iseg_broadcast_rows");
+}
+
+extern "C" int iseg_axpby(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, int dtype,
+                          hipStream_t stream) {
+    ISEG_REQUIRE(a && y && n >= 0, "iseg_axpby: bad arguments");
+    if (n == 0) return ISEG_OK;
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((axpby_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)y, alpha, beta, n);
+    else
+        hipLaunchKernelGGL((axpby_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)y,
+                           alpha, beta, n);
+    return iseg_check_launch("iseg_axpby");
+}
+
+extern "C" int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,
+                             hipStream_t stream) {
+    ISEG_REQUIRE(x && s && y && C % 8 == 0 && rows_per_group > 0, "iseg_rowscale: bad arguments");
+    const unsigned blocks = cap_blocks(rows * (C / 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((rowscale_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, s, (bf16_t*)y, rows, C,
+                           rows_per_group);
+    else
+        hipLaunchKernelGGL((rowscale_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, s, (float*)y, rows, C,
+                           rows_per_group);
+    return iseg_check_launch("iseg_rowscale");
+}
+
+extern "C" int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && y && rate >= 0.f && rate < 1.f, "iseg_dropout: bad arguments");
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, rate,
+                           seed);
+    else
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, n, rate, seed);
+    return iseg_check_launch("iseg_dropout");
+}
+
+extern "C" int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, hipStream_t stream) {
+    ISEG_REQUIRE(s && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "iseg_drop_path_mask: bad arguments");
+    hipLaunchKernelGGL(drop_path_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, s, n, keep_prob, seed);
+    return iseg_check_launch("iseg_drop_path_mask");
+}
+
+extern "C" int iseg_fill_f32(float* p, float value, int64_t n, hipStream_t stream) {
+    ISEG_REQUIRE(p && n >= 0, "iseg_fill_f32: bad arguments");
+    if (n == 0) return ISEG_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(cap_blocks(n)), dim3(256), 0, stream, p, value, n);
+    return iseg_check_launch("iseg_fill_f32");
+}
+
+extern "C" int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, hipStream_t stream) {
+    ISEG_REQUIRE(var && out && n > 0, "iseg_rsqrt_eps: bad arguments");
+    hipLaunchKernelGGL(rsqrt_eps_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, var, eps, out, n);
+    return iseg_check_launch("iseg_rsqrt_eps");
+}
+
+extern "C" size_t iseg_layerscale_grads_workspace_bytes(int K, int N) {
+    return (size_t)layerscale_ksplits(K) * N * sizeof(float);
+}
+
+extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S,
+                                     float* dW2, float* dgamma, float* db2, int K, int N, int accumulate, void* ws,
+                                     size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(Z && W2 && b2 && gamma && S && dW2 && dgamma && db2, "iseg_layerscale_grads: null pointer");
+    const int P = layerscale_ksplits(K);
+    const size_t need = (size_t)P * N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_layerscale_grads: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    hipLaunchKernelGGL(layerscale_stage1_kernel, dim3((N + 63) / 64, P), dim3(256), 0, stream, Z, W2, gamma, dW2, (float*)ws, K, N,
+                       accumulate);
+    hipLaunchKernelGGL(layerscale_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)ws, P, b2, gamma, S,
+                       dgamma, db2, N, accumulate);
+    return iseg_check_launch("iseg_layerscale_grads");
+}

@@ -1,0 +1,173 @@
+// Ignore-label softmax cross-entropy and the argmax/confusion-matrix metric, fp32, HBM-bound.
+//
+// Loss: losses/catecrossentropy_ignore_label.py:44-88 weighted_loss --
+//   mask = y != ignore ; (ignore == 0 -> y -= 1) ; onehot(y) is the zero row for out-of-range y ;
+//   loss_p = mask * w[y] * ( logsumexp(z_p) - z_p[y] )      (CategoricalCrossentropy(from_logits=True), NONE)
+//   Keras then averages over ALL N*H*W positions (ignored ones included) -- the caller passes that 1/P as grad_scale.
+// Metric: metrics/seg_metric_wrapper.py:89-102 + metrics/confusion_matrix.py:65-143 --
+//   pred = first argmax ; ignored labels carry weight 0 ; cm[y][pred] += 1.
+// A block stages PIX pixels x C logits through LDS with fully coalesced 16-B lanes, each lane then owns one
+// pixel (row stride C words; conflict-free for odd C such as 21), writes its gradient row back into the same
+// LDS slab, and the block streams it out coalesced again.
+#include "common.h"
+#include "iseg_hip.h"
+
+namespace {
+
+static inline int pixels_per_block(int C) {
+    int pix = (48 * 1024) / (4 * C);
+    pix = (pix / 64) * 64;
+    if (pix > 256) pix = 256;
+    if (pix < 64) pix = 64;
+    return pix;
+}
+
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                         const float* __restrict__ class_w, int64_t P, int C, int ignore,
+                                                         float* __restrict__ loss_px, float* __restrict__ block_sums,
+                                                         float* __restrict__ dlogits, float grad_scale, int pix) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C]
+    __shared__ float wsum[4];
+    const int64_t p0 = (int64_t)blockIdx.x * pix;
+    const int npx = (int)((P - p0 < pix) ? (P - p0) : pix);
+    const int64_t nel = (int64_t)npx * C;
+    const float* src = logits + p0 * C;
+    const bool vec = ((p0 * C) % 4 == 0) && (nel % 4 == 0);
+    if (vec) {
+        for (int i = threadIdx.x; i < nel / 4; i += 256)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < nel; i += 256) tile[i] = src[i];
+    }
+    __syncthreads();
+    float my_loss = 0.f;
+    if ((int)threadIdx.x < npx) {
+        float* z = tile + threadIdx.x * C;
+        int y = labels[p0 + threadIdx.x];
+        const bool keep = y != ignore;
+        if (ignore == 0) y -= 1;
+        const bool in_range = y >= 0 && y < C;
+        float w = keep ? 1.f : 0.f;
+        if (class_w) w *= in_range ? class_w[y] : 0.f;
+        float mx = z[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(z[c] - mx);
+        const float lse = mx + logf(se);
+        // -sum_c onehot_c * log_softmax_c : zero row when y is out of range
+        my_loss = in_range ? w * (lse - z[y]) : 0.f;
+        if (loss_px) loss_px[p0 + threadIdx.x] = my_loss;
+        if (dlogits) {
+            const float g = w * grad_scale;
+            const float inv = 1.f / se;
+            for (int c = 0; c < C; ++c) {
+                const float sm = in_range ? expf(z[c] - mx) * inv : 0.f;
+                z[c] = g * (sm - ((c == y) ? 1.f : 0.f));
+            }
+        }
+    }
+    if (block_sums) {
+        const float s = wave_sum(my_loss);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (block_sums && threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (dlogits) {
+        float* dst = dlogits + p0 * C;
+        if (vec) {
+            for (int i = threadIdx.x; i < nel / 4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<float4*>(tile)[i];
+        } else {
+            for (int i = threadIdx.x; i < nel; i += 256) dst[i] = tile[i];
+        }
+    }
+}
+
+__global__ void sum_blocks_kernel(const float* __restrict__ v, int n, float* __restrict__ out, float scale) {
+    // single block, fixed-order tree -> deterministic
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                               int64_t P, int C, int ignore, int32_t* __restrict__ pred_out,
+                                                               unsigned long long* __restrict__ cm, int pix) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C] then int hist[C*C] (if it fits)
+    const int64_t p0 = (int64_t)blockIdx.x * pix;
+    const int npx = (int)((P - p0 < pix) ? (P - p0) : pix);
+    const int64_t nel = (int64_t)npx * C;
+    const float* src = logits + p0 * C;
+    const bool vec = ((p0 * C) % 4 == 0) && (nel % 4 == 0);
+    if (vec) {
+        for (int i = threadIdx.x; i < nel / 4; i += 256)
+            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < nel; i += 256) tile[i] = src[i];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < npx) {
+        const float* z = tile + threadIdx.x * C;
+        int best = 0;
+        float bv = z[0];
+        for (int c = 1; c < C; ++c)
+            if (z[c] > bv) {  // strict: first maximal index, as tf.argmax
+                bv = z[c];
+                best = c;
+            }
+        if (pred_out) pred_out[p0 + threadIdx.x] = best;
+        if (cm && labels) {
+            const int y = labels[p0 + threadIdx.x];
+            if (y != ignore && y >= 0 && y < C) atomicAdd(&cm[(int64_t)y * C + best], 1ull);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C) {
+    return (size_t)ceil_div64(P, pixels_per_block(C)) * sizeof(float);
+}
+
+extern "C" int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
+                                      int ignore_label, float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits,
+                                      float grad_scale, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(logits && labels && P > 0 && C > 0, "iseg_softmax_ce_ignore: bad arguments");
+    ISEG_REQUIRE(C <= 640, "iseg_softmax_ce_ignore: num_class %d > 640 unsupported", C);
+    const int pix = pixels_per_block(C);
+    const int64_t blocks = ceil_div64(P, pix);
+    float* bs = nullptr;
+    if (loss_sum) {
+        const size_t need = (size_t)blocks * sizeof(float);
+        if (!ws || ws_bytes < need) {
+            iseg_set_error("iseg_softmax_ce_ignore: needs %zu workspace bytes, got %zu", need, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        bs = (float*)ws;
+    }
+    const size_t lds = (size_t)pix * C * sizeof(float);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, class_w, P, C,
+                       ignore_label, loss_px, bs, dlogits, grad_scale, pix);
+    if (loss_sum)
+        hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, (const float*)bs, (int)blocks, loss_sum,
+                           loss_sum_scale);
+    return iseg_check_launch("iseg_softmax_ce_ignore");
+}
+
+extern "C" int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P, int C, int ignore_label,
+                                     int32_t* pred_out, unsigned long long* cm, hipStream_t stream) {
+    ISEG_REQUIRE(logits && P > 0 && C > 0 && C <= 640, "iseg_argmax_confusion: bad arguments");
+    ISEG_REQUIRE(!cm || labels, "iseg_argmax_confusion: confusion matrix needs labels");
+    const int pix = pixels_per_block(C);
+    const int64_t blocks = ceil_div64(P, pix);
+    const size_t lds = (size_t)pix * C * sizeof(float);
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, P, C, ignore_label,
+                       pred_out, cm, pix);
+    return iseg_check_launch("iseg_argmax_confusion");
+}

@@ -1,0 +1,558 @@
+// Normalisation kernels (HBM-bound): LayerNorm over the channel axis and (Sync)BatchNorm over N,H,W.
+//
+// LayerNorm follows keras.layers.LayerNormalization(axis=-1, epsilon) as used by backbones/convnext.py:27,71,
+// backbones/swin.py (norm1/norm2/PatchMerging.norm) and backbones/vit.py: biased variance, fp32 statistics,
+// (x-mean)*rsqrt(var+eps)*gamma+beta.  BatchNorm follows the synchronized moments path of
+// layers/keras3/bn.py:10-73 / layers/syncbn.py:70-119: per-replica sum, sum of squares and count are reduced
+// (here: packed as one [2C+1] fp32 message for a single RCCL all-reduce), mean = S1/n, var = S2/n - mean^2.
+#include "common.h"
+#include "iseg_hip.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 8;  // 8-element chunks per lane kept in registers
+
+// lanes per row: smallest power of two >= number of 8-element chunks, capped at 64
+static inline int ln_lanes_per_row(int C) {
+    const int chunks = (C + 7) / 8;
+    int l = 1;
+    while (l < chunks && l < 64) l <<= 1;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward: `LPR` lanes cooperate on one row, 64/LPR rows per wave, values stay in registers
+// ------------------------------------------------------------------------------------------------
+template <class T, int CPL>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            int64_t rows, int C, float eps, int lpr) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;  // rows per wave
+    const int sub = lane / lpr, li = lane % lpr;
+    const int nchunks = C / 8;
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
+        const int64_t row = rbase + sub;
+        const bool valid = row < rows;
+        float v[CPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = li + i * lpr;
+            if (valid && c < nchunks) {
+                load8<T>(x + row * C + c * 8, v[i]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[i][u];
+            }
+        }
+        s = group_sum(s, lpr);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = li + i * lpr;
+            if (valid && c < nchunks) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float d = v[i][u] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        q = group_sum(q, lpr);
+        const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = li + i * lpr;
+            if (valid && c < nchunks) {
+                float g[8], b[8], o[8];
+                load8<float>(gamma + c * 8, g);
+                load8<float>(beta + c * 8, b);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = (v[i][u] - mean) * rstd * g[u] + b[u];
+                store8<T>(y + row * C + c * 8, o);
+            }
+        }
+        if (valid && li == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.
+//   g = dy*gamma ; dx = rstd * (g - mean_C(g) - xhat*mean_C(g*xhat))
+//   dgamma = sum_rows dy*xhat ; dbeta = sum_rows dy  -> per-block partials [grid][2][C], reduced by colsum2
+// Each lane always owns the same channel chunks, so the parameter-gradient partials live in registers for
+// the whole row strip and are combined once per block through LDS.
+// ------------------------------------------------------------------------------------------------
+template <class T, int CPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            const T* __restrict__ dx_add, float* __restrict__ partials,
+                                                            int64_t rows, int C, int lpr) {
+    extern __shared__ __attribute__((aligned(16))) float lds_part[];  // [2][C]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;
+    const int sub = lane / lpr, li = lane % lpr;
+    const int nchunks = C / 8;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lds_part[i] = 0.f;
+    __syncthreads();
+
+    float dg[CPL][8], db[CPL][8];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dg[i][u] = db[i][u] = 0.f;
+
+    const int64_t wave_global = (int64_t)blockIdx.x * 4 + wid;
+    const int64_t nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
+        const int64_t row = rbase + sub;
+        const bool valid = row < rows;
+        const float mu = valid ? mean[row] : 0.f, rs = valid ? rstd[row] : 0.f;
+        float gv[CPL][8], xh[CPL][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = li + i * lpr;
+            if (valid && c < nchunks) {
+                float d[8], xv[8], g[8];
+                load8<T>(dy + row * C + c * 8, d);
+                load8<T>(x + row * C + c * 8, xv);
+                load8<float>(gamma + c * 8, g);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float h = (xv[u] - mu) * rs;
+                    xh[i][u] = h;
+                    gv[i][u] = d[u] * g[u];
+                    s1 += gv[i][u];
+                    s2 += gv[i][u] * h;
+                    dg[i][u] += d[u] * h;
+                    db[i][u] += d[u];
+                }
+            }
+        }
+        s1 = group_sum(s1, lpr) / (float)C;
+        s2 = group_sum(s2, lpr) / (float)C;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = li + i * lpr;
+            if (valid && c < nchunks) {
+                float o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = rs * (gv[i][u] - s1 - xh[i][u] * s2);
+                if (dx_add) {
+                    float a[8];
+                    load8<T>(dx_add + row * C + c * 8, a);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] += a[u];
+                }
+                store8<T>(dx + row * C + c * 8, o);
+            }
+        }
+    }
+    // block-level combine (LDS float atomics; order differs run to run only inside one block's 4*rpw adders)
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = li + i * lpr;
+        if (c < nchunks) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float a = dg[i][u], b = db[i][u];
+                // combine the rows-per-wave sub-groups first (same channel, lanes li + k*lpr)
+                for (int o = lpr; o < 64; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (sub == 0) {
+                    atomicAdd(&lds_part[c * 8 + u], a);
+                    atomicAdd(&lds_part[C + c * 8 + u], b);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_part[i];
+}
+
+// out[j] (+)= sum_p partials[p][j]   (fixed order -> deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int P, int n, float* __restrict__ out0,
+                                       float* __restrict__ out1, int n0, int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * n + j];
+    float* dst = j < n0 ? out0 + j : out1 + (j - n0);
+    if (accumulate) s += *dst;
+    *dst = s;
+}
+
+// packed[0:2C] = sum_p partials[p][0:2C] (fixed order), packed[2C] = local element count
+__global__ void bn_pack_kernel(const float* __restrict__ partials, int P, int C, float* __restrict__ packed, float count) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > 2 * C) return;
+    if (j == 2 * C) {
+        packed[j] = count;
+        return;
+    }
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * 2 * C + j];
+    packed[j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm
+// ------------------------------------------------------------------------------------------------
+// per-block partial sums of x and x^2 per channel: block handles a strip of rows; thread owns 8 channels.
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ partials,
+                                                       int64_t rows, int C) {
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [2][C]
+    const int nchunks = C / 8;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lds_s[i] = 0.f;
+    __syncthreads();
+    // thread t handles chunk (t % tpc) of rows (t / tpc) + k*rows_per_iter
+    const int tpc = nchunks < 256 ? nchunks : 256;  // threads across channels
+    const int rpi = 256 / tpc;                      // rows per iteration per block
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const bool active = tr < rpi;
+    for (int c = tc; c < nchunks; c += tpc) {
+        float s[8] = {}, q[8] = {};
+        if (active) {
+            for (int64_t r = (int64_t)blockIdx.x * rpi + tr; r < rows; r += (int64_t)gridDim.x * rpi) {
+                float v[8];
+                load8<T>(x + r * ldx + c * 8, v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s[u] += v[u];
+                    q[u] += v[u] * v[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                atomicAdd(&lds_s[c * 8 + u], s[u]);
+                atomicAdd(&lds_s[C + c * 8 + u], q[u]);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_s[i];
+}
+
+// packed[0:C]=sum, [C:2C]=sumsq, [2C]=count  ->  mean/var(biased), then update moving stats
+__global__ void bn_finalize_kernel(const float* __restrict__ packed, int C, float eps, float momentum, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ moving_mean, float* __restrict__ moving_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float n = packed[2 * C];
+    const float m = packed[c] / n;
+    float var = packed[C + c] / n - m * m;
+    var = fmaxf(var, 0.f);
+    mean[c] = m;
+    rstd[c] = rsqrtf(var + eps);
+    if (moving_mean) moving_mean[c] = moving_mean[c] * momentum + m * (1.f - momentum);
+    if (moving_var) moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
+}
+
+// y = act((x-mean)*rstd*gamma+beta), y may be a channel slice of a wider (concat) buffer
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, T* __restrict__ y, int64_t ldy,
+                                                       int64_t rows, int C, int relu) {
+    const int nchunks = C / 8;
+    const int64_t total = rows * nchunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nchunks;
+        const int c = (int)(i % nchunks) * 8;
+        float v[8], m[8], s[8], g[8], b[8];
+        load8<T>(x + r * ldx + c, v);
+        load8<float>(mean + c, m);
+        load8<float>(rstd + c, s);
+        load8<float>(gamma + c, g);
+        load8<float>(beta + c, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
+            if (relu) o = fmaxf(o, 0.f);
+            v[u] = o;
+        }
+        store8<T>(y + r * ldy + c, v);
+    }
+}
+
+// backward reductions: partial [2][C] = (sum dz, sum dz*xhat) with dz = dy * relu'(y)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
+                                                            int64_t ldx, const T* __restrict__ y, int64_t ldy,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ partials, int64_t rows, int C, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];
+    const int nchunks = C / 8;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) lds_s[i] = 0.f;
+    __syncthreads();
+    const int tpc = nchunks < 256 ? nchunks : 256;
+    const int rpi = 256 / tpc;
+    const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
+    const bool active = tr < rpi;
+    for (int c = tc; c < nchunks; c += tpc) {
+        float s[8] = {}, q[8] = {};
+        if (active) {
+            float m[8], rs[8];
+            load8<float>(mean + c * 8, m);
+            load8<float>(rstd + c * 8, rs);
+            for (int64_t r = (int64_t)blockIdx.x * rpi + tr; r < rows; r += (int64_t)gridDim.x * rpi) {
+                float d[8], xv[8];
+                load8<T>(dy + r * lddy + c * 8, d);
+                load8<T>(x + r * ldx + c * 8, xv);
+                if (relu) {
+                    float yv[8];
+                    load8<T>(y + r * ldy + c * 8, yv);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s[u] += d[u];
+                    q[u] += d[u] * (xv[u] - m[u]) * rs[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                atomicAdd(&lds_s[c * 8 + u], s[u]);
+                atomicAdd(&lds_s[C + c * 8 + u], q[u]);
+            }
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_s[i];
+}
+
+// dx = gamma*rstd * (dz - sum_dz/n - xhat*sum_dzxhat/n) ; sums[0:C]=sum dz, [C:2C]=sum dz*xhat (already all-reduced)
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
+                                                           int64_t ldx, const T* __restrict__ y, int64_t ldy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           float inv_n, T* __restrict__ dx, int64_t lddx, int64_t rows, int C,
+                                                           int relu) {
+    const int nchunks = C / 8;
+    const int64_t total = rows * nchunks;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nchunks;
+        const int c = (int)(i % nchunks) * 8;
+        float d[8], xv[8], m[8], rs[8], g[8], s1[8], s2[8];
+        load8<T>(dy + r * lddy + c, d);
+        load8<T>(x + r * ldx + c, xv);
+        if (relu) {
+            float yv[8];
+            load8<T>(y + r * ldy + c, yv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
+        }
+        load8<float>(mean + c, m);
+        load8<float>(rstd + c, rs);
+        load8<float>(gamma + c, g);
+        load8<float>(sums + c, s1);
+        load8<float>(sums + C + c, s2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float xh = (xv[u] - m[u]) * rs[u];
+            d[u] = g[u] * rs[u] * (d[u] - s1[u] * inv_n - xh * s2[u] * inv_n);
+        }
+        store8<T>(dx + r * lddx + c, d);
+    }
+}
+
+static inline int strip_grid(int64_t rows, int rows_per_block_iter, int max_blocks) {
+    int64_t b = ceil_div64(rows, (int64_t)rows_per_block_iter * 4);
+    if (b > max_blocks) b = max_blocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                  int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
+    ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
+    const int lpr = ln_lanes_per_row(C);
+    ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_fwd: C=%d too wide (max %d)", C, 64 * 8 * LN_MAX_CHUNKS);
+    const int rpw = 64 / lpr;
+    int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int cpl = (C / 8 + lpr - 1) / lpr;
+#define LN_FWD(T, CPL)                                                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
+                       (T*)y, mean, rstd, rows, C, eps, lpr)
+#define LN_FWD_T(T)                  \
+    do {                             \
+        if (cpl <= 1) LN_FWD(T, 1);      \
+        else if (cpl <= 2) LN_FWD(T, 2); \
+        else if (cpl <= 4) LN_FWD(T, 4); \
+        else LN_FWD(T, 8);               \
+    } while (0)
+    if (dtype == ISEG_BF16) LN_FWD_T(bf16_t);
+    else LN_FWD_T(float);
+#undef LN_FWD_T
+#undef LN_FWD
+    return iseg_check_launch("iseg_layernorm_fwd");
+}
+
+static int ln_bwd_blocks(int64_t rows, int C) {
+    const int lpr = ln_lanes_per_row(C);
+    const int rpw = 64 / lpr;
+    int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4 * 8);  // >= 8 row-iterations per block
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+    return (size_t)ln_bwd_blocks(rows, C) * 2 * C * sizeof(float);
+}
+
+extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                  void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads,
+                                  int64_t rows, int C, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "iseg_layernorm_bwd: null pointer");
+    ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_bwd: C=%d must be a positive multiple of 8", C);
+    const int lpr = ln_lanes_per_row(C);
+    ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_bwd: C=%d too wide", C);
+    const int blocks = ln_bwd_blocks(rows, C);
+    const size_t need = (size_t)blocks * 2 * C * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_layernorm_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    float* partials = (float*)ws;
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const int cpl = (C / 8 + lpr - 1) / lpr;
+#define LN_BWD(T, CPL)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
+                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr)
+#define LN_BWD_T(T)                  \
+    do {                             \
+        if (cpl <= 1) LN_BWD(T, 1);      \
+        else if (cpl <= 2) LN_BWD(T, 2); \
+        else if (cpl <= 4) LN_BWD(T, 4); \
+        else LN_BWD(T, 8);               \
+    } while (0)
+    if (dtype == ISEG_BF16) LN_BWD_T(bf16_t);
+    else LN_BWD_T(float);
+#undef LN_BWD_T
+#undef LN_BWD
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partials, blocks, 2 * C, dgamma,
+                       dbeta, C, accumulate_param_grads);
+    return iseg_check_launch("iseg_layernorm_bwd");
+}
+
+static int bn_blocks(int64_t rows, int C) {
+    const int nchunks = C / 8;
+    const int tpc = nchunks < 256 ? nchunks : 256;
+    const int rpi = 256 / tpc;
+    int64_t blocks = ceil_div64(rows, (int64_t)rpi * 4);
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+extern "C" size_t iseg_bn_workspace_bytes(int64_t rows, int C) { return (size_t)bn_blocks(rows, C) * 2 * C * sizeof(float); }
+
+extern "C" int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t rows, int C, int dtype, void* ws,
+                             size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(x && packed, "iseg_bn_stats: null pointer");
+    ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0, "iseg_bn_stats: C=%d ldx=%lld must be multiples of 8", C,
+                 (long long)ldx);
+    const int blocks = bn_blocks(rows, C);
+    const size_t need = (size_t)blocks * 2 * C * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_bn_stats: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)x, ldx, (float*)ws,
+                           rows, C);
+    else
+        hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)x, ldx, (float*)ws, rows,
+                           C);
+    hipLaunchKernelGGL(bn_pack_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, stream, (const float*)ws, blocks, C, packed,
+                       (float)rows);
+    return iseg_check_launch("iseg_bn_stats");
+}
+
+extern "C" int iseg_bn_finalize(const float* packed, int C, float eps, float momentum, float* mean, float* rstd,
+                                float* moving_mean, float* moving_var, hipStream_t stream) {
+    ISEG_REQUIRE(packed && mean && rstd && C > 0, "iseg_bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, packed, C, eps, momentum, mean, rstd,
+                       moving_mean, moving_var);
+    return iseg_check_launch("iseg_bn_finalize");
+}
+
+extern "C" int iseg_bn_apply_fwd(const void* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma,
+                                 const float* beta, void* y, int64_t ldy, int64_t rows, int C, int relu, int dtype,
+                                 hipStream_t stream) {
+    ISEG_REQUIRE(x && mean && rstd && gamma && beta && y, "iseg_bn_apply_fwd: null pointer");
+    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "iseg_bn_apply_fwd: C/ldx/ldy must be multiples of 8");
+    int64_t blocks = ceil_div64(rows * (C / 8), 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, ldx, mean,
+                           rstd, gamma, beta, (bf16_t*)y, ldy, rows, C, relu);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x, ldx, mean,
+                           rstd, gamma, beta, (float*)y, ldy, rows, C, relu);
+    return iseg_check_launch("iseg_bn_apply_fwd");
+}
+
+extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
+                                  const float* mean, const float* rstd, float* sums, int64_t rows, int C, int relu, int dtype,
+                                  void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && mean && rstd && sums && (!relu || y), "iseg_bn_bwd_reduce: null pointer");
+    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && (!relu || ldy % 8 == 0), "iseg_bn_bwd_reduce: alignment");
+    const int blocks = bn_blocks(rows, C);
+    const size_t need = (size_t)blocks * 2 * C * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_bn_bwd_reduce: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)dy, lddy,
+                           (const float*)x, ldx, (const float*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, blocks, 2 * C,
+                       sums, sums, 2 * C, 0);
+    return iseg_check_launch("iseg_bn_bwd_reduce");
+}
+
+extern "C" int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
+                                 const float* mean, const float* rstd, const float* gamma, const float* sums, float inv_n,
+                                 void* dx, int64_t lddx, int64_t rows, int C, int relu, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && (!relu || y), "iseg_bn_bwd_apply: null pointer");
+    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "iseg_bn_bwd_apply: alignment");
+    int64_t blocks = ceil_div64(rows * (C / 8), 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy,
+                           (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, gamma, sums, inv_n, (bf16_t*)dx, lddx, rows,
+                           C, relu);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dy, lddy,
+                           (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, sums, inv_n, (float*)dx, lddx, rows, C,
+                           relu);
+    return iseg_check_launch("iseg_bn_bwd_apply");
+}

@@ -1,0 +1,347 @@
+"""Thin tensor-level wrappers over the C ABI (include/iseg_hip.h).
+
+torch is used here only for device memory (torch.empty), dtype tags and the current HIP stream; every FLOP
+and every byte moved on the hot path happens inside libiseg_hip.so.  Nothing here falls back to torch ops.
+"""
+import ctypes as C
+
+import torch
+
+from . import _hip
+from ._hip import F32, BF16, ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, GemmArgs  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError(f"iseg_amd kernels support float32 and bfloat16 storage, got {t.dtype if isinstance(t, torch.Tensor) else t}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _hip.HipCallError("iseg_amd kernels need device tensors (cuda:N); there is no CPU path")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# workspace: one growable byte buffer per (device, stream); stream order makes reuse across ops safe
+# ---------------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def workspace(nbytes, device):
+    if nbytes <= 0:
+        return None, 0
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise _hip.HipCallError("workspace growth during hipGraph capture; run one eager warm-up step first")
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf, buf.numel()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------------------
+def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
+         rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
+         accumulate=False, split_k=0):
+    _require_cuda(A, B, D)
+    if A.dtype != B.dtype:
+        raise TypeError(f"gemm operands differ in dtype: {A.dtype} vs {B.dtype}")
+    g = GemmArgs()
+    g.A, g.lda, g.a_kcontig = ptr(A), lda, int(a_kcontig)
+    g.B, g.ldb, g.b_kcontig = ptr(B), ldb, int(b_kcontig)
+    g.D, g.ldd = ptr(D), ldd
+    g.M, g.N, g.K = M, N, K
+    g.in_dtype, g.out_dtype = dt(A), dt(D)
+    g.bias, g.colscale, g.rowscale, g.rows_per_group = ptr(bias), ptr(colscale), ptr(rowscale), rows_per_group
+    g.residual, g.ldr = ptr(residual), ldr
+    g.aux, g.ldaux = ptr(aux), ldaux
+    g.pre_out, g.ldp = ptr(pre_out), ldp
+    g.act, g.alpha, g.accumulate, g.split_k = act, alpha, int(accumulate), split_k
+    for t in (residual, aux, pre_out):
+        if t is not None and t.dtype != D.dtype:
+            raise TypeError("gemm residual/aux/pre_out must have the output dtype")
+    for t in (bias, colscale, rowscale):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("gemm bias/colscale/rowscale must be float32")
+    L = _hip.lib()
+    need = L.iseg_gemm_workspace_bytes(C.byref(g))
+    ws, wsb = workspace(need, A.device)
+    _hip.check(L.iseg_gemm(C.byref(g), ptr(ws), wsb, stream()), "iseg_gemm")
+    return D
+
+
+def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=None, pre_out=None, colscale=None,
+              rowscale=None, rows_per_group=0, residual=None):
+    """x2d [M,K] (row stride x2d.stride(0)) @ W [K,N] (Keras Dense / 1x1 conv kernel)."""
+    M, K = x2d.shape
+    N = W.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or x2d.dtype, device=x2d.device)
+    return gemm(x2d, W, out, M, N, K, lda=x2d.stride(0), ldb=W.stride(0), ldd=ldd or out.stride(0), a_kcontig=1, b_kcontig=0,
+                bias=bias, act=act, pre_out=pre_out, ldp=(pre_out.stride(0) if pre_out is not None else 0), colscale=colscale,
+                rowscale=rowscale, rows_per_group=rows_per_group, residual=residual,
+                ldr=(residual.stride(0) if residual is not None else 0))
+
+
+def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, rows_per_group=0, residual=None, accumulate=False):
+    """dX [M,K] = dY [M,N] @ W[K,N]^T : W is consumed as stored (its rows are the N-contiguous reduction)."""
+    M, N = dy2d.shape
+    K = W.shape[0]
+    if out is None:
+        out = torch.empty((M, K), dtype=dy2d.dtype, device=dy2d.device)
+    return gemm(dy2d, W, out, M, K, N, lda=dy2d.stride(0), ldb=W.stride(0), ldd=out.stride(0), a_kcontig=1, b_kcontig=1, act=act,
+                aux=aux, ldaux=(aux.stride(0) if aux is not None else 0), rowscale=rowscale, rows_per_group=rows_per_group,
+                residual=residual, ldr=(residual.stride(0) if residual is not None else 0), accumulate=accumulate)
+
+
+def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0):
+    """dW [K,N] (+)= X[M,K]^T @ dY[M,N]; out is fp32."""
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    return gemm(x2d, dy2d, out, K, N, M, lda=x2d.stride(0), ldb=dy2d.stride(0), ldd=out.stride(0), a_kcontig=0, b_kcontig=0,
+                accumulate=accumulate, alpha=alpha)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------------------
+def layernorm_fwd(x2d, gamma, beta, eps, save_stats=True):
+    _require_cuda(x2d)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device) if save_stats else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device) if save_stats else None
+    _hip.call("iseg_layernorm_fwd", ptr(x2d), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, Cc, eps, dt(x2d), stream())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dgamma, dbeta, dx_add=None, accumulate=True):
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    need = _hip.lib().iseg_layernorm_bwd_workspace_bytes(rows, Cc)
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_layernorm_bwd", ptr(dy2d), ptr(x2d), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dx_add), ptr(dgamma),
+              ptr(dbeta), int(accumulate), rows, Cc, dt(x2d), ptr(ws), wsb, stream())
+    return dx
+
+
+def bn_stats(x2d, ldx, rows, Cc):
+    packed = torch.empty(2 * Cc + 1, dtype=torch.float32, device=x2d.device)
+    need = _hip.lib().iseg_bn_workspace_bytes(rows, Cc)
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_bn_stats", ptr(x2d), ldx, ptr(packed), rows, Cc, dt(x2d), ptr(ws), wsb, stream())
+    return packed
+
+
+def bn_finalize(packed, Cc, eps, momentum, moving_mean, moving_var):
+    mean = torch.empty(Cc, dtype=torch.float32, device=packed.device)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=packed.device)
+    _hip.call("iseg_bn_finalize", ptr(packed), Cc, eps, momentum, ptr(mean), ptr(rstd), ptr(moving_mean), ptr(moving_var), stream())
+    return mean, rstd
+
+
+def bn_apply_fwd(x2d, ldx, mean, rstd, gamma, beta, y2d, ldy, rows, Cc, relu):
+    _hip.call("iseg_bn_apply_fwd", ptr(x2d), ldx, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y2d), ldy, rows, Cc, int(relu),
+              dt(x2d), stream())
+    return y2d
+
+
+def bn_bwd_reduce(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, rows, Cc, relu):
+    sums = torch.empty(2 * Cc, dtype=torch.float32, device=x2d.device)
+    need = _hip.lib().iseg_bn_workspace_bytes(rows, Cc)
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_bn_bwd_reduce", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(sums), rows, Cc,
+              int(relu), dt(x2d), ptr(ws), wsb, stream())
+    return sums
+
+
+def bn_bwd_apply(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, gamma, sums, inv_n, dx2d, lddx, rows, Cc, relu):
+    _hip.call("iseg_bn_bwd_apply", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), inv_n,
+              ptr(dx2d), lddx, rows, Cc, int(relu), dt(x2d), stream())
+    return dx2d
+
+
+def rsqrt_eps(var, eps):
+    out = torch.empty_like(var)
+    _hip.call("iseg_rsqrt_eps", ptr(var), eps, ptr(out), var.numel(), stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# depthwise conv
+# ---------------------------------------------------------------------------------------------------------
+def dwconv2d(x, w, bias, K, dil, pad_t, pad_l, *, flip=False, add=None):
+    """x [N,H,W,C]; w [K*K, C] fp32 (Keras [K,K,C,1]); stride 1."""
+    _require_cuda(x)
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _hip.call("iseg_dwconv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), N, H, W, Cc, K, dil, pad_t, pad_l, int(flip), dt(x),
+              stream())
+    return y
+
+
+def dwconv2d_bwd_weight(x, dy, dw, db, K, dil, pad_t, pad_l, accumulate=True):
+    N, H, W, Cc = x.shape
+    need = _hip.lib().iseg_dwconv2d_bwd_weight_workspace_bytes(N, H, Cc, K)
+    ws, wsb = workspace(need, x.device)
+    _hip.call("iseg_dwconv2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), ptr(db), int(accumulate), N, H, W, Cc, K, dil, pad_t, pad_l,
+              dt(x), ptr(ws), wsb, stream())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layout / elementwise
+# ---------------------------------------------------------------------------------------------------------
+def cast(src, dst_dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, dtype=dst_dtype, device=src.device)
+    _hip.call("iseg_cast", ptr(src), dt(src), ptr(out), dt(out), src.numel(), stream())
+    return out
+
+
+def scale_cols_cast(src, colscale, dst_dtype):
+    rows, cols = src.shape
+    out = torch.empty((rows, cols), dtype=dst_dtype, device=src.device)
+    _hip.call("iseg_scale_cols_cast", ptr(src), ptr(colscale), ptr(out), rows, cols, dt(out), stream())
+    return out
+
+
+def same_pad(in_size, k, s, d):
+    """TF padding="same": returns (out_size, pad_before)."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - in_size, 0)
+    return out, total // 2
+
+
+def im2col(x, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, out_dtype, ldc=None):
+    N, H, W, Cc = x.shape
+    Kd = KH * KW * Cc
+    if ldc is None:
+        ldc = (Kd + 7) // 8 * 8
+    col = torch.empty((N * Ho * Wo, ldc), dtype=out_dtype, device=x.device)
+    _hip.call("iseg_im2col", ptr(x), dt(x), ptr(col), dt(col), N, H, W, Cc, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc, stream())
+    return col
+
+
+def col2im(dcol, N, H, W, Cc, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo):
+    dx = torch.empty((N, H, W, Cc), dtype=dcol.dtype, device=dcol.device)
+    _hip.call("iseg_col2im", ptr(dcol), ptr(dx), N, H, W, Cc, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, dcol.stride(0), dt(dcol),
+              stream())
+    return dx
+
+
+def colsum(x, ldx, batch_stride, batch, rows, Cc, out, scale=1.0, accumulate=False):
+    need = _hip.lib().iseg_colsum_workspace_bytes(batch, rows, Cc)
+    ws, wsb = workspace(need, x.device)
+    _hip.call("iseg_colsum", ptr(x), ldx, batch_stride, batch, rows, Cc, ptr(out), scale, int(accumulate), dt(x), ptr(ws), wsb,
+              stream())
+    return out
+
+
+def broadcast_rows(v, y, ldy, batch_stride, batch, rows, Cc, scale=1.0, accumulate=False):
+    _hip.call("iseg_broadcast_rows", ptr(v), dt(v), ptr(y), ldy, batch_stride, batch, rows, Cc, scale, int(accumulate), dt(y),
+              stream())
+    return y
+
+
+def axpby(a, b, alpha=1.0, beta=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    _hip.call("iseg_axpby", ptr(a), ptr(b), ptr(out), alpha, beta, a.numel(), dt(a), stream())
+    return out
+
+
+def rowscale(x2d, s, rows_per_group):
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    _hip.call("iseg_rowscale", ptr(x2d), ptr(s), ptr(y), rows, Cc, rows_per_group, dt(x2d), stream())
+    return y
+
+
+def dropout(x, rate, seed):
+    y = torch.empty_like(x)
+    _hip.call("iseg_dropout", ptr(x), ptr(y), x.numel(), rate, seed, dt(x), stream())
+    return y
+
+
+def drop_path_mask(n, keep_prob, seed, device):
+    s = torch.empty(n, dtype=torch.float32, device=device)
+    _hip.call("iseg_drop_path_mask", ptr(s), n, keep_prob, seed, stream())
+    return s
+
+
+def fill_f32(t, value):
+    _hip.call("iseg_fill_f32", ptr(t), value, t.numel(), stream())
+    return t
+
+
+def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
+    Kd, Nd = Z.shape
+    need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
+    ws, wsb = workspace(need, Z.device)
+    _hip.call("iseg_layerscale_grads", ptr(Z), ptr(W2), ptr(b2), ptr(gamma), ptr(S), ptr(dW2), ptr(dgamma), ptr(db2), Kd, Nd,
+              int(accumulate), ptr(ws), wsb, stream())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# resize / loss / metric / optimizer
+# ---------------------------------------------------------------------------------------------------------
+def resize_bilinear(x, Ho, Wo, out_dtype=None):
+    _require_cuda(x)
+    N, Hi, Wi, Cc = x.shape
+    y = torch.empty((N, Ho, Wo, Cc), dtype=out_dtype or x.dtype, device=x.device)
+    _hip.call("iseg_resize_bilinear_fwd", ptr(x), dt(x), ptr(y), dt(y), N, Hi, Wi, Ho, Wo, Cc, stream())
+    return y
+
+
+def resize_bilinear_bwd(dy, Hi, Wi, dx_dtype, dx_add=None):
+    N, Ho, Wo, Cc = dy.shape
+    dx = torch.empty((N, Hi, Wi, Cc), dtype=dx_dtype, device=dy.device)
+    need = _hip.lib().iseg_resize_bilinear_bwd_workspace_bytes(N, Hi, Wi, Ho, Wo, Cc)
+    ws, wsb = workspace(need, dy.device)
+    _hip.call("iseg_resize_bilinear_bwd", ptr(dy), dt(dy), ptr(dx), dt(dx), ptr(dx_add), N, Hi, Wi, Ho, Wo, Cc, ptr(ws), wsb, stream())
+    return dx
+
+
+def resize_nearest_i32(x, Ho, Wo):
+    N, Hi, Wi, Cc = x.shape
+    y = torch.empty((N, Ho, Wo, Cc), dtype=torch.int32, device=x.device)
+    _hip.call("iseg_resize_nearest_i32", ptr(x), ptr(y), N, Hi, Wi, Ho, Wo, Cc, stream())
+    return y
+
+
+def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px=True, want_sum=False, sum_scale=1.0,
+                      want_grad=False, grad_scale=1.0):
+    _require_cuda(logits2d, labels1d)
+    P, Cc = logits2d.shape
+    dev = logits2d.device
+    loss_px = torch.empty(P, dtype=torch.float32, device=dev) if want_px else None
+    loss_sum = torch.empty(1, dtype=torch.float32, device=dev) if want_sum else None
+    dlogits = torch.empty_like(logits2d) if want_grad else None
+    need = _hip.lib().iseg_softmax_ce_workspace_bytes(P, Cc) if want_sum else 0
+    ws, wsb = workspace(need, dev)
+    _hip.call("iseg_softmax_ce_ignore", ptr(logits2d), ptr(labels1d), ptr(class_w), P, Cc, ignore_label, ptr(loss_px), ptr(loss_sum),
+              sum_scale, ptr(dlogits), grad_scale, ptr(ws), wsb, stream())
+    return loss_px, loss_sum, dlogits
+
+
+def argmax_confusion(logits2d, labels1d, ignore_label, cm=None, want_pred=False):
+    P, Cc = logits2d.shape
+    pred = torch.empty(P, dtype=torch.int32, device=logits2d.device) if want_pred else None
+    _hip.call("iseg_argmax_confusion", ptr(logits2d), ptr(labels1d), P, Cc, ignore_label, ptr(pred), ptr(cm), stream())
+    return pred

@@ -1,0 +1,252 @@
+"""CPU restatement of the TensorFlow/Keras op semantics that edwardyehuang/iSeg's hot path relies on.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under iseg_amd/ may import this package; only tests/, bench.py's
+`cpu_baseline` leg and __graft_entry__.smoke() do, and only as the checker.
+
+PARITY UNPINNED: the reference is Python on TensorFlow/Keras, which is not installed in the build container
+(no network), and the reference ships no tests or golden vectors for this path.  The
+arithmetic lives in un-vendored third-party packages (TensorFlow >= 2.10 / Keras, README.md:75,87-89 of the
+reference; no lock file).  What follows restates their *published* semantics by hand; each function cites
+the reference call site it stands in for.  It is pinned only by closed-form known-answer tests
+(tests/test_oracle_known_answers.py) and by an independent numpy loop implementation of the trickiest ops
+(oracle/np_loops.py).
+
+All tensors are NHWC torch CPU tensors (float32 or float64); every function is differentiable through torch
+autograd, which is how backward passes of the HIP kernels are checked.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------------
+# padding="same"  (Keras Conv2D / DepthwiseConv2D / pooling)
+# ------------------------------------------------------------------------------------------------------
+def same_pad(in_size, k, s=1, d=1):
+    """out = ceil(in/s); total = max((out-1)*s + (k-1)*d + 1 - in, 0); before = total//2, after = rest."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - in_size, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def conv2d(x, kernel, bias=None, strides=1, dilation=1, padding="same", groups=1):
+    """keras.layers.Conv2D: x [N,H,W,Cin], kernel [kh,kw,Cin/groups,Cout] (layers/model_builder.py:54-64)."""
+    sh, sw = _pair(strides)
+    dh, dw = _pair(dilation)
+    kh, kw = kernel.shape[0], kernel.shape[1]
+    xt = x.permute(0, 3, 1, 2)
+    if padding == "same":
+        _, pt, pb = same_pad(x.shape[1], kh, sh, dh)
+        _, pl, pr = same_pad(x.shape[2], kw, sw, dw)
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    elif padding != "valid":
+        raise ValueError(padding)
+    w = kernel.permute(3, 2, 0, 1)
+    y = F.conv2d(xt, w, bias, stride=(sh, sw), dilation=(dh, dw), groups=groups)
+    return y.permute(0, 2, 3, 1)
+
+
+def depthwise_conv2d(x, kernel, bias=None, strides=1, dilation=1, padding="same"):
+    """keras.layers.DepthwiseConv2D: kernel [kh,kw,C,1] (backbones/convnext.py:25)."""
+    C = x.shape[-1]
+    k = kernel.reshape(kernel.shape[0], kernel.shape[1], 1, C)
+    return conv2d(x, k, bias, strides, dilation, padding, groups=C)
+
+
+def dense(x, kernel, bias=None):
+    """keras.layers.Dense on the last axis, kernel [in,out] (backbones/convnext.py:29-30)."""
+    y = x @ kernel
+    return y if bias is None else y + bias
+
+
+def gelu(x):
+    """keras.activations.gelu(approximate=False): 0.5 x (1 + erf(x/sqrt2))  (backbones/convnext.py:53)."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layer_norm(x, gamma, beta, eps):
+    """keras.layers.LayerNormalization(axis=-1): biased variance (backbones/convnext.py:27)."""
+    mean = x.mean(-1, keepdim=True)
+    var = ((x - mean) ** 2).mean(-1, keepdim=True)
+    return (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+
+
+def batch_norm_train(x, gamma, beta, eps, stats=None):
+    """BatchNormalization(synchronized=True), training: moments from sum / sum of squares / count
+    (layers/keras3/bn.py:10-73, layers/syncbn.py:70-119).  `stats` = (sum, sumsq, count) overrides the local
+    moments (used to emulate the cross-replica all-reduce).  Returns y, mean, var(biased)."""
+    red = tuple(range(x.dim() - 1))
+    if stats is None:
+        n = 1
+        for a in red:
+            n *= x.shape[a]
+        s1, s2 = x.sum(red), (x * x).sum(red)
+    else:
+        s1, s2, n = stats
+    mean = s1 / n
+    var = s2 / n - mean * mean
+    y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
+    return y, mean, var
+
+
+def batch_norm_infer(x, gamma, beta, moving_mean, moving_var, eps):
+    return (x - moving_mean) * torch.rsqrt(moving_var + eps) * gamma + beta
+
+
+def moving_update(moving, batch, momentum):
+    """moving <- moving*momentum + batch*(1-momentum)  (keras BatchNormalization)."""
+    return moving * momentum + batch * (1.0 - momentum)
+
+
+# ------------------------------------------------------------------------------------------------------
+# tf.image.resize (v2, half_pixel_centers=True, antialias=False)   -- utils/common.py:107-134
+# ------------------------------------------------------------------------------------------------------
+def _interp_weights(out_size, in_size, dtype):
+    # TF computes these in float32 (compute_interpolation_weights); keep float32 so ties resolve identically
+    scale = np.float32(in_size) / np.float32(out_size)
+    dst = np.arange(out_size, dtype=np.float32)
+    src = (dst + np.float32(0.5)) * scale - np.float32(0.5)
+    fl = np.floor(src)
+    lo = np.maximum(fl, 0).astype(np.int64)
+    hi = np.minimum(np.ceil(src), in_size - 1).astype(np.int64)
+    t = (src - fl).astype(np.float32)
+    return torch.from_numpy(lo), torch.from_numpy(hi), torch.from_numpy(t).to(dtype)
+
+
+def resize_bilinear(x, size):
+    """value = top + (bottom-top)*ty, top = tl + (tr-tl)*tx; output float (TF returns float32)."""
+    Ho, Wo = size
+    N, Hi, Wi, C = x.shape
+    ylo, yhi, ty = _interp_weights(Ho, Hi, x.dtype)
+    xlo, xhi, tx = _interp_weights(Wo, Wi, x.dtype)
+    top_rows, bot_rows = x[:, ylo], x[:, yhi]
+    tx = tx.view(1, 1, Wo, 1)
+    ty = ty.view(1, Ho, 1, 1)
+    top = top_rows[:, :, xlo] + (top_rows[:, :, xhi] - top_rows[:, :, xlo]) * tx
+    bot = bot_rows[:, :, xlo] + (bot_rows[:, :, xhi] - bot_rows[:, :, xlo]) * tx
+    return top + (bot - top) * ty
+
+
+def resize_nearest(x, size):
+    """src = min(floor((dst+0.5)*in/out), in-1)."""
+    Ho, Wo = size
+    N, Hi, Wi, C = x.shape
+
+    def idx(o, i):
+        scale = np.float32(i) / np.float32(o)
+        d = np.arange(o, dtype=np.float32)
+        return torch.from_numpy(np.minimum(np.floor((d + np.float32(0.5)) * scale), i - 1).astype(np.int64))
+
+    return x[:, idx(Ho, Hi)][:, :, idx(Wo, Wi)]
+
+
+# ------------------------------------------------------------------------------------------------------
+# loss / metric  -- losses/catecrossentropy_ignore_label.py:44-88, metrics/*.py
+# ------------------------------------------------------------------------------------------------------
+def softmax_ce_ignore(y_true, logits, num_class=21, ignore_label=255, class_weights=None):
+    """weighted_loss: per-position loss [N*H*W] (Reduction.NONE); Keras' wrapper then takes the mean over ALL
+    positions, ignored ones included -- callers do `.mean()`."""
+    z = logits.reshape(-1, num_class)
+    y = y_true.reshape(-1).to(torch.int64)
+    w = (y != ignore_label).to(z.dtype)
+    if ignore_label == 0:
+        y = y - 1
+    in_range = (y >= 0) & (y < num_class)
+    yc = y.clamp(0, num_class - 1)
+    onehot = F.one_hot(yc, num_class).to(z.dtype) * in_range.unsqueeze(-1).to(z.dtype)  # tf.one_hot: zero row
+    if class_weights is not None and len(class_weights) > 0:
+        cw = torch.as_tensor(class_weights, dtype=z.dtype)
+        w = w * (onehot * cw.unsqueeze(0)).sum(-1)
+    logp = z - torch.logsumexp(z, dim=-1, keepdim=True)
+    return -(onehot * logp).sum(-1) * w
+
+
+def argmax_first(logits):
+    """tf.argmax: first maximal index."""
+    z = logits.detach().cpu().numpy()
+    return torch.from_numpy(np.argmax(z, axis=-1).astype(np.int64))
+
+
+def confusion_matrix(labels, preds, num_class, ignore_label):
+    """metrics/seg_metric_wrapper.py:89-102 + metrics/confusion_matrix.py:65-143 (weights 0 for ignored)."""
+    y = labels.reshape(-1).to(torch.int64)
+    p = preds.reshape(-1).to(torch.int64)
+    keep = y != ignore_label
+    cm = torch.zeros(num_class, num_class, dtype=torch.float64)
+    idx = y[keep] * num_class + p[keep]
+    cm.view(-1).index_add_(0, idx, torch.ones(idx.numel(), dtype=torch.float64))
+    return cm
+
+
+def per_class_iou(cm):
+    """metrics/mean_iou.py:59-77: iou_c = cm_cc / (row_c + col_c - cm_cc); classes with zero denominator drop out
+    of the mean."""
+    tp = cm.diag()
+    denom = cm.sum(0) + cm.sum(1) - tp
+    valid = denom > 0
+    iou = torch.where(valid, tp / torch.where(valid, denom, torch.ones_like(denom)), torch.zeros_like(denom))
+    n_valid = valid.sum()
+    miou = iou.sum() / n_valid if n_valid > 0 else torch.tensor(0.0, dtype=cm.dtype)
+    return iou, miou
+
+
+# ------------------------------------------------------------------------------------------------------
+# regularisation
+# ------------------------------------------------------------------------------------------------------
+def drop_path(x, keep_mask_scaled):
+    """utils/drops.py:8-22 with the per-sample factor floor(keep+u)/keep given explicitly (RNG streams differ)."""
+    shape = (x.shape[0],) + (1,) * (x.dim() - 1)
+    return x * keep_mask_scaled.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------------
+# optimisers and schedules  -- optimizers/modern/adamw.py:13-74, optimizers/modern/sgd.py:12-51,
+#                              optimizers/polydecay.py:44-76
+# ------------------------------------------------------------------------------------------------------
+def warmup_poly_decay(step, initial_lr, decay_steps, end_lr=0.0001, warmup_steps=0, warmup_lr=1e-4, power=1.0):
+    max_steps = float(decay_steps) - warmup_steps
+    current = min(float(step), max_steps)
+    slow = warmup_lr
+    adjusted = current
+    if warmup_steps > 0:
+        adjusted = max(adjusted - warmup_steps, 0.0)
+        slow = warmup_lr + (initial_lr - warmup_lr) * current / warmup_steps
+    p = adjusted / max_steps
+    lr = (initial_lr - end_lr) * (1.0 - p) ** power + end_lr
+    return slow if step < warmup_steps else lr
+
+
+def adamw_step(w, g, m, v, step, lr, lr_mult=1.0, wd=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
+    """One AdamW_EXT.update_step preceded by Keras' decoupled decay; `step` is 1-based (iterations+1)."""
+    g = torch.where(torch.isnan(g), torch.zeros_like(g), g)
+    w = w - w * wd * lr
+    m = m + (g - m) * (1 - beta1)
+    v = v + (g * g - v) * (1 - beta2)
+    alpha = lr * lr_mult * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    w = w - (m * alpha) / (torch.sqrt(v) + eps)
+    return w, m, v
+
+
+def sgd_step(w, g, m, lr, lr_mult=1.0, momentum=0.9, l2=0.0):
+    g = torch.where(torch.isnan(g), torch.zeros_like(g), g) + 2.0 * l2 * w
+    m = -g * lr * lr_mult + m * momentum
+    return w + m, m
+
+
+# ------------------------------------------------------------------------------------------------------
+# sliding-window tiling  -- utils/sliding_window_inference_utils.py:16-32
+# ------------------------------------------------------------------------------------------------------
+def sliding_start_indexs(length, crop):
+    stride = int(2.0 / 3.0 * crop)
+    times = (length - crop) // stride + 1
+    idx = [stride * i for i in range(times)]
+    if length - (times - 1) * stride > crop:
+        idx.append(length - crop)
+    return idx

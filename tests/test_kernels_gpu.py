@@ -1,0 +1,370 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle on seeded inputs.  fp32 storage is checked at fp32
+tolerances, bf16 storage at bf16 output-rounding tolerances (inputs are rounded to bf16 BEFORE the oracle sees them,
+so only accumulation order and the final rounding differ)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as O
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def K():
+    from iseg_amd import kernels
+
+    return kernels
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale)
+
+
+def q(t, dtype):
+    """round to storage dtype, return (device tensor, float64 CPU copy of the rounded values)"""
+    s = t.to(dtype)
+    return s.cuda(), s.to(torch.float64)
+
+
+def close(got, want, dtype, what="", f32_tol=2e-5, bf16_tol=1.2e-2):
+    got = got.detach().to("cpu", torch.float64)
+    want = want.detach().to(torch.float64)
+    tol = f32_tol if dtype == torch.float32 else bf16_tol
+    scale = max(want.abs().max().item(), 1e-6)
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol:.1e} * scale {scale:.3e}"
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", [(256, 128, 96), (1000, 384, 96), (130, 96, 384), (77, 21, 256), (512, 192, 48), (300, 64, 1280),
+                                   (64, 1536, 384), (33, 40, 24)])
+def test_gemm_forward_orientation(cuda, dtype, M, N, Kd):
+    k = K()
+    x, xr = q(rnd((M, Kd), 1), dtype)
+    w, wr = q(rnd((Kd, N), 2, Kd ** -0.5), dtype)
+    b = rnd((N,), 3).float()
+    y = k.dense_fwd(x, w, b.cuda())
+    close(y, xr @ wr + b.double(), dtype, "dense_fwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(cuda, dtype):
+    k = K()
+    M, N, Kd, G = 384, 96, 384, 128
+    x, xr = q(rnd((M, Kd), 1), dtype)
+    w, wr = q(rnd((Kd, N), 2, Kd ** -0.5), dtype)
+    res, resr = q(rnd((M, N), 4), dtype)
+    b = rnd((N,), 3).float()
+    cs = (rnd((N,), 5) * 0.5 + 1).float()
+    rs = torch.tensor([0.0, 1.25, 1.25])
+    y = k.dense_fwd(x, w, b.cuda(), colscale=cs.cuda(), rowscale=rs.cuda(), rows_per_group=G, residual=res)
+    want = resr + (xr @ wr + b.double()) * cs.double() * rs.double().repeat_interleave(G).unsqueeze(1)
+    close(y, want, dtype, "scale+residual")
+    # gelu with saved pre-activation
+    pre = torch.empty((M, N), dtype=dtype, device="cuda")
+    y = k.dense_fwd(x, w, b.cuda(), act=k.ACT_GELU, pre_out=pre)
+    h = xr @ wr + b.double()
+    close(pre, h, dtype, "pre_out")
+    close(y, O.gelu(h), dtype, "gelu")
+    y = k.dense_fwd(x, w, None, act=k.ACT_RELU)
+    close(y, torch.relu(xr @ wr), dtype, "relu")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd", [(512, 384, 96), (200, 96, 384), (70, 21, 256), (128, 256, 1280)])
+def test_gemm_dgrad_and_gelu_grad(cuda, dtype, M, N, Kd):
+    k = K()
+    dy, dyr = q(rnd((M, N), 1), dtype)
+    w, wr = q(rnd((Kd, N), 2, N ** -0.5), dtype)
+    dx = k.dense_dgrad(dy, w)
+    close(dx, dyr @ wr.T, dtype, "dgrad")
+    h, hr = q(rnd((M, Kd), 3), dtype)
+    dx = k.dense_dgrad(dy, w, act=k.ACT_GELU_GRAD, aux=h)
+    hh = hr.clone().requires_grad_(True)
+    O.gelu(hh).backward(dyr @ wr.T)
+    close(dx, hh.grad, dtype, "dgrad*gelu'")
+    dx = k.dense_dgrad(dy, w, act=k.ACT_RELU_GRAD, aux=h)
+    close(dx, (dyr @ wr.T) * (hr > 0), dtype, "dgrad*relu'")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,Kd,split", [(4096, 384, 96, 0), (5000, 96, 384, 0), (1030, 21, 256, 3), (640, 768, 3072, 0),
+                                         (9000, 256, 200, 0)])
+def test_gemm_wgrad_splitk(cuda, dtype, M, N, Kd, split):
+    k = K()
+    x, xr = q(rnd((M, Kd), 1), dtype)
+    dy, dyr = q(rnd((M, N), 2), dtype)
+    out = torch.full((Kd, N), 0.5, dtype=torch.float32, device="cuda")
+    k.gemm(x, dy, out, Kd, N, M, lda=x.stride(0), ldb=dy.stride(0), ldd=N, a_kcontig=0, b_kcontig=0, accumulate=True, split_k=split)
+    want = xr.T @ dyr + 0.5
+    close(out, want, torch.float32 if dtype == torch.float32 else dtype, "wgrad", f32_tol=5e-5, bf16_tol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_strided_output_into_concat(cuda, dtype):
+    k = K()
+    M, N, Kd = 256, 256, 768
+    x, xr = q(rnd((M, Kd), 1), dtype)
+    w, wr = q(rnd((Kd, N), 2, Kd ** -0.5), dtype)
+    cat = torch.zeros((M, 1280), dtype=dtype, device="cuda")
+    k.dense_fwd(x, w, None, out=cat[:, 512:768], ldd=1280)
+    close(cat[:, 512:768], xr @ wr, dtype, "slice")
+    assert cat[:, :512].abs().max().item() == 0 and cat[:, 768:].abs().max().item() == 0
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1003, 96), (517, 192), (300, 384), (129, 768), (65, 1536), (40, 3072), (7, 8), (1, 96)])
+def test_layernorm_fwd_bwd(cuda, dtype, rows, C):
+    k = K()
+    x, xr = q(rnd((rows, C), 1) * 2 + 0.3, dtype)
+    g = (rnd((C,), 2) * 0.3 + 1).float()
+    b = (rnd((C,), 3) * 0.2).float()
+    y, mean, rstd = k.layernorm_fwd(x, g.cuda(), b.cuda(), 1e-6)
+    xx = xr.clone().requires_grad_(True)
+    gg, bb = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yo = O.layer_norm(xx, gg, bb, 1e-6)
+    close(y, yo, dtype, "ln fwd")
+    close(mean, xr.mean(-1), torch.float32, "ln mean", f32_tol=1e-5)
+    dy, dyr = q(rnd((rows, C), 4), dtype)
+    add, addr = q(rnd((rows, C), 5), dtype)
+    yo.backward(dyr)
+    dgam = torch.zeros(C, device="cuda")
+    dbet = torch.zeros(C, device="cuda")
+    dx = k.layernorm_bwd(dy, x, g.cuda(), mean, rstd, dgam, dbet, dx_add=add)
+    close(dx, xx.grad + addr, dtype, "ln dx", f32_tol=1e-4, bf16_tol=2e-2)
+    close(dgam, gg.grad, torch.float32, "ln dgamma", f32_tol=2e-4 if dtype == torch.float32 else 2e-2)
+    close(dbet, bb.grad, torch.float32, "ln dbeta", f32_tol=2e-4)
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,Kk,dil", [((2, 13, 17, 96), 7, 1), ((1, 16, 16, 768), 7, 2), ((2, 9, 9, 192), 7, 1), ((1, 20, 11, 64), 3, 1),
+                                         ((1, 8, 8, 112), 3, 2), ((1, 33, 5, 384), 5, 1)])
+def test_dwconv_fwd_bwd(cuda, dtype, shape, Kk, dil):
+    k = K()
+    N, H, W, C = shape
+    x, xr = q(rnd(shape, 1), dtype)
+    w = (rnd((Kk, Kk, C, 1), 2) / Kk).float()
+    b = (rnd((C,), 3) * 0.1).float()
+    pad = (Kk - 1) * dil // 2
+    y = k.dwconv2d(x, w.reshape(Kk * Kk, C).cuda(), b.cuda(), Kk, dil, pad, pad)
+    xx = xr.clone().requires_grad_(True)
+    ww, bb = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yo = O.depthwise_conv2d(xx, ww, bb, 1, dil)
+    close(y, yo, dtype, "dw fwd")
+    dy, dyr = q(rnd(shape, 4), dtype)
+    res, resr = q(rnd(shape, 5), dtype)
+    yo.backward(dyr)
+    padb = (Kk - 1) * dil - pad
+    dx = k.dwconv2d(dy, w.reshape(Kk * Kk, C).cuda(), None, Kk, dil, padb, padb, flip=True, add=res)
+    close(dx, xx.grad + resr, dtype, "dw dx")
+    dw = torch.zeros((Kk * Kk, C), device="cuda")
+    db = torch.zeros(C, device="cuda")
+    k.dwconv2d_bwd_weight(x, dy, dw, db, Kk, dil, pad, pad)
+    close(dw, ww.grad.reshape(Kk * Kk, C), torch.float32, "dw dW", f32_tol=1e-4)
+    close(db, bb.grad, torch.float32, "dw db", f32_tol=1e-4)
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,relu", [(4096, 256, True), (16, 256, True), (1000, 48, False), (333, 2048, True)])
+def test_batchnorm_train(cuda, dtype, rows, C, relu):
+    k = K()
+    x, xr = q(rnd((rows, C), 1) * 1.5 + 0.2, dtype)
+    g = (rnd((C,), 2) * 0.3 + 1).float()
+    b = (rnd((C,), 3) * 0.2).float()
+    mm = rnd((C,), 6).float().cuda()
+    mv = (rnd((C,), 7).abs() + 0.5).float().cuda()
+    mm0, mv0 = mm.cpu().double(), mv.cpu().double()
+    packed = k.bn_stats(x, C, rows, C)
+    close(packed[:C], xr.sum(0), torch.float32, "sum", f32_tol=1e-4)
+    close(packed[C:2 * C], (xr * xr).sum(0), torch.float32, "sumsq", f32_tol=1e-4)
+    assert packed[2 * C].item() == rows
+    mean, rstd = k.bn_finalize(packed, C, 1e-3, 0.9, mm, mv)
+    xx = xr.clone().requires_grad_(True)
+    gg, bb = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yo, mo, vo = O.batch_norm_train(xx, gg, bb, 1e-3)
+    if relu:
+        yo = torch.relu(yo)
+    close(mm, O.moving_update(mm0, mo.detach(), 0.9), torch.float32, "moving mean", f32_tol=1e-4)
+    close(mv, O.moving_update(mv0, vo.detach(), 0.9), torch.float32, "moving var", f32_tol=1e-3)
+    y = torch.empty_like(x)
+    k.bn_apply_fwd(x, C, mean, rstd, g.cuda(), b.cuda(), y, C, rows, C, relu)
+    close(y, yo, dtype, "bn fwd", f32_tol=1e-4)
+    dy, dyr = q(rnd((rows, C), 4), dtype)
+    # use the device's own y for the relu mask so that mask ties cannot differ
+    ymask = (y.cpu().double() > 0) if relu else torch.ones_like(dyr, dtype=torch.bool)
+    yo2, _, _ = O.batch_norm_train(xx, gg, bb, 1e-3)
+    yo2.backward(dyr * ymask)
+    sums = k.bn_bwd_reduce(dy, C, x, C, y, C, mean, rstd, rows, C, relu)
+    close(sums[:C], bb.grad, torch.float32, "dbeta", f32_tol=3e-4 if dtype == torch.float32 else 3e-2)
+    close(sums[C:], gg.grad, torch.float32, "dgamma", f32_tol=3e-4 if dtype == torch.float32 else 3e-2)
+    dx = torch.empty_like(x)
+    k.bn_bwd_apply(dy, C, x, C, y, C, mean, rstd, g.cuda(), sums, 1.0 / rows, dx, C, rows, C, relu)
+    close(dx, xx.grad, dtype, "bn dx", f32_tol=3e-4, bf16_tol=3e-2)
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,kh,s,d,Cout", [((2, 16, 16, 64), 3, 1, 3, 32), ((1, 32, 32, 3), 4, 4, 1, 96), ((2, 16, 16, 96), 2, 2, 1, 192),
+                                              ((1, 15, 17, 16), 3, 2, 1, 24), ((1, 12, 12, 40), 3, 1, 9, 16), ((1, 16, 16, 32), 2, 1, 2, 64)])
+def test_conv_via_im2col_gemm(cuda, dtype, shape, kh, s, d, Cout):
+    k = K()
+    N, H, W, C = shape
+    xin = rnd(shape, 1)
+    x, xr = q(xin, dtype)
+    w, wr = q(rnd((kh, kh, C, Cout), 2, (kh * kh * C) ** -0.5), dtype)
+    Ho, pt = k.same_pad(H, kh, s, d)
+    Wo, pl = k.same_pad(W, kh, s, d)
+    col = k.im2col(x, kh, kh, s, s, d, d, pt, pl, Ho, Wo, dtype)
+    Kd = kh * kh * C
+    y = torch.empty((N * Ho * Wo, Cout), dtype=dtype, device="cuda")
+    k.gemm(col, w.reshape(Kd, Cout), y, N * Ho * Wo, Cout, Kd, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=1, b_kcontig=0)
+    xx = xr.clone().requires_grad_(True)
+    yo = O.conv2d(xx, wr, None, s, d)
+    assert tuple(yo.shape) == (N, Ho, Wo, Cout)
+    close(y.reshape(N, Ho, Wo, Cout), yo, dtype, "conv fwd")
+    dy, dyr = q(rnd((N, Ho, Wo, Cout), 3), dtype)
+    yo.backward(dyr)
+    dcol = torch.empty_like(col)
+    if dcol.shape[1] > Kd:
+        dcol.zero_()
+    k.gemm(dy.reshape(-1, Cout), w.reshape(Kd, Cout), dcol, N * Ho * Wo, Kd, Cout, lda=Cout, ldb=Cout, ldd=dcol.stride(0), a_kcontig=1,
+           b_kcontig=1)
+    dx = k.col2im(dcol, N, H, W, C, kh, kh, s, s, d, d, pt, pl, Ho, Wo)
+    close(dx, xx.grad, dtype, "conv dx", bf16_tol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_im2col_casts_f32_image(cuda, dtype):
+    k = K()
+    x = rnd((1, 16, 16, 3), 1).float()
+    col = k.im2col(x.cuda(), 4, 4, 4, 4, 1, 1, 0, 0, 4, 4, dtype)
+    assert col.shape == (16, 48) and col.dtype == dtype
+    want = x.reshape(1, 4, 4, 4, 4, 3).permute(0, 1, 3, 2, 4, 5).reshape(16, 48)
+    close(col, want.to(dtype).double(), dtype, "patchify")
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_broadcast_axpby_rowscale(cuda, dtype):
+    k = K()
+    B, R, C = 3, 257, 96
+    x, xr = q(rnd((B, R, C), 1), dtype)
+    out = torch.zeros((B, C), device="cuda")
+    k.colsum(x, C, R * C, B, R, C, out, scale=1.0 / R)
+    close(out, xr.mean(1), torch.float32, "gap", f32_tol=1e-4 if dtype == torch.float32 else 1e-3)
+    # odd width (21 classes) takes the scalar path
+    x2, x2r = q(rnd((1000, 21), 2), dtype)
+    o2 = torch.ones(21, device="cuda")
+    k.colsum(x2, 21, 0, 1, 1000, 21, o2, accumulate=True)
+    close(o2, x2r.sum(0) + 1, torch.float32, "colsum21", f32_tol=1e-4 if dtype == torch.float32 else 1e-3)
+    # column slice of a concat buffer
+    cat, catr = q(rnd((2, 64, 1280), 3), dtype)
+    o3 = torch.zeros((2, 256), device="cuda")
+    k.colsum(cat[:, :, 256:512], 1280, 64 * 1280, 2, 64, 256, o3)
+    close(o3, catr[:, :, 256:512].sum(1), torch.float32, "slice colsum", f32_tol=1e-4 if dtype == torch.float32 else 1e-3)
+    v, vr = q(rnd((B, C), 4), dtype)
+    y = torch.zeros((B, R, 2 * C), dtype=dtype, device="cuda")
+    k.broadcast_rows(v, y[:, :, C:], 2 * C, R * 2 * C, B, R, C, scale=0.5)
+    close(y[:, :, C:], 0.5 * vr.unsqueeze(1).expand(B, R, C), dtype, "broadcast")
+    assert y[:, :, :C].abs().max().item() == 0
+    a, ar = q(rnd((1001,), 5), dtype)
+    b, br = q(rnd((1001,), 6), dtype)
+    close(k.axpby(a, b, 2.0, -1.0), 2 * ar - br, dtype, "axpby")
+    s = torch.tensor([0.0, 2.0, 1.0])
+    xs, xsr = q(rnd((3 * 40, C), 7), dtype)
+    close(k.rowscale(xs, s.cuda(), 40), xsr * s.double().repeat_interleave(40).unsqueeze(1), dtype, "rowscale")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_and_drop_path(cuda, dtype):
+    k = K()
+    x = torch.ones(1 << 18, dtype=dtype, device="cuda")
+    y = k.dropout(x, 0.1, 1234)
+    yc = y.float().cpu()
+    kept = (yc != 0)
+    assert abs(kept.float().mean().item() - 0.9) < 5e-3
+    assert torch.allclose(yc[kept], torch.full_like(yc[kept], 1 / 0.9), rtol=1e-2)
+    y2 = k.dropout(x, 0.1, 1234)
+    assert torch.equal(y, y2), "mask must be a pure function of the seed (backward re-derives it)"
+    assert not torch.equal(y, k.dropout(x, 0.1, 99))
+    s = k.drop_path_mask(4096, 0.75, 7, x.device).cpu()
+    vals = set(np.round(s.unique().numpy(), 5).tolist())
+    assert vals <= {0.0, round(1 / 0.75, 5)}
+    assert abs((s > 0).float().mean().item() - 0.75) < 0.03
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("in_dtype", DTYPES)
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,C", [(16, 16, 512, 512, 21), (7, 5, 13, 17, 8), (33, 31, 16, 16, 3), (16, 16, 32, 32, 96), (1, 1, 4, 4, 2),
+                                          (20, 20, 20, 20, 5)])
+def test_resize_bilinear_fwd_bwd(cuda, in_dtype, Hi, Wi, Ho, Wo, C):
+    k = K()
+    N = 2
+    x, xr = q(rnd((N, Hi, Wi, C), 1), in_dtype)
+    y = k.resize_bilinear(x, Ho, Wo, out_dtype=torch.float32)
+    xx = xr.clone().requires_grad_(True)
+    yo = O.resize_bilinear(xx, (Ho, Wo))
+    close(y, yo, torch.float32, "resize fwd", f32_tol=1e-5)
+    dy = rnd((N, Ho, Wo, C), 2).float()
+    yo.backward(dy.double())
+    add, addr = q(rnd((N, Hi, Wi, C), 3), in_dtype)
+    dx = k.resize_bilinear_bwd(dy.cuda(), Hi, Wi, in_dtype, dx_add=add)
+    close(dx, xx.grad + addr, in_dtype, "resize bwd", f32_tol=2e-5)
+
+
+def test_resize_nearest_labels(cuda):
+    k = K()
+    lab = torch.randint(0, 21, (2, 16, 12, 1), dtype=torch.int32)
+    y = k.resize_nearest_i32(lab.cuda(), 37, 29)
+    want = O.resize_nearest(lab, (37, 29))
+    assert torch.equal(y.cpu(), want)
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,ignore,use_w", [(21, 255, False), (21, 255, True), (150, 255, False), (19, 0, True), (3, 255, False)])
+def test_softmax_ce_ignore(cuda, C, ignore, use_w):
+    k = K()
+    P = 5 * 37 * 41
+    z = (rnd((P, C), 1) * 3).float()
+    g = torch.Generator().manual_seed(5)
+    y = torch.randint(0, C if ignore != 0 else C + 1, (P,), generator=g, dtype=torch.int32)
+    y[torch.rand(P, generator=g) < 0.1] = ignore
+    cw = (torch.rand(C, generator=g) + 0.5) if use_w else None
+    zz = z.double().requires_grad_(True)
+    lo = O.softmax_ce_ignore(y, zz, C, ignore, cw)
+    scale = 0.37 / P
+    (lo.sum() * scale).backward()
+    px, sm, dz = k.softmax_ce_ignore(z.cuda(), y.cuda(), ignore, class_w=None if cw is None else cw.cuda(), want_px=True, want_sum=True,
+                                     sum_scale=1.0 / P, want_grad=True, grad_scale=scale)
+    close(px, lo, torch.float32, "loss px", f32_tol=1e-5)
+    assert abs(sm.item() - lo.mean().item()) <= 1e-5 * max(1.0, abs(lo.mean().item()))
+    close(dz, zz.grad, torch.float32, "dlogits", f32_tol=1e-5)
+    assert (px.cpu()[y == ignore] == 0).all()
+
+
+def test_argmax_confusion_first_max_and_ignore(cuda):
+    k = K()
+    C, P = 21, 10007
+    z = rnd((P, C), 1).float()
+    z[::7, 5] = z[::7].max(-1).values  # ties: class 5 equals the max -> first maximal index wins
+    z[::7, 3] = z[::7, 5]
+    g = torch.Generator().manual_seed(2)
+    y = torch.randint(0, C, (P,), generator=g, dtype=torch.int32)
+    y[::11] = 255
+    cm = torch.zeros(C * C, dtype=torch.int64, device="cuda")
+    pred = k.argmax_confusion(z.cuda(), y.cuda(), 255, cm=cm, want_pred=True)
+    want_pred = O.argmax_first(z)
+    assert torch.equal(pred.cpu().long(), want_pred)
+    want_cm = O.confusion_matrix(y, want_pred, C, 255)
+    assert torch.equal(cm.cpu().reshape(C, C).double(), want_cm)
+    k.argmax_confusion(z.cuda(), y.cuda(), 255, cm=cm)  # accumulates
+    assert torch.equal(cm.cpu().reshape(C, C).double(), 2 * want_cm)
