@@ -166,6 +166,8 @@ int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int batch, int
 int iseg_broadcast_rows(const void* v, int v_dtype, void* y, int64_t ldy, int64_t batch_stride, int batch, int64_t rows, int C,
                         float scale, int accumulate, int dtype, iseg_stream_t stream);
 int iseg_axpby(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, int dtype, iseg_stream_t stream);
+/* y = x * s_dev[0] (chain rule with a device-resident scalar; no host read) */
+int iseg_scale_dev(const void* x, const float* s_dev, void* y, int64_t n, int dtype, iseg_stream_t stream);
 int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,
                   iseg_stream_t stream);
 /* keras.layers.Dropout: y = x*mask/(1-rate); mask = f(seed, index) so backward = same call on dy */
@@ -173,6 +175,15 @@ int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, i
 /* utils/drops.py:14-20: s[n] = floor(keep + u_n)/keep */
 int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
+/* keras.activations.relu / gelu where no GEMM epilogue is available; bwd: dx = dy*act'(aux) */
+int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, iseg_stream_t stream);
+int iseg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, iseg_stream_t stream);
+/* tf.concat(axis=-1) as slice writes: dst[r][0:cols] = src[r][0:cols] (layers/aspp.py:69) */
+int iseg_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
+                iseg_stream_t stream);
+/* sliding-window inference accumulator (core_inference.py:254-301): dst[r][c] += src[r][c]; y[r][:] = x[r][:]*s[r] */
+int iseg_add2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols, iseg_stream_t stream);
+int iseg_scale_rows_f32(const float* x, const float* s, float* y, int64_t rows, int C, iseg_stream_t stream);
 /* ConvNeXt layer-scale parameter gradients from Z = g^T dout (see iseg_amd/blocks.py) */
 size_t iseg_layerscale_grads_workspace_bytes(int K, int N);
 int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S, float* dW2,
@@ -193,12 +204,12 @@ int iseg_resize_nearest_i32(const int32_t* x, int32_t* y, int N, int Hi, int Wi,
  * losses/catecrossentropy_ignore_label.py:44-88 weighted_loss (CategoricalCrossentropy(from_logits), NONE) and
  * metrics/seg_metric_wrapper.py:89-102 + metrics/confusion_matrix.py:65-143.
  * logits [P,C] fp32, labels [P] int32.  loss_px [P] (optional), loss_sum[0] = loss_sum_scale * sum_p loss_p,
- * dlogits = grad_scale * w_p * (softmax - onehot) (optional).
+ * dlogits = grad_scale * grad_px[p] * w_p * (softmax - onehot) (optional; grad_px NULL = 1).
  * --------------------------------------------------------------------------------------------------------- */
 size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C);
 int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C, int ignore_label,
-                           float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits, float grad_scale, void* ws,
-                           size_t ws_bytes, iseg_stream_t stream);
+                           float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits, float grad_scale,
+                           const float* grad_px, void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* pred_out [P] int32 (optional) = first argmax; cm [C*C] uint64 counts += (label != ignore) at [label][pred] */
 int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P, int C, int ignore_label, int32_t* pred_out,
                           unsigned long long* cm, iseg_stream_t stream);

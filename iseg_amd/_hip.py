@@ -67,10 +67,16 @@ SIGNATURES = {
     "iseg_colsum": (_i, [_p, _l, _l, _i, _l, _i, _p, _f, _i, _i, _p, _z, _p]),
     "iseg_broadcast_rows": (_i, [_p, _i, _p, _l, _l, _i, _l, _i, _f, _i, _i, _p]),
     "iseg_axpby": (_i, [_p, _p, _p, _f, _f, _l, _i, _p]),
+    "iseg_scale_dev": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_rowscale": (_i, [_p, _p, _p, _l, _i, _l, _i, _p]),
     "iseg_dropout": (_i, [_p, _p, _l, _f, _u64, _i, _p]),
     "iseg_drop_path_mask": (_i, [_p, _i, _f, _u64, _p]),
     "iseg_fill_f32": (_i, [_p, _f, _l, _p]),
+    "iseg_act_fwd": (_i, [_p, _p, _l, _i, _i, _p]),
+    "iseg_act_bwd": (_i, [_p, _p, _p, _l, _i, _i, _p]),
+    "iseg_copy2d": (_i, [_p, _l, _p, _l, _l, _i, _i, _p]),
+    "iseg_add2d_f32": (_i, [_p, _l, _p, _l, _l, _l, _p]),
+    "iseg_scale_rows_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_layerscale_grads_workspace_bytes": (_z, [_i, _i]),
     "iseg_layerscale_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -78,7 +84,7 @@ SIGNATURES = {
     "iseg_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "iseg_resize_nearest_i32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_softmax_ce_workspace_bytes": (_z, [_l, _i]),
-    "iseg_softmax_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _z, _p]),
+    "iseg_softmax_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
     "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _l, _p]),

@@ -1,0 +1,65 @@
+"""core_inference.py of the reference: inference_fn :46-57, get_sliding_window_slices_paddings_list :144-207,
+inference_with_sliding_window :230-304; utils/sliding_window_inference_utils.py:16-32 start indices.
+The accumulator and the count map stay in HBM (288 GB) instead of being parked on the host (use_cpu_cache)."""
+import torch
+
+from . import kernels as K
+
+
+def get_sliding_start_indexs(length, crop_length):
+    stride_rate = 2.0 / 3.0
+    stride = int(stride_rate * crop_length)
+    times = (length - crop_length) // stride + 1
+    cond = length - (times - 1) * stride > crop_length
+    cropped_indexs = [stride * i for i in range(times)]
+    if cond:
+        cropped_indexs.append(length - crop_length)
+    return cropped_indexs
+
+
+def get_sliding_window_slices_paddings_list(stride_h, stride_w, inputs_height, inputs_width):
+    """returns (slices [top,bottom,left,right], paddings [top,bottom,left,right], count_map[H,W] int32)"""
+    ys = get_sliding_start_indexs(inputs_height, stride_h)
+    xs = get_sliding_start_indexs(inputs_width, stride_w)
+    slices, paddings = [], []
+    count = torch.zeros((inputs_height, inputs_width), dtype=torch.int32)
+    for top in ys:
+        for left in xs:
+            bottom, right = top + stride_h, left + stride_w
+            slices.append([top, bottom, left, right])
+            paddings.append([top, inputs_height - bottom, left, inputs_width - right])
+            count[top:bottom, left:right] += 1
+    return slices, paddings, count
+
+
+def _first_logits(out):
+    if isinstance(out, (list, tuple)):
+        return out[0]
+    if isinstance(out, dict):
+        return list(out.values())[0]
+    return out
+
+
+def inference_with_sliding_window(inputs, model, training=False, windows_size=(769, 769)):
+    x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+    H, W = int(x.shape[1]), int(x.shape[2])
+    stride_h, stride_w = min(int(windows_size[0]), H), min(int(windows_size[1]), W)
+    slices, paddings, count = get_sliding_window_slices_paddings_list(stride_h, stride_w, H, W)
+    acc = None
+    for (t, b, l, r) in slices:
+        crop = x[:, t:b, l:r, :].contiguous()
+        logits = _first_logits(model(crop, training=training))
+        C = logits.shape[-1]
+        if acc is None:
+            acc = torch.zeros((x.shape[0], H, W, C), dtype=torch.float32, device=x.device)
+        # results += pad(logits): zero-pad-and-add == accumulate into the window's slice of the full-size buffer
+        for n in range(x.shape[0]):
+            K.add2d(logits[n].reshape(b - t, (r - l) * C), (r - l) * C, acc[n, t:b, l:r, :], W * C, b - t, (r - l) * C)
+    inv = (1.0 / count.to(torch.float32)).reshape(-1).repeat(x.shape[0]).to(x.device)
+    return K.scale_rows(acc.reshape(-1, acc.shape[-1]), inv).reshape(acc.shape)
+
+
+def inference_fn(inputs, model, num_class=21, training=False, sliding_window_crop_size=None):
+    if sliding_window_crop_size is None:
+        return _first_logits(model(inputs, training=training))
+    return inference_with_sliding_window(inputs, model, training=training, windows_size=sliding_window_crop_size)

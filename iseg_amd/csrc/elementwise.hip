@@ -230,6 +230,21 @@ __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T
         y[i] = from_f32<T>(alpha * to_f32(a[i]) + (b ? beta * to_f32(b[i]) : 0.f));
 }
 
+template <class T>
+__global__ void scale_dev_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int64_t n) {
+    const float f = s[0];
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] *= f;
+        store8<T>(y + i * 8, v);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(to_f32(x[i]) * f);
+}
+
 // y[m][:] = x[m][:] * s[m / rows_per_group]
 template <class T>
 __global__ void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int64_t rows, int C,
@@ -285,6 +300,55 @@ __global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
 __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float eps, float* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rsqrtf(var[i] + eps);
+}
+
+// standalone activations (keras.activations.relu / gelu) for layers whose activation cannot ride a GEMM epilogue
+template <class T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act) {
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = act == ISEG_ACT_RELU ? fmaxf(v[u], 0.f) : gelu_erf(v[u]);
+        store8<T>(y + i * 8, v);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = to_f32(x[i]);
+        y[i] = from_f32<T>(act == ISEG_ACT_RELU ? fmaxf(v, 0.f) : gelu_erf(v));
+    }
+}
+
+// dx = dy * act'(aux): aux = pre-activation (gelu) or pre-/post-activation (relu)
+template <class T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux, T* __restrict__ dx, int64_t n, int act) {
+    const int64_t nv = n / 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        float d[8], a[8];
+        load8<T>(dy + i * 8, d);
+        load8<T>(aux + i * 8, a);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = act == ISEG_ACT_RELU ? (a[u] > 0.f ? d[u] : 0.f) : d[u] * gelu_erf_grad(a[u]);
+        store8<T>(dx + i * 8, d);
+    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = to_f32(dy[i]), a = to_f32(aux[i]);
+        dx[i] = from_f32<T>(act == ISEG_ACT_RELU ? (a > 0.f ? d : 0.f) : d * gelu_erf_grad(a));
+    }
+}
+
+// dst[r][0:cols] = src[r][0:cols] with independent row strides (tf.concat along channels writes slices in place)
+template <class T>
+__global__ void copy2d_kernel(const T* __restrict__ src, int64_t lds_, T* __restrict__ dst, int64_t ldd, int64_t rows, int cols) {
+    const int cv = cols / 8;
+    const int64_t total = rows * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cv;
+        const int c = (int)(i % cv) * 8;
+        float v[8];
+        load8<T>(src + r * lds_ + c, v);
+        store8<T>(dst + r * ldd + c, v);
+    }
 }
 
 // layer-scale bookkeeping for one ConvNeXt block (backbones/convnext.py:56-57), from Z = g^T @ dout (unscaled):
@@ -546,4 +610,84 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
     hipLaunchKernelGGL(layerscale_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)ws, P, b2, gamma, S,
                        dgamma, db2, N, accumulate);
     return iseg_check_launch("iseg_layerscale_grads");
+}
+
+extern "C" int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && y && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU), "iseg_act_fwd: bad arguments");
+    if (n == 0) return ISEG_OK;
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((act_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, act);
+    else
+        hipLaunchKernelGGL((act_fwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, n, act);
+    return iseg_check_launch("iseg_act_fwd");
+}
+
+extern "C" int iseg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dy && aux && dx && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU), "iseg_act_bwd: bad arguments");
+    if (n == 0) return ISEG_OK;
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dy, (const bf16_t*)aux,
+                           (bf16_t*)dx, n, act);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)dy, (const float*)aux,
+                           (float*)dx, n, act);
+    return iseg_check_launch("iseg_act_bwd");
+}
+
+extern "C" int iseg_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
+                           hipStream_t stream) {
+    ISEG_REQUIRE(src && dst && rows > 0 && cols > 0, "iseg_copy2d: bad arguments");
+    ISEG_REQUIRE(cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0, "iseg_copy2d: cols/ld must be multiples of 8");
+    const unsigned blocks = cap_blocks(rows * (cols / 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((copy2d_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)src, ld_src, (bf16_t*)dst,
+                           ld_dst, rows, cols);
+    else
+        hipLaunchKernelGGL((copy2d_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)src, ld_src, (float*)dst,
+                           ld_dst, rows, cols);
+    return iseg_check_launch("iseg_copy2d");
+}
+
+extern "C" int iseg_scale_dev(const void* x, const float* s_dev, void* y, int64_t n, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && s_dev && y && n >= 0, "iseg_scale_dev: bad arguments");
+    if (n == 0) return ISEG_OK;
+    const unsigned blocks = cap_blocks(ceil_div64(n, 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((scale_dev_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, s_dev, (bf16_t*)y, n);
+    else
+        hipLaunchKernelGGL((scale_dev_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, s_dev, (float*)y, n);
+    return iseg_check_launch("iseg_scale_dev");
+}
+
+// ---- sliding-window accumulation (core_inference.py:254-301 of the reference): fp32, arbitrary widths ----
+namespace {
+__global__ void add2d_f32_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int64_t rows,
+                                 int64_t cols) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols, c = i % cols;
+        dst[r * ldd + c] += src[r * lds_ + c];
+    }
+}
+__global__ void scale_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ y, int64_t rows,
+                                      int C) {
+    const int64_t total = rows * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = x[i] * s[i / C];
+}
+}  // namespace
+
+extern "C" int iseg_add2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                              hipStream_t stream) {
+    ISEG_REQUIRE(src && dst && rows > 0 && cols > 0, "iseg_add2d_f32: bad arguments");
+    hipLaunchKernelGGL(add2d_f32_kernel, dim3(cap_blocks(rows * cols)), dim3(256), 0, stream, src, ld_src, dst, ld_dst, rows, cols);
+    return iseg_check_launch("iseg_add2d_f32");
+}
+
+extern "C" int iseg_scale_rows_f32(const float* x, const float* s, float* y, int64_t rows, int C, hipStream_t stream) {
+    ISEG_REQUIRE(x && s && y && rows > 0 && C > 0, "iseg_scale_rows_f32: bad arguments");
+    hipLaunchKernelGGL(scale_rows_f32_kernel, dim3(cap_blocks(rows * C)), dim3(256), 0, stream, x, s, y, rows, C);
+    return iseg_check_launch("iseg_scale_rows_f32");
 }

@@ -25,7 +25,8 @@ static inline int pixels_per_block(int C) {
 __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                          const float* __restrict__ class_w, int64_t P, int C, int ignore,
                                                          float* __restrict__ loss_px, float* __restrict__ block_sums,
-                                                         float* __restrict__ dlogits, float grad_scale, int pix) {
+                                                         float* __restrict__ dlogits, float grad_scale,
+                                                         const float* __restrict__ grad_px, int pix) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C]
     __shared__ float wsum[4];
     const int64_t p0 = (int64_t)blockIdx.x * pix;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
         my_loss = in_range ? w * (lse - z[y]) : 0.f;
         if (loss_px) loss_px[p0 + threadIdx.x] = my_loss;
         if (dlogits) {
-            const float g = w * grad_scale;
+            const float g = w * grad_scale * (grad_px ? grad_px[p0 + threadIdx.x] : 1.f);
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c) {
                 const float sm = in_range ? expf(z[c] - mx) * inv : 0.f;
@@ -137,7 +138,8 @@ extern "C" size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C) {
 
 extern "C" int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
                                       int ignore_label, float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits,
-                                      float grad_scale, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                      float grad_scale, const float* grad_px, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
     ISEG_REQUIRE(logits && labels && P > 0 && C > 0, "iseg_softmax_ce_ignore: bad arguments");
     ISEG_REQUIRE(C <= 640, "iseg_softmax_ce_ignore: num_class %d > 640 unsupported", C);
     const int pix = pixels_per_block(C);
@@ -153,7 +155,7 @@ extern "C" int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels
     }
     const size_t lds = (size_t)pix * C * sizeof(float);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, class_w, P, C,
-                       ignore_label, loss_px, bs, dlogits, grad_scale, pix);
+                       ignore_label, loss_px, bs, dlogits, grad_scale, grad_px, pix);
     if (loss_sum)
         hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, (const float*)bs, (int)blocks, loss_sum,
                            loss_sum_scale);

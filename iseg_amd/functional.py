@@ -1,0 +1,691 @@
+"""Differentiable operators: explicit forward/backward kernel pairs behind torch.autograd.Function.
+
+torch.autograd only keeps the tape (which Function ran, what it saved); every forward and backward body is a
+sequence of libiseg_hip.so calls.  Parameter gradients are written by the kernels straight into `param.grad`
+(a view of the flat gradient buffer, see param_store.py) -- the Functions return None for parameters, so autograd
+never runs an accumulation kernel of its own for them.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as K
+from . import nn
+from . import dist
+
+
+def _grad(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _dry(shape, like, dtype=None):
+    return torch.empty(tuple(int(v) for v in shape), dtype=dtype or like.dtype, device=like.device)
+
+
+def _check_act_dtype(x):
+    if x.dtype != nn.compute_dtype():
+        raise TypeError(f"activation dtype {x.dtype} != compute dtype {nn.compute_dtype()}; cast the input with F.cast_input")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# input cast (image fp32 -> compute dtype); no gradient
+# ---------------------------------------------------------------------------------------------------------
+def cast_input(x):
+    if x.dtype == nn.compute_dtype():
+        return x
+    if nn.dry_run():
+        return _dry(x.shape, x, nn.compute_dtype())
+    return K.cast(_c(x), nn.compute_dtype())
+
+
+def cast_to(x, dtype):
+    if nn.dry_run():
+        return _dry(x.shape, x, dtype)
+    return _CastFn.apply(x, dtype)
+
+
+class _CastFn(Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src_dtype = x.dtype
+        return x if x.dtype == dtype else K.cast(_c(x), dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (dy if dy.dtype == ctx.src_dtype else K.cast(_c(dy), ctx.src_dtype)), None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Dense / 1x1 conv:  y = act(x @ W + b)         keras.layers.Dense, Conv2D(1x1)
+# ---------------------------------------------------------------------------------------------------------
+class _DenseFn(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, act):
+        Kd, N = W.shape[-2], W.shape[-1]
+        x2 = _c(x).reshape(-1, Kd)
+        Wc = nn.w(W).reshape(Kd, N)
+        bias = b.data if b is not None else None
+        pre = None
+        need_grad = torch.is_grad_enabled()
+        if act == K.ACT_GELU and need_grad:
+            pre = torch.empty((x2.shape[0], N), dtype=x2.dtype, device=x2.device)
+        y = K.dense_fwd(x2, Wc, bias, act=act, pre_out=pre)
+        ctx.act, ctx.W, ctx.b = act, W, b
+        ctx.save_for_backward(x2, pre if act == K.ACT_GELU else (y if act == K.ACT_RELU else None))
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, aux = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        Kd, N = W.shape[-2], W.shape[-1]
+        dy2 = _c(dy).reshape(-1, N)
+        if ctx.act in (K.ACT_GELU, K.ACT_RELU):
+            dy2 = K.act_bwd(dy2, aux, ctx.act)
+        if b is not None and b.requires_grad:
+            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b), accumulate=True)
+        if W.requires_grad:
+            K.dense_wgrad(x2, dy2, _grad(W).reshape(Kd, N))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.dense_dgrad(dy2, nn.w(W).reshape(Kd, N)).reshape(*dy.shape[:-1], Kd)
+        dist.grads_ready(W, b)
+        return dx, None, None, None
+
+
+def dense(x, W, b=None, act=K.ACT_NONE):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry((*x.shape[:-1], W.shape[-1]), x)
+    return _DenseFn.apply(x, W, b, act)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Conv2D (groups=1) through im2col + GEMM;   kernel [kh,kw,Cin,Cout]
+# ---------------------------------------------------------------------------------------------------------
+def _conv_geometry(H, W, kh, kw, strides, dilation, padding):
+    sh, sw = strides
+    dh, dw = dilation
+    if padding == "same":
+        Ho, pt = K.same_pad(H, kh, sh, dh)
+        Wo, pl = K.same_pad(W, kw, sw, dw)
+    elif padding == "valid":
+        Ho = (H - (kh - 1) * dh - 1) // sh + 1
+        Wo = (W - (kw - 1) * dw - 1) // sw + 1
+        pt = pl = 0
+    else:
+        raise ValueError(f"padding {padding!r} not supported")
+    return Ho, Wo, pt, pl
+
+
+class _Conv2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, strides, dilation, padding):
+        kh, kw, Cin, Cout = W.shape
+        N, H, Wd, _ = x.shape
+        Ho, Wo, pt, pl = _conv_geometry(H, Wd, kh, kw, strides, dilation, padding)
+        cdt = nn.compute_dtype()
+        pointwise = kh == 1 and kw == 1 and strides == (1, 1)
+        xc = _c(x)
+        if pointwise and xc.dtype == cdt and Cin % 8 == 0:
+            col = xc.reshape(-1, Cin)
+        else:
+            col = K.im2col(xc, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo, cdt)
+        Kd = kh * kw * Cin
+        y = torch.empty((N * Ho * Wo, Cout), dtype=cdt, device=x.device)
+        K.gemm(col, nn.w(W).reshape(Kd, Cout), y, N * Ho * Wo, Cout, Kd, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=1,
+               b_kcontig=0, bias=(b.data if b is not None else None))
+        ctx.W, ctx.b = W, b
+        ctx.geom = (N, H, Wd, Cin, kh, kw, strides, dilation, pt, pl, Ho, Wo, pointwise)
+        ctx.x_dtype = x.dtype
+        ctx.save_for_backward(xc)
+        return y.reshape(N, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        N, H, Wd, Cin, kh, kw, strides, dilation, pt, pl, Ho, Wo, pointwise = ctx.geom
+        Cout = W.shape[-1]
+        Kd = kh * kw * Cin
+        cdt = nn.compute_dtype()
+        M = N * Ho * Wo
+        dy2 = _c(dy).reshape(M, Cout)
+        if b is not None and b.requires_grad:
+            K.colsum(dy2, Cout, 0, 1, M, Cout, _grad(b), accumulate=True)
+        direct = pointwise and xc.dtype == cdt and Cin % 8 == 0
+        if W.requires_grad:
+            col = xc.reshape(-1, Cin) if direct else K.im2col(xc, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl,
+                                                              Ho, Wo, cdt)
+            K.gemm(col, dy2, _grad(W).reshape(Kd, Cout), Kd, Cout, M, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=0, b_kcontig=0,
+                   accumulate=True)
+            del col
+        dx = None
+        if ctx.needs_input_grad[0]:
+            Wc = nn.w(W).reshape(Kd, Cout)
+            if direct:
+                dx = K.dense_dgrad(dy2, Wc).reshape(N, H, Wd, Cin)
+            else:
+                ldc = (Kd + 7) // 8 * 8
+                dcol = torch.empty((M, ldc), dtype=cdt, device=dy.device)
+                K.gemm(dy2, Wc, dcol, M, Kd, Cout, lda=Cout, ldb=Cout, ldd=ldc, a_kcontig=1, b_kcontig=1)
+                dx = K.col2im(dcol, N, H, Wd, Cin, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo)
+                if dx.dtype != ctx.x_dtype:
+                    dx = K.cast(dx, ctx.x_dtype)
+        dist.grads_ready(W, b)
+        return dx, None, None, None, None, None
+
+
+def conv2d(x, W, b=None, strides=(1, 1), dilation=(1, 1), padding="same"):
+    if nn.dry_run():
+        Ho, Wo, _, _ = _conv_geometry(x.shape[1], x.shape[2], W.shape[0], W.shape[1], tuple(strides), tuple(dilation), padding)
+        return _dry((x.shape[0], Ho, Wo, W.shape[-1]), x, nn.compute_dtype())
+    return _Conv2dFn.apply(x, W, b, tuple(strides), tuple(dilation), padding)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DepthwiseConv2D, stride 1;  kernel [K,K,C,1]
+# ---------------------------------------------------------------------------------------------------------
+class _DWConvFn(Function):
+    @staticmethod
+    def forward(ctx, x, W, b, dil):
+        Kk, C = W.shape[0], W.shape[2]
+        pad = (Kk - 1) * dil // 2
+        xc = _c(x)
+        y = K.dwconv2d(xc, W.data.reshape(Kk * Kk, C), b.data if b is not None else None, Kk, dil, pad, pad)
+        ctx.W, ctx.b, ctx.dil, ctx.pad = W, b, dil, pad
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        W, b, dil, pad = ctx.W, ctx.b, ctx.dil, ctx.pad
+        Kk, C = W.shape[0], W.shape[2]
+        dyc = _c(dy)
+        if W.requires_grad:
+            K.dwconv2d_bwd_weight(xc, dyc, _grad(W).reshape(Kk * Kk, C), _grad(b) if b is not None else None, Kk, dil, pad, pad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            padb = (Kk - 1) * dil - pad
+            dx = K.dwconv2d(dyc, W.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True)
+        dist.grads_ready(W, b)
+        return dx, None, None, None
+
+
+def depthwise_conv2d(x, W, b=None, dilation=1):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _DWConvFn.apply(x, W, b, int(dilation))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# LayerNormalization(axis=-1)
+# ---------------------------------------------------------------------------------------------------------
+class _LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        y, mean, rstd = K.layernorm_fwd(x2, gamma.data, beta.data, eps)
+        ctx.gamma, ctx.beta = gamma, beta
+        ctx.save_for_backward(x2, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        C = x2.shape[-1]
+        dx = K.layernorm_bwd(_c(dy).reshape(-1, C), x2, ctx.gamma.data, mean, rstd, _grad(ctx.gamma), _grad(ctx.beta))
+        dist.grads_ready(ctx.gamma, ctx.beta)
+        return dx.reshape(dy.shape), None, None, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _LayerNormFn.apply(x, gamma, beta, float(eps))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (Sync)BatchNormalization over all axes but the last, optional fused ReLU
+# ---------------------------------------------------------------------------------------------------------
+class _BatchNormTrainFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, momentum, relu, sync):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        rows = x2.shape[0]
+        packed = K.bn_stats(x2, C, rows, C)
+        if sync:
+            dist.all_reduce_sum(packed)          # ONE [2C+1] message (sum, sumsq, count) instead of the reference's three
+        mean, rstd = K.bn_finalize(packed, C, eps, momentum, moving_mean, moving_var)
+        y = torch.empty_like(x2)
+        K.bn_apply_fwd(x2, C, mean, rstd, gamma.data, beta.data, y, C, rows, C, relu)
+        ctx.gamma, ctx.beta, ctx.relu, ctx.sync = gamma, beta, relu, sync
+        ctx.save_for_backward(x2, y if relu else None, mean, rstd, packed)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, mean, rstd, packed = ctx.saved_tensors
+        rows, C = x2.shape
+        dy2 = _c(dy).reshape(rows, C)
+        sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, rows, C, ctx.relu)
+        # local parameter gradients (the gradient all-reduce sums them over ranks later)
+        if ctx.beta.requires_grad:
+            K.axpby(sums[:C], _grad(ctx.beta), 1.0, 1.0, out=_grad(ctx.beta))
+        if ctx.gamma.requires_grad:
+            K.axpby(sums[C:], _grad(ctx.gamma), 1.0, 1.0, out=_grad(ctx.gamma))
+        dist.grads_ready(ctx.gamma, ctx.beta)
+        n_total = rows
+        if ctx.sync and dist.world_size() > 1:
+            sums = sums.clone()
+            dist.all_reduce_sum(sums)
+            n_total = rows * dist.world_size()
+        dx = torch.empty_like(x2)
+        K.bn_bwd_apply(dy2, C, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / n_total, dx, C, rows, C, ctx.relu)
+        return dx.reshape(dy.shape), None, None, None, None, None, None, None, None
+
+
+class _BatchNormInferFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, relu):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        rstd = K.rsqrt_eps(moving_var, eps)
+        y = torch.empty_like(x2)
+        K.bn_apply_fwd(x2, C, moving_mean, rstd, gamma.data, beta.data, y, C, x2.shape[0], C, relu)
+        ctx.gamma, ctx.relu = gamma, relu
+        ctx.save_for_backward(y if relu else None, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        # frozen statistics: dx = dz * gamma * rstd (used when a BN layer runs with training=False inside a train step)
+        y, rstd = ctx.saved_tensors
+        C = dy.shape[-1]
+        dy2 = _c(dy).reshape(-1, C)
+        if ctx.relu:
+            dy2 = K.act_bwd(dy2, y, K.ACT_RELU)
+        scale = K.axpby(ctx.gamma.data, None, 1.0, 0.0)
+        # dx = dy2 * (gamma*rstd) per column: reuse bn_apply with mean=0,rstd=1,beta=0, gamma=gamma*rstd
+        zeros = torch.zeros(C, dtype=torch.float32, device=dy.device)
+        ones = torch.ones(C, dtype=torch.float32, device=dy.device)
+        dx = torch.empty_like(dy2)
+        K.bn_apply_fwd(dy2, C, zeros, rstd, scale, zeros, dx, C, dy2.shape[0], C, False)
+        del ones
+        return dx.reshape(dy.shape), None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, moving_mean, moving_var, eps, momentum, training, relu=False, sync=True):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    if training:
+        return _BatchNormTrainFn.apply(x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum), bool(relu), bool(sync))
+    return _BatchNormInferFn.apply(x, gamma, beta, moving_mean, moving_var, float(eps), bool(relu))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# activations, add, dropout, drop-path
+# ---------------------------------------------------------------------------------------------------------
+class _ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        xc = _c(x)
+        y = K.act_fwd(xc, act)
+        ctx.act = act
+        ctx.save_for_backward(y if act == K.ACT_RELU else xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (aux,) = ctx.saved_tensors
+        return K.act_bwd(_c(dy), aux, ctx.act), None
+
+
+def relu(x):
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ActFn.apply(x, K.ACT_RELU)
+
+
+def gelu(x):
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ActFn.apply(x, K.ACT_GELU)
+
+
+class _AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return K.axpby(_c(a), _c(b), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    if nn.dry_run():
+        return _dry(a.shape, a)
+    return _AddFn.apply(a, b)
+
+
+_RNG_COUNTER = [0]
+
+
+def next_seed():
+    _RNG_COUNTER[0] += 1
+    return (nn.seed() * 0x9E3779B97F4A7C15 + _RNG_COUNTER[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
+class _DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, rate, seed):
+        ctx.rate, ctx.seed = rate, seed
+        return K.dropout(_c(x), rate, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(_c(dy), ctx.rate, ctx.seed), None, None
+
+
+def dropout(x, rate, training):
+    if not training or rate <= 0:
+        return x
+    return _DropoutFn.apply(x, float(rate), next_seed())
+
+
+class _RowScaleFn(Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        C = x.shape[-1]
+        rpg = x.numel() // C // x.shape[0]
+        ctx.rpg = rpg
+        ctx.save_for_backward(s)
+        return K.rowscale(_c(x).reshape(-1, C), s, rpg).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        C = dy.shape[-1]
+        return K.rowscale(_c(dy).reshape(-1, C), s, ctx.rpg).reshape(dy.shape), None
+
+
+def drop_path(x, drop_prob, training, mask=None):
+    """utils/drops.py:8-22.  `mask` (per-sample factors floor(keep+u)/keep) can be injected for parity tests."""
+    if (not training) or drop_prob == 0.0:
+        return x
+    if mask is None:
+        mask = K.drop_path_mask(x.shape[0], 1.0 - drop_prob, next_seed(), x.device)
+    return _RowScaleFn.apply(x, mask)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# resize, pooling, broadcast, concat
+# ---------------------------------------------------------------------------------------------------------
+class _ResizeBilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, out_dtype):
+        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
+        return K.resize_bilinear(_c(x), Ho, Wo, out_dtype=out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        _, Hi, Wi, _ = ctx.in_shape
+        return K.resize_bilinear_bwd(_c(dy), Hi, Wi, ctx.in_dtype), None, None, None
+
+
+def resize_bilinear(x, size, out_dtype=None):
+    Ho, Wo = int(size[0]), int(size[1])
+    if nn.dry_run():
+        return _dry((x.shape[0], Ho, Wo, x.shape[3]), x, out_dtype)
+    if x.shape[1] == Ho and x.shape[2] == Wo and (out_dtype is None or out_dtype == x.dtype):
+        return x
+    return _ResizeBilinearFn.apply(x, Ho, Wo, out_dtype or x.dtype)
+
+
+class _GlobalAvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        xc = _c(x)
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        K.colsum(xc, C, H * W * C, N, H * W, C, out, scale=1.0 / (H * W))
+        ctx.shape = x.shape
+        return K.cast(out, x.dtype).reshape(N, 1, 1, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        K.broadcast_rows(_c(dy).reshape(N, C), dx, C, H * W * C, N, H * W, C, scale=1.0 / (H * W))
+        return dx
+
+
+def global_avg_pool(x):
+    """tf.reduce_mean(x, axis=(1,2), keepdims=True)"""
+    if nn.dry_run():
+        return _dry((x.shape[0], 1, 1, x.shape[3]), x)
+    return _GlobalAvgPoolFn.apply(x)
+
+
+class _BroadcastHWFn(Function):
+    @staticmethod
+    def forward(ctx, v, H, W):
+        N, _, _, C = v.shape
+        y = torch.empty((N, H, W, C), dtype=v.dtype, device=v.device)
+        K.broadcast_rows(_c(v).reshape(N, C), y, C, H * W * C, N, H * W, C)
+        ctx.hw = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = dy.shape
+        out = torch.empty((N, C), dtype=torch.float32, device=dy.device)
+        K.colsum(_c(dy), C, H * W * C, N, H * W, C, out)
+        return K.cast(out, dy.dtype).reshape(N, 1, 1, C), None, None
+
+
+def broadcast_hw(v, H, W):
+    """tf.ones([1,H,W,1]) * v for v [N,1,1,C] (layers/model_builder.py:268)"""
+    if nn.dry_run():
+        return _dry((v.shape[0], H, W, v.shape[3]), v)
+    return _BroadcastHWFn.apply(v, int(H), int(W))
+
+
+class _ConcatFn(Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        lead = xs[0].shape[:-1]
+        widths = [x.shape[-1] for x in xs]
+        total = sum(widths)
+        rows = xs[0].numel() // widths[0]
+        y = torch.empty((*lead, total), dtype=xs[0].dtype, device=xs[0].device)
+        y2 = y.reshape(rows, total)
+        off = 0
+        for x, wd in zip(xs, widths):
+            K.copy2d(_c(x).reshape(rows, wd), wd, y2[:, off:off + wd], total, rows, wd)
+            off += wd
+        ctx.widths = widths
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        outs, off = [], 0
+        for wd in ctx.widths:
+            outs.append(dy[..., off:off + wd])   # strided views; consumers make them contiguous only if they must
+            off += wd
+        return tuple(outs)
+
+
+def concat(xs):
+    """tf.concat(xs, axis=-1)"""
+    if nn.dry_run():
+        return _dry((*xs[0].shape[:-1], sum(x.shape[-1] for x in xs)), xs[0])
+    return _ConcatFn.apply(*xs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ConvNeXt block, fused:  x + drop_path(gamma * pw2(gelu(pw1(LN(dw7x7(x))))))     backbones/convnext.py:47-63
+# ---------------------------------------------------------------------------------------------------------
+class _ConvNeXtBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, dil, eps, dp_mask):
+        N, H, W, C = x.shape
+        xc = _c(x)
+        Kk = p.dw_kernel.shape[0]
+        pad = (Kk - 1) * dil // 2
+        y1 = K.dwconv2d(xc, p.dw_kernel.data.reshape(Kk * Kk, C), p.dw_bias.data, Kk, dil, pad, pad)
+        M = N * H * W
+        y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps)
+        grad = torch.is_grad_enabled()
+        h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
+        g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h)
+        out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
+                          rows_per_group=H * W, residual=xc.reshape(M, C))
+        ctx.p, ctx.dil, ctx.pad = p, dil, pad
+        ctx.save_for_backward(xc, y1, y2, mean, rstd, h, g, dp_mask)
+        return out.reshape(N, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, y1, y2, mean, rstd, h, g, dp_mask = ctx.saved_tensors
+        p, dil, pad = ctx.p, ctx.dil, ctx.pad
+        N, H, W, C = xc.shape
+        M = N * H * W
+        Kk = p.dw_kernel.shape[0]
+        do2 = _c(dout).reshape(M, C)
+        dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
+        cdt = xc.dtype
+        # --- pw2 + layer scale: everything from Z = g^T dbr and S = colsum(dbr), no pass over [M,C] for gamma
+        S = torch.empty(C, dtype=torch.float32, device=xc.device)
+        K.colsum(dbr, C, 0, 1, M, C, S)
+        if p.gamma is not None:
+            Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
+            K.dense_wgrad(g, dbr, Z, accumulate=False)
+            K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+            w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
+        else:
+            K.dense_wgrad(g, dbr, _grad(p.w2))
+            K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
+            w2eff = nn.w(p.w2)
+        del g
+        dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_GELU_GRAD, aux=h)            # [M,4C] = (dbr @ W2g^T) * gelu'(h)
+        del h
+        K.colsum(dh, 4 * C, 0, 1, M, 4 * C, _grad(p.b1), accumulate=True)
+        K.dense_wgrad(y2, dh, _grad(p.w1))
+        dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                    # [M,C]
+        del dh
+        dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
+        dy1 = dy1.reshape(N, H, W, C)
+        K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            padb = (Kk - 1) * dil - pad
+            dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
+        dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma)
+        return dx, None, None, None, None
+
+
+def convnext_block(x, params, dilation, eps, dp_mask):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ConvNeXtBlockFn.apply(x, params, int(dilation), float(eps), dp_mask)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# ignore-label softmax cross-entropy          losses/catecrossentropy_ignore_label.py:44-88
+# ---------------------------------------------------------------------------------------------------------
+class _SoftmaxCEPerPixelFn(Function):
+    """returns the per-position loss vector [N*H*W] exactly like the reference's weighted_loss (Reduction.NONE)"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, num_class, ignore_label, class_w):
+        z = _c(logits).reshape(-1, num_class)
+        if z.dtype != torch.float32:
+            z = K.cast(z, torch.float32)
+        y = _c(labels).reshape(-1)
+        if y.dtype != torch.int32:
+            y = y.to(torch.int32)
+        px, _, _ = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=True)
+        ctx.args = (num_class, ignore_label, class_w)
+        ctx.in_dtype = logits.dtype
+        ctx.save_for_backward(z, y)
+        return px
+
+    @staticmethod
+    def backward(ctx, dpx):
+        z, y = ctx.saved_tensors
+        num_class, ignore_label, class_w = ctx.args
+        gp = _c(dpx)
+        if gp.dtype != torch.float32:
+            gp = K.cast(gp, torch.float32)
+        _, _, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_grad=True, grad_scale=1.0,
+                                       grad_px=gp)
+        if dz.dtype != ctx.in_dtype:
+            dz = K.cast(dz, ctx.in_dtype)
+        return dz.reshape(-1, num_class), None, None, None, None
+
+
+class _SoftmaxCEMeanFn(Function):
+    """mean over ALL positions (Keras' reduction of the NONE loss): loss and d(loss)/d(logits) in one fused pass"""
+
+    @staticmethod
+    def forward(ctx, logits, labels, num_class, ignore_label, class_w, weight):
+        z = _c(logits).reshape(-1, num_class)
+        if z.dtype != torch.float32:
+            z = K.cast(z, torch.float32)
+        y = _c(labels).reshape(-1)
+        if y.dtype != torch.int32:
+            y = y.to(torch.int32)
+        P = z.shape[0]
+        want_grad = torch.is_grad_enabled() and logits.requires_grad
+        _, s, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_sum=True, sum_scale=weight / P,
+                                       want_grad=want_grad, grad_scale=weight / P)
+        ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
+        ctx.save_for_backward(dz)
+        return s.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dz,) = ctx.saved_tensors
+        # dloss is the scalar chain factor.  Inside CoreTrain's step it is exactly 1 (unit_loss_grad()), otherwise it is
+        # applied on the device (a host read here would stall the stream)
+        if not _UNIT_LOSS_GRAD[0]:
+            dz = K.scale_dev(dz, _c(dloss).reshape(1).to(torch.float32))
+        if dz.dtype != ctx.in_dtype:
+            dz = K.cast(dz, ctx.in_dtype)
+        return dz.reshape(ctx.shape), None, None, None, None, None
+
+
+_UNIT_LOSS_GRAD = [False]
+
+
+class unit_loss_grad:
+    """context: the caller guarantees every scalar loss is differentiated with upstream gradient exactly 1"""
+
+    def __enter__(self):
+        self.prev = _UNIT_LOSS_GRAD[0]
+        _UNIT_LOSS_GRAD[0] = True
+
+    def __exit__(self, *a):
+        _UNIT_LOSS_GRAD[0] = self.prev
+
+
+def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None):
+    return _SoftmaxCEPerPixelFn.apply(logits, labels, num_class, ignore_label, class_w)
+
+
+def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0):
+    return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight))

@@ -290,6 +290,33 @@ def fill_f32(t, value):
     return t
 
 
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    _hip.call("iseg_act_fwd", ptr(x), ptr(y), x.numel(), act, dt(x), stream())
+    return y
+
+
+def act_bwd(dy, aux, act):
+    dx = torch.empty_like(dy)
+    _hip.call("iseg_act_bwd", ptr(dy), ptr(aux), ptr(dx), dy.numel(), act, dt(dy), stream())
+    return dx
+
+
+def copy2d(src, ld_src, dst, ld_dst, rows, cols):
+    _hip.call("iseg_copy2d", ptr(src), ld_src, ptr(dst), ld_dst, rows, cols, dt(src), stream())
+    return dst
+
+
+def add2d(src, ld_src, dst, ld_dst, rows, cols):
+    _hip.call("iseg_add2d_f32", ptr(src), ld_src, ptr(dst), ld_dst, rows, cols, stream())
+
+
+def scale_rows(x2d, s):
+    y = torch.empty_like(x2d)
+    _hip.call("iseg_scale_rows_f32", ptr(x2d), ptr(s), ptr(y), x2d.shape[0], x2d.shape[1], stream())
+    return y
+
+
 def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
     Kd, Nd = Z.shape
     need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
@@ -325,8 +352,14 @@ def resize_nearest_i32(x, Ho, Wo):
     return y
 
 
+def scale_dev(x, s_dev):
+    y = torch.empty_like(x)
+    _hip.call("iseg_scale_dev", ptr(x), ptr(s_dev), ptr(y), x.numel(), dt(x), stream())
+    return y
+
+
 def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px=True, want_sum=False, sum_scale=1.0,
-                      want_grad=False, grad_scale=1.0):
+                      want_grad=False, grad_scale=1.0, grad_px=None):
     _require_cuda(logits2d, labels1d)
     P, Cc = logits2d.shape
     dev = logits2d.device
@@ -336,7 +369,7 @@ def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px
     need = _hip.lib().iseg_softmax_ce_workspace_bytes(P, Cc) if want_sum else 0
     ws, wsb = workspace(need, dev)
     _hip.call("iseg_softmax_ce_ignore", ptr(logits2d), ptr(labels1d), ptr(class_w), P, Cc, ignore_label, ptr(loss_px), ptr(loss_sum),
-              sum_scale, ptr(dlogits), grad_scale, ptr(ws), wsb, stream())
+              sum_scale, ptr(dlogits), grad_scale, ptr(grad_px), ptr(ws), wsb, stream())
     return loss_px, loss_sum, dlogits
 
 

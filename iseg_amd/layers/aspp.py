@@ -1,0 +1,39 @@
+"""layers/aspp.py of the reference (:7-71): concat[image level | 1x1 | 3x3 d=r1 | 3x3 d=r2 | 3x3 d=r3]."""
+from .. import functional as F
+from ..nn import Layer
+from .model_builder import ConvNormAct, ImageLevelBlock
+
+
+class AtrousSpatialPyramidPooling(Layer):
+    def __init__(self, filters=256, dilation_rates=[3, 6, 9], dilation_rates_multiplier=1, use_pixel_level=True,
+                 use_image_level=True, name=None):
+        super().__init__(name=name)
+        self.filters = filters
+        self.use_pixel_level = use_pixel_level
+        self.use_image_level = use_image_level
+        self.dilation_rates = list(dilation_rates)
+        self.dilation_rates_multiplier = dilation_rates_multiplier
+
+    def build(self, input_shape):
+        if self.use_image_level:
+            self.image_level_block = ImageLevelBlock(self.filters, name=f"{self.name}/image_level_block")
+        if self.use_pixel_level:
+            self.pixel_level_block = ConvNormAct(self.filters, (1, 1), name=f"{self.name}/pixel_level_block")
+        convs = []
+        for rate in self.dilation_rates:
+            rate = rate * self.dilation_rates_multiplier
+            convs.append(ConvNormAct(self.filters, (3, 3), dilation_rate=rate, name=f"{self.name}/asp_convs_{rate}"))
+        import torch
+
+        self.asp_convs = torch.nn.ModuleList(convs)
+        self.built = True
+
+    def call(self, inputs, training=None):
+        results = []
+        if self.use_image_level:
+            results.append(self.image_level_block(inputs, training=training))
+        if self.use_pixel_level:
+            results.append(self.pixel_level_block(inputs, training=training))
+        for conv in self.asp_convs:
+            results.append(conv(inputs, training=training))
+        return F.concat(results)

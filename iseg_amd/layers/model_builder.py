@@ -1,0 +1,79 @@
+"""layers/model_builder.py of the reference: ConvNormAct (:34-115), ImageLevelBlock (:253-273), CommonEndBlock (:276-296),
+get_training_value (:20-31) -- same constructor keywords, attribute names and call order, on HIP operators."""
+import torch
+
+from .. import functional as F
+from ..nn import Layer
+from ..utils.common import resize_image
+from .base_layers import Conv2D, Dropout, get_activation
+from .normalizations import normalization
+
+
+def get_training_value(training=None):
+    if training is None:
+        return False
+    if isinstance(training, int):
+        training = bool(training)
+    return training
+
+
+class ConvNormAct(Layer):
+    def __init__(self, filters=256, kernel_size=1, dilation_rate=1, use_bn=True, activation="relu",
+                 kernel_initializer="glorot_uniform", dropout_rate=0, dropout_before_bn=False, trainable=True, use_bias=False,
+                 groups=1, conv_func=Conv2D, norm_func=normalization, name=None):
+        super().__init__(trainable=trainable, name=name if name is not None else "ConvBnRelu")
+        self.conv = conv_func(filters, kernel_size, padding="same", use_bias=use_bias, kernel_initializer=kernel_initializer,
+                              dilation_rate=dilation_rate, groups=groups, trainable=trainable, name=f"{self.name}/conv")
+        self.bn = None if not use_bn else norm_func(trainable=trainable, name=f"{self.name}/bn")
+        self.activation = get_activation(activation)
+        self.dropout = None
+        self.dropout_before_bn = dropout_before_bn
+        if dropout_rate > 0:
+            self.dropout = Dropout(dropout_rate, name=f"{self.name}/dropout")
+
+    def call(self, inputs, training=None):
+        x = self.conv(inputs)
+        should_dropout = (self.dropout is not None) and self.trainable
+        if should_dropout and self.dropout_before_bn:
+            x = self.dropout(x, training=training)
+        act = self.activation
+        if self.bn is not None:
+            fuse = act is F.relu and hasattr(self.bn, "moving_mean")   # BN + ReLU in one pass over the activation
+            x = self.bn(x, training=training, fused_relu=True) if fuse else self.bn(x, training=training)
+            if fuse:
+                act = None
+        if act is not None:
+            x = act(x)
+        if should_dropout and not self.dropout_before_bn:
+            x = self.dropout(x, training=training)
+        return x
+
+
+class ImageLevelBlock(Layer):
+    def __init__(self, filters=256, pooling_axis=(1, 2), name=None):
+        super().__init__(name="ImageLevelBlock" if name is None else name)
+        self.convbnrelu = ConvNormAct(filters, (1, 1), name=f"{self.name}/conv")
+        self.pooling_axis = tuple(pooling_axis)
+        if self.pooling_axis != (1, 2):
+            raise NotImplementedError("ImageLevelBlock: pooling over (H, W) only")
+
+    def call(self, inputs, training=None):
+        h, w = inputs.shape[1], inputs.shape[2]
+        x = F.global_avg_pool(inputs)
+        x = self.convbnrelu(x, training=training)
+        return F.broadcast_hw(x, h, w)
+
+
+class CommonEndBlock(Layer):
+    def __init__(self, filters=256, num_class=21, dropout_rate=0.1, name=None):
+        super().__init__(name=name)
+        self.filters, self.num_class, self.dropout_rate = filters, num_class, dropout_rate
+        self.end_conv = ConvNormAct(self.filters, dropout_rate=self.dropout_rate, name=f"{self.name}/end_conv")
+        self.logits_conv = Conv2D(self.num_class, (1, 1), name=f"{self.name}/logits_conv")
+
+    def call(self, inputs, training=False):
+        x, orginal_inputs = inputs
+        x = self.end_conv(x, training=training)
+        x = self.logits_conv(x)
+        x = resize_image(x, orginal_inputs.shape[1:3])
+        return F.cast_to(x, torch.float32)

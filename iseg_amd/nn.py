@@ -1,0 +1,209 @@
+"""Minimal Keras-flavoured layer system on torch tensors (host-side bookkeeping only).
+
+The reference builds everything from keras.Model / keras.layers.Layer objects that are called as
+`layer(inputs, training=None)` and own named variables (utils/keras3_utils.py:25-62).  This module provides the
+same surface: lazily built layers, slash-separated variable names (used by the no-weight-decay rules of
+utils/train_utils.py:8-37), fp32 master parameters with an optional bf16 shadow copy for the MFMA kernels.
+"""
+import contextlib
+import math
+import os
+import zlib
+
+import torch
+
+# ---------------------------------------------------------------------------------------------------------
+# global policy  (utils/common.py:32-64 enable_mixed_precision -> mixed_bfloat16 on MI355X, always)
+# ---------------------------------------------------------------------------------------------------------
+_POLICY = {"compute_dtype": torch.float32, "device": None, "seed": 0}
+
+
+def set_compute_dtype(dtype):
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _POLICY["compute_dtype"] = dtype
+
+
+def compute_dtype():
+    return _POLICY["compute_dtype"]
+
+
+def set_device(device):
+    _POLICY["device"] = torch.device(device) if device is not None else None
+
+
+def device():
+    if _POLICY["device"] is not None:
+        return _POLICY["device"]
+    if torch.cuda.is_available():
+        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    return torch.device("cpu")  # parameters can be laid out without a GPU; every kernel call will refuse to run
+
+
+def set_seed(seed):
+    _POLICY["seed"] = int(seed)
+
+
+def seed():
+    return _POLICY["seed"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# initializers (keras defaults: glorot_uniform kernels, zeros / ones elsewhere); seeded per variable name
+# ---------------------------------------------------------------------------------------------------------
+def _gen(name):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(name.encode()) ^ (_POLICY["seed"] * 0x9E3779B1)) & 0x7FFFFFFF)
+    return g
+
+
+def _fans(shape):
+    if len(shape) < 1:
+        return 1, 1
+    if len(shape) == 1:
+        return shape[0], shape[0]
+    if len(shape) == 2:
+        return shape[0], shape[1]
+    rf = 1
+    for s in shape[:-2]:
+        rf *= s
+    return shape[-2] * rf, shape[-1] * rf
+
+
+def init_tensor(initializer, shape, name):
+    shape = tuple(int(s) for s in shape)
+    if callable(initializer):
+        return torch.as_tensor(initializer(shape), dtype=torch.float32).reshape(shape)
+    if isinstance(initializer, (int, float)):
+        return torch.full(shape, float(initializer))
+    if initializer in ("zeros", None):
+        return torch.zeros(shape)
+    if initializer == "ones":
+        return torch.ones(shape)
+    if initializer == "glorot_uniform":
+        fi, fo = _fans(shape)
+        lim = math.sqrt(6.0 / (fi + fo))
+        return (torch.rand(shape, generator=_gen(name)) * 2 - 1) * lim
+    if initializer == "he_normal":
+        fi, _ = _fans(shape)
+        return torch.randn(shape, generator=_gen(name)) * math.sqrt(2.0 / fi)
+    if isinstance(initializer, tuple) and initializer[0] == "truncated_normal":
+        std = initializer[1]
+        t = torch.randn(shape, generator=_gen(name)).clamp_(-2, 2) * std
+        return t
+    raise ValueError(f"unknown initializer {initializer!r}")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Layer
+# ---------------------------------------------------------------------------------------------------------
+def replace_slash(name):
+    return name
+
+
+class Layer(torch.nn.Module):
+    """keras.layers.Layer / keras.Model look-alike: `layer(inputs, training=None)` -> `call`, lazy `build`."""
+
+    _auto_names = {}
+
+    def __init__(self, name=None, trainable=True, **kwargs):
+        super().__init__()
+        if name is None:
+            base = type(self).__name__.lower()
+            n = Layer._auto_names.get(base, 0)
+            Layer._auto_names[base] = n + 1
+            name = base if n == 0 else f"{base}_{n}"
+        self.__dict__["name"] = name
+        self.trainable = trainable
+        self.built = False
+
+    # -- variables ------------------------------------------------------------------------------------------
+    def add_weight(self, name, shape, initializer="zeros", trainable=True):
+        full = f"{self.name}/{name}"
+        data = init_tensor(initializer, shape, full).to(device())
+        p = torch.nn.Parameter(data, requires_grad=bool(trainable and self.trainable))
+        p.iseg_name = full
+        p.lr_multiplier = 1.0
+        p.iseg_compute = None   # bf16 shadow view, installed by ParamStore
+        attr = name.replace("/", "_").replace(".", "_")
+        self.__dict__.pop(attr, None)      # a plain placeholder attribute (e.g. self.kernel = None) gives way
+        self.register_parameter(attr, p)
+        return p
+
+    def add_state(self, name, shape, initializer="zeros"):
+        """non-trainable variable (BN moving statistics)"""
+        full = f"{self.name}/{name}"
+        t = init_tensor(initializer, shape, full).to(device())
+        t.iseg_name = full
+        attr = name.replace("/", "_")
+        self.__dict__.pop(attr, None)
+        self.register_buffer(attr, t)
+        return t
+
+    # -- call protocol ---------------------------------------------------------------------------------------
+    def build(self, input_shape):
+        self.built = True
+
+    def call(self, inputs, training=None):
+        raise NotImplementedError
+
+    @staticmethod
+    def _shape_of(inputs):
+        if isinstance(inputs, torch.Tensor):
+            return tuple(inputs.shape)
+        if isinstance(inputs, (list, tuple)):
+            return [Layer._shape_of(i) for i in inputs]
+        if isinstance(inputs, dict):
+            return {k: Layer._shape_of(v) for k, v in inputs.items()}
+        return None
+
+    def forward(self, inputs, *args, training=None, **kwargs):
+        if not self.built:
+            self.build(self._shape_of(inputs))
+            self.built = True
+        if training is None:
+            training = False
+        return self.call(inputs, *args, training=training, **kwargs)
+
+    # -- introspection used by train_utils / modelhelper -------------------------------------------------------
+    def sublayers(self):
+        return [m for m in self.modules() if isinstance(m, Layer)]
+
+    @property
+    def weights(self):
+        return list(self.parameters()) + [b for b in self.buffers()]
+
+    @property
+    def trainable_weights(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+
+def w(param):
+    """the tensor a kernel should read for `param`: bf16 shadow under mixed precision, else the fp32 master"""
+    if compute_dtype() == torch.bfloat16:
+        sh = getattr(param, "iseg_compute", None)
+        if sh is None:
+            raise RuntimeError(
+                f"parameter {getattr(param, 'iseg_name', '?')} has no bf16 shadow: call ParamStore(model) / "
+                "model_common_setup before running under mixed precision")
+        return sh
+    return param.data
+
+
+_DRY = [False]
+
+
+def dry_run():
+    """True while layers are being built by shape propagation only (no kernel is launched, outputs are uninitialised)"""
+    return _DRY[0]
+
+
+@contextlib.contextmanager
+def dry_run_scope():
+    prev = _DRY[0]
+    _DRY[0] = True
+    try:
+        with torch.no_grad():
+            yield
+    finally:
+        _DRY[0] = prev

@@ -1,0 +1,108 @@
+"""optimizers/modern/{adamw,sgd}.py of the reference: AdamW_EXT.update_step/_clip_gradients (adamw.py:13-74), SGD_EXT.update_step
+(sgd.py:12-51), on top of Keras' optimizer base (decoupled weight decay with `exclude_from_weight_decay(var_names)`,
+`iterations`).  One fused kernel launch over the flat parameter buffer (csrc/optim.hip)."""
+import math
+import re
+
+import torch
+
+from .. import _hip
+from .. import kernels as K
+from ..param_store import ParamStore
+
+
+class _FlatOptimizer:
+    def __init__(self, learning_rate, clipnorm=None, clipvalue=None):
+        self.learning_rate = learning_rate
+        if clipnorm is not None:
+            raise NotImplementedError("clipnorm needs a global-norm reduction; use clipvalue")
+        self.clipvalue = clipvalue
+        self.iterations = 0
+        self._exclude = []
+        self.store = None
+        self.grad_scale = 1.0
+
+    # Keras API
+    def exclude_from_weight_decay(self, var_list=None, var_names=None):
+        self._exclude = list(var_names or [])
+        self._exclude_vars = [id(v) for v in (var_list or [])]
+        if self.store is not None:
+            self._build_tables()
+
+    def _use_weight_decay(self, p):
+        if id(p) in getattr(self, "_exclude_vars", []):
+            return False
+        name = getattr(p, "iseg_name", "")
+        return not any(re.search(n, name) is not None for n in self._exclude)
+
+    def current_lr(self):
+        lr = self.learning_rate
+        return float(lr(self.iterations)) if callable(lr) else float(lr)
+
+    def build(self, store: ParamStore):
+        self.store = store
+        dev = store.device
+        self.hp = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hp_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        self._build_tables()
+
+    def _build_tables(self):
+        raise NotImplementedError
+
+    def _push_hp(self, vals):
+        for i, v in enumerate(vals):
+            self._hp_host[i] = v
+        self.hp.copy_(self._hp_host, non_blocking=True)
+
+
+class AdamW(_FlatOptimizer):
+    def __init__(self, learning_rate=0.001, weight_decay=0.004, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, clipnorm=None,
+                 clipvalue=None, name="AdamW"):
+        super().__init__(learning_rate, clipnorm, clipvalue)
+        if amsgrad:
+            raise NotImplementedError("amsgrad")
+        self.weight_decay, self.beta_1, self.beta_2, self.epsilon = weight_decay, beta_1, beta_2, epsilon
+
+    def _build_tables(self):
+        st = self.store
+        self.m = getattr(self, "m", None) if getattr(self, "m", None) is not None else torch.zeros_like(st.flat_w)
+        self.v = getattr(self, "v", None) if getattr(self, "v", None) is not None else torch.zeros_like(st.flat_w)
+        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if p.requires_grad else 0.0 for p in st.params]
+        wd = [float(self.weight_decay or 0.0) if (p.requires_grad and self._use_weight_decay(p)) else 0.0 for p in st.params]
+        self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
+        self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=st.device)
+
+    def apply_gradients(self):
+        st = self.store
+        t = self.iterations + 1
+        corr = math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
+        self._push_hp([self.current_lr(), corr, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
+        _hip.call("iseg_adamw_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(self.v), K.ptr(st.flat_bf16),
+                  K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_wd), K.ptr(self.hp), self.beta_1, self.beta_2,
+                  self.epsilon, st.nblocks, K.stream())
+        self.iterations += 1
+
+
+class SGD(_FlatOptimizer):
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, clipnorm=None, clipvalue=None, name="SGD"):
+        super().__init__(learning_rate, clipnorm, clipvalue)
+        if nesterov:
+            raise NotImplementedError("nesterov")
+        self.momentum = momentum
+        self.l2_of = {}      # id(param) -> l2 coefficient, filled by utils.keras_ops.set_weight_decay
+
+    def _build_tables(self):
+        st = self.store
+        self.m = getattr(self, "m", None) if getattr(self, "m", None) is not None else torch.zeros_like(st.flat_w)
+        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if p.requires_grad else 0.0 for p in st.params]
+        l2 = [float(getattr(p, "l2_regularizer", 0.0)) if p.requires_grad else 0.0 for p in st.params]
+        self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
+        self.seg_l2 = torch.tensor(l2, dtype=torch.float32, device=st.device)
+
+    def apply_gradients(self):
+        st = self.store
+        self._push_hp([self.current_lr(), 0.0, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
+        _hip.call("iseg_sgd_momentum_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(st.flat_bf16),
+                  K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_l2), K.ptr(self.hp), self.momentum, st.nblocks,
+                  K.stream())
+        self.iterations += 1

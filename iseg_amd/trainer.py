@@ -1,0 +1,172 @@
+"""The train step Keras' Model.fit runs for the reference (core_train.py:141-152; SURVEY 3.3 "HOT LOOP"), written out:
+
+    zero grads -> forward (training=True) -> sum_k w_k * mean(loss_k) -> backward (kernels write the flat gradient buffer,
+    SyncBN all-reduces inside) -> bucketed gradient all-reduce over RCCL, overlapped with backward -> fused optimizer step
+    (also refreshes the bf16 weight shadows) -> running confusion-matrix metrics.
+
+Everything between the H2D copy of the batch and the optimizer step is enqueued on one HIP stream without a host sync;
+loss values stay on the device until somebody asks for them.
+"""
+import torch
+
+from . import dist
+from . import functional as F
+from . import nn
+from .param_store import ParamStore
+
+
+class TrainableModel:
+    def __init__(self, model, optimizer=None, loss=None, loss_weights=None, metrics=None, jit_compile=None):
+        self.model = model
+        self.optimizer = optimizer
+        self.loss = loss
+        self.loss_weights = loss_weights or {}
+        self.metrics = metrics or {}
+        self.update_metrics = True
+        if isinstance(optimizer, list):
+            raise NotImplementedError("multi-optimizer training (multi_optimizers_layers) is outside this round's hot path")
+        if hasattr(model, "build_with_dummy"):
+            model.build_with_dummy()
+        params = list(model.parameters())
+        self.store = getattr(model, "_iseg_store", None)
+        if self.store is None or [id(p) for p in self.store.params] != [id(p) for p in _unique(params)]:
+            self.store = ParamStore(params)
+            model._iseg_store = self.store
+        if dist.world_size() > 1:
+            self.store.broadcast_from_rank0()
+            for b in model.buffers():
+                dist.broadcast(b, 0)
+        self.reducer = dist.GradReducer(self.store)
+        if optimizer is not None:
+            optimizer.build(self.store)
+        self.last_losses = None
+
+    # ---- helpers ------------------------------------------------------------------------------------------
+    def _key(self, i):
+        return f"output_{i + 1}"
+
+    def _loss_fn(self, i):
+        if isinstance(self.loss, dict):
+            return self.loss[self._key(i)]
+        if isinstance(self.loss, (list, tuple)):
+            return self.loss[i]
+        return self.loss
+
+    def _weight(self, i):
+        if isinstance(self.loss_weights, dict):
+            return float(self.loss_weights.get(self._key(i), 1.0))
+        if isinstance(self.loss_weights, (list, tuple)):
+            return float(self.loss_weights[i])
+        return 1.0
+
+    def _metrics_for(self, i):
+        if isinstance(self.metrics, dict):
+            return self.metrics.get(self._key(i), [])
+        return self.metrics if i == 0 else []
+
+    def __call__(self, x, training=False):
+        return self.model(x, training=training)
+
+    # ---- the hot loop ---------------------------------------------------------------------------------------
+    def train_step(self, x, y):
+        ys = y if isinstance(y, (tuple, list)) else None
+        self.store.zero_grad()
+        dist.set_active_reducer(self.reducer)
+        outputs = self.model(x, training=True)
+        if isinstance(outputs, dict):
+            outputs = list(outputs.values())
+        if not isinstance(outputs, (list, tuple)):
+            outputs = [outputs]
+        losses = []
+        for i, out in enumerate(outputs):
+            fn = self._loss_fn(i)
+            yt = ys[i] if ys is not None else y
+            w = self._weight(i)
+            fused = getattr(fn, "fused_mean", None)
+            if fused is not None:
+                losses.append(fused(yt, out, w))
+            else:
+                lv = fn(yt, out)
+                losses.append(lv.float().mean() * w)
+        with F.unit_loss_grad():
+            torch.autograd.backward(losses)
+        self.reducer.finish()
+        dist.set_active_reducer(None)
+        self.optimizer.grad_scale = 1.0 / dist.world_size()    # per-replica mean losses, summed grads -> global mean
+        self.optimizer.apply_gradients()
+        if self.update_metrics:
+            with torch.no_grad():
+                for i, out in enumerate(outputs):
+                    yt = ys[i] if ys is not None else y
+                    for m in self._metrics_for(i):
+                        m.update_state(yt, out.detach())
+        self.last_losses = losses
+        return losses
+
+    @torch.no_grad()
+    def test_step(self, x, y):
+        out = self.model.inference(x, training=False) if hasattr(self.model, "inference") else self.model(x, training=False)
+        outs = out if isinstance(out, (list, tuple)) else [out]
+        ys = y if isinstance(y, (tuple, list)) else None
+        for i, o in enumerate(outs):
+            yt = ys[i] if ys is not None else y
+            for m in self._metrics_for(i):
+                m.update_state(yt, o)
+        return outs
+
+    def reset_metrics(self):
+        for i in range(8):
+            for m in self._metrics_for(i):
+                m.reset_states()
+
+    def metric_results(self):
+        res = {}
+        for i in range(8):
+            for m in self._metrics_for(i):
+                res[f"{self._key(i)}_{m.name}"] = float(m.result())
+        return res
+
+    def fit(self, train_ds, epochs=1, validation_data=None, callbacks=(), initial_epoch=0, steps_per_epoch=1000, validation_steps=None,
+            verbose=1, validation_freq=1, log_every=50):
+        it = iter(train_ds)
+        history = []
+        for epoch in range(initial_epoch, epochs):
+            for cb in callbacks:
+                cb.on_epoch_begin(epoch)
+            self.reset_metrics()
+            running = None
+            for step in range(steps_per_epoch):
+                x, y = next(it)
+                losses = self.train_step(x, y)
+                if verbose and (step + 1) % log_every == 0:
+                    vals = [float(l) for l in losses]          # the only host sync, once per log interval
+                    print(f"epoch {epoch} step {step + 1}/{steps_per_epoch} loss {sum(vals):.5f} lr {self.optimizer.current_lr():.3e}")
+                running = losses
+            logs = {"loss": float(sum(float(l) for l in running)) if running is not None else float("nan")}
+            logs.update(self.metric_results())
+            if validation_data is not None and (epoch + 1) % validation_freq == 0:
+                self.reset_metrics()
+                vit = iter(validation_data)
+                n = validation_steps if validation_steps is not None else 10 ** 9
+                for _ in range(n):
+                    try:
+                        vx, vy = next(vit)
+                    except StopIteration:
+                        break
+                    self.test_step(vx, vy)
+                logs.update({"val_" + k: v for k, v in self.metric_results().items()})
+            history.append(logs)
+            if verbose:
+                print(f"epoch {epoch}: {logs}")
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+        return history
+
+
+def _unique(params):
+    seen, out = set(), []
+    for p in params:
+        if id(p) not in seen:
+            seen.add(id(p))
+            out.append(p)
+    return out
