@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE config 2: SegManaged(ConvNeXt-T + ASPP), 512x512 crop, bf16 compute, 16 images per GPU, full training
+step (forward + backward + SyncBN / gradient all-reduce over RCCL + fused AdamW + running mIoU), synthetic data.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Rank 0 prints ONE JSON line (see the driver contract); `roofline` describes the dominant kernel measured live with HIP
+events on the launch stream, `cpu_baseline` is the CPU oracle (a "port": the reference itself needs TensorFlow) timed on
+this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA
+TRAIN_GFLOP_PER_IMAGE = 148.6  # 24.77 GMAC fwd x 2 x 3 (OS32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--fp32", action="store_true", help="fp32 storage (parity mode); the headline number is bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_trainer(args):
+    from iseg_amd.core_env import common_env_setup
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.core_train import CoreTrain
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.modelhelper import model_common_setup
+
+    strategy = common_env_setup(use_one_device_strategy=(args.gpus == 1), mixed_precision=not args.fp32, random_seed=0)
+    model = convnext_tiny_aspp(num_class=21, output_stride=32, build_input_size=(args.size, args.size))
+    helper = model_common_setup(model, restore_checkpoint=False)
+    helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-4, end_lr=0.0, epoch_steps=1000, train_epoch=30, optimizer="adamw",
+                                       adamw_weight_decay=0.05))
+    trainer = CoreTrain(helper, None).create_trainable_model(21, ignore_label=255, batch_size=args.batch * strategy.num_replicas_in_sync)
+    return strategy, model, trainer
+
+
+def time_kernel(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(iters):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / iters * 1e-3   # seconds per launch
+
+
+def dominant_kernel_roofline(args):
+    """Stage-0 pwconv1 of ConvNeXt-T (backbones/convnext.py:51-53): [M,96] @ [96,384] + bias -> pre-activation h and GELU g.
+    HBM-bound (59 flop/B, ridge ~310): algorithmic bytes per launch = M*(96 + 2*384)*2 B + weights."""
+    from iseg_amd import kernels as K
+
+    M, Kd, N = args.batch * (args.size // 4) ** 2, 96, 384
+    dt = torch.float32 if args.fp32 else torch.bfloat16
+    es = 4 if args.fp32 else 2
+    x = torch.randn(M, Kd, device="cuda").to(dt)
+    w = (torch.randn(Kd, N, device="cuda") * Kd ** -0.5).to(dt)
+    b = torch.randn(N, device="cuda")
+    pre = torch.empty(M, N, device="cuda", dtype=dt)
+    out = torch.empty(M, N, device="cuda", dtype=dt)
+    sec = time_kernel(lambda: K.dense_fwd(x, w, b, act=K.ACT_GELU, pre_out=pre, out=out))
+    algo_bytes = (M * Kd + Kd * N + 2 * M * N) * es + N * 4
+    achieved = algo_bytes / sec / 1e9
+    return {"bound": "hbm", "kernel": "gemm_bf16_kernel<128x128,A kcontig,B ncontig> (stage-0 pwconv1 + bias + GELU, saves pre-activation)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(sec * 1e6, 2),
+            "tflops": round(2.0 * M * Kd * N / sec / 1e12, 1)}
+
+
+def cpu_baseline(args):
+    """The CPU oracle (oracle/, a port: the TensorFlow reference cannot run here) doing the same train step -- forward, mean
+    ignore-label CE, backward -- in fp32 on the host cores, on a bounded sample: batch 1 at the benchmark resolution."""
+    from oracle import models as OM
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd import nn
+
+    prev = nn.device()
+    nn.set_device("cpu")
+    try:
+        m = convnext_tiny_aspp(num_class=21, build_input_size=(args.size, args.size))
+    finally:
+        nn.set_device(prev if prev.type != "cpu" else None)
+    w = OM.export_weights(m, dtype=torch.float32)
+    x, y = synthetic_batch(1, args.size, args.size, seed=0)
+    cores = torch.get_num_threads()
+
+    def step():
+        wr = {k: (v.clone().requires_grad_(True) if not k.endswith(("moving_mean", "moving_variance")) else v) for k, v in w.items()}
+        out = OM.convnext_aspp_forward(wr, x, training=True)
+        OM.mean_ce_loss(out["logits"], y).backward()
+
+    step()
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < 12.0 and n < 8:
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps (fwd+bwd, fp32, torch-CPU oracle) of ConvNeXt-T+ASPP on 1 image {args.size}x{args.size}"}
+
+
+def main():
+    args = parse()
+    from iseg_amd import dist
+    from iseg_amd.data import synthetic_batch
+
+    strategy, model, trainer = build_trainer(args)
+    rank, world = dist.rank(), dist.world_size()
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+    x, y = synthetic_batch(args.batch, args.size, args.size, seed=100 + rank)
+    x, y = x.cuda(), y.cuda()
+    for _ in range(args.warmup):
+        trainer.train_step(x, y)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = trainer.train_step(x, y)
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+    loss_val = float(losses[0])
+    if rank != 0:
+        return
+    ips = args.batch * world * args.steps / elapsed
+    res = {
+        "metric": "train_images_per_sec (ConvNeXt-T+ASPP 512x512 crop, fwd+bwd+AdamW, whole job)",
+        "value": round(ips, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.fp32 else "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: ConvNeXt-T + ASPP (output stride 32), {args.size}x{args.size}, {args.batch} img/GPU, "
+                               "random-init weights, drop_path 0.1, dropout 0.1, SyncBN, AdamW, running mIoU",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+        "images_per_sec_per_gpu": round(ips / world, 2),
+        "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
+        "final_loss": round(loss_val, 5),
+    }
+    if not args.no_roofline:
+        res["roofline"] = dominant_kernel_roofline(args)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

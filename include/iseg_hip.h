@@ -116,7 +116,7 @@ int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const 
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C,
                       int K, int dil, int pad_t, int pad_l, int flip, int dtype, iseg_stream_t stream);
-size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int C, int K);
+size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int W, int C, int K);
 int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W, int C,
                              int K, int dil, int pad_t, int pad_l, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiseg_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "norm.hip", "dwconv.hip", "elementwise.hip", "resize.hip", "loss.hip", "optim.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_nn.hip", "gemm_nt.hip", "gemm_tn.hip", "norm.hip", "dwconv.hip", "elementwise.hip", "resize.hip", "loss.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"]
 
@@ -31,7 +31,7 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "iseg_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_impl.h"), os.path.join(ROOT, "include", "iseg_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

@@ -93,6 +93,45 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     return v;
 }
 
+// Second stage of every two-stage reduction (LayerNorm / BatchNorm / colsum / depthwise-wgrad parameter gradients):
+//   out[b][j] (+)= scale * sum_{p<P} partials[b*bstride_in + p*pstride + j],  j < n,
+// written to out0 for j < n0 and to out1[j-n0] beyond (out1 may be null).  A block owns 32 columns; 8 row-lanes stride
+// over p and are combined through LDS in a fixed order, so the result is deterministic and the pass takes P/8 dependent
+// steps instead of P.  Template parameter only makes the symbol TU-local-safe.
+template <int TAG>
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int P, int64_t pstride,
+                                                          int64_t bstride_in, int n, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int n0, int64_t bstride_out, float scale,
+                                                          int accumulate) {
+    __shared__ float red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + tx;
+    const float* src = partials + (int64_t)blockIdx.y * bstride_in;
+    float s = 0.f;
+    if (j < n)
+        for (int p = ty; p < P; p += 8) s += src[(int64_t)p * pstride + j];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && j < n) {
+        float t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][tx];
+        t *= scale;
+        float* dst = j < n0 ? out0 + (int64_t)blockIdx.y * bstride_out + j : (out1 ? out1 + (int64_t)blockIdx.y * bstride_out + (j - n0) : nullptr);
+        if (dst) {
+            if (accumulate) t += *dst;
+            *dst = t;
+        }
+    }
+}
+
+static inline void launch_reduce_rows(const float* partials, int P, int64_t pstride, int64_t bstride_in, int batch, int n,
+                                      float* out0, float* out1, int n0, int64_t bstride_out, float scale, int accumulate,
+                                      hipStream_t stream) {
+    hipLaunchKernelGGL((reduce_rows_kernel<0>), dim3((n + 31) / 32, batch), dim3(256), 0, stream, partials, P, pstride, bstride_in,
+                       n, out0, out1, n0, bstride_out, scale, accumulate);
+}
+
 // exact-erf GELU, as keras.activations.gelu(approximate=False)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

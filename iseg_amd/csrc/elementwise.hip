@@ -160,25 +160,12 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (int i = threadIdx.x; i < C; i += 256) out[i] = lds_s[i];
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partials, int P, int C, float* __restrict__ out, float scale,
-                                    int accumulate) {
-    const int b = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= C) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partials[((int64_t)b * P + p) * C + j];
-    s *= scale;
-    float* dst = out + (int64_t)b * C + j;
-    if (accumulate) s += *dst;
-    *dst = s;
-}
-
 static int colsum_blocks(int64_t rows, int C, int V) {
     const int nch = C / V;
     const int tpc = nch < 256 ? nch : 256;
     const int rpi = 256 / tpc;
     int64_t b = ceil_div64(rows, (int64_t)rpi * 8);
-    if (b > 512) b = 512;
+    if (b > 256) b = 256;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -511,8 +498,7 @@ extern "C" int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int
         else COLSUM(float, 1);
     }
 #undef COLSUM
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256, batch), dim3(256), 0, stream, (const float*)ws, P, C, out, scale,
-                       accumulate);
+    launch_reduce_rows((const float*)ws, P, C, (int64_t)P * C, batch, C, out, nullptr, C, C, scale, accumulate, stream);
     return iseg_check_launch("iseg_colsum");
 }
 

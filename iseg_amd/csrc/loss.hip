@@ -97,37 +97,53 @@ __global__ void sum_blocks_kernel(const float* __restrict__ v, int n, float* __r
     if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 
+// persistent blocks walk the pixel tiles; labels/predictions are binned in an LDS histogram (C*C counters, int atomics are
+// order-independent, so the result is exact and deterministic) that is flushed to the global uint64 matrix once per block
 __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
                                                                int64_t P, int C, int ignore, int32_t* __restrict__ pred_out,
-                                                               unsigned long long* __restrict__ cm, int pix) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C] then int hist[C*C] (if it fits)
-    const int64_t p0 = (int64_t)blockIdx.x * pix;
-    const int npx = (int)((P - p0 < pix) ? (P - p0) : pix);
-    const int64_t nel = (int64_t)npx * C;
-    const float* src = logits + p0 * C;
-    const bool vec = ((p0 * C) % 4 == 0) && (nel % 4 == 0);
-    if (vec) {
-        for (int i = threadIdx.x; i < nel / 4; i += 256)
-            reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
-    } else {
-        for (int i = threadIdx.x; i < nel; i += 256) tile[i] = src[i];
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < npx) {
-        const float* z = tile + threadIdx.x * C;
-        int best = 0;
-        float bv = z[0];
-        for (int c = 1; c < C; ++c)
-            if (z[c] > bv) {  // strict: first maximal index, as tf.argmax
-                bv = z[c];
-                best = c;
+                                                               unsigned long long* __restrict__ cm, int pix, int use_hist) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C] floats, then int hist[C*C]
+    unsigned int* hist = reinterpret_cast<unsigned int*>(tile + (int64_t)pix * C);
+    if (use_hist)
+        for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0u;
+    const int64_t ntiles = (P + pix - 1) / pix;
+    for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int64_t p0 = tl * pix;
+        const int npx = (int)((P - p0 < pix) ? (P - p0) : pix);
+        const int64_t nel = (int64_t)npx * C;
+        const float* src = logits + p0 * C;
+        const bool vec = ((p0 * C) % 4 == 0) && (nel % 4 == 0);
+        __syncthreads();  // previous tile fully consumed (and hist zeroed on the first pass)
+        if (vec) {
+            for (int i = threadIdx.x; i < nel / 4; i += 256)
+                reinterpret_cast<float4*>(tile)[i] = reinterpret_cast<const float4*>(src)[i];
+        } else {
+            for (int i = threadIdx.x; i < nel; i += 256) tile[i] = src[i];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < npx) {
+            const float* z = tile + threadIdx.x * C;
+            int best = 0;
+            float bv = z[0];
+            for (int c = 1; c < C; ++c)
+                if (z[c] > bv) {  // strict: first maximal index, as tf.argmax
+                    bv = z[c];
+                    best = c;
+                }
+            if (pred_out) pred_out[p0 + threadIdx.x] = best;
+            if (cm && labels) {
+                const int y = labels[p0 + threadIdx.x];
+                if (y != ignore && y >= 0 && y < C) {
+                    if (use_hist) atomicAdd(&hist[y * C + best], 1u);
+                    else atomicAdd(&cm[(int64_t)y * C + best], 1ull);
+                }
             }
-        if (pred_out) pred_out[p0 + threadIdx.x] = best;
-        if (cm && labels) {
-            const int y = labels[p0 + threadIdx.x];
-            if (y != ignore && y >= 0 && y < C) atomicAdd(&cm[(int64_t)y * C + best], 1ull);
         }
     }
+    __syncthreads();
+    if (use_hist && cm)
+        for (int i = threadIdx.x; i < C * C; i += 256)
+            if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
 }
 
 }  // namespace
@@ -167,9 +183,11 @@ extern "C" int iseg_argmax_confusion(const float* logits, const int32_t* labels,
     ISEG_REQUIRE(logits && P > 0 && C > 0 && C <= 640, "iseg_argmax_confusion: bad arguments");
     ISEG_REQUIRE(!cm || labels, "iseg_argmax_confusion: confusion matrix needs labels");
     const int pix = pixels_per_block(C);
-    const int64_t blocks = ceil_div64(P, pix);
-    const size_t lds = (size_t)pix * C * sizeof(float);
+    int64_t blocks = ceil_div64(P, pix);
+    if (blocks > 2048) blocks = 2048;
+    const int use_hist = (cm != nullptr) && ((size_t)C * C * 4 <= 16 * 1024);
+    const size_t lds = (size_t)pix * C * sizeof(float) + (use_hist ? (size_t)C * C * 4 : 0);
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, P, C, ignore_label,
-                       pred_out, cm, pix);
+                       pred_out, cm, pix, use_hist);
     return iseg_check_launch("iseg_argmax_confusion");
 }

@@ -182,30 +182,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_part[i];
 }
 
-// out[j] (+)= sum_p partials[p][j]   (fixed order -> deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ partials, int P, int n, float* __restrict__ out0,
-                                       float* __restrict__ out1, int n0, int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * n + j];
-    float* dst = j < n0 ? out0 + j : out1 + (j - n0);
-    if (accumulate) s += *dst;
-    *dst = s;
-}
-
-// packed[0:2C] = sum_p partials[p][0:2C] (fixed order), packed[2C] = local element count
-__global__ void bn_pack_kernel(const float* __restrict__ partials, int P, int C, float* __restrict__ packed, float count) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > 2 * C) return;
-    if (j == 2 * C) {
-        packed[j] = count;
-        return;
-    }
-    float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * 2 * C + j];
-    packed[j] = s;
-}
+__global__ void set_scalar_kernel(float* __restrict__ p, float v) { *p = v; }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm
@@ -452,8 +429,7 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
     else LN_BWD_T(float);
 #undef LN_BWD_T
 #undef LN_BWD
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, partials, blocks, 2 * C, dgamma,
-                       dbeta, C, accumulate_param_grads);
+    launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, dgamma, dbeta, C, 0, 1.f, accumulate_param_grads, stream);
     return iseg_check_launch("iseg_layernorm_bwd");
 }
 
@@ -462,7 +438,7 @@ static int bn_blocks(int64_t rows, int C) {
     const int tpc = nchunks < 256 ? nchunks : 256;
     const int rpi = 256 / tpc;
     int64_t blocks = ceil_div64(rows, (int64_t)rpi * 4);
-    if (blocks > 512) blocks = 512;
+    if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -487,8 +463,8 @@ extern "C" int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t 
     else
         hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)x, ldx, (float*)ws, rows,
                            C);
-    hipLaunchKernelGGL(bn_pack_kernel, dim3((2 * C + 1 + 255) / 256), dim3(256), 0, stream, (const float*)ws, blocks, C, packed,
-                       (float)rows);
+    launch_reduce_rows((const float*)ws, blocks, 2 * C, 0, 1, 2 * C, packed, nullptr, 2 * C, 0, 1.f, 0, stream);
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, stream, packed + 2 * C, (float)rows);
     return iseg_check_launch("iseg_bn_stats");
 }
 
@@ -534,8 +510,7 @@ extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)dy, lddy,
                            (const float*)x, ldx, (const float*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, blocks, 2 * C,
-                       sums, sums, 2 * C, 0);
+    launch_reduce_rows((const float*)ws, blocks, 2 * C, 0, 1, 2 * C, sums, nullptr, 2 * C, 0, 1.f, 0, stream);
     return iseg_check_launch("iseg_bn_bwd_reduce");
 }
 

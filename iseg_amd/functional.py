@@ -71,7 +71,7 @@ class _DenseFn(Function):
         Wc = nn.w(W).reshape(Kd, N)
         bias = b.data if b is not None else None
         pre = None
-        need_grad = torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad)     # grad mode is off inside Function.forward; this is the tape's view
         if act == K.ACT_GELU and need_grad:
             pre = torch.empty((x2.shape[0], N), dtype=x2.dtype, device=x2.device)
         y = K.dense_fwd(x2, Wc, bias, act=act, pre_out=pre)
@@ -540,7 +540,11 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 class _ConvNeXtBlockFn(Function):
     @staticmethod
-    def forward(ctx, x, p, dil, eps, dp_mask):
+    def forward(ctx, x, dw_kernel, dw_bias, ln_gamma, ln_beta, w1, b1, w2, b2, gamma, dil, eps, dp_mask):
+        import types
+
+        p = types.SimpleNamespace(dw_kernel=dw_kernel, dw_bias=dw_bias, ln_gamma=ln_gamma, ln_beta=ln_beta, w1=w1, b1=b1, w2=w2,
+                                  b2=b2, gamma=gamma)
         N, H, W, C = x.shape
         xc = _c(x)
         Kk = p.dw_kernel.shape[0]
@@ -548,7 +552,7 @@ class _ConvNeXtBlockFn(Function):
         y1 = K.dwconv2d(xc, p.dw_kernel.data.reshape(Kk * Kk, C), p.dw_bias.data, Kk, dil, pad, pad)
         M = N * H * W
         y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps)
-        grad = torch.is_grad_enabled()
+        grad = any(ctx.needs_input_grad)          # grad mode is off inside Function.forward; this is the tape's view
         h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
         g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h)
         out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
@@ -594,14 +598,16 @@ class _ConvNeXtBlockFn(Function):
             padb = (Kk - 1) * dil - pad
             dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
         dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma)
-        return dx, None, None, None, None
+        return (dx,) + (None,) * 12
 
 
 def convnext_block(x, params, dilation, eps, dp_mask):
     _check_act_dtype(x)
     if nn.dry_run():
         return _dry(x.shape, x)
-    return _ConvNeXtBlockFn.apply(x, params, int(dilation), float(eps), dp_mask)
+    p = params
+    return _ConvNeXtBlockFn.apply(x, p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma, int(dilation),
+                                  float(eps), dp_mask)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -650,7 +656,7 @@ class _SoftmaxCEMeanFn(Function):
         if y.dtype != torch.int32:
             y = y.to(torch.int32)
         P = z.shape[0]
-        want_grad = torch.is_grad_enabled() and logits.requires_grad
+        want_grad = ctx.needs_input_grad[0]
         _, s, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_sum=True, sum_scale=weight / P,
                                        want_grad=want_grad, grad_scale=weight / P)
         ctx.shape, ctx.in_dtype = logits.shape, logits.dtype

@@ -198,7 +198,7 @@ def dwconv2d(x, w, bias, K, dil, pad_t, pad_l, *, flip=False, add=None):
 
 def dwconv2d_bwd_weight(x, dy, dw, db, K, dil, pad_t, pad_l, accumulate=True):
     N, H, W, Cc = x.shape
-    need = _hip.lib().iseg_dwconv2d_bwd_weight_workspace_bytes(N, H, Cc, K)
+    need = _hip.lib().iseg_dwconv2d_bwd_weight_workspace_bytes(N, H, W, Cc, K)
     ws, wsb = workspace(need, x.device)
     _hip.call("iseg_dwconv2d_bwd_weight", ptr(x), ptr(dy), ptr(dw), ptr(db), int(accumulate), N, H, W, Cc, K, dil, pad_t, pad_l,
               dt(x), ptr(ws), wsb, stream())

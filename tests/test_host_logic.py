@@ -1,0 +1,160 @@
+"""Host-side logic that needs no GPU: registry, get_backbone errors, dilation surgery, variable names and the no-weight-decay
+rules, schedules, dataset pipeline, flat parameter store, sliding-window tiling."""
+import re
+
+import pytest
+import torch
+
+
+def test_register_backbone_semantics():
+    from iseg_amd.backbones import backbone_registry as R
+
+    class MyNet:
+        pass
+
+    class Other:
+        pass
+
+    R.register_backbone(MyNet)
+    assert R.backbone_registry_dict["mynet"] is MyNet
+    R.register_backbone(Other, name="mynet")          # first registration wins (backbone_registry.py:17-18)
+    assert R.backbone_registry_dict["mynet"] is MyNet
+    R.register_backbone(Other, name=("o1", "o2"))
+    assert R.backbone_registry_dict["o1"] is Other and R.backbone_registry_dict["o2"] is Other
+
+
+def test_get_backbone_unknown_raises_value_error():
+    from iseg_amd.backbones.feature_extractor import get_backbone
+
+    with pytest.raises(ValueError, match="currently not supported"):
+        get_backbone("no_such_net")
+
+
+def test_registered_backbone_is_constructible_through_get_backbone():
+    from iseg_amd.backbones import convnext as cx
+    from iseg_amd.backbones.backbone_registry import register_backbone
+    from iseg_amd.backbones.feature_extractor import get_backbone
+
+    def convnext_micro(return_endpoints=False):
+        return cx.ConvNeXt(depths=[1, 1, 1, 1], filters_list=[16, 32, 64, 128], return_endpoints=return_endpoints)
+
+    register_backbone(convnext_micro, name="convnext_micro_test")
+    bb = get_backbone("convnext_micro_test", output_stride=16, return_endpoints=True, image_shape=(1, 64, 64, 3))
+    assert bb.downsample_blocks[3].conv.strides == (1, 1) and bb.downsample_blocks[3].conv.dilation_rate == (2, 2)
+    assert bb.stages[3].blocks[0].dwconv.dilation_rate == (2, 2)
+    assert bb.downsample_blocks[2].conv.strides == (2, 2)
+    n = sum(p.numel() for p in bb.parameters())
+    assert n > 0
+
+
+def test_convnext_tiny_aspp_parameter_inventory_and_names():
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.utils.train_utils import get_no_weight_decay_layers_names_from_model
+
+    m = convnext_tiny_aspp(build_input_size=(64, 64))
+    n_backbone = sum(p.numel() for p in m.backbone.parameters())
+    assert abs(n_backbone - 27.82e6) < 0.02e6              # 27.82 M
+    assert abs(sum(p.numel() for p in m.parameters()) - 33.86e6) < 0.05e6
+    names = [p.iseg_name for p in m.parameters()]
+    assert "stages/2/8/pwconv1/kernel" in names and "downsample_layers/0/0/kernel" in names and "seg/logits_conv/bias" in names
+    assert m.backbone.stages[0].blocks[0].gamma.shape == (96,)
+    assert float(m.backbone.stages[0].blocks[0].gamma[0]) == pytest.approx(1e-6)
+    excl = get_no_weight_decay_layers_names_from_model(m)
+    decayed = [n for n in names if not any(re.search(e, n) for e in excl)]
+    assert all(n.endswith("kernel") or n.endswith("/gamma") for n in decayed)
+    assert "stages/0/0/pwconv1/kernel" in decayed and "stages/0/0/gamma" in decayed     # layer scale IS decayed (only norm layers excluded)
+    assert not any("logits" in n or "/norm/" in n or "/bn/" in n or n.endswith("bias") for n in decayed)
+    dp = [b.drop_path_prob for st in m.backbone.stages for b in st.blocks]
+    assert dp[0] == 0.0 and dp[-1] == pytest.approx(0.1) and len(dp) == 18
+
+
+def test_param_store_views_and_segments():
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.param_store import ParamStore
+
+    m = convnext_tiny_aspp(build_input_size=(64, 64))
+    before = {p.iseg_name: p.detach().clone() for p in m.parameters()}
+    st = ParamStore(list(m.parameters()))
+    assert st.total % 256 == 0 and st.seg_of_block.numel() == st.total // 256
+    for p, off, n in st.segments:
+        assert off % 256 == 0
+        assert p.data.data_ptr() == st.flat_w[off:].data_ptr()
+        assert p.grad.data_ptr() == st.flat_g[off:].data_ptr()
+        assert torch.equal(p.data, before[p.iseg_name])
+        assert torch.equal(p.iseg_compute.float(), p.data.bfloat16().float())
+    p0 = st.segments[0][0]
+    p0.grad.fill_(3.0)
+    assert st.flat_g[:p0.numel()].eq(3.0).all()
+    st.zero_grad()
+    assert st.flat_g.abs().sum() == 0
+
+
+def test_schedules_match_oracle():
+    from iseg_amd.optimizers.polydecay import WarmUpPolyDecay
+    from oracle import tf_ops as O
+
+    d = WarmUpPolyDecay(1e-2, 30000, end_learning_rate=0, warmup_steps=1500, warmup_learning_rate=0)
+    for s in (0, 500, 1000, 1500, 2000, 29999, 30000, 40000):
+        assert d(s) == pytest.approx(O.warmup_poly_decay(s, 1e-2, 30000, 0.0, 1500, 0.0, 1.0))
+    d2 = WarmUpPolyDecay(0.007, 30000, end_learning_rate=0.0, power=0.9)
+    assert d2(0) == pytest.approx(0.007) and d2(15000) == pytest.approx(0.007 * 0.5 ** 0.9)
+
+
+def test_get_optimizer_variants_and_errors():
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.optimizers import modern
+
+    s = Strategy(one_device=True)
+    assert isinstance(get_optimizer(s, optimizer="sgd"), modern.SGD)
+    assert isinstance(get_optimizer(s, optimizer="adamw"), modern.AdamW)
+    opts = get_optimizer(s, optimizer=["sgd", "adamw"], initial_lr=[0.1, 0.01])
+    assert isinstance(opts, list) and len(opts) == 2 and opts[1].learning_rate(0) == pytest.approx(0.01)
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        get_optimizer(s, optimizer="lion")
+
+
+def test_dataset_pipeline_contract():
+    from iseg_amd.data import Dataset, synthetic_batch, synthetic_dataset
+
+    ds = synthetic_dataset(10, 8, 8, seed=0)
+    b = next(iter(ds.shuffle(4).repeat().batch(4).prefetch(2)))
+    assert b[0].shape == (4, 8, 8, 3) and b[1].shape == (4, 8, 8) and b[1].dtype == torch.int32
+    assert len(list(Dataset.from_tensors_list(list(range(10))).batch(4))) == 3
+    assert len(list(Dataset.from_tensors_list(list(range(10))).batch(4, drop_remainder=True))) == 2
+    assert list(Dataset.from_tensors_list(list(range(6))).shard(2, 1)) == [1, 3, 5]
+    x, y = synthetic_batch(2, 32, 32, seed=0)
+    assert x.min() >= -1 and x.max() <= 1
+    frac = (y == 255).float().mean().item()
+    assert 0.05 < frac < 0.15 and int(y[y != 255].max()) <= 20
+
+
+def test_sliding_window_tiling():
+    from iseg_amd.core_inference import get_sliding_start_indexs, get_sliding_window_slices_paddings_list
+
+    assert get_sliding_start_indexs(640, 512) == [0, 128]
+    slices, pads, count = get_sliding_window_slices_paddings_list(512, 512, 640, 640)
+    assert slices == [[0, 512, 0, 512], [0, 512, 128, 640], [128, 640, 0, 512], [128, 640, 128, 640]]
+    assert pads[3] == [128, 0, 128, 0]
+    assert int(count.max()) == 4 and int(count.min()) == 1 and int(count[0, 0]) == 1 and int(count[300, 300]) == 4
+
+
+def test_same_pad_matches_oracle():
+    from iseg_amd import kernels as K
+    from oracle import tf_ops as O
+
+    for n in (7, 16, 15, 512, 33):
+        for k in (1, 2, 3, 4, 7):
+            for s in (1, 2, 4):
+                for d in (1, 2, 3):
+                    out, before, _ = O.same_pad(n, k, s, d)
+                    assert K.same_pad(n, k, s, d) == (out, before)
+
+
+def test_get_scaled_size_pad_mode_1():
+    from iseg_amd.utils.common import get_scaled_size
+
+    x = torch.empty(1, 513, 513, 3)
+    assert get_scaled_size(x, 0.5, pad_mode=1) == [257, 257]      # int(256.5)=256 even while input odd -> +1
+    assert get_scaled_size(x, 1.0, pad_mode=1) == [513, 513]
+    assert get_scaled_size(torch.empty(1, 512, 512, 3), 0.75, pad_mode=1) == [384, 384]

@@ -92,10 +92,13 @@ def test_backward_fp32_matches_oracle_autograd(cuda):
     ref_loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
     worst = []
+    gmax = max(wr[p.iseg_name].grad.abs().max().item() for p in model.parameters())
     for p in model.parameters():
         gr = wr[p.iseg_name].grad
         got = p.grad.detach().cpu().double()
-        scale = max(gr.abs().max().item(), 1e-8)
+        # some gradients are analytically ~0 (e.g. the bias in front of the BN-normalised ASPP branches: BN's backward sums
+        # to zero over the batch), so the floor of the scale is tied to the overall gradient magnitude
+        scale = max(gr.abs().max().item(), 1e-3 * gmax)
         worst.append(((got - gr).abs().max().item() / scale, p.iseg_name))
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-3, worst[:5]

@@ -1,0 +1,146 @@
+"""Pins the CPU oracle: closed-form known answers and agreement with the independent numpy-loop statement.
+The reference holds no golden vectors for this path (its only test-named file prints and asserts nothing), so these are
+the pins; the doc-example numbers quoted inside the reference's own sources are checked where they exist."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_loops as NL
+from oracle import tf_ops as O
+
+
+def test_sliding_window_start_indices_examples():
+    # utils/sliding_window_inference_utils.py:16-32
+    assert O.sliding_start_indexs(640, 512) == [0, 128]
+    assert O.sliding_start_indexs(1024, 512) == [0, 341, 512]
+    assert O.sliding_start_indexs(512, 512) == [0]
+    assert O.sliding_start_indexs(769, 769) == [0]
+
+
+def test_warmup_poly_decay_main_example():
+    # optimizers/polydecay.py:90-98  d = WarmUpPolyDecay(1e-2, 30000, end_learning_rate=0, warmup_steps=1500, warmup_learning_rate=0)
+    d = lambda s: O.warmup_poly_decay(s, 1e-2, 30000, end_lr=0.0, warmup_steps=1500, warmup_lr=0.0, power=1.0)
+    assert d(0) == 0.0
+    assert d(500) == pytest.approx(1e-2 * 500 / 1500)
+    assert d(1000) == pytest.approx(1e-2 * 1000 / 1500)
+    assert d(1500) == pytest.approx(1e-2)
+    assert d(2000) == pytest.approx(1e-2 * (1 - 500 / 28500))
+
+
+def test_confusion_matrix_doc_example():
+    # metrics/confusion_matrix.py:79-86: labels [1,2,4], predictions [2,2,4] -> ones at (1,2),(2,2),(4,4)
+    cm = O.confusion_matrix(torch.tensor([1, 2, 4]), torch.tensor([2, 2, 4]), 5, 255)
+    want = torch.zeros(5, 5, dtype=torch.float64)
+    want[1, 2] = want[2, 2] = want[4, 4] = 1
+    assert torch.equal(cm, want)
+
+
+def test_miou_hand_built():
+    cm = torch.tensor([[3.0, 1.0, 0.0], [0.0, 2.0, 0.0], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    iou, miou = O.per_class_iou(cm)
+    assert iou.tolist() == pytest.approx([3 / 4, 2 / 3, 0.0])
+    assert miou.item() == pytest.approx((3 / 4 + 2 / 3) / 2)      # class 2 has a zero denominator and drops out
+
+
+def test_loss_toy_2x2_mean_counts_ignored_pixels():
+    z = torch.zeros(1, 2, 2, 3, dtype=torch.float64)
+    y = torch.tensor([[[0, 1], [2, 255]]])
+    px = O.softmax_ce_ignore(y, z, 3, 255)
+    assert px.tolist() == pytest.approx([math.log(3)] * 3 + [0.0])
+    assert px.mean().item() == pytest.approx(3 * math.log(3) / 4)  # divides by 4, not 3
+
+
+def test_same_padding_rule():
+    assert O.same_pad(512, 4, 4, 1) == (128, 0, 0)
+    assert O.same_pad(16, 3, 1, 9) == (16, 9, 9)
+    assert O.same_pad(16, 2, 1, 2) == (16, 1, 1)
+    assert O.same_pad(15, 3, 2, 1) == (8, 1, 1)
+    assert O.same_pad(16, 3, 2, 1) == (8, 0, 1)          # extra padding goes to the bottom/right (differs from torch)
+    assert O.same_pad(16, 2, 1, 1) == (16, 0, 1)
+
+
+def test_bilinear_closed_forms():
+    x = torch.tensor([[0.0, 1.0]], dtype=torch.float64).reshape(1, 1, 2, 1)
+    y = O.resize_bilinear(x, (1, 4)).reshape(-1)
+    assert y.tolist() == pytest.approx([0.0, 0.25, 0.75, 1.0])   # half-pixel centres, edge clamped
+    c = torch.full((1, 3, 5, 2), 7.0, dtype=torch.float64)
+    assert torch.allclose(O.resize_bilinear(c, (11, 4)), torch.full((1, 11, 4, 2), 7.0, dtype=torch.float64))
+    r = torch.arange(12, dtype=torch.float64).reshape(1, 3, 4, 1)
+    assert torch.equal(O.resize_bilinear(r, (3, 4)), r)
+    lab = torch.arange(4).reshape(1, 2, 2, 1)
+    assert O.resize_nearest(lab, (4, 4))[0, :, :, 0].tolist() == [[0, 0, 1, 1], [0, 0, 1, 1], [2, 2, 3, 3], [2, 2, 3, 3]]
+
+
+def test_gelu_is_exact_erf_form():
+    x = torch.tensor([-2.0, -0.5, 0.0, 0.5, 2.0], dtype=torch.float64)
+    want = [0.5 * v * (1 + math.erf(v / math.sqrt(2))) for v in x.tolist()]
+    assert O.gelu(x).tolist() == pytest.approx(want)
+    assert abs(O.gelu(torch.tensor(1.0, dtype=torch.float64)).item() - 0.8413447460685429) < 1e-12
+
+
+def test_adamw_first_step_closed_form():
+    w = torch.tensor([1.0, -2.0], dtype=torch.float64)
+    g = torch.tensor([0.5, float("nan")], dtype=torch.float64)
+    nw, m, v = O.adamw_step(w, g, torch.zeros(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64), 1, lr=0.1, wd=0.01)
+    # decay: w*(1-0.001); m=(1-b1)g, v=(1-b2)g^2, alpha = lr*sqrt(1-b2)/(1-b1) -> step = lr*g/(|g| + eps*sqrt(1-b2)...) ~ lr*sign(g)
+    assert nw[0].item() == pytest.approx(1.0 * (1 - 0.001) - 0.1 * 0.5 / (0.5 + 1e-7 / math.sqrt(1 - 0.999)), rel=1e-9)
+    assert nw[1].item() == pytest.approx(-2.0 * (1 - 0.001))       # NaN gradient scrubbed to 0
+    w2, m2 = O.sgd_step(torch.tensor([1.0]), torch.tensor([2.0]), torch.tensor([0.5]), lr=0.1, momentum=0.9)
+    assert m2.item() == pytest.approx(-0.2 + 0.45) and w2.item() == pytest.approx(1.25)
+
+
+@pytest.mark.parametrize("k,s,d,groups", [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 3, 1), (2, 2, 1, 1), (4, 4, 1, 1), (7, 1, 2, 6), (2, 1, 2, 1)])
+def test_conv_same_matches_numpy_loops(k, s, d, groups):
+    rng = np.random.default_rng(k * 100 + s * 10 + d)
+    cin, cout = 6, 6 if groups > 1 else 4
+    x = rng.standard_normal((2, 9, 11, cin))
+    w = rng.standard_normal((k, k, cin // groups, cout))
+    b = rng.standard_normal(cout)
+    got = O.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), s, d, "same", groups=groups).numpy()
+    want = NL.conv2d_same(x, w, b, (s, s), (d, d), groups)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 1e-10
+
+
+@pytest.mark.parametrize("hi,wi,ho,wo", [(4, 4, 128, 128), (7, 5, 13, 17), (33, 31, 16, 16), (1, 3, 5, 2)])
+def test_bilinear_matches_numpy_loops(hi, wi, ho, wo):
+    x = np.random.default_rng(1).standard_normal((2, hi, wi, 3))
+    got = O.resize_bilinear(torch.from_numpy(x), (ho, wo)).numpy()
+    assert np.abs(got - NL.resize_bilinear(x, (ho, wo))).max() < 1e-6
+
+
+def test_layernorm_and_loss_match_numpy_loops():
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((3, 4, 5, 16))
+    g, b = rng.standard_normal(16), rng.standard_normal(16)
+    got = O.layer_norm(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b), 1e-6).numpy()
+    assert np.abs(got - NL.layer_norm(x, g, b, 1e-6)).max() < 1e-10
+    z = rng.standard_normal((2, 6, 7, 21)) * 3
+    y = rng.integers(0, 21, size=(2, 6, 7))
+    y[0, 0, :3] = 255
+    cw = rng.random(21) + 0.5
+    got = O.softmax_ce_ignore(torch.from_numpy(y), torch.from_numpy(z), 21, 255, cw).numpy()
+    assert np.abs(got - NL.softmax_ce_ignore(y, z, 21, 255, cw)).max() < 1e-10
+    y0 = rng.integers(0, 20, size=(2, 6, 7))
+    got0 = O.softmax_ce_ignore(torch.from_numpy(y0), torch.from_numpy(z[..., :19]), 19, 0).numpy()
+    assert np.abs(got0 - NL.softmax_ce_ignore(y0, z[..., :19], 19, 0)).max() < 1e-10
+
+
+def test_batchnorm_sync_stats_equal_global_batch():
+    """summing (sum, sumsq, count) over replicas == statistics of the concatenated batch (layers/syncbn.py:91-119)"""
+    x = torch.randn(8, 5, 5, 6, dtype=torch.float64)
+    g, b = torch.rand(6, dtype=torch.float64) + 0.5, torch.randn(6, dtype=torch.float64)
+    y_all, mean, var = O.batch_norm_train(x, g, b, 1e-3)
+    parts = [x[:4], x[4:]]
+    s1 = sum(p.sum((0, 1, 2)) for p in parts)
+    s2 = sum((p * p).sum((0, 1, 2)) for p in parts)
+    y0, m0, v0 = O.batch_norm_train(parts[0], g, b, 1e-3, stats=(s1, s2, 8 * 25))
+    assert torch.allclose(y0, y_all[:4]) and torch.allclose(m0, mean) and torch.allclose(v0, var)
+    assert torch.allclose(var, x.var((0, 1, 2), unbiased=False))
+
+
+def test_argmax_first_on_ties():
+    z = torch.tensor([[1.0, 3.0, 3.0, 2.0], [5.0, 5.0, 5.0, 5.0]])
+    assert O.argmax_first(z).tolist() == [1, 0]
