@@ -132,6 +132,30 @@ static inline void launch_reduce_rows(const float* partials, int P, int64_t pstr
                        n, out0, out1, n0, bstride_out, scale, accumulate);
 }
 
+// Fast Phi(x) = 0.5(1+erf(x/sqrt2)) for bf16-storage kernels: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the
+// bf16 output rounding of 2^-9), one v_exp + one v_rcp instead of libm erff's ~50 VALU instructions -- the pwconv1 GEMM
+// of ConvNeXt evaluates 100 M GELUs per launch at stage 0 and was VALU-bound on erff.  `e` returns exp(-x^2/2).
+__device__ __forceinline__ float norm_cdf_fast(float x, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    e = __expf(-0.5f * x * x);
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float h = 0.5f * p * t * e;  // 0.5 * erfc(|x|/sqrt2)
+    return x >= 0.f ? 1.0f - h : h;
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float e;
+    return x * norm_cdf_fast(x, e);
+}
+__device__ __forceinline__ float gelu_fast_grad(float x) {
+    float e;
+    const float cdf = norm_cdf_fast(x, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 // exact-erf GELU, as keras.activations.gelu(approximate=False)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

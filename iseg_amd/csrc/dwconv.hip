@@ -2,100 +2,123 @@
 // dilation d) -- the 7x7 depthwise of backbones/convnext.py:25,50 (dilated by build_dilated_convnext :245-266)
 // and the 3x3 depthwise of layers/dcn_v3/dcn_v3.py.  49 FMA per element but only 4 B of HBM traffic: the kernels
 // are limited by how many L1/L2 loads they keep in flight, so:
-//   * a lane owns 8 consecutive channels (one 16-B load per pixel) and TW output pixels along W, and slides a
+//   * a lane owns CV (4 or 8) consecutive channels (one 8/16-B load per pixel) and TW output pixels along W, and slides a
 //     register window over the input row so each loaded pixel feeds up to KW taps;
 //   * every load is issued unconditionally from a clamped address and zeroed by a select afterwards (no divergent
 //     branch between loads, so a whole kernel row's loads are in flight together); interior tiles skip the selects;
 //   * weights of the block's channel slab sit in LDS as fp32 (the fp32 master kernel is read directly);
 //   * backward-data is the same kernel with the taps flipped and the complementary padding, and can add the
 //     residual branch's gradient on the way out (dx = dres + dwconv^T(dy));
-//   * backward-weight gives each lane one kernel row (KW taps x 8 channels of accumulators) and a run of
+//   * backward-weight gives each lane one kernel row (KW taps x CV channels of accumulators) and a run of
 //     (image row, W-segment) items, slides a KW-wide register window along W, then reduces lanes -> block (LDS) ->
 //     grid (fixed-order partial sums, deterministic).
 #include "common.h"
 #include "iseg_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int TW = 4;
 
-static inline int groups_per_slab(int C) {
-    const int G = C / 8;
+template <class T, int CV> __device__ __forceinline__ void loadv(const T* p, float* out);
+template <> __device__ __forceinline__ void loadv<float, 8>(const float* p, float* out) { load8<float>(p, out); }
+template <> __device__ __forceinline__ void loadv<bf16_t, 8>(const bf16_t* p, float* out) { load8<bf16_t>(p, out); }
+template <> __device__ __forceinline__ void loadv<float, 4>(const float* p, float* out) { Vec16<float>::load(p, out); }
+template <> __device__ __forceinline__ void loadv<bf16_t, 4>(const bf16_t* p, float* out) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = (float)v[i];
+}
+template <class T, int CV> __device__ __forceinline__ void storev(T* p, const float* in);
+template <> __device__ __forceinline__ void storev<float, 8>(float* p, const float* in) { store8<float>(p, in); }
+template <> __device__ __forceinline__ void storev<bf16_t, 8>(bf16_t* p, const float* in) { store8<bf16_t>(p, in); }
+template <> __device__ __forceinline__ void storev<float, 4>(float* p, const float* in) { Vec16<float>::store(p, in); }
+template <> __device__ __forceinline__ void storev<bf16_t, 4>(bf16_t* p, const float* in) {
+    bf16x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (bf16_t)in[i];
+    *reinterpret_cast<bf16x4*>(p) = v;
+}
+
+// channel groups (of CV channels) per block slab: the largest divisor of C/CV that is <= maxg
+static inline int groups_per_slab(int C, int CV, int maxg) {
+    const int G = C / CV;
     int best = 1;
-    for (int g = 1; g <= 16 && g <= G; ++g)
+    for (int g = 1; g <= maxg && g <= G; ++g)
         if (G % g == 0) best = g;
     return best;
 }
 
 // unconditional load from a clamped pixel index, zeroed when the true index is outside [0, W)
-template <class T, bool CHECK>
+template <class T, int CV, bool CHECK>
 __device__ __forceinline__ void load_px(const T* __restrict__ row, int iw, int W, int C, bool row_ok, float* out) {
     if (CHECK) {
         const bool ok = row_ok && (unsigned)iw < (unsigned)W;
         const int iwc = min(max(iw, 0), W - 1);
-        load8<T>(row + (int64_t)iwc * C, out);
+        loadv<T, CV>(row + iwc * C, out);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) out[u] = ok ? out[u] : 0.f;
+        for (int u = 0; u < CV; ++u) out[u] = ok ? out[u] : 0.f;
     } else {
-        load8<T>(row + (int64_t)iw * C, out);
+        loadv<T, CV>(row + iw * C, out);
     }
 }
 
-template <class T, int K, bool DIL1, bool CHECK>
+template <class T, int K, int CV, bool DIL1, bool CHECK>
 __device__ __forceinline__ void dw_accumulate_row(const T* __restrict__ xr, const float* __restrict__ wrow, int w0, int pad_l, int W,
-                                                  int C, int dil, int sc, float (&acc)[TW][8]) {
+                                                  int C, int dil, int sc, float (&acc)[TW][CV]) {
     if (DIL1) {
-        float xin[TW + K - 1][8];
+        float xin[TW + K - 1][CV];
 #pragma unroll
-        for (int s = 0; s < TW + K - 1; ++s) load_px<T, CHECK>(xr, w0 - pad_l + s, W, C, true, xin[s]);
+        for (int s = 0; s < TW + K - 1; ++s) load_px<T, CV, CHECK>(xr, w0 - pad_l + s, W, C, true, xin[s]);
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
-            float wv[8];
-            load8<float>(wrow + kw * sc, wv);
+            float wv[CV];
+            loadv<float, CV>(wrow + kw * sc, wv);
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[t][u] = fmaf(xin[t + kw][u], wv[u], acc[t][u]);
+                for (int u = 0; u < CV; ++u) acc[t][u] = fmaf(xin[t + kw][u], wv[u], acc[t][u]);
         }
     } else {
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
-            float wv[8];
-            load8<float>(wrow + kw * sc, wv);
-            float xv[TW][8];
+            float wv[CV];
+            loadv<float, CV>(wrow + kw * sc, wv);
+            float xv[TW][CV];
 #pragma unroll
-            for (int t = 0; t < TW; ++t) load_px<T, true>(xr, w0 + t + kw * dil - pad_l, W, C, true, xv[t]);
+            for (int t = 0; t < TW; ++t) load_px<T, CV, true>(xr, w0 + t + kw * dil - pad_l, W, C, true, xv[t]);
 #pragma unroll
             for (int t = 0; t < TW; ++t)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[t][u] = fmaf(xv[t][u], wv[u], acc[t][u]);
+                for (int u = 0; u < CV; ++u) acc[t][u] = fmaf(xv[t][u], wv[u], acc[t][u]);
         }
     }
 }
 
-template <class T, int K, bool DIL1>
+// ROLLED: keep the kernel-row loop rolled so only one row's loads are live (fewer VGPRs, more waves per SIMD)
+template <class T, int K, int CV, bool DIL1, bool ROLLED>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const T* __restrict__ add,
                                                          T* __restrict__ y, int N, int H, int W, int C, int dil, int pad_t,
                                                          int pad_l, int flip, int gs, int pt) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [K*K][gs*8]
-    const int slab_c0 = blockIdx.y * gs * 8;
-    const int sc = gs * 8;
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [K*K][gs*CV]
+    const int sc = gs * CV;
+    const int slab_c0 = blockIdx.y * sc;
     for (int i = threadIdx.x; i < K * K * sc; i += blockDim.x) {
         int tap = i / sc;
         const int c = i % sc;
         if (flip) tap = K * K - 1 - tap;
-        wl[i] = w[(int64_t)tap * C + slab_c0 + c];
+        wl[i] = w[tap * C + slab_c0 + c];
     }
     __syncthreads();
     const int cg = threadIdx.x % gs, ptile = threadIdx.x / gs;
     if (ptile >= pt) return;
     const int wtiles = (W + TW - 1) / TW;
     const int tiles_total = N * H * wtiles;
-    const int c0 = slab_c0 + cg * 8;
-    float bv[8];
+    const int c0 = slab_c0 + cg * CV;
+    float bv[CV];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) bv[u] = bias ? bias[c0 + u] : 0.f;
+    for (int u = 0; u < CV; ++u) bv[u] = bias ? bias[c0 + u] : 0.f;
 
     for (int tile = blockIdx.x * pt + ptile; tile < tiles_total; tile += gridDim.x * pt) {
         const int wt = tile % wtiles;
@@ -103,21 +126,28 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
         const int h = nh % H;
         const int n = nh / H;
         const int w0 = wt * TW;
-        float acc[TW][8];
+        float acc[TW][CV];
 #pragma unroll
         for (int t = 0; t < TW; ++t)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[t][u] = bv[u];
+            for (int u = 0; u < CV; ++u) acc[t][u] = bv[u];
         const T* xn = x + (int64_t)n * H * W * C + c0;
         const bool interior = DIL1 && (w0 - pad_l >= 0) && (w0 - pad_l + TW + K - 2 < W);
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
+        auto row = [&](int kh) {
             const int ih = h + kh * dil - pad_t;
-            if ((unsigned)ih >= (unsigned)H) continue;
-            const T* xr = xn + (int64_t)ih * W * C;
-            const float* wrow = wl + kh * K * sc + cg * 8;
-            if (interior) dw_accumulate_row<T, K, DIL1, false>(xr, wrow, w0, pad_l, W, C, dil, sc, acc);
-            else dw_accumulate_row<T, K, DIL1, true>(xr, wrow, w0, pad_l, W, C, dil, sc, acc);
+            if ((unsigned)ih < (unsigned)H) {
+                const T* xr = xn + ih * W * C;
+                const float* wrow = wl + kh * K * sc + cg * CV;
+                if (interior) dw_accumulate_row<T, K, CV, DIL1, false>(xr, wrow, w0, pad_l, W, C, dil, sc, acc);
+                else dw_accumulate_row<T, K, CV, DIL1, true>(xr, wrow, w0, pad_l, W, C, dil, sc, acc);
+            }
+        };
+        if (ROLLED) {
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) row(kh);
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) row(kh);
         }
 #pragma unroll
         for (int t = 0; t < TW; ++t) {
@@ -125,12 +155,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
             if (ow < W) {
                 const int64_t off = (((int64_t)n * H + h) * W + ow) * C + c0;
                 if (add) {
-                    float a[8];
-                    load8<T>(add + off, a);
+                    float a[CV];
+                    loadv<T, CV>(add + off, a);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) acc[t][u] += a[u];
+                    for (int u = 0; u < CV; ++u) acc[t][u] += a[u];
                 }
-                store8<T>(y + off, acc[t]);
+                storev<T, CV>(y + off, acc[t]);
             }
         }
     }
@@ -138,12 +168,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
 
 // dw[kh][kw][c] = sum_{n,h,w} x[n, h+kh*d-pt, w+kw*d-pl, c] * dy[n,h,w,c];  db[c] = sum dy
 // thread = (channel group, kernel row kh, item lane); an item is (image row, W segment of `wseg` pixels).
-template <class T, int K, bool DIL1>
+template <class T, int K, int CV, bool DIL1>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 float* __restrict__ partials, int N, int H, int W, int C,
                                                                 int dil, int pad_t, int pad_l, int gs, int rt, int wseg, int ipl) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [(K*K+1)][gs*8]
-    const int sc = gs * 8;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [(K*K+1)][gs*CV]
+    const int sc = gs * CV;
     const int slab_c0 = blockIdx.y * sc;
     const int nred = (K * K + 1) * sc;
     for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
@@ -152,14 +182,14 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     const int kh = (threadIdx.x / gs) % K;
     const int rl = threadIdx.x / (gs * K);
     if (rl < rt) {
-        const int c0 = slab_c0 + cg * 8;
-        float acc[K][8], accb[8];
+        const int c0 = slab_c0 + cg * CV;
+        float acc[K][CV], accb[CV];
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[j][u] = 0.f;
+            for (int u = 0; u < CV; ++u) acc[j][u] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) accb[u] = 0.f;
+        for (int u = 0; u < CV; ++u) accb[u] = 0.f;
         const int nseg = (W + wseg - 1) / wseg;
         const int items = N * H * nseg;
         for (int q = 0; q < ipl; ++q) {
@@ -175,51 +205,51 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
             const T* dyr = dy + (((int64_t)n * H + h) * W) * C + c0;
             const T* xr = x + (((int64_t)n * H + (row_ok ? ih : 0)) * W) * C + c0;
             if (DIL1) {
-                float win[K][8];
+                float win[K][CV];
 #pragma unroll
-                for (int j = 0; j < K - 1; ++j) load_px<T, true>(xr, ws - pad_l + j, W, C, row_ok, win[j]);
+                for (int j = 0; j < K - 1; ++j) load_px<T, CV, true>(xr, ws - pad_l + j, W, C, row_ok, win[j]);
                 for (int base = ws; base < we; base += K) {
 #pragma unroll
                     for (int t = 0; t < K; ++t) {
                         const int ow = base + t;
-                        load_px<T, true>(xr, ow - pad_l + (K - 1), W, C, row_ok, win[(t + K - 1) % K]);
-                        float d[8];
-                        load_px<T, true>(dyr, ow < we ? ow : -1, W, C, true, d);
+                        load_px<T, CV, true>(xr, ow - pad_l + (K - 1), W, C, row_ok, win[(t + K - 1) % K]);
+                        float d[CV];
+                        load_px<T, CV, true>(dyr, ow < we ? ow : -1, W, C, true, d);
                         if (kh == 0) {
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) accb[u] += d[u];
+                            for (int u = 0; u < CV; ++u) accb[u] += d[u];
                         }
 #pragma unroll
                         for (int j = 0; j < K; ++j)
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) acc[j][u] = fmaf(win[(t + j) % K][u], d[u], acc[j][u]);
+                            for (int u = 0; u < CV; ++u) acc[j][u] = fmaf(win[(t + j) % K][u], d[u], acc[j][u]);
                     }
                 }
             } else {
                 for (int ow = ws; ow < we; ++ow) {
-                    float d[8];
-                    load8<T>(dyr + (int64_t)ow * C, d);
+                    float d[CV];
+                    loadv<T, CV>(dyr + ow * C, d);
                     if (kh == 0) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) accb[u] += d[u];
+                        for (int u = 0; u < CV; ++u) accb[u] += d[u];
                     }
-                    float xv[K][8];
+                    float xv[K][CV];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) load_px<T, true>(xr, ow + j * dil - pad_l, W, C, row_ok, xv[j]);
+                    for (int j = 0; j < K; ++j) load_px<T, CV, true>(xr, ow + j * dil - pad_l, W, C, row_ok, xv[j]);
 #pragma unroll
                     for (int j = 0; j < K; ++j)
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc[j][u] = fmaf(xv[j][u], d[u], acc[j][u]);
+                        for (int u = 0; u < CV; ++u) acc[j][u] = fmaf(xv[j][u], d[u], acc[j][u]);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&red[(kh * K + j) * sc + cg * 8 + u], acc[j][u]);
+            for (int u = 0; u < CV; ++u) atomicAdd(&red[(kh * K + j) * sc + cg * CV + u], acc[j][u]);
         if (kh == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&red[K * K * sc + cg * 8 + u], accb[u]);
+            for (int u = 0; u < CV; ++u) atomicAdd(&red[K * K * sc + cg * CV + u], accb[u]);
         }
     }
     __syncthreads();
@@ -231,20 +261,30 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     }
 }
 
+// experiment knobs (read once): ISEG_DW_FWD_CV / ISEG_DW_BW_CV in {4,8}, ISEG_DW_FWD_ROLLED in {0,1}
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int fwd_cv() { static int v = env_int("ISEG_DW_FWD_CV", 8); return v == 4 ? 4 : 8; }
+static int fwd_rolled() { static int v = env_int("ISEG_DW_FWD_ROLLED", 1); return v != 0; }
+static int bw_cv() { static int v = env_int("ISEG_DW_BW_CV", 4); return v == 8 ? 8 : 4; }
+
 struct BwGeom {
-    int gs, rt, slabs, wseg, ipl, bx;
+    int cv, gs, rt, slabs, wseg, ipl, bx;
 };
 
 static BwGeom bw_geom(int N, int H, int W, int C, int K) {
     BwGeom g;
-    g.gs = groups_per_slab(C);
+    g.cv = (C % 8 == 0 && bw_cv() == 8) ? 8 : 4;
+    g.gs = groups_per_slab(C, g.cv, g.cv == 8 ? 16 : 12);
     g.rt = 256 / (g.gs * K);
     if (g.rt < 1) g.rt = 1;
-    g.slabs = (C / 8) / g.gs;
+    g.slabs = (C / g.cv) / g.gs;
     g.wseg = W <= 32 ? W : 32;
     const int nseg = (W + g.wseg - 1) / g.wseg;
     const int64_t items = (int64_t)N * H * nseg;
-    // aim at <= ~1024/slabs blocks along x (enough waves to hide L2 latency, small enough partial buffers)
+    // aim at ~1024 blocks in total: enough waves to hide L2 latency, small enough partial buffers
     int64_t target = 1024 / g.slabs;
     if (target < 64) target = 64;
     int64_t ipl = ceil_div64(items, (int64_t)g.rt * target);
@@ -255,36 +295,54 @@ static BwGeom bw_geom(int N, int H, int W, int C, int K) {
     return g;
 }
 
-template <class T, int K>
+template <class T, int K, int CV>
 int launch_fwd(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
                int pad_t, int pad_l, int flip, hipStream_t s) {
-    const int gs = groups_per_slab(C);
+    const int gs = groups_per_slab(C, CV, 16);
     const int pt = 256 / gs;
-    const int slabs = (C / 8) / gs;
+    const int slabs = (C / CV) / gs;
     const int64_t tiles = (int64_t)N * H * ((W + TW - 1) / TW);
     int64_t bx = ceil_div64(tiles, pt);
     const int64_t cap = 256 * 8 / slabs > 1 ? 256 * 8 / slabs : 1;
     if (bx > cap) bx = cap;
-    const size_t lds = (size_t)K * K * gs * 8 * sizeof(float);
-    if (dil == 1)
-        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, true>), dim3((unsigned)bx, slabs), dim3(256), lds, s, (const T*)x, w, bias,
-                           (const T*)add, (T*)y, N, H, W, C, dil, pad_t, pad_l, flip, gs, pt);
-    else
-        hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, false>), dim3((unsigned)bx, slabs), dim3(256), lds, s, (const T*)x, w, bias,
-                           (const T*)add, (T*)y, N, H, W, C, dil, pad_t, pad_l, flip, gs, pt);
+    const size_t lds = (size_t)K * K * gs * CV * sizeof(float);
+#define DW_LAUNCH(D1, RL)                                                                                                         \
+    hipLaunchKernelGGL((dwconv_fwd_kernel<T, K, CV, D1, RL>), dim3((unsigned)bx, slabs), dim3(256), lds, s, (const T*)x, w, bias, \
+                       (const T*)add, (T*)y, N, H, W, C, dil, pad_t, pad_l, flip, gs, pt)
+    if (dil == 1) {
+        if (fwd_rolled()) DW_LAUNCH(true, true);
+        else DW_LAUNCH(true, false);
+    } else {
+        DW_LAUNCH(false, true);
+    }
+#undef DW_LAUNCH
     return iseg_check_launch("iseg_dwconv2d");
 }
 
 template <class T, int K>
+int launch_fwd_cv(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
+                  int pad_t, int pad_l, int flip, hipStream_t s) {
+    if (C % 8 == 0 && fwd_cv() == 8) return launch_fwd<T, K, 8>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, s);
+    return launch_fwd<T, K, 4>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, s);
+}
+
+template <class T, int K, int CV>
 void launch_bw(const void* x, const void* dy, float* ws, int N, int H, int W, int C, int dil, int pad_t, int pad_l, const BwGeom& g,
                hipStream_t s) {
-    const size_t lds = (size_t)(K * K + 1) * g.gs * 8 * sizeof(float);
+    const size_t lds = (size_t)(K * K + 1) * g.gs * CV * sizeof(float);
     if (dil == 1)
-        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, true>), dim3(g.bx, g.slabs), dim3(256), lds, s, (const T*)x, (const T*)dy, ws,
-                           N, H, W, C, dil, pad_t, pad_l, g.gs, g.rt, g.wseg, g.ipl);
+        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, CV, true>), dim3(g.bx, g.slabs), dim3(256), lds, s, (const T*)x,
+                           (const T*)dy, ws, N, H, W, C, dil, pad_t, pad_l, g.gs, g.rt, g.wseg, g.ipl);
     else
-        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, false>), dim3(g.bx, g.slabs), dim3(256), lds, s, (const T*)x, (const T*)dy,
-                           ws, N, H, W, C, dil, pad_t, pad_l, g.gs, g.rt, g.wseg, g.ipl);
+        hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, CV, false>), dim3(g.bx, g.slabs), dim3(256), lds, s, (const T*)x,
+                           (const T*)dy, ws, N, H, W, C, dil, pad_t, pad_l, g.gs, g.rt, g.wseg, g.ipl);
+}
+
+template <class T, int K>
+void launch_bw_cv(const void* x, const void* dy, float* ws, int N, int H, int W, int C, int dil, int pad_t, int pad_l, const BwGeom& g,
+                  hipStream_t s) {
+    if (g.cv == 8) launch_bw<T, K, 8>(x, dy, ws, N, H, W, C, dil, pad_t, pad_l, g, s);
+    else launch_bw<T, K, 4>(x, dy, ws, N, H, W, C, dil, pad_t, pad_l, g, s);
 }
 
 }  // namespace
@@ -295,11 +353,11 @@ extern "C" int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bia
     ISEG_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "iseg_dwconv2d_fwd: C=%d must be a multiple of 8", C);
     ISEG_REQUIRE(K == 3 || K == 5 || K == 7, "iseg_dwconv2d_fwd: kernel size %d unsupported (3,5,7)", K);
     ISEG_REQUIRE(dil >= 1, "iseg_dwconv2d_fwd: dilation must be >= 1");
-    ISEG_REQUIRE((int64_t)N * H * W < (1ll << 31), "iseg_dwconv2d_fwd: more than 2^31 pixels");
-#define DW_FWD(T)                                                                                          \
-    (K == 7   ? launch_fwd<T, 7>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
-     : K == 5 ? launch_fwd<T, 5>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
-              : launch_fwd<T, 3>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream))
+    ISEG_REQUIRE((int64_t)N * H * W * C < (1ll << 31), "iseg_dwconv2d_fwd: more than 2^31 elements");
+#define DW_FWD(T)                                                                                             \
+    (K == 7   ? launch_fwd_cv<T, 7>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
+     : K == 5 ? launch_fwd_cv<T, 5>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
+              : launch_fwd_cv<T, 3>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream))
     return dtype == ISEG_BF16 ? DW_FWD(bf16_t) : DW_FWD(float);
 #undef DW_FWD
 }
@@ -315,7 +373,7 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
     ISEG_REQUIRE(x && dy && dw, "iseg_dwconv2d_bwd_weight: null pointer");
     ISEG_REQUIRE(C % 8 == 0, "iseg_dwconv2d_bwd_weight: C=%d must be a multiple of 8", C);
     ISEG_REQUIRE(K == 3 || K == 5 || K == 7, "iseg_dwconv2d_bwd_weight: kernel size %d unsupported", K);
-    ISEG_REQUIRE((int64_t)N * H * W < (1ll << 31), "iseg_dwconv2d_bwd_weight: more than 2^31 pixels");
+    ISEG_REQUIRE((int64_t)N * H * W * C < (1ll << 31), "iseg_dwconv2d_bwd_weight: more than 2^31 elements");
     const BwGeom g = bw_geom(N, H, W, C, K);
     ISEG_REQUIRE(g.gs * K * g.rt <= 256, "iseg_dwconv2d_bwd_weight: slab does not fit a block");
     const size_t need = (size_t)g.bx * (K * K + 1) * C * sizeof(float);
@@ -324,13 +382,13 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
         return ISEG_ERR_WORKSPACE;
     }
     if (dtype == ISEG_BF16) {
-        if (K == 7) launch_bw<bf16_t, 7>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
-        else if (K == 5) launch_bw<bf16_t, 5>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
-        else launch_bw<bf16_t, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        if (K == 7) launch_bw_cv<bf16_t, 7>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        else if (K == 5) launch_bw_cv<bf16_t, 5>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        else launch_bw_cv<bf16_t, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
     } else {
-        if (K == 7) launch_bw<float, 7>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
-        else if (K == 5) launch_bw<float, 5>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
-        else launch_bw<float, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        if (K == 7) launch_bw_cv<float, 7>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        else if (K == 5) launch_bw_cv<float, 5>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
+        else launch_bw_cv<float, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
     }
     const int n = (K * K + 1) * C;
     launch_reduce_rows((const float*)ws, g.bx, n, 0, 1, n, dw, db, K * K * C, 0, 1.f, accumulate, stream);

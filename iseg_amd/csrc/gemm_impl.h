@@ -60,17 +60,18 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
         for (int i = 0; i < 8; ++i) v[i] += b[i];
     }
     if (e.pre_out) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
+    constexpr bool FAST = sizeof(TO) == 2;  // bf16 storage: approximation error << output rounding; fp32 parity path: libm erf
     if (e.act == ISEG_ACT_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     } else if (e.act == ISEG_ACT_GELU) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+        for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
     } else if (e.act == ISEG_ACT_GELU_GRAD) {
         float a[8];
         load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= gelu_erf_grad(a[i]);
+        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_fast_grad(a[i]) : gelu_erf_grad(a[i]);
     } else if (e.act == ISEG_ACT_RELU_GRAD) {
         float a[8];
         load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
@@ -99,6 +100,81 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
         load8<TO>(D + m * ldd + n, r);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += r[i];
+    }
+    store8<TO>(D + m * ldd + n, v);
+}
+
+// raw 8-element vectors (kept packed in registers while several epilogue rows are prefetched)
+template <class T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    bf16x8 v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ float get(int i) const {
+        return i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : i == 3 ? a.w : i == 4 ? b.x : i == 5 ? b.y : i == 6 ? b.z : b.w;
+    }
+};
+
+template <class TO> struct EpiPrefetch {
+    Raw8<TO> aux, res, old;
+    __device__ __forceinline__ void load(const Epi& e, int64_t m, int64_t n, const TO* D, int64_t ldd) {
+        if (e.act == ISEG_ACT_GELU_GRAD || e.act == ISEG_ACT_RELU_GRAD) aux.load(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n);
+        if (e.residual) res.load(reinterpret_cast<const TO*>(e.residual) + m * e.ldr + n);
+        if (e.accumulate) old.load(D + m * ldd + n);
+    }
+};
+
+// epi_apply8 with the global operands already in registers
+template <class TO>
+__device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPrefetch<TO>& pf, int64_t m, int64_t n, TO* D, int64_t ldd) {
+    constexpr bool FAST = sizeof(TO) == 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+    if (e.bias) {
+        float b[8];
+        load8<float>(e.bias + n, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += b[i];
+    }
+    if (e.pre_out) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
+    if (e.act == ISEG_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    } else if (e.act == ISEG_ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+    } else if (e.act == ISEG_ACT_GELU_GRAD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_fast_grad(pf.aux.get(i)) : gelu_erf_grad(pf.aux.get(i));
+    } else if (e.act == ISEG_ACT_RELU_GRAD) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = pf.aux.get(i) > 0.f ? v[i] : 0.f;
+    }
+    if (e.colscale) {
+        float c[8];
+        load8<float>(e.colscale + n, c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= c[i];
+    }
+    if (e.rowscale) {
+        const float s = e.rowscale[m / e.rows_per_group];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= s;
+    }
+    if (e.residual) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += pf.res.get(i);
+    }
+    if (e.accumulate) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += pf.old.get(i);
     }
     store8<TO>(D + m * ldd + n, v);
 }
@@ -308,23 +384,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
             }
         }
         __builtin_amdgcn_wave_barrier();  // the slab is wave-private and LDS ops of a wave complete in order
-        for (int c = lane; c < EPI_ROWS * CPR; c += 64) {
-            const int rr = c / CPR, cc = (c % CPR) * 8;
-            if (ps * EPI_ROWS + rr >= TM) continue;
-            const int64_t m = m0 + wm * TM + ps * EPI_ROWS + rr;
-            const int64_t n = n0 + wn * TN + cc;
-            if (m >= M || n >= N) continue;
-            float v[8];
-            const float* src = ew + rr * EPI_STRIDE + cc;
-            *reinterpret_cast<float4*>(v) = *reinterpret_cast<const float4*>(src);
-            *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(src + 4);
-            if (split) {
-                float* dst = slab + m * N + n;
-                for (int u = 0; u < 8 && n + u < N; ++u) dst[u] = v[u];
-            } else if (vecD && n + 8 <= N) {
-                epi_apply8<TO>(epi, v, m, n, D, ldd);
-            } else {
-                for (int u = 0; u < 8 && n + u < N; ++u) D[m * ldd + n + u] = from_f32<TO>(epi_apply<TO>(epi, v[u], m, n + u, D, ldd));
+        // all of this pass's rows: LDS reads and global operand loads first (kept packed), then the arithmetic and the stores
+        constexpr int ITERS = (EPI_ROWS * CPR + 63) / 64;
+        constexpr int PF = 2;  // rows whose operands are in flight together (more costs VGPRs -> occupancy)
+#pragma unroll
+        for (int g0 = 0; g0 < ITERS; g0 += PF) {
+            float v[PF][8];
+            EpiPrefetch<TO> pf[PF];
+            int64_t mm[PF], nn[PF];
+            int kind[PF];  // 0 skip, 1 split slab, 2 vector epilogue, 3 scalar epilogue
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int c = lane + (g0 + q) * 64;
+                const int rr = c / CPR, cc = (c % CPR) * 8;
+                mm[q] = m0 + wm * TM + ps * EPI_ROWS + rr;
+                nn[q] = n0 + wn * TN + cc;
+                kind[q] = 0;
+                if (g0 + q < ITERS && c < EPI_ROWS * CPR && ps * EPI_ROWS + rr < TM && mm[q] < M && nn[q] < N) {
+                    const float* src = ew + rr * EPI_STRIDE + cc;
+                    *reinterpret_cast<float4*>(v[q]) = *reinterpret_cast<const float4*>(src);
+                    *reinterpret_cast<float4*>(v[q] + 4) = *reinterpret_cast<const float4*>(src + 4);
+                    kind[q] = split ? 1 : ((vecD && nn[q] + 8 <= N) ? 2 : 3);
+                    if (kind[q] == 2) pf[q].load(epi, mm[q], nn[q], D, ldd);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int64_t m = mm[q], n = nn[q];
+                if (kind[q] == 1) {
+                    float* dst = slab + m * N + n;
+                    if (n + 8 <= N && (N % 4 == 0)) {
+                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v[q]);
+                        *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(v[q] + 4);
+                    } else {
+                        for (int u = 0; u < 8 && n + u < N; ++u) dst[u] = v[q][u];
+                    }
+                } else if (kind[q] == 2) {
+                    epi_finish8<TO>(epi, v[q], pf[q], m, n, D, ldd);
+                } else if (kind[q] == 3) {
+                    for (int u = 0; u < 8 && n + u < N; ++u)
+                        D[m * ldd + n + u] = from_f32<TO>(epi_apply<TO>(epi, v[q][u], m, n + u, D, ldd));
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();

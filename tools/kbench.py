@@ -9,7 +9,7 @@ import torch
 from iseg_amd import kernels as K
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=20, warm=3, name=""):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -22,12 +22,16 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+ONLY = os.environ.get("KB_ONLY", "")
+
+
 def report(name, sec, nbytes, flops=0):
     print(f"{name:58s} {sec * 1e6:9.1f} us  {nbytes / sec / 1e9:8.1f} GB/s  {flops / sec / 1e12:7.1f} TF/s", flush=True)
 
 
 def main():
     B = int(os.environ.get("KB_BATCH", "16"))
+    only = os.environ.get("KB_ONLY", "")
     dt = torch.bfloat16
     stages = [(128, 96), (64, 192), (32, 384), (16, 768)]
     for (S, C) in stages:
