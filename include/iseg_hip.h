@@ -89,6 +89,8 @@ typedef struct iseg_gemm_args {
     float alpha;
     int accumulate;
     int split_k;
+    int a_act; /* ISEG_ACT_NONE or ISEG_ACT_GELU: A := gelu(A) applied while the operand is staged (the GELU output of
+                  backbones/convnext.py:53 is never materialised; pwconv2 and its weight gradient re-derive it) */
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("pre_out", C.c_void_p), ("ldp", C.c_int64),
-        ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int),
+        ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int), ("a_act", C.c_int),
     ]
 
 

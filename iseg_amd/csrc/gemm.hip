@@ -19,6 +19,18 @@
 
 using namespace iseg_mm;
 
+#include <stdlib.h>
+namespace iseg_mm {
+int tile_waves() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_WAVES");
+        const int w = e ? atoi(e) : 8;
+        return (w == 4 || w == 16) ? w : 8;
+    }();
+    return v;
+}
+}  // namespace iseg_mm
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -28,7 +40,8 @@ template <class TO>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                        const float* __restrict__ B, int64_t sbk, int64_t sbn,
                                                        TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N, int64_t K,
-                                                       int tiles_n, int64_t k_per_split, float* __restrict__ slabs, Epi epi) {
+                                                       int tiles_n, int64_t k_per_split, float* __restrict__ slabs, Epi epi,
+                                                       int a_act) {
     constexpr int TB = 64, TK = 16;
     __shared__ float sA[TK][TB + 1];
     __shared__ float sB[TK][TB + 1];
@@ -45,7 +58,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             int ka, ma;
             if (sak == 1) { ka = e % TK; ma = e / TK; } else { ma = e % TB; ka = e / TB; }
             const int64_t m = m0 + ma, k = k0 + ka;
-            sA[ka][ma] = (m < M && k < kend) ? A[m * sam + k * sak] : 0.f;
+            float av = (m < M && k < kend) ? A[m * sam + k * sak] : 0.f;
+            if (a_act == ISEG_ACT_GELU) av = gelu_erf(av);
+            sA[ka][ma] = av;
             int kb, nb;
             if (sbk == 1) { kb = e % TK; nb = e / TK; } else { nb = e % TB; kb = e / TB; }
             const int64_t n = n0 + nb, k2 = k0 + kb;
@@ -121,6 +136,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     ISEG_REQUIRE(!(g->in_dtype == ISEG_F32 && g->out_dtype == ISEG_BF16), "iseg_gemm: f32 inputs need f32 output");
     ISEG_REQUIRE(!g->rowscale || g->rows_per_group > 0, "iseg_gemm: rowscale needs rows_per_group");
     ISEG_REQUIRE((g->act != ISEG_ACT_GELU_GRAD && g->act != ISEG_ACT_RELU_GRAD) || g->aux, "iseg_gemm: act needs aux");
+    ISEG_REQUIRE(g->a_act == ISEG_ACT_NONE || g->a_act == ISEG_ACT_GELU, "iseg_gemm: a_act must be NONE or GELU");
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate};
     const int nsplit = iseg_gemm_splits(g);
@@ -150,7 +166,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
         const int64_t sbk = g->b_kcontig ? 1 : g->ldb, sbn = g->b_kcontig ? g->ldb : 1;
         hipLaunchKernelGGL((gemm_f32_kernel<float>), dim3(tiles_m * tiles_n, eff_split), dim3(256), 0, stream,
                            (const float*)g->A, sam, sak, (const float*)g->B, sbk, sbn, (float*)g->D, g->ldd, g->M, g->N, g->K,
-                           tiles_n, kps, slabs, epi);
+                           tiles_n, kps, slabs, epi, g->a_act);
     }
     if (slabs) {
         const int64_t total = g->M * g->N;

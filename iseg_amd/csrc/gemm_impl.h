@@ -251,6 +251,14 @@ template <int ROWS, bool KC, int NTHREADS, int BK> struct Stager {
             }
         }
     }
+    // operand transform on the staged registers: A := gelu(A).  Lets the pre-activation be the only [M,4C] tensor that
+    // ConvNeXt's MLP ever writes (backbones/convnext.py:51-54): pwconv2 and the pwconv2 weight gradient re-derive gelu(h).
+    __device__ __forceinline__ void apply_gelu() {
+#pragma unroll
+        for (int i = 0; i < PER_THREAD; ++i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) regs[i][u] = (bf16_t)gelu_fast((float)regs[i][u]);
+    }
     __device__ __forceinline__ void store(bf16_t* lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
                                                                  const bf16_t* __restrict__ B, int64_t ldb, TO* __restrict__ D,
                                                                  int64_t ldd, int64_t M, int64_t N, int64_t K, int tiles_n,
                                                                  int ntiles, int64_t k_per_split, float* __restrict__ slabs,
-                                                                 Epi epi, int vecA, int vecB, int vecD) {
+                                                                 Epi epi, int vecA, int vecB, int vecD, int a_act) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
     constexpr int TM = FM * 16, TN = FN * 16;
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
 
     sa.load(A, lda, m0, kbeg, M, kend, vecA != 0, tid);
     sb.load(B, ldb, n0, kbeg, N, kend, vecB != 0, tid);
+    if (a_act == ISEG_ACT_GELU) sa.apply_gelu();
     sa.store(lds, tid);
     sb.store(lds + GA::elems, tid);
     __syncthreads();
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         }
         __syncthreads();  // every wave is done reading the tile (also fences the epilogue's reuse of the LDS)
         if (more) {
+            if (a_act == ISEG_ACT_GELU) sa.apply_gelu();
             sa.store(lds, tid);
             sb.store(lds + GA::elems, tid);
             __syncthreads();
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         __builtin_amdgcn_wave_barrier();  // the slab is wave-private and LDS ops of a wave complete in order
         // all of this pass's rows: LDS reads and global operand loads first (kept packed), then the arithmetic and the stores
         constexpr int ITERS = (EPI_ROWS * CPR + 63) / 64;
-        constexpr int PF = 2;  // rows whose operands are in flight together (more costs VGPRs -> occupancy)
+        constexpr int PF = 1;  // rows whose operands are in flight together (2 was measured: no gain, costs occupancy)
 #pragma unroll
         for (int g0 = 0; g0 < ITERS; g0 += PF) {
             float v[PF][8];
@@ -431,6 +441,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
     }
 }
 
+// experiment knob (read once)
+int tile_waves();   // ISEG_GEMM_WAVES in {4,8,16}: workgroup size of the 128x128 tile (default 8)
+
 template <int WM, int WN, int FM, int FN, bool AKC, bool BKC, int BK, class TO>
 void launch_bf16(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
     constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
@@ -448,16 +461,19 @@ void launch_bf16(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_
     if (g->colscale) vecD = vecD && ((uintptr_t)g->colscale % 16 == 0);
     dim3 grid(ntiles, nsplit);
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, FM, FN, AKC, BKC, BK, TO>), grid, dim3(WM * WN * 64), 0, s, A, g->lda, B, g->ldb,
-                       (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecA, vecB, vecD);
+                       (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecA, vecB, vecD, g->a_act);
 }
 
 template <bool AKC, bool BKC, int BK, class TO>
 void dispatch_tile(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     const int64_t N = g->N;
-    if (N <= 32) launch_bf16<4, 1, 2, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
-    else if (N <= 64) launch_bf16<2, 2, 4, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
-    else if (N % 128 != 0 && N % 96 == 0) launch_bf16<2, 2, 4, 3, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
-    else launch_bf16<2, 2, 4, 4, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
+    // all tiles are 128 rows; 8 waves per workgroup measured ~2x faster than 4 on these epilogue-heavy, HBM-bound shapes
+    if (N <= 32) launch_bf16<8, 1, 1, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);                               // 128x32
+    else if (N <= 64) launch_bf16<4, 2, 2, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);                          // 128x64
+    else if (N % 128 != 0 && N % 96 == 0) launch_bf16<4, 2, 2, 3, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);      // 128x96
+    else if (tile_waves() == 4) launch_bf16<2, 2, 4, 4, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);                // 128x128
+    else if (tile_waves() == 16) launch_bf16<4, 4, 2, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
+    else launch_bf16<2, 4, 4, 2, AKC, BKC, BK, TO>(g, epi, nsplit, kps, slabs, s);
 }
 
 // one K-tile for short reductions (no loop, all loads issued up front), BK = 64 otherwise

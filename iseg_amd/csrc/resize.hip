@@ -3,8 +3,10 @@
 // path layers/fpn.py:40-61; multi-scale inference core_model.py:170-229).
 //   src = (dst + 0.5) * in/out - 0.5 ; lo = max(floor(src),0) ; hi = min(ceil(src), in-1) ; t = src - floor(src)
 //   out = top + (bottom - top)*ty with top = tl + (tr - tl)*tx            (lerp order kept: it fixes rounding)
-// HBM-bound: the forward is one coalesced write of the output; the backward is the exact transpose in gather
-// form, separated into an X pass and a Y pass so that no atomics are needed and the result is deterministic.
+// HBM-bound.  Forward: one workgroup per output row (n, oy); the two source rows are L1-resident, the output row
+// is written with 16-B lanes and 32-bit index math.  Backward: the exact transpose in gather form, separated into an
+// X pass (one workgroup per gradient row, staged once through LDS with coalesced 16-B loads) and a Y pass, so that no
+// atomics are needed and the result is deterministic.
 #include "common.h"
 #include "iseg_hip.h"
 
@@ -25,50 +27,108 @@ __device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
     return l;
 }
 
+template <class TO> __device__ __forceinline__ void store4(TO* p, const float* v);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float* v) {
+    bf16x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = (bf16_t)v[u];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// grid.x = N*Ho output rows (grid-stride), 256 threads walk the Wo*C elements of the row four at a time
 template <class TI, class TO>
-__global__ void resize_bilinear_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int Hi, int Wi, int Ho, int Wo,
-                                           int C, float sy, float sx) {
-    const int64_t total = (int64_t)N * Ho * Wo * C;
-    for (int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4; i0 < total; i0 += (int64_t)gridDim.x * blockDim.x * 4) {
-        float out[4];
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int Hi, int Wi,
+                                                                  int Ho, int Wo, int C, float sy, float sx) {
+    const int rowlen = Wo * C;
+    const bool vec = (rowlen % 4 == 0);
+    for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+        const int n = row / Ho, oy = row - n * Ho;
+        const Lerp ly = lerp_of(oy, sy, Hi);
+        const TI* top = x + ((int64_t)n * Hi + ly.lo) * Wi * C;
+        const TI* bot = x + ((int64_t)n * Hi + ly.hi) * Wi * C;
+        TO* out = y + (int64_t)row * rowlen;
+        for (int e0 = threadIdx.x * 4; e0 < rowlen; e0 += 256 * 4) {
+            float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t i = i0 + u;
-            out[u] = 0.f;
-            if (i < total) {
-                const int c = (int)(i % C);
-                int64_t r = i / C;
-                const int ox = (int)(r % Wo);
-                r /= Wo;
-                const int oy = (int)(r % Ho);
-                const int n = (int)(r / Ho);
-                const Lerp ly = lerp_of(oy, sy, Hi), lx = lerp_of(ox, sx, Wi);
-                const TI* base = x + (int64_t)n * Hi * Wi * C + c;
-                const float tl = to_f32(base[((int64_t)ly.lo * Wi + lx.lo) * C]);
-                const float tr = to_f32(base[((int64_t)ly.lo * Wi + lx.hi) * C]);
-                const float bl = to_f32(base[((int64_t)ly.hi * Wi + lx.lo) * C]);
-                const float br = to_f32(base[((int64_t)ly.hi * Wi + lx.hi) * C]);
-                const float top = tl + (tr - tl) * lx.t;
-                const float bot = bl + (br - bl) * lx.t;
-                out[u] = top + (bot - top) * ly.t;
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u;
+                v[u] = 0.f;
+                if (e < rowlen) {
+                    const int ox = e / C, c = e - ox * C;
+                    const Lerp lx = lerp_of(ox, sx, Wi);
+                    const float tl = to_f32(top[lx.lo * C + c]), tr = to_f32(top[lx.hi * C + c]);
+                    const float bl = to_f32(bot[lx.lo * C + c]), br = to_f32(bot[lx.hi * C + c]);
+                    const float tp = tl + (tr - tl) * lx.t;
+                    const float bt = bl + (br - bl) * lx.t;
+                    v[u] = tp + (bt - tp) * ly.t;
+                }
             }
-        }
-        if (i0 + 4 <= total && (total % 4 == 0)) {
-            if (sizeof(TO) == 4) {
-                *reinterpret_cast<float4*>(y + i0) = make_float4(out[0], out[1], out[2], out[3]);
-            } else {
-                bf16x4 v;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = (bf16_t)out[u];
-                *reinterpret_cast<bf16x4*>(y + i0) = v;
-            }
-        } else {
-            for (int u = 0; u < 4 && i0 + u < total; ++u) y[i0 + u] = from_f32<TO>(out[u]);
+            if (vec) store4<TO>(out + e0, v);
+            else
+                for (int u = 0; u < 4 && e0 + u < rowlen; ++u) out[e0 + u] = from_f32<TO>(v[u]);
         }
     }
 }
 
-// one axis of the transposed interpolation: out[o, j, q] = sum_{d in D(j)} w(d -> j) * in[o, d, q]
+// transposed interpolation weights of forward destination d onto source j
+__device__ __forceinline__ float bwd_weight(int d, int j, float scale, int J) {
+    const Lerp l = lerp_of(d, scale, J);
+    float w = 0.f;
+    if (l.lo == j) w += 1.f - l.t;
+    if (l.hi == j) w += l.t;
+    return w;
+}
+
+__device__ __forceinline__ void bwd_range(int j, int J, int Dn, float inv, int& d0, int& d1) {
+    // destinations whose lo or hi can equal j: src in (j-1, j+1)  ->  dst in ((j-0.5)*inv-0.5 , (j+1.5)*inv-0.5)
+    d0 = (int)floorf(((float)j - 0.5f) * inv - 0.5f) - 1;
+    d1 = (int)ceilf(((float)j + 1.5f) * inv - 0.5f) + 1;
+    if (j == 0) d0 = 0;           // clamped sources: everything below maps to lo = hi = 0
+    if (j == J - 1) d1 = Dn - 1;  // and everything above to J-1
+    d0 = max(d0, 0);
+    d1 = min(d1, Dn - 1);
+}
+
+// X pass with the gradient row staged in LDS: grid.x = N*Ho rows; tmp[row][ix][c] = sum_ox w(ox -> ix) dy[row][ox][c]
+template <class TI>
+__global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restrict__ dy, float* __restrict__ tmp, int rows, int Wo,
+                                                               int Wi, int C, float sx) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];  // [Wo*C]
+    const int rowlen = Wo * C;
+    const float inv = 1.0f / sx;
+    constexpr int V = 16 / sizeof(TI);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const TI* src = dy + (int64_t)row * rowlen;
+        __syncthreads();
+        if (rowlen % V == 0 && ((int64_t)row * rowlen) % V == 0) {
+            for (int i = threadIdx.x; i < rowlen / V; i += 256) {
+                float v[V];
+                Vec16<TI>::load(src + i * V, v);
+#pragma unroll
+                for (int u = 0; u < V; ++u) srow[i * V + u] = v[u];
+            }
+        } else {
+            for (int i = threadIdx.x; i < rowlen; i += 256) srow[i] = to_f32(src[i]);
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < Wi * C; o += 256) {
+            const int ix = o / C, c = o - ix * C;
+            int d0, d1;
+            bwd_range(ix, Wi, Wo, inv, d0, d1);
+            float acc = 0.f;
+            for (int d = d0; d <= d1; ++d) {
+                const float w = bwd_weight(d, ix, sx, Wi);
+                if (w != 0.f) acc = fmaf(w, srow[d * C + c], acc);
+            }
+            tmp[(int64_t)row * Wi * C + o] = acc;
+        }
+    }
+}
+
+// one axis of the transposed interpolation, generic gather: out[o, j, q] = sum_{d in D(j)} w(d -> j) * in[o, d, q]
 //   outer o (size O), reduced axis d (size Dn, "destination" of the forward), kept axis j (size J, forward source),
 //   inner q (size Q, contiguous).   scale = J / Dn (forward in/out ratio along this axis)
 template <class TI, class TO>
@@ -80,20 +140,12 @@ __global__ void resize_bwd_axis_kernel(const TI* __restrict__ in, TO* __restrict
         const int64_t q = i % Q;
         const int j = (int)((i / Q) % J);
         const int64_t o = i / (Q * J);
-        // destinations whose lo or hi can equal j: src in (j-1, j+1)  ->  dst in ((j-0.5)*inv-0.5 , (j+1.5)*inv-0.5)
-        int d0 = (int)floorf(((float)j - 0.5f) * inv - 0.5f) - 1;
-        int d1 = (int)ceilf(((float)j + 1.5f) * inv - 0.5f) + 1;
-        if (j == 0) d0 = 0;             // clamped sources: everything below maps to lo = hi = 0
-        if (j == J - 1) d1 = Dn - 1;    // and everything above to J-1
-        d0 = max(d0, 0);
-        d1 = min(d1, Dn - 1);
+        int d0, d1;
+        bwd_range(j, J, Dn, inv, d0, d1);
         float acc = 0.f;
         const TI* p = in + o * Dn * Q + q;
         for (int d = d0; d <= d1; ++d) {
-            const Lerp l = lerp_of(d, scale, J);
-            float w = 0.f;
-            if (l.lo == j) w += 1.f - l.t;
-            if (l.hi == j) w += l.t;
+            const float w = bwd_weight(d, j, scale, J);
             if (w != 0.f) acc += w * to_f32(p[(int64_t)d * Q]);
         }
         if (add) acc += to_f32(add[i]);
@@ -130,11 +182,14 @@ static inline unsigned cap_blocks(int64_t items) {
 extern "C" int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, int out_dtype, int N, int Hi, int Wi, int Ho, int Wo,
                                         int C, hipStream_t stream) {
     ISEG_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "iseg_resize_bilinear_fwd: bad arguments");
+    ISEG_REQUIRE((int64_t)Wo * C < (1ll << 30) && (int64_t)Wi * C < (1ll << 30) && (int64_t)N * Ho < (1ll << 31),
+                 "iseg_resize_bilinear_fwd: row too long");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-    const unsigned blocks = cap_blocks(ceil_div64((int64_t)N * Ho * Wo * C, 4));
-#define RS(TI, TO)                                                                                                            \
-    hipLaunchKernelGGL((resize_bilinear_fwd_kernel<TI, TO>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, (TO*)y, N, Hi, Wi, \
-                       Ho, Wo, C, sy, sx)
+    int64_t blocks = (int64_t)N * Ho;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define RS(TI, TO)                                                                                                                    \
+    hipLaunchKernelGGL((resize_bilinear_fwd_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TI*)x, (TO*)y, N, Hi, \
+                       Wi, Ho, Wo, C, sy, sx)
     if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RS(float, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RS(bf16_t, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RS(bf16_t, bf16_t);
@@ -166,12 +221,23 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     // X pass: [N*Ho, Wo, C] -> [N*Ho, Wi, C]
     const int64_t t1 = (int64_t)N * Ho * Wi * C;
-    if (dy_dtype == ISEG_BF16)
+    const size_t row_bytes = (size_t)Wo * C * sizeof(float);
+    if (row_bytes <= 64 * 1024 && (int64_t)N * Ho < (1ll << 31)) {
+        int64_t blocks = (int64_t)N * Ho;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        if (dy_dtype == ISEG_BF16)
+            hipLaunchKernelGGL((resize_bwd_x_lds_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), row_bytes, stream, (const bf16_t*)dy,
+                               tmp, N * Ho, Wo, Wi, C, sx);
+        else
+            hipLaunchKernelGGL((resize_bwd_x_lds_kernel<float>), dim3((unsigned)blocks), dim3(256), row_bytes, stream, (const float*)dy,
+                               tmp, N * Ho, Wo, Wi, C, sx);
+    } else if (dy_dtype == ISEG_BF16) {
         hipLaunchKernelGGL((resize_bwd_axis_kernel<bf16_t, float>), dim3(cap_blocks(t1)), dim3(256), 0, stream, (const bf16_t*)dy,
                            tmp, (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
-    else
+    } else {
         hipLaunchKernelGGL((resize_bwd_axis_kernel<float, float>), dim3(cap_blocks(t1)), dim3(256), 0, stream, (const float*)dy, tmp,
                            (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
+    }
     // Y pass: [N, Ho, Wi*C] -> [N, Hi, Wi*C]
     const int64_t t2 = (int64_t)N * Hi * Wi * C;
     if (dx_dtype == ISEG_BF16)

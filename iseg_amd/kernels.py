@@ -58,7 +58,7 @@ def workspace(nbytes, device):
 # ---------------------------------------------------------------------------------------------------------
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
-         accumulate=False, split_k=0):
+         accumulate=False, split_k=0, a_act=ACT_NONE):
     _require_cuda(A, B, D)
     if A.dtype != B.dtype:
         raise TypeError(f"gemm operands differ in dtype: {A.dtype} vs {B.dtype}")
@@ -72,7 +72,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.residual, g.ldr = ptr(residual), ldr
     g.aux, g.ldaux = ptr(aux), ldaux
     g.pre_out, g.ldp = ptr(pre_out), ldp
-    g.act, g.alpha, g.accumulate, g.split_k = act, alpha, int(accumulate), split_k
+    g.act, g.alpha, g.accumulate, g.split_k, g.a_act = act, alpha, int(accumulate), split_k, a_act
     for t in (residual, aux, pre_out):
         if t is not None and t.dtype != D.dtype:
             raise TypeError("gemm residual/aux/pre_out must have the output dtype")
@@ -87,7 +87,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
 
 
 def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=None, pre_out=None, colscale=None,
-              rowscale=None, rows_per_group=0, residual=None):
+              rowscale=None, rows_per_group=0, residual=None, a_act=ACT_NONE):
     """x2d [M,K] (row stride x2d.stride(0)) @ W [K,N] (Keras Dense / 1x1 conv kernel)."""
     M, K = x2d.shape
     N = W.shape[1]
@@ -96,7 +96,7 @@ def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=
     return gemm(x2d, W, out, M, N, K, lda=x2d.stride(0), ldb=W.stride(0), ldd=ldd or out.stride(0), a_kcontig=1, b_kcontig=0,
                 bias=bias, act=act, pre_out=pre_out, ldp=(pre_out.stride(0) if pre_out is not None else 0), colscale=colscale,
                 rowscale=rowscale, rows_per_group=rows_per_group, residual=residual,
-                ldr=(residual.stride(0) if residual is not None else 0))
+                ldr=(residual.stride(0) if residual is not None else 0), a_act=a_act)
 
 
 def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, rows_per_group=0, residual=None, accumulate=False):
@@ -110,12 +110,12 @@ def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, row
                 residual=residual, ldr=(residual.stride(0) if residual is not None else 0), accumulate=accumulate)
 
 
-def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0):
+def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE):
     """dW [K,N] (+)= X[M,K]^T @ dY[M,N]; out is fp32."""
     M, K = x2d.shape
     N = dy2d.shape[1]
     return gemm(x2d, dy2d, out, K, N, M, lda=x2d.stride(0), ldb=dy2d.stride(0), ldd=out.stride(0), a_kcontig=0, b_kcontig=0,
-                accumulate=accumulate, alpha=alpha)
+                accumulate=accumulate, alpha=alpha, a_act=a_act)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -42,17 +42,27 @@ class _FlatOptimizer:
     def build(self, store: ParamStore):
         self.store = store
         dev = store.device
-        self.hp = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hp_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        # step-dependent scalars travel through a ring of pinned-host -> device slots: the async copy of step t must not be
+        # overwritten on the host before the GPU has consumed it, and the host never runs 64 steps ahead of the stream
+        self._ring = 64
+        self._hp_dev = torch.zeros(self._ring, 4, dtype=torch.float32, device=dev)
+        self._hp_host = torch.zeros(self._ring, 4, dtype=torch.float32)
+        if dev.type == "cuda":
+            self._hp_host = self._hp_host.pin_memory()
+        self._slot = 0
+        self.hp = self._hp_dev[0]
         self._build_tables()
 
     def _build_tables(self):
         raise NotImplementedError
 
     def _push_hp(self, vals):
+        slot = self._slot
+        self._slot = (slot + 1) % self._ring
         for i, v in enumerate(vals):
-            self._hp_host[i] = v
-        self.hp.copy_(self._hp_host, non_blocking=True)
+            self._hp_host[slot, i] = v
+        self.hp = self._hp_dev[slot]
+        self.hp.copy_(self._hp_host[slot], non_blocking=True)
 
 
 class AdamW(_FlatOptimizer):

@@ -107,6 +107,22 @@ def test_gemm_wgrad_splitk(cuda, dtype, M, N, Kd, split):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(520, 96), (300, 192), (130, 384)])
+def test_gemm_a_operand_gelu_transform(cuda, dtype, M, C):
+    """pwconv2(gelu(h)) and Z = gelu(h)^T dout with GELU applied while the A operand is staged (no gelu tensor in HBM)"""
+    k = K()
+    h, hr = q(rnd((M, 4 * C), 1), dtype)
+    w2, w2r = q(rnd((4 * C, C), 2, (4 * C) ** -0.5), dtype)
+    b2 = rnd((C,), 3).float()
+    y = k.dense_fwd(h, w2, b2.cuda(), a_act=k.ACT_GELU)
+    close(y, O.gelu(hr) @ w2r + b2.double(), dtype, "fwd gelu(A)", bf16_tol=2e-2)
+    dy, dyr = q(rnd((M, C), 4), dtype)
+    Z = torch.zeros((4 * C, C), device="cuda")
+    k.dense_wgrad(h, dy, Z, accumulate=False, a_act=k.ACT_GELU)
+    close(Z, O.gelu(hr).T @ dyr, torch.float32, "wgrad gelu(A)", f32_tol=5e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_output_into_concat(cuda, dtype):
     k = K()
     M, N, Kd = 256, 256, 768

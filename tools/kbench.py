@@ -45,18 +45,18 @@ def main():
         h = torch.empty(M, 4 * C, device="cuda", dtype=dt)
         g = torch.empty(M, 4 * C, device="cuda", dtype=dt)
         out = torch.empty(M, C, device="cuda", dtype=dt)
-        t = timeit(lambda: K.dense_fwd(x, w1, b1, act=K.ACT_GELU, pre_out=h, out=g))
-        report(f"S{S} C{C} pw1 fwd (+bias+gelu, save pre)", t, (M * C + 2 * M * 4 * C) * 2, 2 * M * C * 4 * C)
-        t = timeit(lambda: K.dense_fwd(g, w2, b2, colscale=gam, residual=x, out=out))
-        report(f"S{S} C{C} pw2 fwd (+bias+scale+residual)", t, (M * 4 * C + 2 * M * C) * 2, 2 * M * C * 4 * C)
+        t = timeit(lambda: K.dense_fwd(x, w1, b1, out=h))
+        report(f"S{S} C{C} pw1 fwd (+bias -> h)", t, (M * C + M * 4 * C) * 2, 2 * M * C * 4 * C)
+        t = timeit(lambda: K.dense_fwd(h, w2, b2, colscale=gam, residual=x, out=out, a_act=K.ACT_GELU))
+        report(f"S{S} C{C} pw2 fwd (gelu(A)+bias+scale+residual)", t, (M * 4 * C + 2 * M * C) * 2, 2 * M * C * 4 * C)
         dh = torch.empty(M, 4 * C, device="cuda", dtype=dt)
         t = timeit(lambda: K.dense_dgrad(out, w2, act=K.ACT_GELU_GRAD, aux=h, out=dh))
         report(f"S{S} C{C} pw2 dgrad (*gelu'(h))", t, (M * C + 2 * M * 4 * C) * 2, 2 * M * C * 4 * C)
         t = timeit(lambda: K.dense_dgrad(dh, w1, out=out))
         report(f"S{S} C{C} pw1 dgrad", t, (M * 4 * C + M * C) * 2, 2 * M * C * 4 * C)
         Z = torch.empty(4 * C, C, device="cuda")
-        t = timeit(lambda: K.dense_wgrad(g, out, Z, accumulate=False))
-        report(f"S{S} C{C} pw2 wgrad (g^T dout)", t, (M * 4 * C + M * C) * 2, 2 * M * C * 4 * C)
+        t = timeit(lambda: K.dense_wgrad(h, out, Z, accumulate=False, a_act=K.ACT_GELU))
+        report(f"S{S} C{C} pw2 wgrad (gelu(h)^T dout)", t, (M * 4 * C + M * C) * 2, 2 * M * C * 4 * C)
         dW1 = torch.zeros(C, 4 * C, device="cuda")
         t = timeit(lambda: K.dense_wgrad(x, dh, dW1))
         report(f"S{S} C{C} pw1 wgrad (y2^T dh)", t, (M * 4 * C + M * C) * 2, 2 * M * C * 4 * C)
