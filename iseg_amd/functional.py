@@ -553,17 +553,20 @@ class _ConvNeXtBlockFn(Function):
         M = N * H * W
         y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps)
         grad = any(ctx.needs_input_grad)          # grad mode is off inside Function.forward; this is the tape's view
-        # only the pre-activation h = pw1(y2)+b1 is written; pwconv2 applies GELU while staging its A operand
-        h = K.dense_fwd(y2, nn.w(p.w1), p.b1.data)
-        out = K.dense_fwd(h, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
-                          rows_per_group=H * W, residual=xc.reshape(M, C), a_act=K.ACT_GELU)
+        # measured on MI355X (tools/kbench_gemm.py): writing both h and g = gelu(h) from the pw1 epilogue (175+83+117 us at
+        # stage 0 for pw1/pw2/wgrad2) beats writing h only and re-deriving gelu(h) while staging the A operand of pw2 and of
+        # the pw2 weight gradient (83+147+185 us): the transform sits on the load->LDS critical path.  a_act stays available.
+        h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
+        g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h)
+        out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
+                          rows_per_group=H * W, residual=xc.reshape(M, C))
         ctx.p, ctx.dil, ctx.pad = p, dil, pad
-        ctx.save_for_backward(xc, y1, y2, mean, rstd, h if grad else None, dp_mask)
+        ctx.save_for_backward(xc, y1, y2, mean, rstd, h, g if grad else None, dp_mask)
         return out.reshape(N, H, W, C)
 
     @staticmethod
     def backward(ctx, dout):
-        xc, y1, y2, mean, rstd, h, dp_mask = ctx.saved_tensors
+        xc, y1, y2, mean, rstd, h, g, dp_mask = ctx.saved_tensors
         p, dil, pad = ctx.p, ctx.dil, ctx.pad
         N, H, W, C = xc.shape
         M = N * H * W
@@ -576,13 +579,14 @@ class _ConvNeXtBlockFn(Function):
         K.colsum(dbr, C, 0, 1, M, C, S)
         if p.gamma is not None:
             Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
-            K.dense_wgrad(h, dbr, Z, accumulate=False, a_act=K.ACT_GELU)       # Z = gelu(h)^T dbr
+            K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr
             K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
             w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
         else:
-            K.dense_wgrad(h, dbr, _grad(p.w2), a_act=K.ACT_GELU)
+            K.dense_wgrad(g, dbr, _grad(p.w2))
             K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
             w2eff = nn.w(p.w2)
+        del g
         dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_GELU_GRAD, aux=h)            # [M,4C] = (dbr @ W2g^T) * gelu'(h)
         del h
         K.colsum(dh, 4 * C, 0, 1, M, 4 * C, _grad(p.b1), accumulate=True)
