@@ -91,6 +91,10 @@ typedef struct iseg_gemm_args {
     int split_k;
     int a_act; /* ISEG_ACT_NONE or ISEG_ACT_GELU: A := gelu(A) applied while the operand is staged (the GELU output of
                   backbones/convnext.py:53 is never materialised; pwconv2 and its weight gradient re-derive it) */
+    float* colsum_out; /* [N] or NULL.  wgrad orientation only (a_kcontig=0,b_kcontig=0, bf16, M % 128 != 0): also returns
+                          sum_k B(k,:) -- the Dense bias gradient -- from a virtual ones-row of A, i.e. without another pass
+                          over the [pixels, N] gradient tensor */
+    int colsum_accumulate;
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);

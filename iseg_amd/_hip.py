@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("pre_out", C.c_void_p), ("ldp", C.c_int64),
         ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int), ("a_act", C.c_int),
+        ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int),
     ]
 
 

@@ -166,6 +166,150 @@ __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x
     }
 }
 
+// LDS-tiled forward / data-gradient: a workgroup stages the (TH + halo) x (16 + halo) input patch of its channel slab once
+// (coalesced 16-B loads, zero-filled outside the image), then every lane computes 4 pixels x 8 channels from LDS.
+// Replaces ~70 L1/L2 loads per lane by one cooperative patch load (halo read amplification ~2.4x, served by L2).
+constexpr int TWB = 16;  // output columns per workgroup tile (4 lanes x TW)
+
+template <class T, int K, bool DIL1>
+__global__ __launch_bounds__(256) void dwconv_fwd_lds_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, const T* __restrict__ add,
+                                                             T* __restrict__ y, int N, int H, int W, int C, int dil, int pad_t,
+                                                             int pad_l, int flip, int gs, int TH, int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem_dw[];
+    const int sc = gs * 8;
+    const int halo = (K - 1) * dil;
+    const int IH = TH + halo, IW = TWB + halo;
+    float* wl = reinterpret_cast<float*>(smem_dw);                        // [K*K][sc] fp32
+    T* xt = reinterpret_cast<T*>(smem_dw + (size_t)K * K * sc * sizeof(float));  // [IH][IW][sc]
+    const int slab_c0 = blockIdx.y * sc;
+    int b = blockIdx.x;
+    const int tw_i = b % tiles_w;
+    b /= tiles_w;
+    const int th_i = b % tiles_h;
+    const int n = b / tiles_h;
+    const int h0 = th_i * TH, w0 = tw_i * TWB;
+    // Both fills are written as "issue a batch of independent loads, then store the batch": with a plain strided loop hipcc
+    // waits for every load before issuing the next one, and the ~12 dependent L2 round trips per lane dominated the kernel.
+    {
+        const int nw4 = K * K * sc / 4;  // weights as float4 (sc is a multiple of 8)
+        constexpr int WB = 5;
+        for (int base = threadIdx.x; base < nw4; base += 256 * WB) {
+            float4 wr[WB];
+#pragma unroll
+            for (int q = 0; q < WB; ++q) {
+                const int i = base + q * 256;
+                if (i < nw4) {
+                    int tap = (i * 4) / sc;
+                    const int c = (i * 4) % sc;
+                    if (flip) tap = K * K - 1 - tap;
+                    wr[q] = *reinterpret_cast<const float4*>(w + tap * C + slab_c0 + c);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < WB; ++q) {
+                const int i = base + q * 256;
+                if (i < nw4) reinterpret_cast<float4*>(wl)[i] = wr[q];
+            }
+        }
+    }
+    const T* xn = x + (int64_t)n * H * W * C + slab_c0;
+    const int nchunks = IH * IW * gs;
+    constexpr int XB = (sizeof(T) == 2) ? 12 : 6;  // 16-B (bf16) / 32-B (fp32) chunks in flight per lane
+    for (int base = threadIdx.x; base < nchunks; base += 256 * XB) {
+        float4 ra[XB], rb[XB];
+        int pcs[XB];
+#pragma unroll
+        for (int q = 0; q < XB; ++q) {
+            const int i = base + q * 256;
+            pcs[q] = -1;
+            if (i < nchunks) {
+                const int g = i % gs;
+                const int pc = i / gs;
+                const int c = pc % IW, r = pc / IW;
+                const int ih = h0 - pad_t + r, iw = w0 - pad_l + c;
+                const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                const T* src = xn + ((ok ? ih : 0) * W + (ok ? iw : 0)) * C + g * 8;
+                ra[q] = *reinterpret_cast<const float4*>(src);
+                if (sizeof(T) == 4) rb[q] = *reinterpret_cast<const float4*>(src + 4);
+                if (!ok) ra[q] = rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                pcs[q] = pc * sc + g * 8;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < XB; ++q) {
+            if (pcs[q] >= 0) {
+                T* dst = xt + pcs[q];
+                *reinterpret_cast<float4*>(dst) = ra[q];
+                if (sizeof(T) == 4) *reinterpret_cast<float4*>(dst + 4) = rb[q];
+            }
+        }
+    }
+    __syncthreads();
+    const int cg = threadIdx.x % gs, pt = threadIdx.x / gs;
+    const int ty = pt / (TWB / TW), tx = pt % (TWB / TW);
+    if (ty >= TH) return;
+    const int oh = h0 + ty;
+    if (oh >= H) return;
+    const int c0 = slab_c0 + cg * 8;
+    float acc[TW][8];
+    {
+        float bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[u] = bias ? bias[c0 + u] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[t][u] = bv[u];
+    }
+#pragma unroll 1  // rolled on purpose: unrolled, hipcc hoists all 70 LDS reads and spills 400 VGPRs to scratch
+    for (int kh = 0; kh < K; ++kh) {
+        const T* xr = xt + (size_t)((ty + kh * dil) * IW + tx * TW) * sc + cg * 8;
+        const float* wrow = wl + kh * K * sc + cg * 8;
+        if (DIL1) {
+            float xin[TW + K - 1][8];
+#pragma unroll
+            for (int s = 0; s < TW + K - 1; ++s) load8<T>(xr + s * sc, xin[s]);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float wv[8];
+                load8<float>(wrow + kw * sc, wv);
+#pragma unroll
+                for (int t = 0; t < TW; ++t)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[t][u] = fmaf(xin[t + kw][u], wv[u], acc[t][u]);
+            }
+        } else {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                float wv[8];
+                load8<float>(wrow + kw * sc, wv);
+#pragma unroll
+                for (int t = 0; t < TW; ++t) {
+                    float xv[8];
+                    load8<T>(xr + (t + kw * dil) * sc, xv);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[t][u] = fmaf(xv[u], wv[u], acc[t][u]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int ow = w0 + tx * TW + t;
+        if (ow < W) {
+            const int64_t off = (((int64_t)n * H + oh) * W + ow) * C + c0;
+            if (add) {
+                float a[8];
+                load8<T>(add + off, a);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[t][u] += a[u];
+            }
+            store8<T>(y + off, acc[t]);
+        }
+    }
+}
+
 // dw[kh][kw][c] = sum_{n,h,w} x[n, h+kh*d-pt, w+kw*d-pl, c] * dy[n,h,w,c];  db[c] = sum dy
 // thread = (channel group, kernel row kh, item lane); an item is (image row, W segment of `wseg` pixels).
 template <class T, int K, int CV, bool DIL1>
@@ -319,9 +463,35 @@ int launch_fwd(const void* x, const float* w, const float* bias, const void* add
     return iseg_check_launch("iseg_dwconv2d");
 }
 
+static int use_lds() { static int v = env_int("ISEG_DW_LDS", 1); return v != 0; }
+
+template <class T, int K>
+bool launch_fwd_lds(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
+                    int pad_t, int pad_l, int flip, hipStream_t s) {
+    const int gs = groups_per_slab(C, 8, 12);
+    const int TH = (256 / gs) / (TWB / TW);
+    if (TH < 1) return false;
+    const int halo = (K - 1) * dil;
+    const size_t lds = (size_t)K * K * gs * 8 * sizeof(float) + (size_t)(TH + halo) * (TWB + halo) * gs * 8 * sizeof(T);
+    if (lds > 64 * 1024) return false;
+    const int slabs = (C / 8) / gs;
+    const int tiles_h = (H + TH - 1) / TH, tiles_w = (W + TWB - 1) / TWB;
+    const int64_t bx = (int64_t)N * tiles_h * tiles_w;
+    if (bx >= (1ll << 31)) return false;
+    if (dil == 1)
+        hipLaunchKernelGGL((dwconv_fwd_lds_kernel<T, K, true>), dim3((unsigned)bx, slabs), dim3(256), lds, s, (const T*)x, w, bias,
+                           (const T*)add, (T*)y, N, H, W, C, dil, pad_t, pad_l, flip, gs, TH, tiles_h, tiles_w);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_lds_kernel<T, K, false>), dim3((unsigned)bx, slabs), dim3(256), lds, s, (const T*)x, w, bias,
+                           (const T*)add, (T*)y, N, H, W, C, dil, pad_t, pad_l, flip, gs, TH, tiles_h, tiles_w);
+    return true;
+}
+
 template <class T, int K>
 int launch_fwd_cv(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
                   int pad_t, int pad_l, int flip, hipStream_t s) {
+    if (use_lds() && C % 8 == 0 && launch_fwd_lds<T, K>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, s))
+        return iseg_check_launch("iseg_dwconv2d");
     if (C % 8 == 0 && fwd_cv() == 8) return launch_fwd<T, K, 8>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, s);
     return launch_fwd<T, K, 4>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, s);
 }

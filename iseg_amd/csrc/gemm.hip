@@ -94,13 +94,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // sum split-K slabs in slab order (deterministic) and apply the epilogue
 template <class TO>
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit, TO* __restrict__ D, int64_t ldd, int64_t M,
-                                     int64_t N, Epi epi) {
-    const int64_t total = M * N;
+                                     int64_t N, Epi epi, int64_t slab_rows) {
+    const int64_t total = slab_rows * N;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int z = 0; z < nsplit; ++z) s += slabs[(int64_t)z * total + i];
         const int64_t m = i / N, n = i % N;
-        D[m * ldd + n] = from_f32<TO>(epi_apply<TO>(epi, s, m, n, D, ldd));
+        if (m < M) D[m * ldd + n] = from_f32<TO>(epi_apply<TO>(epi, s, m, n, D, ldd));
+        else epi.colsum_out[n] = s + (epi.colsum_accumulate ? epi.colsum_out[n] : 0.f);   // the virtual ones-row
     }
 }
 
@@ -124,7 +125,7 @@ extern "C" int iseg_gemm_splits(const iseg_gemm_args* g) {
 
 extern "C" size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* g) {
     const int s = iseg_gemm_splits(g);
-    return s > 1 ? (size_t)s * (size_t)g->M * (size_t)g->N * sizeof(float) : 0;
+    return s > 1 ? (size_t)s * (size_t)(g->M + (g->colsum_out ? 1 : 0)) * (size_t)g->N * sizeof(float) : 0;
 }
 
 extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -138,12 +139,17 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     ISEG_REQUIRE((g->act != ISEG_ACT_GELU_GRAD && g->act != ISEG_ACT_RELU_GRAD) || g->aux, "iseg_gemm: act needs aux");
     ISEG_REQUIRE(g->a_act == ISEG_ACT_NONE || g->a_act == ISEG_ACT_GELU, "iseg_gemm: a_act must be NONE or GELU");
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
-            g->act, g->alpha, g->accumulate};
+            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate};
+    if (g->colsum_out) {
+        ISEG_REQUIRE(g->in_dtype == ISEG_BF16 && !g->a_kcontig && !g->b_kcontig, "iseg_gemm: colsum_out needs the bf16 wgrad orientation");
+        ISEG_REQUIRE(g->M % 128 != 0 && g->M % 8 == 0, "iseg_gemm: colsum_out needs a spare row in the last 128-row tile (M %% 128 != 0)");
+    }
+    const int64_t slab_rows = g->M + (g->colsum_out ? 1 : 0);
     const int nsplit = iseg_gemm_splits(g);
     float* slabs = nullptr;
     int64_t kps = g->K;
     if (nsplit > 1) {
-        const size_t need = (size_t)nsplit * g->M * g->N * sizeof(float);
+        const size_t need = (size_t)nsplit * slab_rows * g->N * sizeof(float);
         if (!ws || ws_bytes < need) {
             iseg_set_error("iseg_gemm: split-K needs %zu workspace bytes, got %zu", need, ws_bytes);
             return ISEG_ERR_WORKSPACE;
@@ -169,14 +175,14 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
                            tiles_n, kps, slabs, epi, g->a_act);
     }
     if (slabs) {
-        const int64_t total = g->M * g->N;
+        const int64_t total = slab_rows * g->N;
         const int blocks = (int)(ceil_div64(total, 256) < 2048 ? ceil_div64(total, 256) : 2048);
         if (g->out_dtype == ISEG_BF16)
             hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, slabs, eff_split,
-                               (bf16_t*)g->D, g->ldd, g->M, g->N, epi);
+                               (bf16_t*)g->D, g->ldd, g->M, g->N, epi, slab_rows);
         else
             hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, stream, slabs, eff_split,
-                               (float*)g->D, g->ldd, g->M, g->N, epi);
+                               (float*)g->D, g->ldd, g->M, g->N, epi, slab_rows);
     }
     return iseg_check_launch("iseg_gemm");
 }

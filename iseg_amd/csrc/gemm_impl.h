@@ -30,6 +30,8 @@ struct Epi {
     int act;
     float alpha;
     int accumulate;
+    float* colsum_out;      // wgrad only: column sums of B over the reduction (bias gradient) through a virtual ones-row of A
+    int colsum_accumulate;
 };
 
 template <class TO>
@@ -240,7 +242,7 @@ template <int ROWS, bool KC, int NTHREADS, int BK> struct Stager {
         }
     }
     __device__ __forceinline__ void load(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t k0, int64_t R,
-                                         int64_t Kend, bool vec, int tid) {
+                                         int64_t Kend, bool vec, int tid, bool ones_row = false) {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i) {
             const int c = tid + i * NTHREADS;
@@ -248,6 +250,8 @@ template <int ROWS, bool KC, int NTHREADS, int BK> struct Stager {
                 int r, k;
                 decode(c, r, k);
                 regs[i] = load_chunk<KC>(base, ld, row0 + r, k0 + k, R, Kend, vec);
+                // virtual row R of an MN-contiguous A filled with ones: output row R becomes sum_k B(k, :)
+                if (!KC && ones_row && row0 + r == R && k0 + k < Kend) regs[i][0] = (bf16_t)1.0f;
             }
         }
     }
@@ -337,7 +341,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
     Stager<BM, AKC, NT, BK> sa;
     Stager<BN, BKC, NT, BK> sb;
 
-    sa.load(A, lda, m0, kbeg, M, kend, vecA != 0, tid);
+    const bool ones_row = !AKC && epi.colsum_out != nullptr;
+    sa.load(A, lda, m0, kbeg, M, kend, vecA != 0, tid, ones_row);
     sb.load(B, ldb, n0, kbeg, N, kend, vecB != 0, tid);
     if (a_act == ISEG_ACT_GELU) sa.apply_gelu();
     sa.store(lds, tid);
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         const bool more = kt + 1 < nk;
         if (more) {  // next tile's HBM loads fly during this tile's MFMAs
             const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-            sa.load(A, lda, m0, k0, M, kend, vecA != 0, tid);
+            sa.load(A, lda, m0, k0, M, kend, vecA != 0, tid, ones_row);
             sb.load(B, ldb, n0, k0, N, kend, vecB != 0, tid);
         }
 #pragma unroll
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
     // ---- epilogue: accumulators -> per-wave LDS slab (fp32) -> 8-column coalesced rows ----
     float* const ew = reinterpret_cast<float*>(smem) + wid * EPI_ROWS * EPI_STRIDE;
     const bool split = slabs != nullptr;
-    float* const slab = split ? slabs + (int64_t)blockIdx.y * M * N : nullptr;
+    const int64_t slab_rows = M + (ones_row ? 1 : 0);
+    float* const slab = split ? slabs + (int64_t)blockIdx.y * slab_rows * N : nullptr;
     constexpr int PASSES = (TM + EPI_ROWS - 1) / EPI_ROWS;
     constexpr int FPP = EPI_ROWS / 16;  // fragments (in M) per pass
     constexpr int CPR = TN / 8;         // 8-column groups per row
@@ -410,11 +416,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
                 mm[q] = m0 + wm * TM + ps * EPI_ROWS + rr;
                 nn[q] = n0 + wn * TN + cc;
                 kind[q] = 0;
-                if (g0 + q < ITERS && c < EPI_ROWS * CPR && ps * EPI_ROWS + rr < TM && mm[q] < M && nn[q] < N) {
+                if (g0 + q < ITERS && c < EPI_ROWS * CPR && ps * EPI_ROWS + rr < TM && mm[q] < slab_rows && nn[q] < N) {
                     const float* src = ew + rr * EPI_STRIDE + cc;
                     *reinterpret_cast<float4*>(v[q]) = *reinterpret_cast<const float4*>(src);
                     *reinterpret_cast<float4*>(v[q] + 4) = *reinterpret_cast<const float4*>(src + 4);
-                    kind[q] = split ? 1 : ((vecD && nn[q] + 8 <= N) ? 2 : 3);
+                    kind[q] = split ? 1 : (mm[q] == M ? 4 : ((vecD && nn[q] + 8 <= N) ? 2 : 3));
                     if (kind[q] == 2) pf[q].load(epi, mm[q], nn[q], D, ldd);
                 }
             }
@@ -434,6 +440,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
                 } else if (kind[q] == 3) {
                     for (int u = 0; u < 8 && n + u < N; ++u)
                         D[m * ldd + n + u] = from_f32<TO>(epi_apply<TO>(epi, v[q][u], m, n + u, D, ldd));
+                } else if (kind[q] == 4) {  // the ones-row: column sums of B
+                    for (int u = 0; u < 8 && n + u < N; ++u)
+                        epi.colsum_out[n + u] = v[q][u] + (epi.colsum_accumulate ? epi.colsum_out[n + u] : 0.f);
                 }
             }
         }

@@ -589,8 +589,7 @@ class _ConvNeXtBlockFn(Function):
         del g
         dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_GELU_GRAD, aux=h)            # [M,4C] = (dbr @ W2g^T) * gelu'(h)
         del h
-        K.colsum(dh, 4 * C, 0, 1, M, 4 * C, _grad(p.b1), accumulate=True)
-        K.dense_wgrad(y2, dh, _grad(p.w1))
+        K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))      # db1 rides the wgrad GEMM (virtual ones-row) when C % 128 != 0
         dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                    # [M,C]
         del dh
         dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))

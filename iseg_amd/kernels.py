@@ -58,7 +58,7 @@ def workspace(nbytes, device):
 # ---------------------------------------------------------------------------------------------------------
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
-         accumulate=False, split_k=0, a_act=ACT_NONE):
+         accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False):
     _require_cuda(A, B, D)
     if A.dtype != B.dtype:
         raise TypeError(f"gemm operands differ in dtype: {A.dtype} vs {B.dtype}")
@@ -73,6 +73,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.aux, g.ldaux = ptr(aux), ldaux
     g.pre_out, g.ldp = ptr(pre_out), ldp
     g.act, g.alpha, g.accumulate, g.split_k, g.a_act = act, alpha, int(accumulate), split_k, a_act
+    g.colsum_out, g.colsum_accumulate = ptr(colsum_out), int(colsum_accumulate)
     for t in (residual, aux, pre_out):
         if t is not None and t.dtype != D.dtype:
             raise TypeError("gemm residual/aux/pre_out must have the output dtype")
@@ -110,12 +111,21 @@ def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, row
                 residual=residual, ldr=(residual.stride(0) if residual is not None else 0), accumulate=accumulate)
 
 
-def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE):
-    """dW [K,N] (+)= X[M,K]^T @ dY[M,N]; out is fp32."""
+def wgrad_can_fuse_bias(x2d):
+    """the bias gradient can ride the weight-gradient GEMM when the last 128-row output tile has a spare row"""
+    return x2d.dtype == torch.bfloat16 and x2d.shape[1] % 128 != 0 and x2d.shape[1] % 8 == 0
+
+
+def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE, bias_grad=None):
+    """dW [K,N] (+)= X[M,K]^T @ dY[M,N]; out is fp32.  bias_grad [N] (+)= colsum(dY) if given (fused when possible)."""
     M, K = x2d.shape
     N = dy2d.shape[1]
+    fuse = bias_grad is not None and wgrad_can_fuse_bias(x2d)
+    if bias_grad is not None and not fuse:
+        colsum(dy2d, dy2d.stride(0), 0, 1, M, N, bias_grad, accumulate=accumulate)
     return gemm(x2d, dy2d, out, K, N, M, lda=x2d.stride(0), ldb=dy2d.stride(0), ldd=out.stride(0), a_kcontig=0, b_kcontig=0,
-                accumulate=accumulate, alpha=alpha, a_act=a_act)
+                accumulate=accumulate, alpha=alpha, a_act=a_act, colsum_out=(bias_grad if fuse else None),
+                colsum_accumulate=accumulate)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -123,6 +123,23 @@ def test_gemm_a_operand_gelu_transform(cuda, dtype, M, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,N", [(5000, 96, 384), (700, 192, 768), (300, 384, 1536), (64, 96, 21)])
+def test_wgrad_with_fused_bias_gradient(cuda, dtype, M, C, N):
+    """db = colsum(dY) rides the weight-gradient GEMM through a virtual ones-row of X^T when C % 128 != 0 (else: colsum)"""
+    k = K()
+    x, xr = q(rnd((M, C), 1), dtype)
+    dy, dyr = q(rnd((M, N), 2), dtype)
+    dW = torch.full((C, N), 0.25, device="cuda")
+    db = torch.full((N,), -1.0, device="cuda")
+    k.dense_wgrad(x, dy, dW, bias_grad=db)
+    close(dW, xr.T @ dyr + 0.25, torch.float32, "dW", f32_tol=5e-5 if dtype == torch.float32 else 2e-4)
+    close(db, dyr.sum(0) - 1.0, torch.float32, "db", f32_tol=5e-5 if dtype == torch.float32 else 2e-4)
+    k.dense_wgrad(x, dy, dW, bias_grad=db, accumulate=False)
+    close(dW, xr.T @ dyr, torch.float32, "dW overwrite", f32_tol=5e-5 if dtype == torch.float32 else 2e-4)
+    close(db, dyr.sum(0), torch.float32, "db overwrite", f32_tol=5e-5 if dtype == torch.float32 else 2e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_strided_output_into_concat(cuda, dtype):
     k = K()
     M, N, Kd = 256, 256, 768
