@@ -95,27 +95,35 @@ __device__ __forceinline__ float group_sum(float v, int width) {
 
 // Second stage of every two-stage reduction (LayerNorm / BatchNorm / colsum / depthwise-wgrad parameter gradients):
 //   out[b][j] (+)= scale * sum_{p<P} partials[b*bstride_in + p*pstride + j],  j < n,
-// written to out0 for j < n0 and to out1[j-n0] beyond (out1 may be null).  A block owns 32 columns; 8 row-lanes stride
-// over p and are combined through LDS in a fixed order, so the result is deterministic and the pass takes P/8 dependent
+// written to out0 for j < n0 and to out1[j-n0] beyond (out1 may be null).  A block owns 16 columns; 16 row-lanes stride
+// over p and are combined through LDS in a fixed order, so the result is deterministic and the pass takes P/64 dependent
 // steps instead of P.  Template parameter only makes the symbol TU-local-safe.
 template <int TAG>
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partials, int P, int64_t pstride,
-                                                          int64_t bstride_in, int n, float* __restrict__ out0,
-                                                          float* __restrict__ out1, int n0, int64_t bstride_out, float scale,
+                                                          int64_t bstride_in, int64_t n, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int64_t n0, int64_t bstride_out, float scale,
                                                           int accumulate) {
-    __shared__ float red[8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + tx;
+    // 16 columns x 16 row-lanes per workgroup: P/16 dependent steps, 64-B coalesced segments
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + tx;
     const float* src = partials + (int64_t)blockIdx.y * bstride_in;
     float s = 0.f;
-    if (j < n)
-        for (int p = ty; p < P; p += 8) s += src[(int64_t)p * pstride + j];
+    if (j < n) {
+        int p = ty;
+        for (; p + 48 < P; p += 64) {  // four independent loads in flight
+            const float a = src[(int64_t)p * pstride + j], b = src[(int64_t)(p + 16) * pstride + j];
+            const float c = src[(int64_t)(p + 32) * pstride + j], d = src[(int64_t)(p + 48) * pstride + j];
+            s += (a + b) + (c + d);
+        }
+        for (; p < P; p += 16) s += src[(int64_t)p * pstride + j];
+    }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && j < n) {
         float t = red[0][tx];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) t += red[k][tx];
+        for (int k = 1; k < 16; ++k) t += red[k][tx];
         t *= scale;
         float* dst = j < n0 ? out0 + (int64_t)blockIdx.y * bstride_out + j : (out1 ? out1 + (int64_t)blockIdx.y * bstride_out + (j - n0) : nullptr);
         if (dst) {
@@ -125,11 +133,11 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-static inline void launch_reduce_rows(const float* partials, int P, int64_t pstride, int64_t bstride_in, int batch, int n,
-                                      float* out0, float* out1, int n0, int64_t bstride_out, float scale, int accumulate,
+static inline void launch_reduce_rows(const float* partials, int P, int64_t pstride, int64_t bstride_in, int batch, int64_t n,
+                                      float* out0, float* out1, int64_t n0, int64_t bstride_out, float scale, int accumulate,
                                       hipStream_t stream) {
-    hipLaunchKernelGGL((reduce_rows_kernel<0>), dim3((n + 31) / 32, batch), dim3(256), 0, stream, partials, P, pstride, bstride_in,
-                       n, out0, out1, n0, bstride_out, scale, accumulate);
+    hipLaunchKernelGGL((reduce_rows_kernel<0>), dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, stream, partials, P, pstride,
+                       bstride_in, n, out0, out1, n0, bstride_out, scale, accumulate);
 }
 
 // Fast Phi(x) = 0.5(1+erf(x/sqrt2)) for bf16-storage kernels: Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void dwconv_fwd_lds_kernel(const T* __restrict
     const int halo = (K - 1) * dil;
     const int IH = TH + halo, IW = TWB + halo;
     float* wl = reinterpret_cast<float*>(smem_dw);                        // [K*K][sc] fp32
-    T* xt = reinterpret_cast<T*>(smem_dw + (size_t)K * K * sc * sizeof(float));  // [IH][IW][sc]
+    T* xt = reinterpret_cast<T*>(smem_dw + (size_t)K * K * sc * sizeof(float));  // [IH][IW][scp]
+    const int scp = sc + (int)(16 / sizeof(T));  // pixel stride padded by one 16-B slot: neighbouring 4-pixel tiles hit other banks
     const int slab_c0 = blockIdx.y * sc;
     int b = blockIdx.x;
     const int tw_i = b % tiles_w;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_lds_kernel(const T* __restrict
                 ra[q] = *reinterpret_cast<const float4*>(src);
                 if (sizeof(T) == 4) rb[q] = *reinterpret_cast<const float4*>(src + 4);
                 if (!ok) ra[q] = rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                pcs[q] = pc * sc + g * 8;
+                pcs[q] = pc * scp + g * 8;
             }
         }
 #pragma unroll
@@ -264,12 +265,12 @@ __global__ __launch_bounds__(256) void dwconv_fwd_lds_kernel(const T* __restrict
     }
 #pragma unroll 1  // rolled on purpose: unrolled, hipcc hoists all 70 LDS reads and spills 400 VGPRs to scratch
     for (int kh = 0; kh < K; ++kh) {
-        const T* xr = xt + (size_t)((ty + kh * dil) * IW + tx * TW) * sc + cg * 8;
+        const T* xr = xt + (size_t)((ty + kh * dil) * IW + tx * TW) * scp + cg * 8;
         const float* wrow = wl + kh * K * sc + cg * 8;
         if (DIL1) {
             float xin[TW + K - 1][8];
 #pragma unroll
-            for (int s = 0; s < TW + K - 1; ++s) load8<T>(xr + s * sc, xin[s]);
+            for (int s = 0; s < TW + K - 1; ++s) load8<T>(xr + s * scp, xin[s]);
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
                 float wv[8];
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void dwconv_fwd_lds_kernel(const T* __restrict
 #pragma unroll
                 for (int t = 0; t < TW; ++t) {
                     float xv[8];
-                    load8<T>(xr + (t + kw * dil) * sc, xv);
+                    load8<T>(xr + (t + kw * dil) * scp, xv);
 #pragma unroll
                     for (int u = 0; u < 8; ++u) acc[t][u] = fmaf(xv[u], wv[u], acc[t][u]);
                 }
@@ -405,6 +406,130 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     }
 }
 
+// LDS-tiled weight gradient (dil == 1): persistent workgroups walk (image, row-band, column-band) tiles of a channel slab;
+// the dy tile and the x tile (with halo) are staged once per tile, lane (cg, kh, rl) slides a K-wide window along row rl of
+// the tile for kernel row kh, accumulators live in registers across all tiles of the workgroup.
+constexpr int BWW = 32;  // tile columns
+
+template <class T, int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_lds_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    float* __restrict__ partials, int N, int H, int W, int C,
+                                                                    int pad_t, int pad_l, int gs, int rt, int tiles_h, int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) char smem_bw[];
+    const int sc = gs * 8;
+    const int TH = rt;
+    const int IH = TH + K - 1, IW = BWW + K - 1;
+    T* xt = reinterpret_cast<T*>(smem_bw);                                   // [IH][IW][sc]
+    T* dt = xt + (size_t)IH * IW * sc;                                       // [TH][BWW][sc]
+    float* red = reinterpret_cast<float*>(dt + (size_t)TH * BWW * sc);       // [(K*K+1)][sc]
+    const int slab_c0 = blockIdx.y * sc;
+    const int nred = (K * K + 1) * sc;
+    for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
+    const int cg = threadIdx.x % gs;
+    const int kh = (threadIdx.x / gs) % K;
+    const int rl = threadIdx.x / (gs * K);
+    const bool worker = rl < rt;
+    float acc[K][8], accb[8];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[j][u] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) accb[u] = 0.f;
+    const int ntiles = N * tiles_h * tiles_w;
+    constexpr int XB = (sizeof(T) == 2) ? 8 : 4;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw_i = b % tiles_w;
+        b /= tiles_w;
+        const int th_i = b % tiles_h;
+        const int n = b / tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * BWW;
+        __syncthreads();  // previous tile consumed
+        const T* xn = x + (int64_t)n * H * W * C + slab_c0;
+        const T* dn = dy + (int64_t)n * H * W * C + slab_c0;
+        const int nx = IH * IW * gs, nd = TH * BWW * gs;
+        for (int base = threadIdx.x; base < nx + nd; base += 256 * XB) {
+            float4 ra[XB], rb[XB];
+            int dsts[XB];
+#pragma unroll
+            for (int q = 0; q < XB; ++q) {
+                int i = base + q * 256;
+                dsts[q] = -1;
+                if (i < nx + nd) {
+                    const bool is_x = i < nx;
+                    if (!is_x) i -= nx;
+                    const int g = i % gs;
+                    const int pc = i / gs;
+                    const int cw = is_x ? IW : BWW;
+                    const int c = pc % cw, r = pc / cw;
+                    const int ih = is_x ? h0 - pad_t + r : h0 + r;
+                    const int iw = is_x ? w0 - pad_l + c : w0 + c;
+                    const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                    const T* src = (is_x ? xn : dn) + ((ok ? ih : 0) * W + (ok ? iw : 0)) * C + g * 8;
+                    ra[q] = *reinterpret_cast<const float4*>(src);
+                    if (sizeof(T) == 4) rb[q] = *reinterpret_cast<const float4*>(src + 4);
+                    if (!ok) ra[q] = rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    dsts[q] = (is_x ? 0 : IH * IW * sc) + pc * sc + g * 8;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < XB; ++q) {
+                if (dsts[q] >= 0) {
+                    T* dst = xt + dsts[q];
+                    *reinterpret_cast<float4*>(dst) = ra[q];
+                    if (sizeof(T) == 4) *reinterpret_cast<float4*>(dst + 4) = rb[q];
+                }
+            }
+        }
+        __syncthreads();
+        if (worker) {
+            const T* xr = xt + (size_t)((rl + kh) * IW) * sc + cg * 8;   // x row (rl + kh) of the halo tile
+            const T* dr = dt + (size_t)(rl * BWW) * sc + cg * 8;
+            float win[K][8];
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) load8<T>(xr + j * sc, win[j]);
+#pragma unroll 1
+            for (int base = 0; base < BWW; base += K) {
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    const int ow = base + t;
+                    if (ow < BWW) {   // uniform: BWW and K are compile-time
+                        load8<T>(xr + (ow + K - 1) * sc, win[(t + K - 1) % K]);
+                        float d[8];
+                        load8<T>(dr + ow * sc, d);
+                        if (kh == 0) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) accb[u] += d[u];
+                        }
+#pragma unroll
+                        for (int j = 0; j < K; ++j)
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) acc[j][u] = fmaf(win[(t + j) % K][u], d[u], acc[j][u]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (worker) {
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) atomicAdd(&red[(kh * K + j) * sc + cg * 8 + u], acc[j][u]);
+        if (kh == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) atomicAdd(&red[K * K * sc + cg * 8 + u], accb[u]);
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * (K * K + 1) * C;
+    for (int i = threadIdx.x; i < nred; i += 256) {
+        const int tap = i / sc, c = i % sc;
+        out[(int64_t)tap * C + slab_c0 + c] = red[i];
+    }
+}
+
 // experiment knobs (read once): ISEG_DW_FWD_CV / ISEG_DW_BW_CV in {4,8}, ISEG_DW_FWD_ROLLED in {0,1}
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -416,10 +541,38 @@ static int bw_cv() { static int v = env_int("ISEG_DW_BW_CV", 4); return v == 8 ?
 
 struct BwGeom {
     int cv, gs, rt, slabs, wseg, ipl, bx;
+    int lds, tiles_h, tiles_w;   // LDS-tiled variant
+    size_t lds_bytes;
 };
 
-static BwGeom bw_geom(int N, int H, int W, int C, int K) {
+static int use_bw_lds() { static int v = env_int("ISEG_DW_BW_LDS", 1); return v != 0; }
+
+static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     BwGeom g;
+    g.lds = 0;
+    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= 48) {   // measured: the LDS variant wins for wide rows (stages 0-1) only
+        // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes
+        const int gs = groups_per_slab(C, 8, 6);
+        const int rt = 256 / (gs * K);
+        const size_t bytes = ((size_t)(rt + K - 1) * (BWW + K - 1) + (size_t)rt * BWW) * gs * 8 * elem + (size_t)(K * K + 1) * gs * 8 * 4;
+        if (rt >= 1 && bytes <= 80 * 1024) {
+            g.lds = 1;
+            g.cv = 8;
+            g.gs = gs;
+            g.rt = rt;
+            g.slabs = (C / 8) / gs;
+            g.tiles_h = (H + rt - 1) / rt;
+            g.tiles_w = (W + BWW - 1) / BWW;
+            const int64_t ntiles = (int64_t)N * g.tiles_h * g.tiles_w;
+            int64_t bx = 512 / g.slabs;
+            if (bx < 32) bx = 32;
+            if (bx > ntiles) bx = ntiles;
+            g.bx = (int)bx;
+            g.lds_bytes = bytes;
+            g.wseg = g.ipl = 0;
+            return g;
+        }
+    }
     g.cv = (C % 8 == 0 && bw_cv() == 8) ? 8 : 4;
     g.gs = groups_per_slab(C, g.cv, g.cv == 8 ? 16 : 12);
     g.rt = 256 / (g.gs * K);
@@ -464,16 +617,17 @@ int launch_fwd(const void* x, const float* w, const float* bias, const void* add
 }
 
 static int use_lds() { static int v = env_int("ISEG_DW_LDS", 1); return v != 0; }
+static int fwd_lds_groups() { static int v = env_int("ISEG_DW_LDS_GROUPS", 6); return v < 1 ? 1 : (v > 16 ? 16 : v); }
 
 template <class T, int K>
 bool launch_fwd_lds(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
                     int pad_t, int pad_l, int flip, hipStream_t s) {
-    const int gs = groups_per_slab(C, 8, 12);
+    const int gs = groups_per_slab(C, 8, fwd_lds_groups());
     const int TH = (256 / gs) / (TWB / TW);
     if (TH < 1) return false;
     const int halo = (K - 1) * dil;
-    const size_t lds = (size_t)K * K * gs * 8 * sizeof(float) + (size_t)(TH + halo) * (TWB + halo) * gs * 8 * sizeof(T);
-    if (lds > 64 * 1024) return false;
+    const size_t lds = (size_t)K * K * gs * 8 * sizeof(float) + (size_t)(TH + halo) * (TWB + halo) * (gs * 8 * sizeof(T) + 16);
+    if (lds > 80 * 1024) return false;
     const int slabs = (C / 8) / gs;
     const int tiles_h = (H + TH - 1) / TH, tiles_w = (W + TWB - 1) / TWB;
     const int64_t bx = (int64_t)N * tiles_h * tiles_w;
@@ -533,8 +687,13 @@ extern "C" int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bia
 }
 
 extern "C" size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int W, int C, int K) {
-    const BwGeom g = bw_geom(N, H, W, C, K);
-    return (size_t)g.bx * (K * K + 1) * C * sizeof(float);
+    // upper bound over storage dtypes and over the LDS / non-LDS variants
+    const BwGeom g = bw_geom(N, H, W, C, K, 1, 4);
+    const BwGeom g2 = bw_geom(N, H, W, C, K, 2, 4);
+    const BwGeom g3 = bw_geom(N, H, W, C, K, 1, 2);
+    int bx = g.bx > g2.bx ? g.bx : g2.bx;
+    if (g3.bx > bx) bx = g3.bx;
+    return (size_t)bx * (K * K + 1) * C * sizeof(float);
 }
 
 extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W,
@@ -544,14 +703,28 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
     ISEG_REQUIRE(C % 8 == 0, "iseg_dwconv2d_bwd_weight: C=%d must be a multiple of 8", C);
     ISEG_REQUIRE(K == 3 || K == 5 || K == 7, "iseg_dwconv2d_bwd_weight: kernel size %d unsupported", K);
     ISEG_REQUIRE((int64_t)N * H * W * C < (1ll << 31), "iseg_dwconv2d_bwd_weight: more than 2^31 elements");
-    const BwGeom g = bw_geom(N, H, W, C, K);
+    const BwGeom g = bw_geom(N, H, W, C, K, dil, dtype == ISEG_BF16 ? 2 : 4);
     ISEG_REQUIRE(g.gs * K * g.rt <= 256, "iseg_dwconv2d_bwd_weight: slab does not fit a block");
     const size_t need = (size_t)g.bx * (K * K + 1) * C * sizeof(float);
     if (!ws || ws_bytes < need) {
         iseg_set_error("iseg_dwconv2d_bwd_weight: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    if (dtype == ISEG_BF16) {
+    if (g.lds) {
+#define DW_BWL(T, KK)                                                                                                               \
+    hipLaunchKernelGGL((dwconv_bwd_weight_lds_kernel<T, KK>), dim3(g.bx, g.slabs), dim3(256), g.lds_bytes, stream, (const T*)x,         \
+                       (const T*)dy, (float*)ws, N, H, W, C, pad_t, pad_l, g.gs, g.rt, g.tiles_h, g.tiles_w)
+        if (dtype == ISEG_BF16) {
+            if (K == 7) DW_BWL(bf16_t, 7);
+            else if (K == 5) DW_BWL(bf16_t, 5);
+            else DW_BWL(bf16_t, 3);
+        } else {
+            if (K == 7) DW_BWL(float, 7);
+            else if (K == 5) DW_BWL(float, 5);
+            else DW_BWL(float, 3);
+        }
+#undef DW_BWL
+    } else if (dtype == ISEG_BF16) {
         if (K == 7) launch_bw_cv<bf16_t, 7>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
         else if (K == 5) launch_bw_cv<bf16_t, 5>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
         else launch_bw_cv<bf16_t, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);

@@ -174,7 +174,16 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
                            (const float*)g->A, sam, sak, (const float*)g->B, sbk, sbn, (float*)g->D, g->ldd, g->M, g->N, g->K,
                            tiles_n, kps, slabs, epi, g->a_act);
     }
-    if (slabs) {
+    const bool plain_epilogue = !g->bias && !g->colscale && !g->rowscale && !g->residual && !g->pre_out && g->act == ISEG_ACT_NONE &&
+                                g->out_dtype == ISEG_F32 && g->ldd == g->N &&
+                                (!g->colsum_out || (g->colsum_accumulate != 0) == (g->accumulate != 0));
+    if (slabs && plain_epilogue) {
+        // weight gradients: D (+)= alpha * sum_z slab[z] (and the ones-row -> colsum_out) with the 2-D parallel reducer
+        const int64_t mn = g->M * g->N;
+        launch_reduce_rows(slabs, eff_split, slab_rows * g->N, 0, 1, slab_rows * g->N, (float*)g->D, g->colsum_out, mn, 0, g->alpha,
+                           g->accumulate, stream);
+        (void)mn;
+    } else if (slabs) {
         const int64_t total = slab_rows * g->N;
         const int blocks = (int)(ceil_div64(total, 256) < 2048 ? ceil_div64(total, 256) : 2048);
         if (g->out_dtype == ISEG_BF16)

@@ -23,10 +23,7 @@ for (S, C) in [(128, 96), (64, 192), (32, 384), (16, 768)]:
     out.append(f"S{S}C{C} fwd {f:6.1f} bww {b:6.1f}")
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
-for cv in ("8", "4"):
-    for rolled in ("1", "0"):
-        for bcv in ("4", "8"):
-            if bcv == "8" and not (cv == "8" and rolled == "1"):
-                continue
-            env = dict(os.environ, ISEG_DW_FWD_CV=cv, ISEG_DW_FWD_ROLLED=rolled, ISEG_DW_BW_CV=bcv, TAG=f"fwd_cv={cv} rolled={rolled} bw_cv={bcv}")
-            subprocess.run([sys.executable, "-c", code], env=env)
+for groups in ("6", "12"):
+    for bwl in ("1", "0"):
+        env = dict(os.environ, ISEG_DW_LDS_GROUPS=groups, ISEG_DW_BW_LDS=bwl, TAG=f"fwd_lds_groups={groups} bw_lds={bwl}")
+        subprocess.run([sys.executable, "-c", code], env=env)
