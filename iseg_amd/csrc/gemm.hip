@@ -21,6 +21,13 @@ using namespace iseg_mm;
 
 #include <stdlib.h>
 namespace iseg_mm {
+int long_k_tile() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_BK");
+        return (e && atoi(e) == 64) ? 64 : 128;
+    }();
+    return v;
+}
 int tile_waves() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_WAVES");
@@ -155,7 +162,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
             return ISEG_ERR_WORKSPACE;
         }
         slabs = (float*)ws;
-        kps = ceil_div64(ceil_div64(g->K, nsplit), 64) * 64;
+        kps = ceil_div64(ceil_div64(g->K, nsplit), 128) * 128;
     }
     const int eff_split = (int)ceil_div64(g->K, kps);
     if (g->in_dtype == ISEG_BF16) {

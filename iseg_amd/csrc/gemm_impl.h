@@ -451,6 +451,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
 }
 
 // experiment knob (read once)
+int long_k_tile();  // ISEG_GEMM_BK in {64,128}: K-tile depth for reductions >= 256 (default 128)
 int tile_waves();   // ISEG_GEMM_WAVES in {4,8,16}: workgroup size of the 128x128 tile (default 8)
 
 template <int WM, int WN, int FM, int FN, bool AKC, bool BKC, int BK, class TO>
@@ -490,7 +491,8 @@ template <bool AKC, bool BKC, class TO>
 void dispatch_bk(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     const int64_t kspan = kps < g->K ? kps : g->K;
     if (AKC && kspan > 64 && kspan <= 96) dispatch_tile<AKC, BKC, 96, TO>(g, epi, nsplit, kps, slabs, s);
-    else dispatch_tile<AKC, BKC, 64, TO>(g, epi, nsplit, kps, slabs, s);
+    else if (kspan >= 256 && long_k_tile() == 128) dispatch_tile<AKC, BKC, 128, TO>(g, epi, nsplit, kps, slabs, s);  // long reductions:
+    else dispatch_tile<AKC, BKC, 64, TO>(g, epi, nsplit, kps, slabs, s);   // twice the bytes in flight per barrier pair
 }
 
 // implemented in gemm_nn.hip (A K-contig, B N-contig), gemm_nt.hip (both K-contig), gemm_tn.hip (both MN-contig)

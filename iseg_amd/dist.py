@@ -36,8 +36,8 @@ def init(backend=None):
     if ws <= 1:
         return
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = os.environ.get("ISEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
         torch.cuda.set_device(local_rank())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")

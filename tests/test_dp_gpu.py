@@ -1,0 +1,91 @@
+"""Data-parallel semantics on the GPU path: two ranks (both on cuda:0, gloo transport because one box has one GPU) with half
+the batch each must reproduce the single-process step on the full batch -- SyncBN statistics (packed all-reduce, forward and
+backward), bucketed gradient all-reduce, 1/world gradient scaling, identical post-step weights on both ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _step(rank, world, port, q, size, batch):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                          ISEG_DIST_BACKEND="gloo")
+    else:
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            os.environ.pop(k, None)
+    from iseg_amd import dist, nn
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.trainer import TrainableModel
+    from tests.util_models import randomize_parameters
+
+    nn.set_compute_dtype(torch.float32)
+    strat = Strategy(one_device=(world == 1))
+    model = convnext_tiny_aspp(num_class=21, build_input_size=size, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0)
+    randomize_parameters(model, 0)
+    opt = get_optimizer(strat, initial_lr=1e-3, epoch_steps=10, train_epoch=1, optimizer="sgd", sgd_momentum_rate=0.9)
+    tm = TrainableModel(model, optimizer=opt, loss=model.custom_losses(21, 255, batch), loss_weights=model.custom_losses_weights(),
+                        metrics=model.custom_metrics(21, 255))
+    randomize_parameters(model, 0)      # after the ParamStore took over the storage
+    x, y = synthetic_batch(batch, size[0], size[1], seed=3)
+    per = batch // world
+    xs, ys = x[rank * per:(rank + 1) * per].cuda(), y[rank * per:(rank + 1) * per].cuda()
+    losses = [float(tm.train_step(xs, ys)[0]) for _ in range(2)]
+    torch.cuda.synchronize()
+    # numpy arrays are pickled by value (torch tensors would travel through /dev/shm handles that die with this process)
+    out = {p.iseg_name: p.detach().cpu().numpy().copy() for p in model.parameters()}
+    out.update({b.iseg_name: b.detach().cpu().numpy().copy() for b in model.buffers() if hasattr(b, "iseg_name")})
+    miou = tm.metric_results()["output_1_IOU"]
+    q.put((rank, world, losses, out, miou))
+    if world > 1:
+        dist.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def _run(world, size, batch):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_step, args=(r, world, port, q, size, batch)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(res, key=lambda r: r[0])
+
+
+def test_two_ranks_equal_one_rank_full_batch(cuda):
+    size, batch = (64, 64), 4
+    single = _run(1, size, batch)[0]
+    double = _run(2, size, batch)
+    w1 = single[3]
+    for rank, world, losses, w, miou in double:
+        worst = max((float(abs(w[k] - w1[k]).max()) / max(float(abs(w1[k]).max()), 1e-6), k) for k in w1)
+        assert worst[0] < 2e-4, (rank, worst)
+        assert abs(miou - single[4]) < 1e-3      # confusion matrices are summed over ranks when the metric is read
+    # per-rank losses are per-replica means: their average is the full-batch mean
+    for step in range(2):
+        avg = sum(d[2][step] for d in double) / 2
+        assert abs(avg - single[2][step]) < 1e-4 * max(1.0, abs(single[2][step]))
+    for k in double[0][3]:
+        assert (double[0][3][k] == double[1][3][k]).all(), f"ranks diverged on {k}"

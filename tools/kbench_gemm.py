@@ -22,17 +22,18 @@ for (S, C) in [(128, 96), (64, 192), (32, 384), (16, 768)]:
     b1 = torch.randn(4*C, device="cuda"); b2 = torch.randn(C, device="cuda"); gam = torch.rand(C, device="cuda")+0.5
     h = torch.empty(M, 4*C, device="cuda", dtype=dt); g = torch.empty(M, 4*C, device="cuda", dtype=dt); o = torch.empty(M, C, device="cuda", dtype=dt)
     dh = torch.empty(M, 4*C, device="cuda", dtype=dt)
-    a = timeit(lambda: K.dense_fwd(x, w1, b1, out=h))
-    b = timeit(lambda: K.dense_fwd(h, w2, b2, colscale=gam, residual=x, out=o, a_act=K.ACT_GELU))
+    a = timeit(lambda: K.dense_fwd(x, w1, b1, act=K.ACT_GELU, pre_out=h, out=g))
+    b = timeit(lambda: K.dense_fwd(g, w2, b2, colscale=gam, residual=x, out=o))
     c = timeit(lambda: K.dense_dgrad(o, w2, act=K.ACT_GELU_GRAD, aux=h, out=dh))
     d = timeit(lambda: K.dense_dgrad(dh, w1, out=o))
     Z = torch.empty(4*C, C, device="cuda")
-    e = timeit(lambda: K.dense_wgrad(h, o, Z, accumulate=False, a_act=K.ACT_GELU))
+    e = timeit(lambda: K.dense_wgrad(g, o, Z, accumulate=False))
     dW1 = torch.zeros(C, 4*C, device="cuda")
-    f = timeit(lambda: K.dense_wgrad(x, dh, dW1))
+    db1 = torch.zeros(4*C, device="cuda")
+    f = timeit(lambda: K.dense_wgrad(x, dh, dW1, bias_grad=db1))
     out.append(f"C{C}: pw1f {a:5.0f} pw2f {b:5.0f} dg2 {c:5.0f} dg1 {d:5.0f} wg2 {e:5.0f} wg1 {f:5.0f}")
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
-for waves in ("4", "8", "16"):
-    env = dict(os.environ, ISEG_GEMM_WAVES=waves, TAG=f"waves={waves}")
+for bk in ("64", "128"):
+    env = dict(os.environ, ISEG_GEMM_BK=bk, TAG=f"bk={bk}")
     subprocess.run([sys.executable, "-c", code], env=env)
