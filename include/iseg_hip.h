@@ -95,11 +95,14 @@ typedef struct iseg_gemm_args {
                           sum_k B(k,:) -- the Dense bias gradient -- from a virtual ones-row of A, i.e. without another pass
                           over the [pixels, N] gradient tensor */
     int colsum_accumulate;
+    int defer_reduce; /* 1: a split-K problem only writes its slabs; the caller finishes with iseg_gemm_reduce (lets the two
+                         kernels be timed / scheduled separately) */
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
 int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
+int iseg_gemm_reduce(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis: keras.layers.LayerNormalization(axis=-1, epsilon)

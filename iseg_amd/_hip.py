@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
         ("aux", C.c_void_p), ("ldaux", C.c_int64),
         ("pre_out", C.c_void_p), ("ldp", C.c_int64),
         ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int), ("a_act", C.c_int),
-        ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int),
+        ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int), ("defer_reduce", C.c_int),
     ]
 
 
@@ -47,6 +47,7 @@ SIGNATURES = {
     "iseg_gemm_splits": (_i, [C.POINTER(GemmArgs)]),
     "iseg_gemm_workspace_bytes": (_z, [C.POINTER(GemmArgs)]),
     "iseg_gemm": (_i, [C.POINTER(GemmArgs), _p, _z, _p]),
+    "iseg_gemm_reduce": (_i, [C.POINTER(GemmArgs), _p, _z, _p]),
     "iseg_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "iseg_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),

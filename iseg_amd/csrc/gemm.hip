@@ -126,6 +126,8 @@ int choose_split(const iseg_gemm_args* g, int tile) {
 
 }  // namespace
 
+int gemm_reduce(const iseg_gemm_args* g, const Epi& epi, float* slabs, int eff_split, int64_t slab_rows, hipStream_t stream);
+
 extern "C" int iseg_gemm_splits(const iseg_gemm_args* g) {
     return choose_split(g, g->in_dtype == ISEG_BF16 ? 128 : 64);
 }
@@ -181,6 +183,11 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
                            (const float*)g->A, sam, sak, (const float*)g->B, sbk, sbn, (float*)g->D, g->ldd, g->M, g->N, g->K,
                            tiles_n, kps, slabs, epi, g->a_act);
     }
+    if (g->defer_reduce) return iseg_check_launch("iseg_gemm");   // caller runs iseg_gemm_reduce itself
+    return gemm_reduce(g, epi, slabs, eff_split, slab_rows, stream);
+}
+
+int gemm_reduce(const iseg_gemm_args* g, const Epi& epi, float* slabs, int eff_split, int64_t slab_rows, hipStream_t stream) {
     const bool plain_epilogue = !g->bias && !g->colscale && !g->rowscale && !g->residual && !g->pre_out && g->act == ISEG_ACT_NONE &&
                                 g->out_dtype == ISEG_F32 && g->ldd == g->N &&
                                 (!g->colsum_out || (g->colsum_accumulate != 0) == (g->accumulate != 0));
@@ -201,4 +208,22 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
                                (float*)g->D, g->ldd, g->M, g->N, epi, slab_rows);
     }
     return iseg_check_launch("iseg_gemm");
+}
+
+// second half of a deferred split-K GEMM (args.defer_reduce = 1): slab-order sum + epilogue.  No-op when the problem is not split.
+extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(g && g->D, "iseg_gemm_reduce: null argument");
+    const int nsplit = iseg_gemm_splits(g);
+    if (nsplit <= 1) return ISEG_OK;
+    const int64_t slab_rows = g->M + (g->colsum_out ? 1 : 0);
+    const size_t need = (size_t)nsplit * slab_rows * g->N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_gemm_reduce: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const int64_t kps = ceil_div64(ceil_div64(g->K, nsplit), 128) * 128;
+    const int eff_split = (int)ceil_div64(g->K, kps);
+    Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
+            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate};
+    return gemm_reduce(g, epi, (float*)ws, eff_split, slab_rows, stream);
 }

@@ -54,6 +54,39 @@ def workspace(nbytes, device):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# optional per-launch timing with HIP events on the launch stream (bench.py's live roofline measurement)
+# ---------------------------------------------------------------------------------------------------------
+KERNEL_TIMER = [None]
+
+
+class KernelTimer:
+    """records a (start, stop) event pair around every instrumented launch, grouped by a shape key; no host sync until report()"""
+
+    def __init__(self):
+        self.records = {}
+        self._cur = None
+
+    def begin(self, key):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._cur = (key, e0)
+
+    def end(self):
+        key, e0 = self._cur
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1))
+
+    def report(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, pairs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[key] = (sum(ms) / len(ms) * 1e-3, len(ms))     # seconds per launch, launches
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------------------
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
@@ -83,7 +116,16 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     L = _hip.lib()
     need = L.iseg_gemm_workspace_bytes(C.byref(g))
     ws, wsb = workspace(need, A.device)
+    g.defer_reduce = 1 if need > 0 else 0
+    timer = KERNEL_TIMER[0]
+    if timer is not None:
+        timer.begin(("gemm", int(a_kcontig), int(b_kcontig), int(M), int(N), int(K), int(act), pre_out is not None, residual is not None,
+                     aux is not None, A.dtype, D.dtype, need > 0))
     _hip.check(L.iseg_gemm(C.byref(g), ptr(ws), wsb, stream()), "iseg_gemm")
+    if timer is not None:
+        timer.end()
+    if need > 0:
+        _hip.check(L.iseg_gemm_reduce(C.byref(g), ptr(ws), wsb, stream()), "iseg_gemm_reduce")
     return D
 
 
