@@ -75,8 +75,9 @@ def _gemm_group_model(key):
     return 2.0 * M * N * K, nbytes
 
 
-def roofline_from_timer(report, steps):
-    """pick the GEMM launch group (kernel template + shape) with the largest share of the timed region"""
+def roofline_from_timer(report, steps, survey=None):
+    """the GEMM launch group (kernel template + shape) with the largest share of the step; `report` holds the live
+    HIP-event timings of the timed region, `survey` (all GEMM groups, one warm-up step) gives its share of GEMM time"""
     best = max(report.items(), key=lambda kv: kv[1][0] * kv[1][1])
     key, (sec, launches) = best
     flops, nbytes = _gemm_group_model(key)
@@ -84,11 +85,25 @@ def roofline_from_timer(report, steps):
     orient = {(1, 0): "forward x[M,K] @ kernel[K,N]", (1, 1): "dgrad dy[M,K] @ kernel[N,K]^T", (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
     intensity = flops / nbytes
     ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)
-    total = sum(v[0] * v[1] for v in report.values())
+    if survey is not None and key in survey:
+        share = survey[key][0] * survey[key][1] / sum(v[0] * v[1] for v in survey.values())
+    else:
+        share = sec * launches / sum(v[0] * v[1] for v in report.values())
     common = {"kernel": f"iseg_mm::gemm_bf16_kernel ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''})",
               "launches_per_step": launches / steps, "launch_us": round(sec * 1e6, 2),
-              "share_of_gemm_time": round(sec * launches / total, 4), "algorithmic_bytes_per_launch": int(nbytes),
+              "share_of_gemm_time": round(share, 4), "algorithmic_bytes_per_launch": int(nbytes),
               "algorithmic_flops_per_launch": int(flops), "flop_per_byte": round(intensity, 1), "traffic": None}
+    # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the figure comes from the
+    # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py, corrections
+    # per MI355X_MICROARCH.md) committed under profiles/; null when no measurement for this kernel+shape is on file.
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f).get(common["kernel"])
+        if rec:
+            common["traffic"] = rec["traffic"]
+            common["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
+    except OSError:
+        pass
     if intensity >= ridge:
         ach = flops / sec / 1e12
         common.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -145,13 +160,27 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
     x, y = synthetic_batch(args.batch, args.size, args.size, seed=100 + rank)
     x, y = x.cuda(), y.cuda()
-    for _ in range(args.warmup):
-        trainer.train_step(x, y)
     from iseg_amd import kernels as K
 
+    # Roofline: the last warm-up step times every GEMM launch with HIP events on the launch stream to find the dominant
+    # (template, shape) group; the timed region then brackets only that group's launches (a few event pairs per step), so
+    # the headline throughput is not taxed by ~300 event records per step.
+    want_roofline = rank == 0 and not args.no_roofline
+    survey = None
+    for i in range(args.warmup):
+        if want_roofline and i == args.warmup - 1:
+            survey = K.KernelTimer()
+            K.KERNEL_TIMER[0] = survey
+        trainer.train_step(x, y)
+    K.KERNEL_TIMER[0] = None
     timer = None
-    if rank == 0 and not args.no_roofline:
-        timer = K.KernelTimer()          # HIP events around every GEMM launch of the timed region (no host sync)
+    survey_report = None
+    if want_roofline:
+        dominant = None
+        if survey is not None:
+            survey_report = survey.report()
+            dominant = max(survey_report.items(), key=lambda kv: kv[1][0] * kv[1][1])[0]
+        timer = K.KernelTimer(only=dominant)
         K.KERNEL_TIMER[0] = timer
     dist.barrier()
     torch.cuda.synchronize()
@@ -183,7 +212,7 @@ def main():
         "final_loss": round(loss_val, 5),
     }
     if timer is not None:
-        res["roofline"] = roofline_from_timer(timer.report(), args.steps)
+        res["roofline"] = roofline_from_timer(timer.report(), args.steps, survey_report)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args)
     print(json.dumps(res))

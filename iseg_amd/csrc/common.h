@@ -133,9 +133,50 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
+// Wide variant for few, long partial rows (split-K slabs of the big weight gradients: n ~ 10^5..10^6, P <= 32): a lane owns
+// four consecutive columns (16-B loads, 1 KiB per wave per row) and walks the P rows in order -- same fixed summation order
+// for every element, no LDS.  Requires pstride % 4 == 0, n % 4 == 0, n0 % 4 == 0 and 16-B aligned bases (checked on the host).
+template <int TAG>
+__global__ __launch_bounds__(256) void reduce_rows_wide_kernel(const float* __restrict__ partials, int P, int64_t pstride,
+                                                               int64_t n, float* __restrict__ out0, float* __restrict__ out1,
+                                                               int64_t n0, float scale, int accumulate) {
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= n) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = 0;
+    for (; p + 3 < P; p += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(partials + (int64_t)p * pstride + j);
+        const float4 b = *reinterpret_cast<const float4*>(partials + (int64_t)(p + 1) * pstride + j);
+        const float4 c = *reinterpret_cast<const float4*>(partials + (int64_t)(p + 2) * pstride + j);
+        const float4 d = *reinterpret_cast<const float4*>(partials + (int64_t)(p + 3) * pstride + j);
+        s.x += (a.x + b.x) + (c.x + d.x);
+        s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z);
+        s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; p < P; ++p) {
+        const float4 a = *reinterpret_cast<const float4*>(partials + (int64_t)p * pstride + j);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;
+    float* dst = j < n0 ? out0 + j : (out1 ? out1 + (j - n0) : nullptr);
+    if (!dst) return;
+    if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dst) = s;
+}
+
 static inline void launch_reduce_rows(const float* partials, int P, int64_t pstride, int64_t bstride_in, int batch, int64_t n,
                                       float* out0, float* out1, int64_t n0, int64_t bstride_out, float scale, int accumulate,
                                       hipStream_t stream) {
+    const bool aligned = (((uintptr_t)partials | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0;
+    if (batch == 1 && P <= 32 && n >= 32768 && n % 4 == 0 && n0 % 4 == 0 && pstride % 4 == 0 && aligned) {
+        hipLaunchKernelGGL((reduce_rows_wide_kernel<0>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, partials, P,
+                           pstride, n, out0, out1, n0, scale, accumulate);
+        return;
+    }
     hipLaunchKernelGGL((reduce_rows_kernel<0>), dim3((unsigned)((n + 15) / 16), batch), dim3(256), 0, stream, partials, P, pstride,
                        bstride_in, n, out0, out1, n0, bstride_out, scale, accumulate);
 }

@@ -546,14 +546,25 @@ struct BwGeom {
 };
 
 static int use_bw_lds() { static int v = env_int("ISEG_DW_BW_LDS", 1); return v != 0; }
+static int bw_lds_min_w() { static int v = env_int("ISEG_DW_BW_LDS_MINW", 48); return v; }
 
 static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     BwGeom g;
     g.lds = 0;
-    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= 48) {   // measured: the LDS variant wins for wide rows (stages 0-1) only
-        // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes
-        const int gs = groups_per_slab(C, 8, 6);
-        const int rt = 256 / (gs * K);
+    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w()) {
+        // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes.  Small planes (W <= 32: one tile spans the row) take
+        // the widest slab whose lane rows still cover the whole image height, so one tile = one image plane.
+        int gs = groups_per_slab(C, 8, 6);
+        if (W <= BWW) {
+            gs = 1;
+            for (int cand = 6; cand >= 1; --cand)
+                if ((C / 8) % cand == 0 && 256 / (cand * K) >= H) {
+                    gs = cand;
+                    break;
+                }
+        }
+        int rt = 256 / (gs * K);
+        if (rt > H) rt = H;
         const size_t bytes = ((size_t)(rt + K - 1) * (BWW + K - 1) + (size_t)rt * BWW) * gs * 8 * elem + (size_t)(K * K + 1) * gs * 8 * 4;
         if (rt >= 1 && bytes <= 80 * 1024) {
             g.lds = 1;

@@ -62,16 +62,22 @@ KERNEL_TIMER = [None]
 class KernelTimer:
     """records a (start, stop) event pair around every instrumented launch, grouped by a shape key; no host sync until report()"""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}
         self._cur = None
+        self.only = only        # None: every instrumented launch; else the one shape key to time
 
     def begin(self, key):
+        if self.only is not None and key != self.only:
+            self._cur = None
+            return
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         self._cur = (key, e0)
 
     def end(self):
+        if self._cur is None:
+            return
         key, e0 = self._cur
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
