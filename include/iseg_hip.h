@@ -235,6 +235,39 @@ int iseg_sgd_momentum_step(float* w, const float* g, float* m, void* w_bf16, con
                            const float* seg_lr_mult, const float* seg_l2, const float* hp, float momentum, int64_t nblocks,
                            iseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * utils/op_utils.py:43-60 replace_nan_or_inf (layers/fpn.py:52): NaN -> nan_value, then clip to the [min, max] of the
+ * tensor with +-inf counted as 0.  ws: 8 bytes.  Gradient passes where x is finite.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_replace_nan_or_inf(const void* x, void* y, int64_t n, float nan_value, int dtype, void* ws, size_t ws_bytes,
+                            iseg_stream_t stream);
+int iseg_replace_nan_or_inf_bwd(const void* x, const void* dy, void* dx, int64_t n, int dtype, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * layers/groupnorm.py:148-207 GroupNormalization (axis=-1): x [N,HW,C], moments over (HW, C/G) per (n, g);
+ * mean, rstd [N*G].  layers/rmsnorm.py:22-29 RMSNormalization: y = x * rsqrt(mean_c(x^2)+eps) * (1+scale), rstd [rows].
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_groupnorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int N, int HW,
+                       int C, int G, float eps, int dtype, iseg_stream_t stream);
+size_t iseg_groupnorm_bwd_workspace_bytes(int N, int C);
+int iseg_groupnorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                       float* dgamma, float* dbeta, int accumulate_param_grads, int N, int HW, int C, int G, int dtype, void* ws,
+                       size_t ws_bytes, iseg_stream_t stream);
+int iseg_rmsnorm_fwd(const void* x, const float* scale, void* y, float* rstd, int64_t rows, int C, float eps, int dtype,
+                     iseg_stream_t stream);
+size_t iseg_rmsnorm_bwd_workspace_bytes(int64_t rows, int C);
+int iseg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const float* rstd, void* dx, float* dscale,
+                     int accumulate_param_grads, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * keras MaxPooling2D(3, strides=2, "same") backbones/resnet_common.py:215-217 and tf.nn.avg_pool2d(..., "SAME")
+ * backbones/resnet_blocks.py:182-186.  mode 0 = max (gradient to the first maximal cell), 1 = average over valid cells.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_pool2d_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t, int pad_l,
+                    int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
+int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t,
+                    int pad_l, int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,6 +81,16 @@ SIGNATURES = {
     "iseg_scale_rows_f32": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_layerscale_grads_workspace_bytes": (_z, [_i, _i]),
     "iseg_layerscale_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "iseg_replace_nan_or_inf": (_i, [_p, _p, _l, _f, _i, _p, _z, _p]),
+    "iseg_replace_nan_or_inf_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
+    "iseg_groupnorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),
+    "iseg_groupnorm_bwd_workspace_bytes": (_z, [_i, _i]),
+    "iseg_groupnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "iseg_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "iseg_rmsnorm_bwd_workspace_bytes": (_z, [_l, _i]),
+    "iseg_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_pool2d_fwd": (_i, [_p, _p] + [_i] * 14 + [_p]),
+    "iseg_pool2d_bwd": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),
     "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_resize_bilinear_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "iseg_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -303,16 +303,25 @@ class _BatchNormInferFn(Function):
         rstd = K.rsqrt_eps(moving_var, eps)
         y = torch.empty_like(x2)
         K.bn_apply_fwd(x2, C, moving_mean, rstd, gamma.data, beta.data, y, C, x2.shape[0], C, relu)
-        ctx.gamma, ctx.relu = gamma, relu
-        ctx.save_for_backward(y if relu else None, rstd)
+        ctx.gamma, ctx.beta, ctx.relu = gamma, beta, relu
+        want_param_grads = gamma.requires_grad or beta.requires_grad
+        ctx.save_for_backward(y if relu else None, rstd, x2 if want_param_grads else None, moving_mean if want_param_grads else None)
         return y.reshape(x.shape)
 
     @staticmethod
     def backward(ctx, dy):
-        # frozen statistics: dx = dz * gamma * rstd (used when a BN layer runs with training=False inside a train step)
-        y, rstd = ctx.saved_tensors
+        # frozen statistics: dx = dz * gamma * rstd; gamma / beta still receive their gradients (Keras keeps them trainable
+        # when a BN layer is called with training=False inside a train step)
+        y, rstd, x2, mean = ctx.saved_tensors
         C = dy.shape[-1]
         dy2 = _c(dy).reshape(-1, C)
+        if x2 is not None:
+            sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, x2.shape[0], C, ctx.relu)
+            if ctx.beta.requires_grad:
+                K.axpby(sums[:C], _grad(ctx.beta), 1.0, 1.0, out=_grad(ctx.beta))
+            if ctx.gamma.requires_grad:
+                K.axpby(sums[C:], _grad(ctx.gamma), 1.0, 1.0, out=_grad(ctx.gamma))
+            dist.grads_ready(ctx.gamma, ctx.beta)
         if ctx.relu:
             dy2 = K.act_bwd(dy2, y, K.ACT_RELU)
         scale = K.axpby(ctx.gamma.data, None, 1.0, 0.0)
@@ -697,3 +706,115 @@ def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None):
 
 def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0):
     return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# replace_nan_or_inf (utils/op_utils.py:43-60), GroupNormalization, RMSNormalization, pooling
+# ---------------------------------------------------------------------------------------------------------
+class _ReplaceNanInfFn(Function):
+    @staticmethod
+    def forward(ctx, x, nan_value):
+        xc = _c(x)
+        ctx.save_for_backward(xc)
+        return K.replace_nan_or_inf(xc, nan_value)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        return K.replace_nan_or_inf_bwd(xc, _c(dy)), None
+
+
+def replace_nan_or_inf(x, nan_value=0.0):
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ReplaceNanInfFn.apply(x, float(nan_value))
+
+
+class _GroupNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        N, C = x.shape[0], x.shape[-1]
+        x3 = _c(x).reshape(N, -1, C)
+        y, mean, rstd = K.groupnorm_fwd(x3, gamma.data if gamma is not None else None, beta.data if beta is not None else None, groups, eps)
+        ctx.gamma, ctx.beta, ctx.groups = gamma, beta, groups
+        ctx.save_for_backward(x3, mean, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, mean, rstd = ctx.saved_tensors
+        g, b = ctx.gamma, ctx.beta
+        dx = K.groupnorm_bwd(_c(dy).reshape(x3.shape), x3, g.data if g is not None else None, mean, rstd, ctx.groups,
+                             _grad(g) if g is not None and g.requires_grad else None,
+                             _grad(b) if b is not None and b.requires_grad else None)
+        dist.grads_ready(g, b)
+        return dx.reshape(dy.shape), None, None, None, None
+
+
+def group_norm(x, gamma, beta, groups, eps):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _GroupNormFn.apply(x, gamma, beta, int(groups), float(eps))
+
+
+class _RMSNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, scale, eps):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        y, rstd = K.rmsnorm_fwd(x2, scale.data, eps)
+        ctx.scale = scale
+        ctx.save_for_backward(x2, rstd)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, rstd = ctx.saved_tensors
+        dx = K.rmsnorm_bwd(_c(dy).reshape(x2.shape), x2, ctx.scale.data, rstd, _grad(ctx.scale))
+        dist.grads_ready(ctx.scale)
+        return dx.reshape(dy.shape), None, None
+
+
+def rms_norm(x, scale, eps):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _RMSNormFn.apply(x, scale, float(eps))
+
+
+class _Pool2dFn(Function):
+    @staticmethod
+    def forward(ctx, x, geom, mode):
+        xc = _c(x)
+        kh, kw, sh, sw, pt, pl, Ho, Wo = geom
+        ctx.geom, ctx.mode = geom, mode
+        ctx.save_for_backward(xc)
+        return K.pool2d_fwd(xc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        kh, kw, sh, sw, pt, pl, _, _ = ctx.geom
+        return K.pool2d_bwd(xc, _c(dy), kh, kw, sh, sw, pt, pl, ctx.mode), None, None
+
+
+def _pool(x, pool_size, strides, padding, mode):
+    kh, kw = (pool_size, pool_size) if isinstance(pool_size, int) else tuple(pool_size)
+    if strides is None:
+        strides = (kh, kw)
+    sh, sw = (strides, strides) if isinstance(strides, int) else tuple(strides)
+    Ho, Wo, pt, pl = _conv_geometry(x.shape[1], x.shape[2], kh, kw, (sh, sw), (1, 1), padding.lower())
+    if nn.dry_run():
+        return _dry((x.shape[0], Ho, Wo, x.shape[3]), x)
+    return _Pool2dFn.apply(x, (kh, kw, sh, sw, pt, pl, Ho, Wo), mode)
+
+
+def max_pool2d(x, pool_size, strides=None, padding="same"):
+    """keras.layers.MaxPooling2D / tf.nn.max_pool2d"""
+    return _pool(x, pool_size, strides, padding, K.POOL_MAX)
+
+
+def avg_pool2d(x, pool_size, strides=None, padding="same"):
+    """tf.nn.avg_pool2d: padded cells do not count in the divisor"""
+    return _pool(x, pool_size, strides, padding, K.POOL_AVG)

@@ -436,3 +436,86 @@ def argmax_confusion(logits2d, labels1d, ignore_label, cm=None, want_pred=False)
     pred = torch.empty(P, dtype=torch.int32, device=logits2d.device) if want_pred else None
     _hip.call("iseg_argmax_confusion", ptr(logits2d), ptr(labels1d), P, Cc, ignore_label, ptr(pred), ptr(cm), stream())
     return pred
+
+
+# ---------------------------------------------------------------------------------------------------------
+# replace_nan_or_inf, GroupNorm, RMSNorm, pooling (csrc/misc.hip)
+# ---------------------------------------------------------------------------------------------------------
+def replace_nan_or_inf(x, nan_value=0.0):
+    _require_cuda(x)
+    y = torch.empty_like(x)
+    ws, wsb = workspace(8, x.device)
+    _hip.check(_hip.lib().iseg_replace_nan_or_inf(ptr(x), ptr(y), x.numel(), float(nan_value), dt(x), ptr(ws), wsb, stream()),
+               "iseg_replace_nan_or_inf")
+    return y
+
+
+def replace_nan_or_inf_bwd(x, dy):
+    _require_cuda(x, dy)
+    dx = torch.empty_like(dy)
+    _hip.check(_hip.lib().iseg_replace_nan_or_inf_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), dt(x), stream()), "iseg_replace_nan_or_inf_bwd")
+    return dx
+
+
+def groupnorm_fwd(x3d, gamma, beta, groups, eps):
+    """x3d [N, HW, C] contiguous -> y, mean [N*G], rstd [N*G]"""
+    _require_cuda(x3d)
+    N, HW, Cc = x3d.shape
+    y = torch.empty_like(x3d)
+    mean = torch.empty(N * groups, dtype=torch.float32, device=x3d.device)
+    rstd = torch.empty_like(mean)
+    _hip.check(_hip.lib().iseg_groupnorm_fwd(ptr(x3d), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), N, HW, Cc, groups, float(eps),
+                                            dt(x3d), stream()), "iseg_groupnorm_fwd")
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy3d, x3d, gamma, mean, rstd, groups, dgamma, dbeta, accumulate=True):
+    _require_cuda(dy3d, x3d)
+    N, HW, Cc = x3d.shape
+    dx = torch.empty_like(x3d)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_groupnorm_bwd_workspace_bytes(N, Cc), x3d.device)
+    _hip.check(L.iseg_groupnorm_bwd(ptr(dy3d), ptr(x3d), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate),
+                                    N, HW, Cc, groups, dt(x3d), ptr(ws), wsb, stream()), "iseg_groupnorm_bwd")
+    return dx
+
+
+def rmsnorm_fwd(x2d, scale, eps):
+    _require_cuda(x2d)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _hip.check(_hip.lib().iseg_rmsnorm_fwd(ptr(x2d), ptr(scale), ptr(y), ptr(rstd), rows, Cc, float(eps), dt(x2d), stream()), "iseg_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy2d, x2d, scale, rstd, dscale, accumulate=True):
+    _require_cuda(dy2d, x2d)
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_rmsnorm_bwd_workspace_bytes(rows, Cc), x2d.device)
+    _hip.check(L.iseg_rmsnorm_bwd(ptr(dy2d), ptr(x2d), ptr(scale), ptr(rstd), ptr(dx), ptr(dscale), int(accumulate), rows, Cc, dt(x2d),
+                                  ptr(ws), wsb, stream()), "iseg_rmsnorm_bwd")
+    return dx
+
+
+POOL_MAX, POOL_AVG = 0, 1
+
+
+def pool2d_fwd(x, kh, kw, sh, sw, pt, pl, Ho, Wo, mode):
+    _require_cuda(x)
+    N, H, W, Cc = x.shape
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _hip.check(_hip.lib().iseg_pool2d_fwd(ptr(x), ptr(y), N, H, W, Cc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode, dt(x), stream()), "iseg_pool2d_fwd")
+    return y
+
+
+def pool2d_bwd(x, dy, kh, kw, sh, sw, pt, pl, mode):
+    _require_cuda(x, dy)
+    N, H, W, Cc = x.shape
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    dx = torch.empty_like(x)
+    _hip.check(_hip.lib().iseg_pool2d_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode, dt(x), stream()),
+               "iseg_pool2d_bwd")
+    return dx

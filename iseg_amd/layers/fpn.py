@@ -1,0 +1,34 @@
+"""layers/fpn.py of the reference (:16-61): top-down pathway.  The coarsest map is used raw; every finer level is
+`ConvNormAct(1x1)(replace_nan_or_inf(f_i))` plus the bilinearly up-sampled running map.  Returns all levels, fine -> coarse."""
+import torch
+
+from .. import functional as F
+from ..nn import Layer
+from ..utils.common import resize_image
+from .model_builder import ConvNormAct
+
+
+class FeaturePyramidNetwork(Layer):
+    def __init__(self, skip_conv_filters=256, trainable=True, name=None):
+        super().__init__(name=name, trainable=trainable)
+        self.skip_conv_filters = skip_conv_filters
+
+    def build(self, input_shape):
+        feature_map_shapes = input_shape
+        convs = [ConvNormAct(self.skip_conv_filters, name=f"{self.name}/skip_conv_filters{i}")
+                 for i in range(len(feature_map_shapes) - 1)]
+        self.skip_convs = torch.nn.ModuleList(convs)
+        self.built = True
+
+    def call(self, inputs, training=None):
+        feature_map_list = list(inputs)
+        x = feature_map_list[-1]
+        result_endpoints = [x]
+        for i in range(len(self.skip_convs) - 1, -1, -1):
+            skip_feature = F.replace_nan_or_inf(feature_map_list[i], 0.0)
+            skip_feature = self.skip_convs[i](skip_feature, training=training)
+            x = resize_image(x, size=skip_feature.shape[1:3])
+            x = F.add(x, skip_feature)
+            result_endpoints.append(x)
+        result_endpoints.reverse()
+        return result_endpoints

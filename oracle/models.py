@@ -97,3 +97,24 @@ def convnext_aspp_forward(w, x, training=False, output_stride=32, dp_factors=Non
 def mean_ce_loss(logits, labels, num_class=21, ignore_label=255, class_weights=None):
     """Keras: mean over ALL positions of the NONE-reduced weighted loss"""
     return O.softmax_ce_ignore(labels, logits, num_class, ignore_label, class_weights).mean()
+
+
+# ------------------------------------------------------------------------------------------------------
+# layers/fpn.py:16-61 FeaturePyramidNetwork, layers/simpledecoder.py:8-36 SimpleDecoder
+# ------------------------------------------------------------------------------------------------------
+def fpn(w, prefix, feats, training, new_stats=None):
+    x = feats[-1]
+    outs = [x]
+    for i in range(len(feats) - 2, -1, -1):
+        skip = conv_norm_act(w, f"{prefix}/skip_conv_filters{i}", O.replace_nan_or_inf(feats[i], 0.0), training, new_stats=new_stats)
+        x = O.resize_bilinear(x, skip.shape[1:3]) + skip
+        outs.append(x)
+    outs.reverse()
+    return outs
+
+
+def simple_decoder(w, prefix, low, high, training, new_stats=None):
+    low = conv_norm_act(w, f"{prefix}/low_level_entry_conv", low, training, new_stats=new_stats)
+    x = torch.cat([low, O.resize_bilinear(high, low.shape[1:3])], dim=-1)
+    x = conv_norm_act(w, f"{prefix}/finetune_conv0", x, training, new_stats=new_stats)
+    return conv_norm_act(w, f"{prefix}/finetune_conv1", x, training, new_stats=new_stats)

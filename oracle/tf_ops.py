@@ -250,3 +250,64 @@ def sliding_start_indexs(length, crop):
     if length - (times - 1) * stride > crop:
         idx.append(length - crop)
     return idx
+
+
+# ------------------------------------------------------------------------------------------------------
+# utils/op_utils.py:43-60  replace_nan / replace_inf / replace_nan_or_inf   (layers/fpn.py:52)
+# ------------------------------------------------------------------------------------------------------
+def replace_nan_or_inf(x, nan_value=0.0):
+    """tf.where(is_nan(x), value, x) then tf.clip_by_value(x, min, max) with min / max taken over the tensor whose +-inf
+    entries were replaced by 0.  The clip bounds are treated as constants for the gradient (they only move when an inf
+    is present)."""
+    x = torch.where(torch.isnan(x), torch.full_like(x, nan_value), x)
+    fin = torch.where(torch.isinf(x), torch.zeros_like(x), x).detach()
+    return torch.clamp(x, min=fin.min().item(), max=fin.max().item())   # gradient passes wherever min <= x <= max (tf.clip_by_value)
+
+
+# ------------------------------------------------------------------------------------------------------
+# layers/groupnorm.py:148-207 GroupNormalization, layers/rmsnorm.py:22-29 RMSNormalization
+# ------------------------------------------------------------------------------------------------------
+def group_norm(x, gamma, beta, groups, eps=1e-3):
+    """reshape [N,H,W,G,C/G]; tf.nn.moments over (H, W, C/G) (biased variance); tf.nn.batch_normalization."""
+    N, H, W, C = x.shape
+    xg = x.reshape(N, H, W, groups, C // groups)
+    mean = xg.mean(dim=(1, 2, 4), keepdim=True)
+    var = ((xg - mean) ** 2).mean(dim=(1, 2, 4), keepdim=True)
+    y = ((xg - mean) * torch.rsqrt(var + eps)).reshape(N, H, W, C)
+    if gamma is not None:
+        y = y * gamma
+    if beta is not None:
+        y = y + beta
+    return y
+
+
+def rms_norm(x, scale, eps=1e-6):
+    var = (x * x).mean(dim=-1, keepdim=True)
+    return x * (1.0 / torch.sqrt(var + eps)) * (1.0 + scale)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pooling with padding="SAME": keras MaxPooling2D (backbones/resnet_common.py:215-217), tf.nn.avg_pool2d
+# (backbones/resnet_blocks.py:182-186; padded cells are excluded from the divisor)
+# ------------------------------------------------------------------------------------------------------
+def _pool_same_pads(H, W, k, s):
+    kh, kw = _pair(k)
+    sh, sw = _pair(s)
+    _, pt, pb = same_pad(H, kh, sh)
+    _, pl, pr = same_pad(W, kw, sw)
+    return (kh, kw), (sh, sw), (pl, pr, pt, pb)
+
+
+def max_pool_same(x, k, s):
+    (kh, kw), (sh, sw), pads = _pool_same_pads(x.shape[1], x.shape[2], k, s)
+    xp = F.pad(x.permute(0, 3, 1, 2), pads, value=float("-inf"))
+    return F.max_pool2d(xp, (kh, kw), (sh, sw)).permute(0, 2, 3, 1)
+
+
+def avg_pool_same(x, k, s):
+    (kh, kw), (sh, sw), pads = _pool_same_pads(x.shape[1], x.shape[2], k, s)
+    xp = F.pad(x.permute(0, 3, 1, 2), pads)
+    ones = F.pad(torch.ones_like(x[:1, :, :, :1]).permute(0, 3, 1, 2), pads)
+    tot = F.avg_pool2d(xp, (kh, kw), (sh, sw), divisor_override=1)
+    cnt = F.avg_pool2d(ones, (kh, kw), (sh, sw), divisor_override=1)
+    return (tot / cnt).permute(0, 2, 3, 1)

@@ -144,3 +144,33 @@ def test_batchnorm_sync_stats_equal_global_batch():
 def test_argmax_first_on_ties():
     z = torch.tensor([[1.0, 3.0, 3.0, 2.0], [5.0, 5.0, 5.0, 5.0]])
     assert O.argmax_first(z).tolist() == [1, 0]
+
+
+def test_group_norm_matches_torch_second_opinion():
+    import torch.nn.functional as TF
+
+    x = torch.randn(2, 5, 4, 12, dtype=torch.float64)
+    g, b = torch.rand(12, dtype=torch.float64) + 0.5, torch.randn(12, dtype=torch.float64)
+    want = TF.group_norm(x.permute(0, 3, 1, 2), 3, g, b, eps=1e-3).permute(0, 2, 3, 1)
+    assert torch.allclose(O.group_norm(x, g, b, 3, 1e-3), want, atol=1e-12)
+
+
+def test_rms_norm_closed_form():
+    x = torch.tensor([[3.0, 4.0]], dtype=torch.float64)          # mean square 12.5
+    y = O.rms_norm(x, torch.tensor([0.0, 1.0], dtype=torch.float64), eps=0.0)
+    assert torch.allclose(y, torch.tensor([[3 / 12.5 ** 0.5, 8 / 12.5 ** 0.5]], dtype=torch.float64))
+
+
+def test_same_pooling_edges():
+    # 5 wide, k=2, s=2, SAME: out 3, pad (0, 1): the last window holds one valid cell -> average = that cell
+    x = torch.arange(25, dtype=torch.float64).reshape(1, 5, 5, 1)
+    a = O.avg_pool_same(x, 2, 2)[0, :, :, 0]
+    assert a[2, 2].item() == 24.0 and a[0, 2].item() == (4 + 9) / 2 and a[0, 0].item() == (0 + 1 + 5 + 6) / 4
+    # 3x3/s2 SAME on 4 wide: out 2, pad (0, 1); padding never wins the max even for negative inputs
+    m = O.max_pool_same(-x[:, :4, :4], 3, 2)[0, :, :, 0]
+    assert m[1, 1].item() == -12.0 and m[0, 0].item() == 0.0
+
+
+def test_replace_nan_or_inf_semantics():
+    x = torch.tensor([1.0, float("nan"), float("inf"), -2.0, float("-inf")], dtype=torch.float64)
+    assert O.replace_nan_or_inf(x, 0.0).tolist() == [1.0, 0.0, 1.0, -2.0, -2.0]
