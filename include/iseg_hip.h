@@ -265,6 +265,8 @@ int iseg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const fl
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_pool2d_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t, int pad_l,
                     int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
+/* relu(a + b), n % 8 == 0: residual join of backbones/resnet_blocks.py:106-107,202-203 */
+int iseg_add_relu(const void* a, const void* b, void* y, int64_t n, int dtype, iseg_stream_t stream);
 int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t,
                     int pad_l, int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
 

@@ -89,6 +89,7 @@ SIGNATURES = {
     "iseg_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_rmsnorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "iseg_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_add_relu": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_pool2d_fwd": (_i, [_p, _p] + [_i] * 14 + [_p]),
     "iseg_pool2d_bwd": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),
     "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

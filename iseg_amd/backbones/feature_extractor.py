@@ -6,6 +6,7 @@ from .. import nn
 from .. import static_strings as ss
 from .backbone_registry import backbone_registry_dict
 from .convnext import build_dilated_convnext, convnext_large, convnext_tiny, convnext_xlarge, convnext_xxlarge
+from .resnet_common import apply_multi_grid, build_atrous_resnet, resnet50, resnet101, resnet152
 
 
 def _builtin_backbones():
@@ -14,6 +15,11 @@ def _builtin_backbones():
         ss.CONVNEXT_LARGE: convnext_large,
         ss.CONVNEXT_XLARGE: convnext_xlarge,
         ss.CONVNEXT_XXLARGE: convnext_xxlarge,
+        ss.RESNET50: resnet50,
+        ss.RESNET52: resnet50,
+        ss.RESNET101: resnet101,
+        ss.RESNET103: resnet101,
+        ss.RESNET152: resnet152,
     }
     try:   # families added in later rounds register themselves here
         from .swin import swin_base_384, swin_large_384, swin_tiny_224
@@ -29,6 +35,9 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
                  efficientnet_use_top=True, moat_use_pos_encoding=False):
     name = name.lower()
     general_kwargs = {"return_endpoints": return_endpoints}
+    if ss.RESNET in name:      # :58-66
+        general_kwargs.update({"use_bias": False, "replace_7x7_conv": True, "slim_behaviour": resnet_slim,
+                               "custom_block": custom_resblock})
     backbone_dicts = _builtin_backbones()
     backbone_dicts.update(backbone_registry_dict)
     if name not in backbone_dicts:
@@ -37,7 +46,10 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
         backbone = custom_backbone_fn(**general_kwargs)
     else:
         backbone = backbone_dicts[name](**general_kwargs)
-    if ss.CONVNEXT in name:
+    if ss.RESNET in name:
+        build_atrous_resnet(backbone, output_stride=output_stride)
+        apply_multi_grid(backbone, block_index=-1, grids=resnet_multi_grids)
+    elif ss.CONVNEXT in name:
         build_dilated_convnext(backbone, output_stride=output_stride)
     # build by shape propagation (the reference runs backbone(tf.ones(image_shape)), :153-164)
     with nn.dry_run_scope():

@@ -310,6 +310,19 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const T* __restrict__ x
     }
 }
 
+// residual join of the ResNet bottleneck: relu(a + b)   (backbones/resnet_blocks.py:106-107,202-203)
+template <class T>
+__global__ __launch_bounds__(256) void add_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n8) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float u[8], v[8];
+        load8<T>(a + i * 8, u);
+        load8<T>(b + i * 8, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = fmaxf(u[k] + v[k], 0.f);
+        store8<T>(y + i * 8, u);
+    }
+}
+
 static inline unsigned ew_blocks(int64_t n) {
     int64_t b = ceil_div64(n, 256);
     if (b > 256 * 16) b = 256 * 16;
@@ -458,4 +471,15 @@ extern "C" int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, i
         hipLaunchKernelGGL((pool2d_bwd_kernel<float>), dim3(ew_blocks(total)), dim3(256), 0, stream, (const float*)x, (const float*)dy,
                            (float*)dx, N, H, W, C, kh, kw, sh, sw, pad_t, pad_l, Ho, Wo, mode);
     return iseg_check_launch("iseg_pool2d_bwd");
+}
+
+extern "C" int iseg_add_relu(const void* a, const void* b, void* y, int64_t n, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "iseg_add_relu: n=%lld must be a positive multiple of 8", (long long)n);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((add_relu_kernel<bf16_t>), dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
+                           (bf16_t*)y, n / 8);
+    else
+        hipLaunchKernelGGL((add_relu_kernel<float>), dim3(ew_blocks(n / 8)), dim3(256), 0, stream, (const float*)a, (const float*)b,
+                           (float*)y, n / 8);
+    return iseg_check_launch("iseg_add_relu");
 }

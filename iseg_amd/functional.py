@@ -118,6 +118,10 @@ def _conv_geometry(H, W, kh, kw, strides, dilation, padding):
         Ho = (H - (kh - 1) * dh - 1) // sh + 1
         Wo = (W - (kw - 1) * dw - 1) // sw + 1
         pt = pl = 0
+    elif isinstance(padding, tuple):          # ((top, bottom), (left, right)): ZeroPadding2D followed by a "valid" window op
+        (pt, pb), (pl, pr) = padding
+        Ho = (H + pt + pb - (kh - 1) * dh - 1) // sh + 1
+        Wo = (W + pl + pr - (kw - 1) * dw - 1) // sw + 1
     else:
         raise ValueError(f"padding {padding!r} not supported")
     return Ho, Wo, pt, pl
@@ -804,7 +808,8 @@ def _pool(x, pool_size, strides, padding, mode):
     if strides is None:
         strides = (kh, kw)
     sh, sw = (strides, strides) if isinstance(strides, int) else tuple(strides)
-    Ho, Wo, pt, pl = _conv_geometry(x.shape[1], x.shape[2], kh, kw, (sh, sw), (1, 1), padding.lower())
+    Ho, Wo, pt, pl = _conv_geometry(x.shape[1], x.shape[2], kh, kw, (sh, sw), (1, 1),
+                                    padding.lower() if isinstance(padding, str) else padding)
     if nn.dry_run():
         return _dry((x.shape[0], Ho, Wo, x.shape[3]), x)
     return _Pool2dFn.apply(x, (kh, kw, sh, sw, pt, pl, Ho, Wo), mode)
@@ -818,3 +823,26 @@ def max_pool2d(x, pool_size, strides=None, padding="same"):
 def avg_pool2d(x, pool_size, strides=None, padding="same"):
     """tf.nn.avg_pool2d: padded cells do not count in the divisor"""
     return _pool(x, pool_size, strides, padding, K.POOL_AVG)
+
+
+class _AddReluFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        y = K.add_relu(_c(a), _c(b))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        d = K.act_bwd(_c(dy), y, K.ACT_RELU)
+        return d, d
+
+
+def add_relu(a, b):
+    """tf.nn.relu(tf.add(a, b))"""
+    if nn.dry_run():
+        return _dry(a.shape, a)
+    if a.numel() % 8 != 0:
+        return relu(add(a, b))
+    return _AddReluFn.apply(a, b)

@@ -519,3 +519,10 @@ def pool2d_bwd(x, dy, kh, kw, sh, sw, pt, pl, mode):
     _hip.check(_hip.lib().iseg_pool2d_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode, dt(x), stream()),
                "iseg_pool2d_bwd")
     return dx
+
+
+def add_relu(a, b):
+    _require_cuda(a, b)
+    y = torch.empty_like(a)
+    _hip.check(_hip.lib().iseg_add_relu(ptr(a), ptr(b), ptr(y), a.numel(), dt(a), stream()), "iseg_add_relu")
+    return y

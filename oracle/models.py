@@ -118,3 +118,78 @@ def simple_decoder(w, prefix, low, high, training, new_stats=None):
     x = torch.cat([low, O.resize_bilinear(high, low.shape[1:3])], dim=-1)
     x = conv_norm_act(w, f"{prefix}/finetune_conv0", x, training, new_stats=new_stats)
     return conv_norm_act(w, f"{prefix}/finetune_conv1", x, training, new_stats=new_stats)
+
+
+# ------------------------------------------------------------------------------------------------------
+# ResNet "slim/beta" as get_backbone builds it (feature_extractor.py:58-66,139-141; resnet_common.py:94-184,245-345,
+# 523-598; resnet_blocks.py:111-205): 3x3 deep stem, max-pool 3x3/s2 SAME, Stack2 (stride in the LAST block of stacks
+# 0..2), BlockType2 bottleneck with average-pooled identity shortcut, atrous surgery + multi-grid on the last stack.
+# ------------------------------------------------------------------------------------------------------
+def _bn(w, prefix, y, training, eps, momentum=0.9, new_stats=None):
+    g, b = w[f"{prefix}/gamma"], w[f"{prefix}/beta"]
+    if training:
+        y, mean, var = O.batch_norm_train(y, g, b, eps)
+        if new_stats is not None:
+            new_stats[f"{prefix}/moving_mean"] = O.moving_update(w[f"{prefix}/moving_mean"], mean.detach(), momentum)
+            new_stats[f"{prefix}/moving_variance"] = O.moving_update(w[f"{prefix}/moving_variance"], var.detach(), momentum)
+        return y
+    return O.batch_norm_infer(y, g, b, w[f"{prefix}/moving_mean"], w[f"{prefix}/moving_variance"], eps)
+
+
+def resnet_plan(num_of_blocks=(3, 4, 6, 3), output_stride=32, multi_grids=(1, 2, 4)):
+    """per stack, per block: (stride, dilation, conv_shortcut) after build_atrous_resnet + apply_multi_grid(block_index=-1)"""
+    plan = []
+    for si, nb in enumerate(num_of_blocks):
+        stride1 = [2, 2, 2, 1][si]
+        blocks = []
+        for bi in range(nb):
+            last = bi == nb - 1
+            blocks.append([stride1 if last else 1, 1, bi == 0])
+        plan.append(blocks)
+    current_os, rate = 4, 1
+    for blocks in plan:
+        for blk in blocks:
+            if blk[0] > 1:
+                if current_os >= output_stride:
+                    rate *= 2
+                    blk[0] = 1
+                    blk[1] = blk[1] * rate
+                else:
+                    current_os *= 2
+            else:
+                blk[1] = blk[1] * rate
+    for bi, blk in enumerate(plan[-1]):
+        blk[1] = blk[1] * multi_grids[bi]
+    return plan
+
+
+def resnet_block2(w, name, x, stride, dilation, conv_shortcut, training, eps=1.001e-5, new_stats=None):
+    shortcut = x
+    if conv_shortcut:
+        shortcut = _bn(w, f"{name}_0_bn", O.conv2d(x, w[f"{name}_0_conv/kernel"], None, stride, 1, "valid"), training, eps,
+                       new_stats=new_stats)
+    if stride > 1:
+        shortcut = O.avg_pool_same(shortcut, stride, stride)
+    y = torch.relu(_bn(w, f"{name}_1_bn", O.conv2d(x, w[f"{name}_1_conv/kernel"], None, 1, 1, "valid"), training, eps, new_stats=new_stats))
+    y = torch.relu(_bn(w, f"{name}_2_bn", O.conv2d(y, w[f"{name}_2_conv/kernel"], None, stride, dilation, "same"), training, eps,
+                       new_stats=new_stats))
+    y = _bn(w, f"{name}_3_bn", O.conv2d(y, w[f"{name}_3_conv/kernel"], None, 1, 1, "valid"), training, eps, new_stats=new_stats)
+    return torch.relu(shortcut + y)
+
+
+def resnet_forward(w, x, num_of_blocks=(3, 4, 6, 3), output_stride=32, multi_grids=(1, 2, 4), training=False, new_stats=None):
+    eps = 1.001e-5
+    for i, s in ((1, 2), (2, 1), (3, 1)):
+        x = torch.relu(_bn(w, f"conv1_{i}_bn", O.conv2d(x, w[f"conv1_{i}_conv/kernel"], None, s, 1, "same"), training, eps,
+                           new_stats=new_stats))
+    endpoints = [x]
+    x = O.max_pool_same(x, 3, 1 if output_stride == 2 else 2)
+    plan = resnet_plan(num_of_blocks, output_stride, multi_grids)
+    for si, blocks in enumerate(plan):
+        emits = [2, 2, 2, 1][si] > 1          # Stack2.output_endpoint is fixed at construction (stride1 > 1)
+        for bi, (stride, dil, conv_sc) in enumerate(blocks):
+            if bi == len(blocks) - 1 and emits:
+                endpoints.append(x)           # value before the (possibly removed) stride
+            x = resnet_block2(w, f"conv{si + 2}_block{bi + 1}", x, stride, dil, conv_sc, training, eps, new_stats)
+    endpoints.append(x)
+    return endpoints
