@@ -68,7 +68,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 def _gemm_group_model(key):
     """algorithmic flops and HBM bytes of one launch of a timed GEMM group (operands read once, outputs written once)"""
-    _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux, adt, ddt, split = key
+    _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux, adt, ddt, split = key[:13]
     ea = 2 if adt == torch.bfloat16 else 4
     ed = 2 if ddt == torch.bfloat16 else 4
     nbytes = (M * K + K * N) * ea + M * N * ed * (1 + int(has_pre)) + M * N * ed * (int(has_res) + int(has_aux))
@@ -81,7 +81,7 @@ def roofline_from_timer(report, steps, survey=None):
     best = max(report.items(), key=lambda kv: kv[1][0] * kv[1][1])
     key, (sec, launches) = best
     flops, nbytes = _gemm_group_model(key)
-    _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux, adt, ddt, split = key
+    _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux, adt, ddt, split = key[:13]
     orient = {(1, 0): "forward x[M,K] @ kernel[K,N]", (1, 1): "dgrad dy[M,K] @ kernel[N,K]^T", (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
     intensity = flops / nbytes
     ridge = MFMA_BF16_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)

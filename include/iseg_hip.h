@@ -97,6 +97,11 @@ typedef struct iseg_gemm_args {
     int colsum_accumulate;
     int defer_reduce; /* 1: a split-K problem only writes its slabs; the caller finishes with iseg_gemm_reduce (lets the two
                          kernels be timed / scheduled separately) */
+    /* strided batch (attention: one problem per (sample, head)); batch <= 1 = a single problem.  Problem z reads/writes at
+       X + (z / batch_inner) * sX_outer + (z % batch_inner) * sX_inner (elements).  Batched problems take only the
+       alpha / accumulate epilogue and are never split along K. */
+    int batch, batch_inner;
+    int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
@@ -269,6 +274,31 @@ int iseg_pool2d_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, 
 int iseg_add_relu(const void* a, const void* b, void* y, int64_t n, int dtype, iseg_stream_t stream);
 int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t,
                     int pad_l, int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Attention pieces around the strided-batch GEMMs (iseg_gemm with batch > 1):
+ *   softmax over keys of scores [problems, Tq, ld] (cols valid, pad columns written as 0) with the additive terms of
+ *   backbones/swin.py:131-158 -- bias [heads,Tq,cols] fp32 (problem z uses head z % heads) and shift mask [windows,Tq,cols]
+ *   fp32 (window (z / heads) % windows) -- and the optional probability clip of layers/multihead_self_attention.py:138
+ *   (clip_hi > clip_lo enables it).  Backward: dS = P * (g - sum_j g_j P_j), g = dP where the clip passed.
+ *   Keras MultiHeadAttention (backbones/vit.py:142-147) uses the same kernels without bias / mask / clip.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_softmax_rows_fwd(const void* scores, void* probs, int64_t problems, int Tq, int cols, int ld, const float* bias, int heads,
+                          const float* mask, int windows, float clip_lo, float clip_hi, int dtype, iseg_stream_t stream);
+int iseg_softmax_rows_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int cols, int ld, float clip_lo,
+                          float clip_hi, int dtype, iseg_stream_t stream);
+/* tf.clip_by_value and its gradient (passes where lo <= x <= hi) */
+int iseg_clip_fwd(const void* x, void* y, int64_t n, float lo, float hi, int dtype, iseg_stream_t stream);
+int iseg_clip_bwd(const void* x, const void* dy, void* dx, int64_t n, float lo, float hi, int dtype, iseg_stream_t stream);
+/* y[r,:] = idx[r] >= 0 ? x[idx[r],:] : 0 -- tf.pad / tf.roll / window_partition / window_reverse / crop of
+ * backbones/swin.py:46-64,258-288 and PatchMerging's 2x2 space-to-depth (:316-327) as one row permutation each */
+int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int64_t rows_in, int64_t rows_out, int C, int dtype,
+                     iseg_stream_t stream);
+/* backbones/swin.py:134-142: bias[h,i,j] = table[index[i,j], h]; gradient dtable[k,h] (+)= sum_{index[i,j]==k} dbias[h,i,j]
+ * (dbias rows have stride ld) */
+int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bias, int heads, int TT, iseg_stream_t stream);
+int iseg_relpos_bias_scatter_grad(const float* dbias, int ld, const int32_t* index, float* dtable, int entries, int heads, int T,
+                                  int accumulate, iseg_stream_t stream);
 
 #ifdef __cplusplus
 }

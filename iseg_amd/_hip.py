@@ -35,6 +35,9 @@ class GemmArgs(C.Structure):
         ("pre_out", C.c_void_p), ("ldp", C.c_int64),
         ("act", C.c_int), ("alpha", C.c_float), ("accumulate", C.c_int), ("split_k", C.c_int), ("a_act", C.c_int),
         ("colsum_out", C.c_void_p), ("colsum_accumulate", C.c_int), ("defer_reduce", C.c_int),
+        ("batch", C.c_int), ("batch_inner", C.c_int),
+        ("sa_outer", C.c_int64), ("sa_inner", C.c_int64), ("sb_outer", C.c_int64), ("sb_inner", C.c_int64),
+        ("sd_outer", C.c_int64), ("sd_inner", C.c_int64),
     ]
 
 
@@ -89,6 +92,13 @@ SIGNATURES = {
     "iseg_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_rmsnorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "iseg_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_softmax_rows_fwd": (_i, [_p, _p, _l, _i, _i, _i, _p, _i, _p, _i, _f, _f, _i, _p]),
+    "iseg_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _i, _p]),
+    "iseg_clip_fwd": (_i, [_p, _p, _l, _f, _f, _i, _p]),
+    "iseg_clip_bwd": (_i, [_p, _p, _p, _l, _f, _f, _i, _p]),
+    "iseg_gather_rows": (_i, [_p, _p, _p, _l, _l, _i, _i, _p]),
+    "iseg_relpos_bias_gather": (_i, [_p, _p, _p, _i, _i, _p]),
+    "iseg_relpos_bias_scatter_grad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "iseg_add_relu": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_pool2d_fwd": (_i, [_p, _p] + [_i] * 14 + [_p]),
     "iseg_pool2d_bwd": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),

@@ -21,12 +21,11 @@ def _builtin_backbones():
         ss.RESNET103: resnet101,
         ss.RESNET152: resnet152,
     }
-    try:   # families added in later rounds register themselves here
-        from .swin import swin_base_384, swin_large_384, swin_tiny_224
+    from .swin import swin_base_384, swin_large_384, swin_tiny_224
+    from .vit import ViT16B, ViT16L
 
-        d.update({ss.SWIN_TINY_224: swin_tiny_224, ss.SWIN_BASE_384: swin_base_384, ss.SWIN_LARGE_384: swin_large_384})
-    except ImportError:
-        pass
+    d.update({ss.SWIN_TINY_224: swin_tiny_224, ss.SWIN_BASE_384: swin_base_384, ss.SWIN_LARGE_384: swin_large_384,
+              ss.VIT_B: ViT16B, ss.VIT_L: ViT16L})
     return d
 
 

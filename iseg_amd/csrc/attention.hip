@@ -1,0 +1,253 @@
+// Attention support kernels.  The score / context products are strided-batch GEMMs (gemm.hip, one problem per (sample, head));
+// this file holds what sits between them and around them:
+//   * row softmax over keys with the additive terms of backbones/swin.py:131-158 (relative-position bias [heads,T,T], shift
+//     mask [nW,T,T]) and the probability clip of layers/multihead_self_attention.py:138, forward and backward
+//   * tf.clip_by_value forward / backward (used when dropout sits between softmax and clip)
+//   * row gather with an int32 index (-1 = zero row): tf.pad + tf.roll + window_partition / window_reverse + crop of
+//     backbones/swin.py:46-64,258-288 and the 2x2 space-to-depth of PatchMerging (:316-327) are all row permutations
+//   * relative-position bias table gather (swin.py:134-142) and its gradient
+#include "common.h"
+#include "iseg_hip.h"
+
+#include <float.h>
+
+namespace {
+
+// one wave per row; `cols` valid entries, row stride `ld` (>= cols, pad columns are written as zeros)
+template <class T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const T* __restrict__ s, T* __restrict__ p, int64_t rows, int Tq, int cols,
+                                                          int ld, const float* __restrict__ bias, int heads,
+                                                          const float* __restrict__ mask, int nW, float clip_lo, float clip_hi) {
+    const int lane = threadIdx.x & 63;
+    const bool clip = clip_hi > clip_lo;
+    for (int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t z = r / Tq;
+        const int i = (int)(r % Tq);
+        const T* sr = s + r * ld;
+        T* pr = p + r * ld;
+        const float* br = bias ? bias + ((int64_t)(z % heads) * Tq + i) * cols : nullptr;
+        const float* mr = mask ? mask + ((int64_t)((z / heads) % nW) * Tq + i) * cols : nullptr;
+        float mx = -FLT_MAX;
+        for (int j = lane; j < cols; j += 64) {
+            float v = to_f32(sr[j]);
+            if (br) v += br[j];
+            if (mr) v += mr[j];
+            mx = fmaxf(mx, v);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int j = lane; j < cols; j += 64) {
+            float v = to_f32(sr[j]);
+            if (br) v += br[j];
+            if (mr) v += mr[j];
+            sum += __expf(v - mx);
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < ld; j += 64) {
+            float out = 0.f;
+            if (j < cols) {
+                float v = to_f32(sr[j]);
+                if (br) v += br[j];
+                if (mr) v += mr[j];
+                out = __expf(v - mx) * inv;
+                if (clip) out = fminf(fmaxf(out, clip_lo), clip_hi);
+            }
+            pr[j] = from_f32<T>(out);
+        }
+    }
+}
+
+// dS = P * (g - sum_j g_j P_j), g = dP where the clip passed (lo < P < hi as stored), else 0.  In place on dP is allowed.
+template <class T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ p, const T* __restrict__ dp, T* __restrict__ ds,
+                                                          int64_t rows, int cols, int ld, float clip_lo, float clip_hi) {
+    const int lane = threadIdx.x & 63;
+    const bool clip = clip_hi > clip_lo;
+    for (int64_t r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const T* pr = p + r * ld;
+        const T* dr = dp + r * ld;
+        T* or_ = ds + r * ld;
+        float dot = 0.f;
+        for (int j = lane; j < cols; j += 64) {
+            const float pv = to_f32(pr[j]);
+            float g = to_f32(dr[j]);
+            if (clip && !(pv > clip_lo && pv < clip_hi)) g = 0.f;
+            dot = fmaf(g, pv, dot);
+        }
+        dot = wave_sum(dot);
+        for (int j = lane; j < ld; j += 64) {
+            float out = 0.f;
+            if (j < cols) {
+                const float pv = to_f32(pr[j]);
+                float g = to_f32(dr[j]);
+                if (clip && !(pv > clip_lo && pv < clip_hi)) g = 0.f;
+                out = pv * (g - dot);
+            }
+            or_[j] = from_f32<T>(out);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void clip_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float lo, float hi) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = from_f32<T>(fminf(fmaxf(to_f32(x[i]), lo), hi));
+}
+template <class T>
+__global__ __launch_bounds__(256) void clip_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int64_t n,
+                                                       float lo, float hi) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = to_f32(x[i]);
+        dx[i] = (v >= lo && v <= hi) ? dy[i] : from_f32<T>(0.f);
+    }
+}
+
+// y[r, :] = idx[r] >= 0 ? x[idx[r], :] : 0     (rows of C elements; 16-byte chunks when C*sizeof(T) % 16 == 0)
+template <class T, int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, const int32_t* __restrict__ idx, T* __restrict__ y,
+                                                          int64_t rows_out, int C) {
+    const int chunks = C / VEC;
+    const int64_t total = rows_out * chunks;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i % chunks) * VEC;
+        const int32_t src = idx[r];
+        if (VEC * sizeof(T) == 16) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) v = *reinterpret_cast<const float4*>(x + (int64_t)src * C + c);
+            *reinterpret_cast<float4*>(y + r * C + c) = v;
+        } else {
+#pragma unroll
+            for (int u = 0; u < VEC; ++u) y[r * C + c + u] = src >= 0 ? x[(int64_t)src * C + c + u] : from_f32<T>(0.f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ index,
+                                                            float* __restrict__ bias, int heads, int TT) {
+    const int total = heads * TT;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int h = i / TT, ij = i % TT;
+        bias[i] = table[(int64_t)index[ij] * heads + h];
+    }
+}
+
+// dtable[k, h] (+)= sum over (i,j) with index[i,j] == k of dbias[h, i, j]; one thread per table entry, fixed order
+__global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __restrict__ dbias, int ld, const int32_t* __restrict__ index,
+                                                             float* __restrict__ dtable, int entries, int heads, int T,
+                                                             int accumulate) {
+    const int total = entries * heads;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k = i / heads, h = i % heads;
+        float s = 0.f;
+        for (int a = 0; a < T; ++a)
+            for (int b = 0; b < T; ++b)
+                if (index[a * T + b] == k) s += dbias[((int64_t)h * T + a) * ld + b];
+        dtable[i] = accumulate ? dtable[i] + s : s;
+    }
+}
+
+static inline unsigned row_blocks(int64_t rows) {
+    int64_t b = ceil_div64(rows, 4);
+    if (b > 256 * 32) b = 256 * 32;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static inline unsigned ew_blocks(int64_t n) {
+    int64_t b = ceil_div64(n, 256);
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int iseg_softmax_rows_fwd(const void* scores, void* probs, int64_t problems, int Tq, int cols, int ld, const float* bias,
+                                     int heads, const float* mask, int windows, float clip_lo, float clip_hi, int dtype,
+                                     hipStream_t stream) {
+    ISEG_REQUIRE(scores && probs && problems > 0 && Tq > 0 && cols > 0 && ld >= cols, "iseg_softmax_rows_fwd: bad arguments");
+    ISEG_REQUIRE((!bias && !mask) || heads > 0, "iseg_softmax_rows_fwd: bias / mask need the head count");
+    ISEG_REQUIRE(!mask || windows > 0, "iseg_softmax_rows_fwd: mask needs the window count");
+    const int64_t rows = problems * Tq;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const bf16_t*)scores,
+                           (bf16_t*)probs, rows, Tq, cols, ld, bias, heads > 0 ? heads : 1, mask, windows > 0 ? windows : 1, clip_lo,
+                           clip_hi);
+    else
+        hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const float*)scores,
+                           (float*)probs, rows, Tq, cols, ld, bias, heads > 0 ? heads : 1, mask, windows > 0 ? windows : 1, clip_lo,
+                           clip_hi);
+    return iseg_check_launch("iseg_softmax_rows_fwd");
+}
+
+extern "C" int iseg_softmax_rows_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int cols, int ld, float clip_lo,
+                                     float clip_hi, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(probs && dprobs && dscores && rows > 0 && cols > 0 && ld >= cols, "iseg_softmax_rows_bwd: bad arguments");
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const bf16_t*)probs,
+                           (const bf16_t*)dprobs, (bf16_t*)dscores, rows, cols, ld, clip_lo, clip_hi);
+    else
+        hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const float*)probs,
+                           (const float*)dprobs, (float*)dscores, rows, cols, ld, clip_lo, clip_hi);
+    return iseg_check_launch("iseg_softmax_rows_bwd");
+}
+
+extern "C" int iseg_clip_fwd(const void* x, void* y, int64_t n, float lo, float hi, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && y && n > 0 && hi >= lo, "iseg_clip_fwd: bad arguments");
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((clip_fwd_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, lo, hi);
+    else
+        hipLaunchKernelGGL((clip_fwd_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const float*)x, (float*)y, n, lo, hi);
+    return iseg_check_launch("iseg_clip_fwd");
+}
+
+extern "C" int iseg_clip_bwd(const void* x, const void* dy, void* dx, int64_t n, float lo, float hi, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && dy && dx && n > 0 && hi >= lo, "iseg_clip_bwd: bad arguments");
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((clip_bwd_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
+                           (bf16_t*)dx, n, lo, hi);
+    else
+        hipLaunchKernelGGL((clip_bwd_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const float*)x, (const float*)dy,
+                           (float*)dx, n, lo, hi);
+    return iseg_check_launch("iseg_clip_bwd");
+}
+
+extern "C" int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int64_t rows_in, int64_t rows_out, int C, int dtype,
+                                hipStream_t stream) {
+    ISEG_REQUIRE(x && idx && y && rows_in > 0 && rows_out > 0 && C > 0, "iseg_gather_rows: bad arguments");
+    (void)rows_in;   // the caller guarantees idx[r] < rows_in (index tables are built on the host from static geometry)
+    const size_t es = dtype_size(dtype);
+    const bool vec = ((size_t)C * es) % 16 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+    if (dtype == ISEG_BF16) {
+        if (vec)
+            hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 8>), dim3(ew_blocks(rows_out * (C / 8))), dim3(256), 0, stream,
+                               (const bf16_t*)x, idx, (bf16_t*)y, rows_out, C);
+        else
+            hipLaunchKernelGGL((gather_rows_kernel<bf16_t, 1>), dim3(ew_blocks(rows_out * C)), dim3(256), 0, stream, (const bf16_t*)x,
+                               idx, (bf16_t*)y, rows_out, C);
+    } else {
+        if (vec)
+            hipLaunchKernelGGL((gather_rows_kernel<float, 4>), dim3(ew_blocks(rows_out * (C / 4))), dim3(256), 0, stream, (const float*)x,
+                               idx, (float*)y, rows_out, C);
+        else
+            hipLaunchKernelGGL((gather_rows_kernel<float, 1>), dim3(ew_blocks(rows_out * C)), dim3(256), 0, stream, (const float*)x, idx,
+                               (float*)y, rows_out, C);
+    }
+    return iseg_check_launch("iseg_gather_rows");
+}
+
+extern "C" int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bias, int heads, int TT, hipStream_t stream) {
+    ISEG_REQUIRE(table && index && bias && heads > 0 && TT > 0, "iseg_relpos_bias_gather: bad arguments");
+    hipLaunchKernelGGL(relpos_gather_kernel, dim3((heads * TT + 255) / 256), dim3(256), 0, stream, table, index, bias, heads, TT);
+    return iseg_check_launch("iseg_relpos_bias_gather");
+}
+
+extern "C" int iseg_relpos_bias_scatter_grad(const float* dbias, int ld, const int32_t* index, float* dtable, int entries, int heads,
+                                             int T, int accumulate, hipStream_t stream) {
+    ISEG_REQUIRE(dbias && index && dtable && entries > 0 && heads > 0 && T > 0 && ld >= T, "iseg_relpos_bias_scatter_grad: bad arguments");
+    hipLaunchKernelGGL(relpos_scatter_kernel, dim3((entries * heads + 255) / 256), dim3(256), 0, stream, dbias, ld, index, dtable,
+                       entries, heads, T, accumulate);
+    return iseg_check_launch("iseg_relpos_bias_scatter_grad");
+}

@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     __shared__ float sB[TK][TB + 1];
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
+    if (gridDim.z > 1) {   // strided batch
+        A += epi.off_a(blockIdx.z);
+        B += epi.off_b(blockIdx.z);
+        D += epi.off_d(blockIdx.z);
+    }
     const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
     const int64_t m0 = (int64_t)tile_m * TB, n0 = (int64_t)tile_n * TB;
     const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
@@ -116,7 +121,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
 int choose_split(const iseg_gemm_args* g, int tile) {
     if (g->split_k > 0) return g->split_k;
     const int64_t tiles = ceil_div64(g->M, tile) * ceil_div64(g->N, tile);
-    if (tiles >= 256 || g->K < 2048) return 1;
+    if (tiles >= 256 || g->K < 2048 || g->batch > 1) return 1;
     int64_t want = ceil_div64(512, tiles);
     const int64_t maxs = g->K / 512 > 0 ? g->K / 512 : 1;
     if (want > maxs) want = maxs;
@@ -148,7 +153,15 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     ISEG_REQUIRE((g->act != ISEG_ACT_GELU_GRAD && g->act != ISEG_ACT_RELU_GRAD) || g->aux, "iseg_gemm: act needs aux");
     ISEG_REQUIRE(g->a_act == ISEG_ACT_NONE || g->a_act == ISEG_ACT_GELU, "iseg_gemm: a_act must be NONE or GELU");
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
-            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate};
+            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
+            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner};
+    const int batch = g->batch > 1 ? g->batch : 1;
+    if (batch > 1) {
+        ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);
+        ISEG_REQUIRE(!g->bias && !g->colscale && !g->rowscale && !g->residual && !g->aux && !g->pre_out && !g->colsum_out &&
+                         g->act == ISEG_ACT_NONE && g->a_act == ISEG_ACT_NONE,
+                     "iseg_gemm: a batched problem takes only the alpha / accumulate epilogue");
+    }
     if (g->colsum_out) {
         ISEG_REQUIRE(g->in_dtype == ISEG_BF16 && !g->a_kcontig && !g->b_kcontig, "iseg_gemm: colsum_out needs the bf16 wgrad orientation");
         ISEG_REQUIRE(g->M % 128 != 0 && g->M % 8 == 0, "iseg_gemm: colsum_out needs a spare row in the last 128-row tile (M %% 128 != 0)");
@@ -179,7 +192,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
         const int tiles_m = (int)ceil_div64(g->M, 64), tiles_n = (int)ceil_div64(g->N, 64);
         const int64_t sam = g->a_kcontig ? g->lda : 1, sak = g->a_kcontig ? 1 : g->lda;
         const int64_t sbk = g->b_kcontig ? 1 : g->ldb, sbn = g->b_kcontig ? g->ldb : 1;
-        hipLaunchKernelGGL((gemm_f32_kernel<float>), dim3(tiles_m * tiles_n, eff_split), dim3(256), 0, stream,
+        hipLaunchKernelGGL((gemm_f32_kernel<float>), dim3(tiles_m * tiles_n, eff_split, batch), dim3(256), 0, stream,
                            (const float*)g->A, sam, sak, (const float*)g->B, sbk, sbn, (float*)g->D, g->ldd, g->M, g->N, g->K,
                            tiles_n, kps, slabs, epi, g->a_act);
     }
@@ -224,6 +237,14 @@ extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_byt
     const int64_t kps = ceil_div64(ceil_div64(g->K, nsplit), 128) * 128;
     const int eff_split = (int)ceil_div64(g->K, kps);
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
-            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate};
+            g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
+            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner};
+    const int batch = g->batch > 1 ? g->batch : 1;
+    if (batch > 1) {
+        ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);
+        ISEG_REQUIRE(!g->bias && !g->colscale && !g->rowscale && !g->residual && !g->aux && !g->pre_out && !g->colsum_out &&
+                         g->act == ISEG_ACT_NONE && g->a_act == ISEG_ACT_NONE,
+                     "iseg_gemm: a batched problem takes only the alpha / accumulate epilogue");
+    }
     return gemm_reduce(g, epi, (float*)ws, eff_split, slab_rows, stream);
 }

@@ -32,6 +32,12 @@ struct Epi {
     int accumulate;
     float* colsum_out;      // wgrad only: column sums of B over the reduction (bias gradient) through a virtual ones-row of A
     int colsum_accumulate;
+    // strided batch: problem z = blockIdx.z
+    int batch_inner;
+    int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
+    __device__ __forceinline__ int64_t off_a(int z) const { return (z / batch_inner) * sa_outer + (z % batch_inner) * sa_inner; }
+    __device__ __forceinline__ int64_t off_b(int z) const { return (z / batch_inner) * sb_outer + (z % batch_inner) * sb_inner; }
+    __device__ __forceinline__ int64_t off_d(int z) const { return (z / batch_inner) * sd_outer + (z % batch_inner) * sd_inner; }
 };
 
 template <class TO>
@@ -324,6 +330,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
+    if (gridDim.z > 1) {   // strided batch
+        A += epi.off_a(blockIdx.z);
+        B += epi.off_b(blockIdx.z);
+        D += epi.off_d(blockIdx.z);
+    }
 
     const int t = xcd_remap(blockIdx.x, ntiles);
     const int tile_n = t % tiles_n, tile_m = t / tiles_n;
@@ -469,9 +480,16 @@ void launch_bf16(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_
     if (g->pre_out) vecD = vecD && ((uintptr_t)g->pre_out % 16 == 0) && (g->ldp % 8 == 0);
     if (g->bias) vecD = vecD && ((uintptr_t)g->bias % 16 == 0);
     if (g->colscale) vecD = vecD && ((uintptr_t)g->colscale % 16 == 0);
-    dim3 grid(ntiles, nsplit);
+    const int batch = g->batch > 1 ? g->batch : 1;
+    int vA = vecA, vB = vecB, vD = vecD;
+    if (batch > 1) {   // every problem of the batch must keep the 16-byte alignment the vector paths assume
+        vA = vA && g->sa_outer % 8 == 0 && g->sa_inner % 8 == 0;
+        vB = vB && g->sb_outer % 8 == 0 && g->sb_inner % 8 == 0;
+        vD = vD && g->sd_outer % 8 == 0 && g->sd_inner % 8 == 0;
+    }
+    dim3 grid(ntiles, nsplit, batch);
     hipLaunchKernelGGL((gemm_bf16_kernel<WM, WN, FM, FN, AKC, BKC, BK, TO>), grid, dim3(WM * WN * 64), 0, s, A, g->lda, B, g->ldb,
-                       (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecA, vecB, vecD, g->a_act);
+                       (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vA, vB, vD, g->a_act);
 }
 
 template <bool AKC, bool BKC, int BK, class TO>

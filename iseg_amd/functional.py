@@ -65,17 +65,17 @@ class _CastFn(Function):
 # ---------------------------------------------------------------------------------------------------------
 class _DenseFn(Function):
     @staticmethod
-    def forward(ctx, x, W, b, act):
-        Kd, N = W.shape[-2], W.shape[-1]
+    def forward(ctx, x, W, b, act, kshape=None):
+        Kd, N = kshape if kshape is not None else (W.shape[-2], W.shape[-1])
         x2 = _c(x).reshape(-1, Kd)
         Wc = nn.w(W).reshape(Kd, N)
-        bias = b.data if b is not None else None
+        bias = b.data.reshape(-1) if b is not None else None
         pre = None
         need_grad = any(ctx.needs_input_grad)     # grad mode is off inside Function.forward; this is the tape's view
         if act == K.ACT_GELU and need_grad:
             pre = torch.empty((x2.shape[0], N), dtype=x2.dtype, device=x2.device)
         y = K.dense_fwd(x2, Wc, bias, act=act, pre_out=pre)
-        ctx.act, ctx.W, ctx.b = act, W, b
+        ctx.act, ctx.W, ctx.b, ctx.kshape = act, W, b, (Kd, N)
         ctx.save_for_backward(x2, pre if act == K.ACT_GELU else (y if act == K.ACT_RELU else None))
         return y.reshape(*x.shape[:-1], N)
 
@@ -83,26 +83,27 @@ class _DenseFn(Function):
     def backward(ctx, dy):
         x2, aux = ctx.saved_tensors
         W, b = ctx.W, ctx.b
-        Kd, N = W.shape[-2], W.shape[-1]
+        Kd, N = ctx.kshape
         dy2 = _c(dy).reshape(-1, N)
         if ctx.act in (K.ACT_GELU, K.ACT_RELU):
             dy2 = K.act_bwd(dy2, aux, ctx.act)
         if b is not None and b.requires_grad:
-            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b), accumulate=True)
+            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b).reshape(-1), accumulate=True)
         if W.requires_grad:
             K.dense_wgrad(x2, dy2, _grad(W).reshape(Kd, N))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.dense_dgrad(dy2, nn.w(W).reshape(Kd, N)).reshape(*dy.shape[:-1], Kd)
         dist.grads_ready(W, b)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
-def dense(x, W, b=None, act=K.ACT_NONE):
+def dense(x, W, b=None, act=K.ACT_NONE, kshape=None):
+    """kshape=(in, out) re-interprets a higher-rank kernel (keras MultiHeadAttention: [C, heads, d] / [heads, d, C]) as [in, out]"""
     _check_act_dtype(x)
     if nn.dry_run():
-        return _dry((*x.shape[:-1], W.shape[-1]), x)
-    return _DenseFn.apply(x, W, b, act)
+        return _dry((*x.shape[:-1], kshape[1] if kshape is not None else W.shape[-1]), x)
+    return _DenseFn.apply(x, W, b, act, kshape)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -846,3 +847,280 @@ def add_relu(a, b):
     if a.numel() % 8 != 0:
         return relu(add(a, b))
     return _AddReluFn.apply(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# multi-head self-attention core on a packed [q | k | v] tensor:
+#   softmax(scale * q k^T + bias[h] + mask[w]) (-> dropout) (-> clip) @ v
+# backbones/swin.py:117-167 (bias, shift mask), keras MultiHeadAttention in backbones/vit.py:142-147, and
+# layers/multihead_self_attention.py:106-150 (clip).  Score / context products are strided-batch GEMMs, one problem per
+# (sample, head); probabilities are kept for the backward pass (288 GB HBM: cheaper than recomputing them).
+# ---------------------------------------------------------------------------------------------------------
+_MAX_GRID_Z = 65535
+
+
+def _attn_chunks(B, heads):
+    per = max(1, _MAX_GRID_Z // heads)
+    return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
+
+
+class _AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed):
+        B, T, ld = qkv.shape
+        assert ld == 2 * Cq + Cv
+        qkv = _c(qkv)
+        dq, dv = Cq // heads, Cv // heads
+        Tp = (T + 7) // 8 * 8
+        dev, dtp = qkv.device, qkv.dtype
+        P = torch.empty((B * heads, T, Tp), dtype=dtp, device=dev)
+        O = torch.empty((B, T, Cv), dtype=dtp, device=dev)
+        bias = None
+        if bias_table is not None:
+            bias = K.relpos_bias_gather(bias_table.data, bias_index, heads, T)
+        qv, kv, vv = qkv[:, :, :Cq], qkv[:, :, Cq:2 * Cq], qkv[:, :, 2 * Cq:]
+        Pd = P
+        for b0, b1 in _attn_chunks(B, heads):
+            nb = (b1 - b0) * heads
+            Pz = P[b0 * heads:b1 * heads]
+            K.gemm(qv[b0:b1], kv[b0:b1], Pz, T, T, dq, lda=ld, ldb=ld, ldd=Tp, a_kcontig=1, b_kcontig=1, alpha=scale, batch=nb,
+                   batch_inner=heads, sa=(T * ld, dq), sb=(T * ld, dq), sd=(heads * T * Tp, T * Tp))
+            # problems of a chunk start at a multiple of `windows` samples only if b0 % windows == 0: chunks are sample-aligned
+            K.softmax_rows_fwd(Pz, nb, T, T, Tp, bias=bias, heads=heads, mask=mask, windows=windows)
+        if drop_rate > 0:
+            Pd = K.dropout(P, drop_rate, seed)
+        ctx.pre_clip = None
+        if clip is not None:      # the exact softmax output is kept for the backward pass; the clipped copy feeds P @ V
+            ctx.pre_clip = Pd
+            Pd = K.clip_fwd(Pd, clip[0], clip[1])
+        for b0, b1 in _attn_chunks(B, heads):
+            nb = (b1 - b0) * heads
+            K.gemm(Pd[b0 * heads:b1 * heads], vv[b0:b1], O[b0:b1], T, dv, T, lda=Tp, ldb=ld, ldd=Cv, a_kcontig=1, b_kcontig=0,
+                   batch=nb, batch_inner=heads, sa=(heads * T * Tp, T * Tp), sb=(T * ld, dv), sd=(T * Cv, dv))
+        ctx.cfg = (heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp)
+        ctx.bias_table, ctx.bias_index = bias_table, bias_index
+        ctx.save_for_backward(qkv, P, Pd if Pd is not P else None)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, P, Pd = ctx.saved_tensors
+        heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp = ctx.cfg
+        B, T, ld = qkv.shape
+        dq, dv = Cq // heads, Cv // heads
+        dO = _c(dO)
+        Pd = P if Pd is None else Pd
+        dqkv = torch.empty_like(qkv)
+        dP = torch.empty_like(P)
+        qv, kv, vv = qkv[:, :, :Cq], qkv[:, :, Cq:2 * Cq], qkv[:, :, 2 * Cq:]
+        dqv, dkv, dvv = dqkv[:, :, :Cq], dqkv[:, :, Cq:2 * Cq], dqkv[:, :, 2 * Cq:]
+        sP = (heads * T * Tp, T * Tp)
+        for b0, b1 in _attn_chunks(B, heads):
+            nb = (b1 - b0) * heads
+            z0, z1 = b0 * heads, b1 * heads
+            # dP = dO V^T ; dV = P^T dO
+            K.gemm(dO[b0:b1], vv[b0:b1], dP[z0:z1], T, T, dv, lda=Cv, ldb=ld, ldd=Tp, a_kcontig=1, b_kcontig=1, batch=nb,
+                   batch_inner=heads, sa=(T * Cv, dv), sb=(T * ld, dv), sd=sP)
+            K.gemm(Pd[z0:z1], dO[b0:b1], dvv[b0:b1], T, dv, T, lda=Tp, ldb=Cv, ldd=ld, a_kcontig=0, b_kcontig=0, batch=nb,
+                   batch_inner=heads, sa=sP, sb=(T * Cv, dv), sd=(T * ld, dv))
+        if clip is not None:
+            dP = K.clip_bwd(ctx.pre_clip, dP, clip[0], clip[1])
+        if drop_rate > 0:
+            dP = K.dropout(dP, drop_rate, seed)
+        K.softmax_rows_bwd(P, dP, B * heads * T, T, Tp)
+        if ctx.bias_table is not None and ctx.bias_table.requires_grad:
+            dbias = torch.empty(heads * T * Tp, dtype=torch.float32, device=qkv.device)
+            K.colsum(dP, heads * T * Tp, 0, 1, B, heads * T * Tp, dbias)
+            K.relpos_bias_scatter_grad(dbias, Tp, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True)
+            dist.grads_ready(ctx.bias_table)
+        for b0, b1 in _attn_chunks(B, heads):
+            nb = (b1 - b0) * heads
+            z0, z1 = b0 * heads, b1 * heads
+            # dQ = scale * dS K ; dK = scale * dS^T Q
+            K.gemm(dP[z0:z1], kv[b0:b1], dqv[b0:b1], T, dq, T, lda=Tp, ldb=ld, ldd=ld, a_kcontig=1, b_kcontig=0, alpha=scale,
+                   batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
+            K.gemm(dP[z0:z1], qv[b0:b1], dkv[b0:b1], T, dq, T, lda=Tp, ldb=ld, ldd=ld, a_kcontig=0, b_kcontig=0, alpha=scale,
+                   batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None
+
+
+def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=None, mask=None, windows=1, clip=None,
+                     dropout_rate=0.0, training=False):
+    """qkv [B, T, 2*Cq + Cv] (columns [q | k | v], each split into `heads` contiguous head slices) -> [B, T, Cv].
+    bias_table [entries, heads] fp32 parameter + bias_index int32 [T*T]; mask fp32 [windows, T, T] (sample b uses mask
+    b % windows); clip = (lo, hi) on the probabilities."""
+    _check_act_dtype(qkv)
+    if nn.dry_run():
+        return _dry((qkv.shape[0], qkv.shape[1], Cv), qkv)
+    if mask is not None and (_MAX_GRID_Z // heads) % windows != 0 and qkv.shape[0] * heads > _MAX_GRID_Z:
+        raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
+    rate = float(dropout_rate) if training else 0.0
+    return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip,
+                              rate, next_seed() if rate > 0 else 0)
+
+
+class _GatherRowsFn(Function):
+    @staticmethod
+    def forward(ctx, x, idx_fwd, idx_bwd, out_shape):
+        C = x.shape[-1]
+        ctx.in_shape, ctx.idx_bwd = x.shape, idx_bwd
+        return K.gather_rows(_c(x).reshape(-1, C), idx_fwd, idx_fwd.numel()).reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = dy.shape[-1]
+        idx = ctx.idx_bwd
+        return K.gather_rows(_c(dy).reshape(-1, C), idx, idx.numel()).reshape(ctx.in_shape), None, None, None
+
+
+def permute_rows(x, idx_fwd, idx_bwd, out_shape):
+    """rows of x (last axis = channels) re-ordered by a static index table; idx_bwd is the inverse table (-1 where a source
+    row has no destination / a destination is padding).  Each source row may appear at most once in idx_fwd."""
+    if nn.dry_run():
+        return _dry(out_shape, x)
+    return _GatherRowsFn.apply(x, idx_fwd, idx_bwd, tuple(out_shape))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# token-axis helpers of backbones/vit.py:277-323: class token, position embedding, token slicing
+# ---------------------------------------------------------------------------------------------------------
+class _PrependTokenFn(Function):
+    @staticmethod
+    def forward(ctx, x, token):
+        B, T, C = x.shape
+        xc = _c(x)
+        y = torch.empty((B, T + 1, C), dtype=x.dtype, device=x.device)
+        tok = K.cast(token.data.reshape(1, C), x.dtype)
+        K.copy2d(tok, 0, y, (T + 1) * C, B, C)                          # row stride 0: the same token for every sample
+        K.copy2d(xc, T * C, y.reshape(B, -1)[:, C:], (T + 1) * C, B, T * C)
+        ctx.token = token
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T1, C = dy.shape
+        dyc = _c(dy)
+        if ctx.token.requires_grad:
+            K.colsum(dyc, T1 * C, 0, 1, B, C, _grad(ctx.token).reshape(-1), accumulate=True)
+            dist.grads_ready(ctx.token)
+        dx = torch.empty((B, T1 - 1, C), dtype=dy.dtype, device=dy.device)
+        K.copy2d(dyc.reshape(B, -1)[:, C:], T1 * C, dx, (T1 - 1) * C, B, (T1 - 1) * C)
+        return dx, None
+
+
+def prepend_token(x, token):
+    """tf.concat([broadcast(class_token), x], axis=1); token is an fp32 parameter [1,1,C]"""
+    if nn.dry_run():
+        return _dry((x.shape[0], x.shape[1] + 1, x.shape[2]), x)
+    return _PrependTokenFn.apply(x, token)
+
+
+class _DropTokensFn(Function):
+    @staticmethod
+    def forward(ctx, x, n_extra):
+        B, T, C = x.shape
+        ctx.n_extra, ctx.shape = n_extra, x.shape
+        y = torch.empty((B, T - n_extra, C), dtype=x.dtype, device=x.device)
+        K.copy2d(_c(x).reshape(B, -1)[:, n_extra * C:], T * C, y, (T - n_extra) * C, B, (T - n_extra) * C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, C = ctx.shape
+        e = ctx.n_extra
+        dx = torch.empty(ctx.shape, dtype=dy.dtype, device=dy.device)
+        zero = torch.zeros((1, e * C), dtype=dy.dtype, device=dy.device)
+        K.copy2d(zero, 0, dx, T * C, B, e * C)
+        K.copy2d(_c(dy), (T - e) * C, dx.reshape(B, -1)[:, e * C:], T * C, B, (T - e) * C)
+        return dx, None
+
+
+def drop_tokens(x, n_extra):
+    """x[:, n_extra:]"""
+    if n_extra == 0:
+        return x
+    if nn.dry_run():
+        return _dry((x.shape[0], x.shape[1] - n_extra, x.shape[2]), x)
+    return _DropTokensFn.apply(x, int(n_extra))
+
+
+class _AddBatchBroadcastFn(Function):
+    @staticmethod
+    def forward(ctx, x, v):
+        B = x.shape[0]
+        n = x.numel() // B
+        y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        K.copy2d(_c(x), n, y, n, B, n)
+        K.broadcast_rows(_c(v).reshape(1, n), y, n, 0, 1, B, n, accumulate=True)
+        ctx.v_dtype, ctx.v_shape = v.dtype, v.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B = dy.shape[0]
+        n = dy.numel() // B
+        dv = torch.empty(n, dtype=torch.float32, device=dy.device)
+        K.colsum(_c(dy), n, 0, 1, B, n, dv)
+        dv = dv if ctx.v_dtype == torch.float32 else K.cast(dv, ctx.v_dtype)
+        return dy, dv.reshape(ctx.v_shape)
+
+
+def add_batch_broadcast(x, v):
+    """x [B, ...] + v [1, ...] (tf.add with broadcasting over the batch axis: position embedding)"""
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _AddBatchBroadcastFn.apply(x, v)
+
+
+class _PosEmbedResizeFn(Function):
+    """backbones/vit.py:19-63 resize_pos_embed: the grid part [1, g*g, C] of the fp32 position embedding is resampled to
+    (Ho, Wo) by tf.image.resize(bicubic) -- a separable linear map, expressed as two fp32 GEMMs y = Wy @ x @ Wx^T per channel
+    with constant weight matrices built on the host (utils/bicubic.py) -- the extra (class) tokens are passed through, and the
+    result is cast to the compute dtype.  The gradient is written straight into the parameter's gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, pos, Wy, Wx, n_extra, out_dtype):
+        _, L, C = pos.shape
+        Hi, Wi = Wy.shape[1], Wx.shape[1]
+        Ho, Wo = Wy.shape[0], Wx.shape[0]
+        assert L == n_extra + Hi * Wi
+        src = pos.data.reshape(L, C)
+        out = torch.empty((1, n_extra + Ho * Wo, C), dtype=torch.float32, device=pos.device)
+        o2 = out.reshape(-1, C)
+        if n_extra:
+            K.copy2d(src, C, o2, C, n_extra, C)
+        grid = src[n_extra:]
+        t = torch.empty((Ho, Wi * C), dtype=torch.float32, device=pos.device)
+        K.gemm(Wy, grid, t, Ho, Wi * C, Hi, lda=Hi, ldb=Wi * C, ldd=Wi * C, a_kcontig=1, b_kcontig=0)
+        K.gemm(Wx, t, o2[n_extra:], Wo, C, Wi, lda=Wi, ldb=C, ldd=C, a_kcontig=1, b_kcontig=0, batch=Ho, batch_inner=1,
+               sa=(0, 0), sb=(Wi * C, 0), sd=(Wo * C, 0))
+        ctx.pos, ctx.n_extra = pos, n_extra
+        ctx.save_for_backward(Wy, Wx)
+        return out if out_dtype == torch.float32 else K.cast(out, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Wy, Wx = ctx.saved_tensors
+        pos, e = ctx.pos, ctx.n_extra
+        if not pos.requires_grad:
+            return None, None, None, None, None
+        C = pos.shape[-1]
+        Hi, Wi = Wy.shape[1], Wx.shape[1]
+        Ho, Wo = Wy.shape[0], Wx.shape[0]
+        d = _c(dy) if dy.dtype == torch.float32 else K.cast(_c(dy), torch.float32)
+        d2 = d.reshape(-1, C)
+        g = _grad(pos).reshape(-1, C)
+        if e:
+            K.add2d(d2, C, g, C, e, C)
+        dt_ = torch.empty((Ho, Wi * C), dtype=torch.float32, device=dy.device)
+        K.gemm(Wx, d2[e:], dt_, Wi, C, Wo, lda=Wi, ldb=C, ldd=C, a_kcontig=0, b_kcontig=0, batch=Ho, batch_inner=1, sa=(0, 0),
+               sb=(Wo * C, 0), sd=(Wi * C, 0))
+        K.gemm(Wy, dt_, g[e:], Hi, Wi * C, Ho, lda=Hi, ldb=Wi * C, ldd=Wi * C, a_kcontig=0, b_kcontig=0, accumulate=True)
+        dist.grads_ready(pos)
+        return None, None, None, None, None
+
+
+def resize_pos_embed(pos, Wy, Wx, n_extra, out_dtype):
+    if nn.dry_run():
+        return _dry((1, n_extra + Wy.shape[0] * Wx.shape[0], pos.shape[-1]), pos, out_dtype)
+    return _PosEmbedResizeFn.apply(pos, Wy, Wx, int(n_extra), out_dtype)

@@ -97,7 +97,9 @@ class KernelTimer:
 # ---------------------------------------------------------------------------------------------------------
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
-         accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False):
+         accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False, batch=1, batch_inner=1,
+         sa=(0, 0), sb=(0, 0), sd=(0, 0)):
+    """batch > 1: problem z uses X + (z // batch_inner) * sX[0] + (z % batch_inner) * sX[1] (element strides)"""
     _require_cuda(A, B, D)
     if A.dtype != B.dtype:
         raise TypeError(f"gemm operands differ in dtype: {A.dtype} vs {B.dtype}")
@@ -113,6 +115,8 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.pre_out, g.ldp = ptr(pre_out), ldp
     g.act, g.alpha, g.accumulate, g.split_k, g.a_act = act, alpha, int(accumulate), split_k, a_act
     g.colsum_out, g.colsum_accumulate = ptr(colsum_out), int(colsum_accumulate)
+    g.batch, g.batch_inner = int(batch), int(batch_inner)
+    (g.sa_outer, g.sa_inner), (g.sb_outer, g.sb_inner), (g.sd_outer, g.sd_inner) = sa, sb, sd
     for t in (residual, aux, pre_out):
         if t is not None and t.dtype != D.dtype:
             raise TypeError("gemm residual/aux/pre_out must have the output dtype")
@@ -126,7 +130,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     timer = KERNEL_TIMER[0]
     if timer is not None:
         timer.begin(("gemm", int(a_kcontig), int(b_kcontig), int(M), int(N), int(K), int(act), pre_out is not None, residual is not None,
-                     aux is not None, A.dtype, D.dtype, need > 0))
+                     aux is not None, A.dtype, D.dtype, need > 0) + ((int(batch),) if batch > 1 else ()))
     _hip.check(L.iseg_gemm(C.byref(g), ptr(ws), wsb, stream()), "iseg_gemm")
     if timer is not None:
         timer.end()
@@ -526,3 +530,63 @@ def add_relu(a, b):
     y = torch.empty_like(a)
     _hip.check(_hip.lib().iseg_add_relu(ptr(a), ptr(b), ptr(y), a.numel(), dt(a), stream()), "iseg_add_relu")
     return y
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention pieces (csrc/attention.hip) around the strided-batch GEMMs
+# ---------------------------------------------------------------------------------------------------------
+def softmax_rows_fwd(scores, problems, Tq, cols, ld, *, bias=None, heads=1, mask=None, windows=1, clip=None, out=None):
+    _require_cuda(scores)
+    out = scores if out is None else out
+    lo, hi = clip if clip is not None else (0.0, 0.0)
+    _hip.check(_hip.lib().iseg_softmax_rows_fwd(ptr(scores), ptr(out), problems, Tq, cols, ld, ptr(bias), heads, ptr(mask), windows,
+                                               float(lo), float(hi), dt(scores), stream()), "iseg_softmax_rows_fwd")
+    return out
+
+
+def softmax_rows_bwd(probs, dprobs, rows, cols, ld, *, clip=None, out=None):
+    _require_cuda(probs, dprobs)
+    out = dprobs if out is None else out
+    lo, hi = clip if clip is not None else (0.0, 0.0)
+    _hip.check(_hip.lib().iseg_softmax_rows_bwd(ptr(probs), ptr(dprobs), ptr(out), rows, cols, ld, float(lo), float(hi), dt(probs),
+                                               stream()), "iseg_softmax_rows_bwd")
+    return out
+
+
+def clip_fwd(x, lo, hi):
+    _require_cuda(x)
+    y = torch.empty_like(x)
+    _hip.check(_hip.lib().iseg_clip_fwd(ptr(x), ptr(y), x.numel(), float(lo), float(hi), dt(x), stream()), "iseg_clip_fwd")
+    return y
+
+
+def clip_bwd(x, dy, lo, hi):
+    _require_cuda(x, dy)
+    dx = torch.empty_like(dy)
+    _hip.check(_hip.lib().iseg_clip_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), float(lo), float(hi), dt(x), stream()), "iseg_clip_bwd")
+    return dx
+
+
+def gather_rows(x2d, idx, rows_out):
+    """y[r] = x2d[idx[r]] (idx int32 on device, -1 -> zero row)"""
+    _require_cuda(x2d, idx)
+    if idx.dtype != torch.int32 or idx.numel() != rows_out:
+        raise TypeError("gather_rows: idx must be int32 with one entry per output row")
+    rows_in, Cc = x2d.shape
+    y = torch.empty((rows_out, Cc), dtype=x2d.dtype, device=x2d.device)
+    _hip.check(_hip.lib().iseg_gather_rows(ptr(x2d), ptr(idx), ptr(y), rows_in, rows_out, Cc, dt(x2d), stream()), "iseg_gather_rows")
+    return y
+
+
+def relpos_bias_gather(table, index, heads, T):
+    _require_cuda(table, index)
+    bias = torch.empty((heads, T, T), dtype=torch.float32, device=table.device)
+    _hip.check(_hip.lib().iseg_relpos_bias_gather(ptr(table), ptr(index), ptr(bias), heads, T * T, stream()), "iseg_relpos_bias_gather")
+    return bias
+
+
+def relpos_bias_scatter_grad(dbias, ld, index, dtable, heads, T, accumulate=True):
+    _require_cuda(dbias, index, dtable)
+    _hip.check(_hip.lib().iseg_relpos_bias_scatter_grad(ptr(dbias), ld, ptr(index), ptr(dtable), dtable.shape[0], heads, T, int(accumulate),
+                                                       stream()), "iseg_relpos_bias_scatter_grad")
+    return dtable

@@ -87,6 +87,8 @@ def init_tensor(initializer, shape, name):
     if initializer == "he_normal":
         fi, _ = _fans(shape)
         return torch.randn(shape, generator=_gen(name)) * math.sqrt(2.0 / fi)
+    if isinstance(initializer, tuple) and initializer[0] == "uniform":      # keras RandomUniform(-v, v)
+        return (torch.rand(shape, generator=_gen(name)) * 2 - 1) * float(initializer[1])
     if isinstance(initializer, tuple) and initializer[0] == "truncated_normal":
         std = initializer[1]
         t = torch.randn(shape, generator=_gen(name)).clamp_(-2, 2) * std

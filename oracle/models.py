@@ -193,3 +193,159 @@ def resnet_forward(w, x, num_of_blocks=(3, 4, 6, 3), output_stride=32, multi_gri
             x = resnet_block2(w, f"conv{si + 2}_block{bi + 1}", x, stride, dil, conv_sc, training, eps, new_stats)
     endpoints.append(x)
     return endpoints
+
+
+# ------------------------------------------------------------------------------------------------------
+# layers/multihead_self_attention.py:170-203
+# ------------------------------------------------------------------------------------------------------
+def mhsa_layer(w, prefix, x, heads):
+    def conv1x1(name, t):
+        return O.conv2d(t, w[f"{prefix}/{name}/kernel"], w.get(f"{prefix}/{name}/bias"), 1, 1, "valid")
+
+    q, k, v = conv1x1("query_conv", x), conv1x1("key_conv", x), conv1x1("value_conv", x)
+    return O.mhsa_core(q, k, v, heads)
+
+
+# ------------------------------------------------------------------------------------------------------
+# backbones/vit.py:19-63,66-113,163-183,277-323
+# ------------------------------------------------------------------------------------------------------
+def vit_forward(w, x, name, num_layer, pretrain_size, patch=16, dp_factors=None):
+    """x [N,H,W,3] -> [N,H/16,W/16,C]; dp_factors[i] = (f_attn [N], f_mlp [N]) or None"""
+    x = O.conv2d(x, w[f"{name}/patch_embed/projection/kernel"], w[f"{name}/patch_embed/projection/bias"], patch, 1, "same")
+    N, H, W, C = x.shape
+    x = x.reshape(N, H * W, C)
+    x = torch.cat([w[f"{name}/class_token"].expand(N, 1, C), x], dim=1)
+    pos = w[f"{name}/pos_embed"]
+    g = pretrain_size // patch
+    grid = O.resize_bicubic(pos[:, 1:].reshape(1, g, g, C), (H, W)).reshape(1, H * W, C)
+    x = x + torch.cat([pos[:, :1], grid], dim=1)
+    for i in range(num_layer):
+        p = f"{name}/layers/{i}"
+        y = O.layer_norm(x, w[f"{p}/ln1/gamma"], w[f"{p}/ln1/beta"], 1e-6)
+        y = O.keras_mha_self(y, w[f"{p}/attn/query/kernel"], w[f"{p}/attn/query/bias"], w[f"{p}/attn/key/kernel"], w[f"{p}/attn/key/bias"],
+                             w[f"{p}/attn/value/kernel"], w[f"{p}/attn/value/bias"], w[f"{p}/attn/attention_output/kernel"],
+                             w[f"{p}/attn/attention_output/bias"])
+        if dp_factors is not None and dp_factors[i] is not None:
+            y = y * dp_factors[i][0].reshape(-1, 1, 1)
+        x = ident = y + x
+        y = O.layer_norm(x, w[f"{p}/ln2/gamma"], w[f"{p}/ln2/beta"], 1e-6)
+        y = O.gelu(O.dense(y, w[f"{p}/ffn/dense0/kernel"], w[f"{p}/ffn/dense0/bias"]))
+        y = O.dense(y, w[f"{p}/ffn/dense1/kernel"], w[f"{p}/ffn/dense1/bias"])
+        if dp_factors is not None and dp_factors[i] is not None:
+            y = y * dp_factors[i][1].reshape(-1, 1, 1)
+        x = y + ident
+    return x[:, 1:].reshape(N, H, W, C)
+
+
+# ------------------------------------------------------------------------------------------------------
+# backbones/swin.py: window_partition/reverse :46-64, WindowAttention :117-167, block :237-294, PatchMerging :309-337,
+# mask :391-433, PatchEmbed :479-501, model :601-622
+# ------------------------------------------------------------------------------------------------------
+def _window_partition(x, ws):
+    B, H, W, C = x.shape
+    x = x.reshape(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, ws, ws, C)
+
+
+def _window_reverse(win, ws, H, W, C):
+    x = win.reshape(-1, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5)
+    return x.reshape(-1, H, W, C)
+
+
+def swin_attention_mask(H, W, ws, shift, dtype=torch.float64):
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    parts, cnt = [], 0
+    for hl in (Hp - ws, ws - shift, shift):
+        row = []
+        for wl in (Wp - ws, ws - shift, shift):
+            row.append(torch.full((1, hl, wl, 1), float(cnt), dtype=dtype))
+            cnt += 1
+        parts.append(torch.cat(row, dim=2))
+    img = torch.cat(parts, dim=1)
+    mw = _window_partition(img, ws).reshape(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return torch.where(m != 0, torch.full_like(m, -100.0), torch.zeros_like(m))
+
+
+def _rel_index(ws):
+    import numpy as np
+
+    coords = np.stack(np.meshgrid(np.arange(ws), np.arange(ws), indexing="ij")).reshape(2, -1)
+    rel = (coords[:, :, None] - coords[:, None, :]).transpose(1, 2, 0).copy()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return torch.from_numpy(rel.sum(-1).astype(np.int64))
+
+
+def swin_window_attention(w, p, x, heads, ws, mask):
+    B_, N, C = x.shape
+    qkv = O.dense(x, w[f"{p}/qkv/kernel"], w[f"{p}/qkv/bias"]).reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-1, -2)
+    bias = w[f"{p}/relative_position_bias_table"][_rel_index(ws).reshape(-1)].reshape(N, N, heads).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = (attn.reshape(-1, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).reshape(-1, heads, N, N)
+    attn = torch.softmax(attn, dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(B_, N, C)
+    return O.dense(x, w[f"{p}/proj/kernel"], w[f"{p}/proj/bias"])
+
+
+def swin_block(w, p, x, heads, ws, shift, mask, dp=None):
+    import torch.nn.functional as TF
+
+    B, H, W, C = x.shape
+    shortcut = x.reshape(B, H * W, C)
+    y = O.layer_norm(x, w[f"{p}/norm1/gamma"], w[f"{p}/norm1/beta"], 1e-5)
+    ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+    y = TF.pad(y, (0, 0, 0, pw, 0, ph))
+    Hp, Wp = H + ph, W + pw
+    if shift > 0:
+        y = torch.roll(y, (-shift, -shift), dims=(1, 2))
+    win = _window_partition(y, ws).reshape(-1, ws * ws, C)
+    win = swin_window_attention(w, f"{p}/attn", win, heads, ws, mask if shift > 0 else None)
+    y = _window_reverse(win.reshape(-1, ws, ws, C), ws, Hp, Wp, C)
+    if shift > 0:
+        y = torch.roll(y, (shift, shift), dims=(1, 2))
+    y = y[:, :H, :W].reshape(B, H * W, C)
+    if dp is not None:
+        y = y * dp[0].reshape(-1, 1, 1)
+    x = shortcut + y
+    y = O.layer_norm(x, w[f"{p}/norm2/gamma"], w[f"{p}/norm2/beta"], 1e-5)
+    y = O.dense(O.gelu(O.dense(y, w[f"{p}/mlp/fc1/kernel"], w[f"{p}/mlp/fc1/bias"])), w[f"{p}/mlp/fc2/kernel"], w[f"{p}/mlp/fc2/bias"])
+    if dp is not None:
+        y = y * dp[1].reshape(-1, 1, 1)
+    return (x + y).reshape(B, H, W, C)
+
+
+def swin_patch_merging(w, p, x):
+    import torch.nn.functional as TF
+
+    B, H, W, C = x.shape
+    x = TF.pad(x, (0, 0, 0, W % 2, 0, H % 2))
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], dim=-1)
+    H2, W2 = x.shape[1], x.shape[2]
+    x = O.layer_norm(x.reshape(B, H2 * W2, 4 * C), w[f"{p}/norm/gamma"], w[f"{p}/norm/beta"], 1e-5)
+    return O.dense(x, w[f"{p}/reduction/kernel"]).reshape(B, H2, W2, 2 * C)
+
+
+def swin_forward(w, x, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, patch=4, dp_factors=None):
+    """endpoints [patch_embed, l0, l1, l2, l3] (pre-downsample).  dp_factors[layer][block] = (f_attn, f_mlp) or None"""
+    import torch.nn.functional as TF
+
+    H, W = x.shape[1], x.shape[2]
+    x = TF.pad(x, (0, 0, 0, (patch - W % patch) % patch, 0, (patch - H % patch) % patch))
+    x = O.conv2d(x, w["patch_embed/proj/kernel"], w["patch_embed/proj/bias"], patch, 1, "valid")
+    x = O.layer_norm(x, w["patch_embed/norm/gamma"], w["patch_embed/norm/beta"], 1e-5)
+    endpoints = [x]
+    for li, depth in enumerate(depths):
+        mask = swin_attention_mask(x.shape[1], x.shape[2], ws, ws // 2, x.dtype)
+        for bi in range(depth):
+            dp = None if dp_factors is None else dp_factors[li][bi]
+            x = swin_block(w, f"layers/{li}/blocks/{bi}", x, heads[li], ws, 0 if bi % 2 == 0 else ws // 2, mask, dp)
+        endpoints.append(x)
+        if li < len(depths) - 1:
+            x = swin_patch_merging(w, f"layers/{li}/downsample", x)
+    return endpoints

@@ -311,3 +311,77 @@ def avg_pool_same(x, k, s):
     tot = F.avg_pool2d(xp, (kh, kw), (sh, sw), divisor_override=1)
     cnt = F.avg_pool2d(ones, (kh, kw), (sh, sw), divisor_override=1)
     return (tot / cnt).permute(0, 2, 3, 1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# tf.image.resize(method="bicubic") (backbones/vit.py:49-54): TF2 default = ResizeBicubic, half-pixel centres, Keys a=-0.5.
+# Restated from tensorflow/core/kernels/image/resize_bicubic_op.cc (GetWeightsAndIndices, half_pixel_centers branch):
+# float32 source coordinate, fraction quantised to 1/1024 (coefficient table), out-of-image taps dropped, weights renormalised.
+# ------------------------------------------------------------------------------------------------------
+def _bicubic_taps(out_size, in_size):
+    a = -0.5
+    taps = []
+    scale = np.float32(in_size) / np.float32(out_size)
+    for o in range(out_size):
+        src = np.float32((np.float32(o) + np.float32(0.5)) * scale - np.float32(0.5))
+        loc = math.floor(float(src))
+        delta = np.float32(src - np.float32(loc))
+        off = int(np.rint(delta * np.float32(1024)))
+
+        def near(x):
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0
+
+        def far(x):
+            return ((a * x - 5.0 * a) * x + 8.0 * a) * x - 4.0 * a
+
+        x0, x1 = off / 1024.0, (1024 - off) / 1024.0
+        cand = [(loc - 1, far(x0 + 1.0)), (loc, near(x0)), (loc + 1, near(x1)), (loc + 2, far(x1 + 1.0))]
+        cand = [(i, w if 0 <= i < in_size else 0.0) for i, w in cand]
+        tot = sum(w for _, w in cand)
+        taps.append([(min(max(i, 0), in_size - 1), w / tot) for i, w in cand])
+    return taps
+
+
+def resize_bicubic(x, size):
+    """x [N,H,W,C] -> [N,size[0],size[1],C] (differentiable)"""
+    N, H, W, C = x.shape
+    ty, tx = _bicubic_taps(size[0], H), _bicubic_taps(size[1], W)
+    rows = []
+    for oy in range(size[0]):
+        r = sum(x[:, i] * w for i, w in ty[oy])
+        rows.append(r)
+    t = torch.stack(rows, dim=1)                     # [N, Ho, W, C]
+    cols = []
+    for ox in range(size[1]):
+        cols.append(sum(t[:, :, i] * w for i, w in tx[ox]))
+    return torch.stack(cols, dim=2)
+
+
+# ------------------------------------------------------------------------------------------------------
+# attention cores
+# ------------------------------------------------------------------------------------------------------
+def keras_mha_self(x, wq, bq, wk, bk, wv, bv, wo, bo):
+    """keras.layers.MultiHeadAttention(x, x) (backbones/vit.py:142-147,166): kernels [C,heads,d], output kernel [heads,d,C]"""
+    dk = wq.shape[-1]
+    q = torch.einsum("btc,chd->bthd", x, wq) + bq
+    k = torch.einsum("btc,chd->bthd", x, wk) + bk
+    v = torch.einsum("btc,chd->bthd", x, wv) + bv
+    q = q * (float(dk) ** -0.5)
+    p = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k), dim=-1)
+    ctx = torch.einsum("bhqk,bkhd->bqhd", p, v)
+    return torch.einsum("bqhd,hdc->bqc", ctx, wo) + bo
+
+
+def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7):
+    """layers/multihead_self_attention.py:106-150 on finite inputs: per-head softmax(q k^T / sqrt(d)), clip, context"""
+    N, H, W, Cq = q.shape
+    Cv = v.shape[-1]
+    qh = q.reshape(N, H * W, heads, Cq // heads).permute(0, 2, 1, 3)
+    kh = k.reshape(N, H * W, heads, Cq // heads).permute(0, 2, 3, 1)
+    vh = v.reshape(N, H * W, heads, Cv // heads).permute(0, 2, 1, 3)
+    a = qh @ kh
+    if apply_scale:
+        a = a / math.sqrt(Cq // heads)
+    a = torch.softmax(a, dim=-1)
+    a = torch.clamp(a, eps, 1.0 - eps)
+    return (a @ vh).permute(0, 2, 1, 3).reshape(N, H, W, Cv)

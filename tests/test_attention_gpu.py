@@ -1,0 +1,255 @@
+"""Strided-batch GEMMs, the attention core (softmax with relative-position bias / shift mask / probability clip), the row
+gather behind pad + roll + window partition, and the layers built from them (MultiHeadSelfAttentionLayer, keras-style
+MultiHeadAttention inside ViT, Swin) vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as OM
+from oracle import tf_ops as O
+from tests.test_kernels_gpu import DTYPES, close, q, rnd
+from tests.util_models import randomize_parameters
+
+pytestmark = pytest.mark.gpu
+
+
+def K():
+    from iseg_amd import kernels
+
+    return kernels
+
+
+def _rel(a, b):
+    a = a.detach().cpu()
+    d = a.double() - b
+    if a.dtype == torch.bfloat16:
+        return d.norm().item() / max(b.norm().item(), 1e-8)
+    return d.abs().max().item() / max(b.abs().max().item(), 1e-8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,d,heads,B", [(49, 32, 3, 5), (64, 64, 2, 2), (17, 8, 4, 3), (130, 40, 1, 2)])
+def test_batched_gemm_all_orientations(cuda, dtype, T, d, heads, B):
+    k = K()
+    C = heads * d
+    Tp = (T + 7) // 8 * 8
+    x, xr = q(rnd((B, T, 2 * C), 1), dtype)          # [q | k]
+    qr, kr = xr[..., :C].reshape(B, T, heads, d), xr[..., C:].reshape(B, T, heads, d)
+    # NT: S = 0.5 * q k^T
+    S = torch.zeros((B * heads, T, Tp), dtype=dtype, device="cuda")
+    k.gemm(x[:, :, :C], x[:, :, C:], S, T, T, d, lda=2 * C, ldb=2 * C, ldd=Tp, a_kcontig=1, b_kcontig=1, alpha=0.5, batch=B * heads,
+           batch_inner=heads, sa=(T * 2 * C, d), sb=(T * 2 * C, d), sd=(heads * T * Tp, T * Tp))
+    want = 0.5 * torch.einsum("bqhd,bkhd->bhqk", qr, kr).reshape(B * heads, T, T)
+    close(S[:, :, :T], want, dtype, "batched NT")
+    assert S[:, :, T:].abs().max().item() == 0 if Tp > T else True
+    # NN: O = S v  (v := k)
+    Sq = S.to(torch.float64).cpu()[:, :, :T]
+    Oo = torch.empty((B, T, C), dtype=dtype, device="cuda")
+    k.gemm(S, x[:, :, C:], Oo, T, d, T, lda=Tp, ldb=2 * C, ldd=C, a_kcontig=1, b_kcontig=0, batch=B * heads, batch_inner=heads,
+           sa=(heads * T * Tp, T * Tp), sb=(T * 2 * C, d), sd=(T * C, d))
+    want = torch.einsum("bhqk,bkhd->bqhd", Sq.reshape(B, heads, T, T), kr).reshape(B, T, C)
+    close(Oo, want, dtype, "batched NN", bf16_tol=2e-2)
+    # TN: G = S^T q
+    G = torch.empty((B, T, C), dtype=dtype, device="cuda")
+    k.gemm(S, x[:, :, :C], G, T, d, T, lda=Tp, ldb=2 * C, ldd=C, a_kcontig=0, b_kcontig=0, batch=B * heads, batch_inner=heads,
+           sa=(heads * T * Tp, T * Tp), sb=(T * 2 * C, d), sd=(T * C, d))
+    want = torch.einsum("bhqk,bqhd->bkhd", Sq.reshape(B, heads, T, T), qr).reshape(B, T, C)
+    close(G, want, dtype, "batched TN", bf16_tol=2e-2)
+
+
+def _ref_attention(qkv, heads, C, scale, bias=None, mask=None, clip=None):
+    B, T, _ = qkv.shape
+    d = C // heads
+    qh, kh, vh = [qkv[..., i * C:(i + 1) * C].reshape(B, T, heads, d).permute(0, 2, 1, 3) for i in range(3)]
+    a = scale * (qh @ kh.transpose(-1, -2))
+    if bias is not None:
+        a = a + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        a = (a.reshape(-1, nW, heads, T, T) + mask.unsqueeze(1).unsqueeze(0)).reshape(B, heads, T, T)
+    p = torch.softmax(a, dim=-1)
+    if clip is not None:
+        p = torch.clamp(p, clip[0], clip[1])
+    return (p @ vh).permute(0, 2, 1, 3).reshape(B, T, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", ["plain", "swin", "clip"])
+def test_attention_core_forward_backward(cuda, dtype, variant):
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import relative_position_index, shift_attention_mask
+
+    nn.set_compute_dtype(dtype)
+    try:
+        heads, d = 3, 32
+        C = heads * d
+        if variant == "swin":
+            ws, nW, T = 7, 4, 49
+            B = 2 * nW
+            table = torch.nn.Parameter((rnd((169, heads), 3) * 0.5).float().cuda())
+            index = torch.from_numpy(relative_position_index((ws, ws)).reshape(-1)).cuda()
+            mask_np = shift_attention_mask(14, 14, ws, 3)
+            mask = torch.from_numpy(mask_np).cuda()
+        else:
+            B, T = 3, 37
+        qkv, qkvr = q(rnd((B, T, 3 * C), 1), dtype)
+        dy, dyr = q(rnd((B, T, C), 2), dtype)
+        qkv.requires_grad_(True)
+        qkvr.requires_grad_(True)
+        scale = d ** -0.5
+        if variant == "swin":
+            y = F.attention_packed(qkv, heads, C, C, scale, bias_table=table, bias_index=index, mask=mask, windows=nW)
+            tr = table.detach().cpu().double().requires_grad_(True)
+            bias_r = tr[index.cpu().long()].reshape(T, T, heads).permute(2, 0, 1)
+            yr = _ref_attention(qkvr, heads, C, scale, bias_r, torch.from_numpy(mask_np).double())
+        elif variant == "clip":
+            y = F.attention_packed(qkv, heads, C, C, scale, clip=(1e-2, 0.5))
+            yr = _ref_attention(qkvr, heads, C, scale, clip=(1e-2, 0.5))
+        else:
+            y = F.attention_packed(qkv, heads, C, C, scale)
+            yr = _ref_attention(qkvr, heads, C, scale)
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        assert _rel(y, yr.detach()) < tol
+        y.backward(dy)
+        yr.backward(dyr)
+        gtol = 1e-4 if dtype == torch.float32 else (0.2 if variant == "clip" else 3e-2)   # bf16 clip: boundary membership flips
+        assert _rel(qkv.grad, qkvr.grad) < gtol
+        if variant == "swin":
+            assert _rel(table.grad, tr.grad) < (1e-4 if dtype == torch.float32 else 3e-2)
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gather_rows(cuda, dtype):
+    k = K()
+    for C in (96, 20, 3):
+        x = rnd((50, C), 1).to(dtype)
+        idx = torch.tensor([3, -1, 49, 0, 0, 17, -1], dtype=torch.int32)
+        y = k.gather_rows(x.cuda(), idx.cuda(), idx.numel()).cpu()
+        want = torch.where(idx[:, None] >= 0, x[idx.clamp(min=0).long()], torch.zeros(1, dtype=dtype))
+        assert torch.equal(y, want)
+
+
+def _setup(layer, build_inputs):
+    from iseg_amd import nn
+    from iseg_amd.param_store import ParamStore
+
+    with nn.dry_run_scope():
+        layer(build_inputs)
+    layer._iseg_store = ParamStore(list(layer.parameters()))
+    randomize_parameters(layer, 7)
+
+
+def _check_grads(layer, w, tol, l2=False, skip=()):
+    gmax = max(w[p.iseg_name].grad.abs().max().item() for p in layer.parameters() if w[p.iseg_name].grad is not None)
+    bad = {}
+    for p in layer.parameters():
+        r = w[p.iseg_name].grad
+        if r is None or p.iseg_name.endswith(tuple(skip)) and skip:
+            continue
+        d = p.grad.detach().cpu().double() - r
+        if l2:
+            e = d.norm().item() / max(r.norm().item(), 1e-3 * gmax * r.numel() ** 0.5)
+        else:
+            e = d.abs().max().item() / max(r.abs().max().item(), 1e-3 * gmax)
+        if e > tol:
+            bad[p.iseg_name] = e
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mhsa_layer(cuda, dtype):
+    from iseg_amd import nn
+    from iseg_amd.layers.multihead_self_attention import MultiHeadSelfAttentionLayer
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        shape = (2, 6, 5, 64)
+        layer = MultiHeadSelfAttentionLayer(num_heads=4, name="mhsa")
+        _setup(layer, torch.empty(shape, dtype=dtype, device="cuda"))
+        x = rnd(shape, 1).to(dtype)
+        xg = x.cuda().requires_grad_(True)
+        y = layer(xg, training=True)
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(layer).items()}
+        xr = x.double().requires_grad_(True)
+        yr = OM.mhsa_layer(w, "mhsa", xr, 4)
+        assert _rel(y, yr.detach()) < (2e-5 if dtype == torch.float32 else 3e-2)
+        dy = rnd(shape, 2).to(dtype)
+        y.backward(dy.cuda())
+        yr.backward(dy.double())
+        assert _rel(xg.grad, xr.grad) < (2e-4 if dtype == torch.float32 else 5e-2)
+        # the key bias shifts every score of a row by the same amount: its gradient is analytically zero (rounding noise only)
+        _check_grads(layer, w, 2e-4 if dtype == torch.float32 else 6e-2, l2=dtype != torch.float32, skip=("key_conv/bias",))
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vit_small(cuda, dtype):
+    """a 2-layer member of the ViT family (same code path as ViT-B/16): bicubic position-embedding resize 4x4 -> 3x5, class
+    token, keras-MHA-shaped attention, drop-path with injected factors"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.vit import VisionTransformer
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        shape = (2, 48, 80, 3)
+        vit = VisionTransformer(patch_size=16, num_layer=2, num_head=4, filters=64, mlp_filters=128, pretrain_size=64, drop_path_rate=0.2,
+                                return_endpoints=True, name="ViT-test")
+        _setup(vit, torch.empty(shape, dtype=torch.float32, device="cuda"))
+        g = torch.Generator().manual_seed(0)
+        f = [None, (torch.tensor([1.25, 0.0]), torch.tensor([0.0, 1.25]))]
+        vit.blocks[1].drop_path_masks = tuple(t.cuda() for t in f[1])
+        x = torch.randn(shape, generator=g)
+        (y,) = vit(x.cuda(), training=True)
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(vit).items()}
+        yr = OM.vit_forward(w, x.double(), "ViT-test", 2, 64, dp_factors=[None, tuple(t.double() for t in f[1])])
+        assert tuple(y.shape) == tuple(yr.shape) == (2, 3, 5, 64)
+        assert _rel(y, yr.detach()) < (1e-4 if dtype == torch.float32 else 4e-2)
+        dy = torch.randn(tuple(yr.shape), generator=g)
+        y.backward(dy.cuda().to(dtype))
+        yr.backward(dy.to(dtype).double())
+        _check_grads(vit, w, 5e-4 if dtype == torch.float32 else 8e-2, l2=dtype != torch.float32)
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_swin_small(cuda, dtype):
+    """a 2-stage member of the Swin family (window 7, shift 3): 58x75 input -> 15x19 tokens (padded to 21x21: pad tokens take
+    part in attention), odd sizes through PatchMerging, drop-path with injected factors"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import SwinTransformerModel
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        shape = (2, 58, 75, 3)
+        swin = SwinTransformerModel(embed_dim=32, depths=[2, 2], num_heads=[2, 4], window_size=7, drop_path_rate=0.2,
+                                    return_endpoints=True, name="swin_test")
+        _setup(swin, torch.empty(shape, dtype=torch.float32, device="cuda"))
+        g = torch.Generator().manual_seed(0)
+        fa, fb = torch.tensor([1.25, 0.0]), torch.tensor([1.25, 1.25])
+        dp = [[None, (fb.double(), fa.double())], [(fa.double(), fa.double()), (fa.double(), fb.double())]]
+        for li in range(2):          # every block whose stochastic-depth rate is non-zero gets its factors injected
+            for bi in range(2):
+                if dp[li][bi] is not None:
+                    assert swin.basic_layers[li].blocks[bi].drop_path_prob > 0
+                    swin.basic_layers[li].blocks[bi].drop_path_masks = tuple(t.float().cuda() for t in dp[li][bi])
+        x = torch.randn(shape, generator=g)
+        eps = swin(x.cuda(), training=True)
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(swin).items()}
+        ref = OM.swin_forward(w, x.double(), depths=(2, 2), heads=(2, 4), ws=7, dp_factors=dp)
+        assert [tuple(e.shape) for e in eps] == [tuple(r.shape) for r in ref]
+        for a, b in zip(eps, ref):
+            assert _rel(a, b.detach()) < (1e-4 if dtype == torch.float32 else 4e-2)
+        dys = [torch.randn(tuple(r.shape), generator=g).to(dtype) for r in ref]
+        torch.autograd.backward(list(eps), [d.cuda() for d in dys])
+        torch.autograd.backward(ref, [d.double() for d in dys])
+        _check_grads(swin, w, 5e-4 if dtype == torch.float32 else 8e-2, l2=dtype != torch.float32)
+    finally:
+        nn.set_compute_dtype(torch.float32)

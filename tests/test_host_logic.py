@@ -2,6 +2,8 @@
 rules, schedules, dataset pipeline, flat parameter store, sliding-window tiling."""
 import re
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -158,3 +160,63 @@ def test_get_scaled_size_pad_mode_1():
     assert get_scaled_size(x, 0.5, pad_mode=1) == [257, 257]      # int(256.5)=256 even while input odd -> +1
     assert get_scaled_size(x, 1.0, pad_mode=1) == [513, 513]
     assert get_scaled_size(torch.empty(1, 512, 512, 3), 0.75, pad_mode=1) == [384, 384]
+
+
+# --------------------------------------------------------------------------------------------------------
+# Swin / ViT host-side geometry tables (backbones/swin.py, utils/bicubic.py) vs the oracle's tensor-op restatement
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,ws,shift", [(2, 10, 12, 7, 3), (1, 14, 14, 7, 0), (3, 7, 7, 7, 3), (1, 20, 9, 4, 2)])
+def test_swin_window_index_tables_match_pad_roll_partition(N, H, W, ws, shift):
+    import torch.nn.functional as TF
+
+    from iseg_amd.backbones.swin import window_index_tables
+    from oracle import models as OM
+
+    C = 3
+    x = torch.randn(N, H, W, C)
+    part, rev, Hp, Wp = window_index_tables(N, H, W, ws, shift)
+    flat = x.reshape(-1, C)
+    got = torch.where(part.long()[:, None] >= 0, flat[part.long().clamp(min=0)], torch.zeros(1))
+    y = TF.pad(x, (0, 0, 0, Wp - W, 0, Hp - H))
+    y = torch.roll(y, (-shift, -shift), dims=(1, 2))
+    win = OM._window_partition(y, ws).reshape(-1, C)
+    assert torch.equal(got, win)
+    back = torch.roll(OM._window_reverse(win.reshape(-1, ws, ws, C), ws, Hp, Wp, C), (shift, shift), dims=(1, 2))[:, :H, :W]
+    assert torch.equal(win[rev.long()], back.reshape(-1, C))
+
+
+def test_swin_merge_tables_mask_and_relative_index():
+    import torch.nn.functional as TF
+
+    from iseg_amd.backbones.swin import merge_index_tables, relative_position_index, shift_attention_mask
+    from oracle import models as OM
+
+    x = torch.randn(2, 5, 7, 3)
+    fwd, bwd, H2, W2 = merge_index_tables(2, 5, 7)
+    flat = x.reshape(-1, 3)
+    got = torch.where(fwd.long()[:, None] >= 0, flat[fwd.long().clamp(min=0)], torch.zeros(1)).reshape(2, H2, W2, 12)
+    xp = TF.pad(x, (0, 0, 0, 1, 0, 1))
+    ref = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1)
+    assert torch.equal(got, ref)
+    assert torch.equal(got.reshape(-1, 3)[bwd.long()], flat)
+    for (H, W) in ((14, 14), (19, 23), (7, 7)):
+        assert np.array_equal(shift_attention_mask(H, W, 7, 3), OM.swin_attention_mask(H, W, 7, 3).numpy().astype(np.float32))
+    idx = relative_position_index((7, 7))
+    assert idx.shape == (49, 49) and idx.min() == 0 and idx.max() == 168 and idx[0, 0] == 84 and idx[0, 48] == 0 and idx[48, 0] == 168
+    assert np.array_equal(idx, OM._rel_index(7).numpy())
+
+
+def test_bicubic_matrices_match_oracle_taps():
+    from iseg_amd.utils.bicubic import bicubic_matrix
+    from oracle import tf_ops as O
+
+    x = torch.randn(1, 24, 24, 3, dtype=torch.float64)
+    y = O.resize_bicubic(x, (40, 31))
+    Wy, Wx = torch.from_numpy(bicubic_matrix(40, 24)).double(), torch.from_numpy(bicubic_matrix(31, 24)).double()
+    y2 = torch.einsum("pw,nowc->nopc", Wx, torch.einsum("oh,nhwc->nowc", Wy, x))
+    assert (y - y2).abs().max().item() < 5e-6
+    assert np.allclose(bicubic_matrix(24, 24), np.eye(24))
+    # 2x up-sampling of a ramp stays a ramp away from the borders (cubic convolution reproduces linear functions)
+    r = torch.arange(16, dtype=torch.float64).reshape(1, 16, 1, 1).expand(1, 16, 2, 1)
+    up = O.resize_bicubic(r, (32, 2))[0, 4:28, 0, 0]
+    assert torch.allclose(up, (torch.arange(4, 28, dtype=torch.float64) + 0.5) / 2 - 0.5, atol=1e-3)
