@@ -300,6 +300,24 @@ int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bia
 int iseg_relpos_bias_scatter_grad(const float* dbias, int ld, const int32_t* index, float* dtable, int entries, int heads, int T,
                                   int accumulate, iseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * layers/dcn_v3/op.py:16-109 dcnv3_op + utils.py:14-209 (reference points, dilation grids, bilinear sampler), restated
+ * exactly (see csrc/dcnv3.hip for the formulae and the [y,x]-vs-[x,y] quirk).  x [N,H,W,G*Cg] (unpadded; `pad` zero ring is
+ * implicit), offset [N,Ho,Wo,G*kh*kw*2], mask [N,Ho,Wo,G*kh*kw] (already soft-maxed), y [N,Ho,Wo,G*Cg].
+ * Backward: dx_f32 [N,H,W,G*Cg] fp32, ZEROED by the caller, receives atomic adds; doffset / dmask in the storage dtype.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mask, void* y, int N, int H, int W, int G, int Cg, int kh, int kw,
+                   int stride, int dil, int pad, float offset_scale, int dtype, iseg_stream_t stream);
+int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset, void* dmask,
+                   int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype,
+                   iseg_stream_t stream);
+/* out[c] (+)= sum_r a[r][c]*b[r][c]: gradient of the per-channel layer scale x * gamma (backbones/intern_image/
+ * intern_image_layer.py:128,136,160,168) */
+int iseg_scale_cols(const void* x, const float* colscale, void* y, int64_t rows, int C, int dtype, iseg_stream_t stream);
+size_t iseg_mul_colsum_workspace_bytes(int64_t rows, int C);
+int iseg_mul_colsum(const void* a, const void* b, int64_t rows, int C, float* out, int accumulate, int dtype, void* ws,
+                    size_t ws_bytes, iseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,10 +22,12 @@ def _builtin_backbones():
         ss.RESNET152: resnet152,
     }
     from .swin import swin_base_384, swin_large_384, swin_tiny_224
+    from .intern_image import intern_image_small, intern_image_tiny
     from .vit import ViT16B, ViT16L
 
     d.update({ss.SWIN_TINY_224: swin_tiny_224, ss.SWIN_BASE_384: swin_base_384, ss.SWIN_LARGE_384: swin_large_384,
-              ss.VIT_B: ViT16B, ss.VIT_L: ViT16L})
+              ss.VIT_B: ViT16B, ss.VIT_L: ViT16L, ss.INTERN_IMAGE_TINY: intern_image_tiny,
+              ss.INTERN_IMAGE_SMALL: intern_image_small})
     return d
 
 

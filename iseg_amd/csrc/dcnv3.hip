@@ -1,0 +1,303 @@
+// DCNv3 core of the reference (layers/dcn_v3/op.py:16-109 + utils.py:14-209), restated exactly, quirks included:
+//
+//   xp = zero-pad(x, pad) [N, Hin = H + 2 pad, Win = W + 2 pad, G*Cg]          (never materialised: reads are bounds-checked)
+//   ref[h]   = ((dil*(k-1))/2 + 0.5 + h*stride) / Hin   and likewise over Win   -> stacked [y, x]            (utils.py:26-56)
+//   grid[p]  = (gx[p / kh] / Win, gy[p % kh] / Hin),  gx, gy in {-(dil*(k-1))/2 + i*dil}  -> stacked [x, y]  (utils.py:75-101)
+//   e0 = ref_y[h] + grid_x[p]*s + offset[n,h,w,(g*P+p)*2+0] * s / Win                                        (op.py:77-85)
+//   e1 = ref_x[w] + grid_y[p]*s + offset[n,h,w,(g*P+p)*2+1] * s / Hin
+//   px = 0.5*((2*e0 - 1) + 1)*(Win - 2),  py = 0.5*((2*e1 - 1) + 1)*(Hin - 2)                                 (utils.py:139-143)
+//   x0 = floor(px), x1 = x0 + 1, y0 = floor(py), y1 = y0 + 1, each clipped to the padded image; the four bilinear weights are
+//   formed from the CLIPPED corners (:146-172), so they can be negative or exceed 1 near the border
+//   out[n,h,w,g,:] = sum_p mask[n,h,w,g*P+p] * (wa*xp[y0,x0] + wb*xp[y1,x0] + wc*xp[y0,x1] + wd*xp[y1,x1])[g*Cg:(g+1)*Cg]
+//
+// i.e. channel 0 of the sampling location mixes the ROW reference with the x offset (for square inputs the base sampling grid is
+// transposed) -- reproduced here because parity with the reference is the contract.  Coordinates are computed in fp32 whatever
+// the storage dtype (the reference computes them in the compute dtype, a precision hazard under bf16).
+//
+// One lane = one (n, h, w, g): it walks the P sampling points, 4 corners and Cg channels, so the gradients of offset and mask
+// (reductions over the group's channels) need no cross-lane step; the gradient of x is scattered with fp32 atomics.
+#include "common.h"
+#include "iseg_hip.h"
+
+namespace {
+
+struct DcnGeom {
+    int N, H, W, G, Cg, kh, kw, stride, dil, pad, Hin, Win, Ho, Wo;
+    float s;
+};
+
+struct Tap {
+    int x0, x1, y0, y1;          // clipped corners, padded coordinates
+    float dx0, dx1, dy0, dy1;    // px - x0, x1 - px, py - y0, y1 - py
+};
+
+__device__ __forceinline__ Tap dcn_tap(const DcnGeom& g, int h, int w, int p, float off0, float off1) {
+    const float half = (float)((g.dil * (g.kh - 1)) / 2);
+    const float halfw = (float)((g.dil * (g.kw - 1)) / 2);
+    const float ref_y = (half + 0.5f + (float)(h * g.stride)) / (float)g.Hin;
+    const float ref_x = (halfw + 0.5f + (float)(w * g.stride)) / (float)g.Win;
+    const float gx = (-halfw + (float)((p / g.kh) * g.dil)) / (float)g.Win;
+    const float gy = (-half + (float)((p % g.kh) * g.dil)) / (float)g.Hin;
+    const float e0 = ref_y + gx * g.s + off0 * g.s / (float)g.Win;
+    const float e1 = ref_x + gy * g.s + off1 * g.s / (float)g.Hin;
+    const float px = 0.5f * (((2.f * e0 - 1.f) + 1.0f) * (float)(g.Win - 2));
+    const float py = 0.5f * (((2.f * e1 - 1.f) + 1.0f) * (float)(g.Hin - 2));
+    Tap t;
+    const int fx = (int)floorf(px), fy = (int)floorf(py);
+    t.x0 = min(max(fx, 0), g.Win - 1);
+    t.x1 = min(max(fx + 1, 0), g.Win - 1);
+    t.y0 = min(max(fy, 0), g.Hin - 1);
+    t.y1 = min(max(fy + 1, 0), g.Hin - 1);
+    t.dx0 = px - (float)t.x0;
+    t.dx1 = (float)t.x1 - px;
+    t.dy0 = py - (float)t.y0;
+    t.dy1 = (float)t.y1 - py;
+    return t;
+}
+
+// element offset of padded pixel (y, x) in the UNPADDED tensor, or -1 inside the zero ring
+__device__ __forceinline__ int64_t dcn_src(const DcnGeom& g, int n, int y, int x) {
+    const int uy = y - g.pad, ux = x - g.pad;
+    if ((unsigned)uy >= (unsigned)g.H || (unsigned)ux >= (unsigned)g.W) return -1;
+    return (((int64_t)n * g.H + uy) * g.W + ux) * (g.G * g.Cg);
+}
+
+template <class T, int CV>
+__device__ __forceinline__ void ldv(const T* p, float* v) {
+    if (CV == 8) load8<T>(p, v);
+    else v[0] = to_f32(p[0]);
+}
+
+template <class T, int CV>
+__global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
+                                                        T* __restrict__ y, DcnGeom g) {
+    const int P = g.kh * g.kw;
+    const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gi = (int)(i % g.G);
+        int64_t t = i / g.G;
+        const int w = (int)(t % g.Wo);
+        t /= g.Wo;
+        const int h = (int)(t % g.Ho);
+        const int n = (int)(t / g.Ho);
+        const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
+        const T* op = offset + (pix * g.G + gi) * P * 2;
+        const T* mp = mask + (pix * g.G + gi) * P;
+        T* yp = y + (pix * g.G + gi) * g.Cg;
+        for (int c0 = 0; c0 < g.Cg; c0 += CV) {
+            float acc[CV];
+#pragma unroll
+            for (int u = 0; u < CV; ++u) acc[u] = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const Tap tp = dcn_tap(g, h, w, p, to_f32(op[2 * p]), to_f32(op[2 * p + 1]));
+                const float m = to_f32(mp[p]);
+                const float wgt[4] = {tp.dx1 * tp.dy1, tp.dx1 * tp.dy0, tp.dx0 * tp.dy1, tp.dx0 * tp.dy0};
+                const int ys[4] = {tp.y0, tp.y1, tp.y0, tp.y1};
+                const int xs[4] = {tp.x0, tp.x0, tp.x1, tp.x1};
+                float px[CV];
+#pragma unroll
+                for (int u = 0; u < CV; ++u) px[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t src = dcn_src(g, n, ys[k], xs[k]);
+                    if (src >= 0) {
+                        float v[CV];
+                        ldv<T, CV>(x + src + gi * g.Cg + c0, v);
+#pragma unroll
+                        for (int u = 0; u < CV; ++u) px[u] = fmaf(wgt[k], v[u], px[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CV; ++u) acc[u] = fmaf(px[u], m, acc[u]);
+            }
+            if (CV == 8) store8<T>(yp + c0, acc);
+            else yp[c0] = from_f32<T>(acc[0]);
+        }
+    }
+}
+
+// gradients: dx (fp32, atomics; zero-initialised by the caller), doffset, dmask (written once per (n,h,w,g,p))
+template <class T, int CV>
+__global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
+                                                        const T* __restrict__ dy, float* __restrict__ dx, T* __restrict__ doffset,
+                                                        T* __restrict__ dmask, DcnGeom g) {
+    const int P = g.kh * g.kw;
+    const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gi = (int)(i % g.G);
+        int64_t t = i / g.G;
+        const int w = (int)(t % g.Wo);
+        t /= g.Wo;
+        const int h = (int)(t % g.Ho);
+        const int n = (int)(t / g.Ho);
+        const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
+        const T* op = offset + (pix * g.G + gi) * P * 2;
+        const T* mp = mask + (pix * g.G + gi) * P;
+        const T* dyp = dy + (pix * g.G + gi) * g.Cg;
+        for (int p = 0; p < P; ++p) {
+            const Tap tp = dcn_tap(g, h, w, p, to_f32(op[2 * p]), to_f32(op[2 * p + 1]));
+            const float m = to_f32(mp[p]);
+            const float wgt[4] = {tp.dx1 * tp.dy1, tp.dx1 * tp.dy0, tp.dx0 * tp.dy1, tp.dx0 * tp.dy0};
+            // d weight / d px and / d py (floor and clip carry no gradient)
+            const float wpx[4] = {-tp.dy1, -tp.dy0, tp.dy1, tp.dy0};
+            const float wpy[4] = {-tp.dx1, tp.dx1, -tp.dx0, tp.dx0};
+            const int ys[4] = {tp.y0, tp.y1, tp.y0, tp.y1};
+            const int xs[4] = {tp.x0, tp.x0, tp.x1, tp.x1};
+            float gm = 0.f, gpx = 0.f, gpy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t src = dcn_src(g, n, ys[k], xs[k]);
+                if (src < 0) continue;
+                float dot = 0.f;    // sum_c dy[c] * xp[corner][c]
+                for (int c0 = 0; c0 < g.Cg; c0 += CV) {
+                    float v[CV], d[CV];
+                    ldv<T, CV>(x + src + gi * g.Cg + c0, v);
+                    ldv<T, CV>(dyp + c0, d);
+#pragma unroll
+                    for (int u = 0; u < CV; ++u) {
+                        dot = fmaf(d[u], v[u], dot);
+                        atomicAdd(dx + src + gi * g.Cg + c0 + u, d[u] * m * wgt[k]);
+                    }
+                }
+                gm = fmaf(wgt[k], dot, gm);
+                gpx = fmaf(wpx[k], dot, gpx);
+                gpy = fmaf(wpy[k], dot, gpy);
+            }
+            dmask[(pix * g.G + gi) * P + p] = from_f32<T>(gm);
+            // px = e0 * (Win - 2), e0 = ... + off0 * s / Win
+            doffset[((pix * g.G + gi) * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
+            doffset[((pix * g.G + gi) * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
+        }
+    }
+}
+
+// dgamma partials of a per-channel scale y = x * gamma[c]:  out[c] = sum_r a[r][c] * b[r][c]
+template <class T>
+__global__ __launch_bounds__(256) void mul_colsum_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t rows, int C,
+                                                                 float* __restrict__ partials) {
+    // block handles a contiguous row range; thread c-strides the channels (coalesced), sums its rows in order
+    const int64_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s = fmaf(to_f32(a[r * C + c]), to_f32(b[r * C + c]), s);
+        partials[(int64_t)blockIdx.x * C + c] = s;
+    }
+}
+
+// y[r][c] = x[r][c] * s[c]   (per-channel layer scale in the storage dtype)
+template <class T>
+__global__ __launch_bounds__(256) void scale_cols_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y,
+                                                         int64_t n, int C) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = from_f32<T>(to_f32(x[i]) * s[i % C]);
+}
+
+static inline int mc_blocks(int64_t rows) {
+    int64_t b = ceil_div64(rows, 64);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static inline unsigned lane_blocks(int64_t n) {
+    int64_t b = ceil_div64(n, 256);
+    if (b > 256 * 64) b = 256 * 64;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static int make_geom(DcnGeom* g, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float s,
+                     const char* who) {
+    ISEG_REQUIRE(N > 0 && H > 0 && W > 0 && G > 0 && Cg > 0 && kh > 0 && kw > 0 && stride > 0 && dil > 0 && pad >= 0,
+                 "%s: bad geometry", who);
+    g->N = N; g->H = H; g->W = W; g->G = G; g->Cg = Cg; g->kh = kh; g->kw = kw; g->stride = stride; g->dil = dil; g->pad = pad;
+    g->Hin = H + 2 * pad;
+    g->Win = W + 2 * pad;
+    g->Ho = (g->Hin - (dil * (kh - 1) + 1)) / stride + 1;
+    g->Wo = (g->Win - (dil * (kw - 1) + 1)) / stride + 1;
+    g->s = s;
+    ISEG_REQUIRE(g->Ho > 0 && g->Wo > 0, "%s: empty output", who);
+    ISEG_REQUIRE((int64_t)N * g->Hin * g->Win * G * Cg < (1ll << 40), "%s: tensor too large", who);
+    return ISEG_OK;
+}
+
+}  // namespace
+
+extern "C" int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mask, void* y, int N, int H, int W, int G, int Cg, int kh,
+                              int kw, int stride, int dil, int pad, float offset_scale, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && offset && mask && y, "iseg_dcnv3_fwd: null pointer");
+    DcnGeom g;
+    const int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_fwd");
+    if (rc != ISEG_OK) return rc;
+    const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
+    const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+#define DCN_FWD(T, CV)                                                                                                              \
+    hipLaunchKernelGGL((dcnv3_fwd_kernel<T, CV>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset,   \
+                       (const T*)mask, (T*)y, g)
+    if (dtype == ISEG_BF16) {
+        if (v8) DCN_FWD(bf16_t, 8);
+        else DCN_FWD(bf16_t, 1);
+    } else {
+        if (v8) DCN_FWD(float, 8);
+        else DCN_FWD(float, 1);
+    }
+#undef DCN_FWD
+    return iseg_check_launch("iseg_dcnv3_fwd");
+}
+
+extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset,
+                              void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
+                              float offset_scale, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && offset && mask && dy && dx_f32 && doffset && dmask, "iseg_dcnv3_bwd: null pointer");
+    DcnGeom g;
+    const int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd");
+    if (rc != ISEG_OK) return rc;
+    const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
+    const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
+#define DCN_BWD(T, CV)                                                                                                              \
+    hipLaunchKernelGGL((dcnv3_bwd_kernel<T, CV>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset,   \
+                       (const T*)mask, (const T*)dy, dx_f32, (T*)doffset, (T*)dmask, g)
+    if (dtype == ISEG_BF16) {
+        if (v8) DCN_BWD(bf16_t, 8);
+        else DCN_BWD(bf16_t, 1);
+    } else {
+        if (v8) DCN_BWD(float, 8);
+        else DCN_BWD(float, 1);
+    }
+#undef DCN_BWD
+    return iseg_check_launch("iseg_dcnv3_bwd");
+}
+
+extern "C" size_t iseg_mul_colsum_workspace_bytes(int64_t rows, int C) { return (size_t)mc_blocks(rows) * C * sizeof(float); }
+
+extern "C" int iseg_mul_colsum(const void* a, const void* b, int64_t rows, int C, float* out, int accumulate, int dtype, void* ws,
+                               size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(a && b && out && rows > 0 && C > 0, "iseg_mul_colsum: bad arguments");
+    const int blocks = mc_blocks(rows);
+    const size_t need = (size_t)blocks * C * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_mul_colsum: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((mul_colsum_partial_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,
+                           rows, C, (float*)ws);
+    else
+        hipLaunchKernelGGL((mul_colsum_partial_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, rows,
+                           C, (float*)ws);
+    launch_reduce_rows((const float*)ws, blocks, C, 0, 1, C, out, nullptr, C, 0, 1.f, accumulate, stream);
+    return iseg_check_launch("iseg_mul_colsum");
+}
+
+extern "C" int iseg_scale_cols(const void* x, const float* colscale, void* y, int64_t rows, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && colscale && y && rows > 0 && C > 0, "iseg_scale_cols: bad arguments");
+    const int64_t n = rows * C;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((scale_cols_kernel<bf16_t>), dim3(lane_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, colscale, (bf16_t*)y,
+                           n, C);
+    else
+        hipLaunchKernelGGL((scale_cols_kernel<float>), dim3(lane_blocks(n)), dim3(256), 0, stream, (const float*)x, colscale, (float*)y, n,
+                           C);
+    return iseg_check_launch("iseg_scale_cols");
+}

@@ -1124,3 +1124,89 @@ def resize_pos_embed(pos, Wy, Wx, n_extra, out_dtype):
     if nn.dry_run():
         return _dry((1, n_extra + Wy.shape[0] * Wx.shape[0], pos.shape[-1]), pos, out_dtype)
     return _PosEmbedResizeFn.apply(pos, Wy, Wx, int(n_extra), out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DCNv3 core (layers/dcn_v3/op.py:16-109), softmax over the last axis in groups, per-channel scale
+# ---------------------------------------------------------------------------------------------------------
+class _Dcnv3Fn(Function):
+    @staticmethod
+    def forward(ctx, x, offset, mask, cfg):
+        G, Cg, kh, kw, stride, dil, pad, s = cfg
+        xc, oc, mc = _c(x), _c(offset), _c(mask)
+        ctx.cfg = cfg
+        ctx.save_for_backward(xc, oc, mc)
+        return K.dcnv3_fwd(xc, oc, mc, G, Cg, kh, kw, stride, dil, pad, s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, oc, mc = ctx.saved_tensors
+        G, Cg, kh, kw, stride, dil, pad, s = ctx.cfg
+        dx, doff, dmask = K.dcnv3_bwd(xc, oc, mc, _c(dy), G, Cg, kh, kw, stride, dil, pad, s)
+        if dx.dtype != xc.dtype:
+            dx = K.cast(dx, xc.dtype)
+        return dx, doff, dmask, None
+
+
+def dcnv3_core(x, offset, mask, groups, group_channels, kernel_size=(3, 3), stride=1, dilation=1, pad=1, offset_scale=1.0):
+    kh, kw = kernel_size
+    if nn.dry_run():
+        Ho, Wo = K.dcnv3_out_hw(x.shape[1], x.shape[2], kh, kw, stride, dilation, pad)
+        return _dry((x.shape[0], Ho, Wo, x.shape[3]), x)
+    return _Dcnv3Fn.apply(x, offset, mask, (int(groups), int(group_channels), int(kh), int(kw), int(stride), int(dilation), int(pad),
+                                             float(offset_scale)))
+
+
+class _GroupSoftmaxFn(Function):
+    @staticmethod
+    def forward(ctx, x, P):
+        xc = _c(x)
+        rows = xc.numel() // P
+        y = torch.empty_like(xc)
+        K.softmax_rows_fwd(xc, rows, 1, P, P, out=y)
+        ctx.P = P
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        P = ctx.P
+        d = torch.empty_like(y)
+        K.softmax_rows_bwd(y, _c(dy), y.numel() // P, P, P, out=d)
+        return d, None
+
+
+def softmax_groups(x, P):
+    """softmax over consecutive runs of P entries of the last axis (tf.reshape [..., G, P] -> tf.nn.softmax -> reshape back)"""
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _GroupSoftmaxFn.apply(x, int(P))
+
+
+class _ScaleChannelsFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        ctx.gamma = gamma
+        ctx.save_for_backward(x2)
+        return K.scale_cols(x2, gamma.data).reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        g = ctx.gamma
+        C = x2.shape[1]
+        dy2 = _c(dy).reshape(-1, C)
+        if g.requires_grad:
+            K.mul_colsum(dy2, x2, _grad(g), accumulate=True)
+            dist.grads_ready(g)
+        return K.scale_cols(dy2, g.data).reshape(dy.shape), None
+
+
+def scale_channels(x, gamma):
+    """x * gamma[c] with an fp32 parameter gamma (layer scale)"""
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ScaleChannelsFn.apply(x, gamma)

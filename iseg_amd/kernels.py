@@ -590,3 +590,55 @@ def relpos_bias_scatter_grad(dbias, ld, index, dtable, heads, T, accumulate=True
     _hip.check(_hip.lib().iseg_relpos_bias_scatter_grad(ptr(dbias), ld, ptr(index), ptr(dtable), dtable.shape[0], heads, T, int(accumulate),
                                                        stream()), "iseg_relpos_bias_scatter_grad")
     return dtable
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DCNv3 core + per-channel scale gradient (csrc/dcnv3.hip)
+# ---------------------------------------------------------------------------------------------------------
+def dcnv3_out_hw(H, W, kh, kw, stride, dil, pad):
+    return (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1, (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+
+
+def dcnv3_fwd(x, offset, mask, G, Cg, kh, kw, stride, dil, pad, offset_scale):
+    _require_cuda(x, offset, mask)
+    N, H, W, Cc = x.shape
+    Ho, Wo = dcnv3_out_hw(H, W, kh, kw, stride, dil, pad)
+    if Cc != G * Cg or tuple(offset.shape) != (N, Ho, Wo, G * kh * kw * 2) or tuple(mask.shape) != (N, Ho, Wo, G * kh * kw):
+        raise ValueError(f"dcnv3_fwd: shapes x {tuple(x.shape)} offset {tuple(offset.shape)} mask {tuple(mask.shape)} do not match "
+                         f"G={G} Cg={Cg} k={kh}x{kw} -> {Ho}x{Wo}")
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _hip.check(_hip.lib().iseg_dcnv3_fwd(ptr(x), ptr(offset), ptr(mask), ptr(y), N, H, W, G, Cg, kh, kw, stride, dil, pad,
+                                        float(offset_scale), dt(x), stream()), "iseg_dcnv3_fwd")
+    return y
+
+
+def dcnv3_bwd(x, offset, mask, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale):
+    _require_cuda(x, offset, mask, dy)
+    N, H, W, Cc = x.shape
+    Ho, Wo = dcnv3_out_hw(H, W, kh, kw, stride, dil, pad)
+    if tuple(dy.shape) != (N, Ho, Wo, Cc) or Cc != G * Cg:
+        raise ValueError("dcnv3_bwd: dy shape does not match the forward geometry")
+    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
+    fill_f32(dx, 0.0)
+    doff = torch.empty_like(offset)
+    dmask = torch.empty_like(mask)
+    _hip.check(_hip.lib().iseg_dcnv3_bwd(ptr(x), ptr(offset), ptr(mask), ptr(dy), ptr(dx), ptr(doff), ptr(dmask), N, H, W, G, Cg, kh, kw,
+                                        stride, dil, pad, float(offset_scale), dt(x), stream()), "iseg_dcnv3_bwd")
+    return dx, doff, dmask
+
+
+def mul_colsum(a2d, b2d, out, accumulate=True):
+    _require_cuda(a2d, b2d, out)
+    rows, Cc = a2d.shape
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_mul_colsum_workspace_bytes(rows, Cc), a2d.device)
+    _hip.check(L.iseg_mul_colsum(ptr(a2d), ptr(b2d), rows, Cc, ptr(out), int(accumulate), dt(a2d), ptr(ws), wsb, stream()), "iseg_mul_colsum")
+    return out
+
+
+def scale_cols(x2d, colscale):
+    _require_cuda(x2d, colscale)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    _hip.check(_hip.lib().iseg_scale_cols(ptr(x2d), ptr(colscale), ptr(y), rows, Cc, dt(x2d), stream()), "iseg_scale_cols")
+    return y

@@ -1,0 +1,50 @@
+"""layers/dcn_v3/dcn_v3.py of the reference (:15-150): input projection, depthwise conv -> LN -> GELU branch producing the
+sampling offsets and the (soft-maxed) modulation mask, the DCNv3 sampling core (op.py / utils.py -> csrc/dcnv3.hip), optional
+centre-feature scale, output projection."""
+from ... import functional as F
+from ...nn import Layer
+from ..base_layers import Dense, DepthwiseConv2D, LayerNormalization
+
+LAYER_NORM_EPSILON = 1e-6
+
+
+class DeformableConvolutionV3(Layer):
+    def __init__(self, filters=64, kernel_size=3, depthwise_kernel_size=None, strides=1, padding="SAME", dilation_rate=1, groups=4,
+                 offset_scale=1.0, activation="gelu", center_feature_scale=False, name=None):
+        super().__init__(name=name)
+        assert filters % groups == 0, "filters must be divisible by groups"
+        self.offset_scale, self.filters, self.kernel_size = offset_scale, filters, kernel_size
+        self.depthwise_kernel_size = depthwise_kernel_size or kernel_size
+        self.strides, self.padding, self.dilation_rate = strides, padding, dilation_rate
+        if activation not in ("gelu", None):
+            raise NotImplementedError("DeformableConvolutionV3: activation gelu / None")
+        self.activation = activation
+        self.groups, self.filters_per_group = groups, filters // groups
+        self.center_feature_scale = center_feature_scale
+        if center_feature_scale:
+            raise NotImplementedError("center_feature_scale (only intern_image_huge uses it)")
+
+    def build(self, input_shape):
+        input_channel = int(input_shape[-1])
+        k2 = self.kernel_size * self.kernel_size
+        self.dw_conv = DepthwiseConv2D(kernel_size=self.depthwise_kernel_size, strides=1, padding=self.padding.lower(),
+                                       name=f"{self.name}/dw_conv")
+        self.dw_norm = LayerNormalization(epsilon=LAYER_NORM_EPSILON, name=f"{self.name}/dw_conv_norm")
+        self.offset = Dense(2 * self.groups * k2, kernel_initializer="zeros", bias_initializer="zeros", name=f"{self.name}/offset")
+        self.mask = Dense(self.groups * k2, kernel_initializer="zeros", bias_initializer="zeros", name=f"{self.name}/mask")
+        self.input_proj = Dense(input_channel, name=f"{self.name}/input_proj")
+        self.output_proj = Dense(self.filters, name=f"{self.name}/output_proj")
+        self.built = True
+
+    def call(self, inputs, training=False):
+        x = inputs
+        x_proj = self.input_proj(x)
+        x1 = self.dw_norm(self.dw_conv(x))
+        if self.activation == "gelu":
+            x1 = F.gelu(x1)
+        offset = self.offset(x1)
+        mask = F.softmax_groups(self.mask(x1), self.kernel_size * self.kernel_size)
+        pad = self.kernel_size // 2 if self.padding.upper() == "SAME" else 0
+        x = F.dcnv3_core(x_proj, offset, mask, self.groups, self.filters_per_group, (self.kernel_size, self.kernel_size),
+                         self.strides, self.dilation_rate, pad, self.offset_scale)
+        return self.output_proj(x)

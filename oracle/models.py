@@ -349,3 +349,61 @@ def swin_forward(w, x, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, patch=4,
         if li < len(depths) - 1:
             x = swin_patch_merging(w, f"layers/{li}/downsample", x)
     return endpoints
+
+
+# ------------------------------------------------------------------------------------------------------
+# layers/dcn_v3/dcn_v3.py:107-150 and backbones/intern_image/*
+# ------------------------------------------------------------------------------------------------------
+def dcnv3_layer(w, p, x, groups, kernel_size=3, dw_kernel=None, offset_scale=1.0):
+    N, H, W, C = x.shape
+    x_proj = O.dense(x, w[f"{p}/input_proj/kernel"], w[f"{p}/input_proj/bias"])
+    x1 = O.depthwise_conv2d(x, w[f"{p}/dw_conv/depthwise_kernel"], w[f"{p}/dw_conv/bias"], 1, 1, "same")
+    x1 = O.gelu(O.layer_norm(x1, w[f"{p}/dw_conv_norm/gamma"], w[f"{p}/dw_conv_norm/beta"], 1e-6))
+    offset = O.dense(x1, w[f"{p}/offset/kernel"], w[f"{p}/offset/bias"])
+    mask = O.dense(x1, w[f"{p}/mask/kernel"], w[f"{p}/mask/bias"])
+    mask = torch.softmax(mask.reshape(N, H, W, groups, -1), dim=-1).reshape(N, H, W, -1)
+    y = O.dcnv3_op(x_proj, offset, mask, (kernel_size, kernel_size), (1, 1), "SAME", (1, 1), groups, C // groups, offset_scale)
+    return O.dense(y, w[f"{p}/output_proj/kernel"], w[f"{p}/output_proj/bias"])
+
+
+def intern_image_layer(w, p, x, groups, post_norm, dp=None):
+    def ln(name, t):
+        return O.layer_norm(t, w[f"{p}/{name}/gamma"], w[f"{p}/{name}/beta"], 1e-6)
+
+    def mlp(t):
+        t = O.gelu(O.dense(t, w[f"{p}/mlp/fc1/kernel"], w[f"{p}/mlp/fc1/bias"]))
+        return O.dense(t, w[f"{p}/mlp/fc2/kernel"], w[f"{p}/mlp/fc2/bias"])
+
+    def drop(t, i):
+        return t if dp is None else t * dp[i].reshape(-1, 1, 1, 1)
+
+    residual = x
+    if post_norm:
+        y = drop(ln("norm1", dcnv3_layer(w, f"{p}/dcn", x, groups)) * w[f"{p}/gamma1"], 0)
+        residual = x = residual + y
+        y = drop(ln("norm2", mlp(x)) * w[f"{p}/gamma2"], 1)
+        return y + residual
+    y = drop(dcnv3_layer(w, f"{p}/dcn", ln("norm1", x), groups) * w[f"{p}/gamma1"], 0)
+    residual = x = residual + y
+    y = drop(mlp(ln("norm2", x)) * w[f"{p}/gamma2"], 1)
+    return y + residual
+
+
+def intern_image_forward(w, x, depths, groups, post_norm, dp_factors=None):
+    """endpoints [stem before 2nd stride, b0, b1, ...] (pre-downsample)"""
+    def ln(p, t):
+        return O.layer_norm(t, w[f"{p}/gamma"], w[f"{p}/beta"], 1e-6)
+
+    x = O.gelu(ln("patch_embed/norm1", O.conv2d(x, w["patch_embed/conv1/kernel"], w["patch_embed/conv1/bias"], 2, 1, "same")))
+    endpoints = [x]
+    x = ln("patch_embed/norm2", O.conv2d(x, w["patch_embed/conv2/kernel"], w["patch_embed/conv2/bias"], 2, 1, "same"))
+    for bi, depth in enumerate(depths):
+        for li in range(depth):
+            dp = None if dp_factors is None else dp_factors[bi][li]
+            x = intern_image_layer(w, f"block/{bi}/layer/{li}", x, groups[bi], post_norm, dp)
+        if not post_norm:
+            x = ln(f"block/{bi}/norm", x)
+        endpoints.append(x)
+        if bi < len(depths) - 1:
+            x = ln(f"block/{bi}/downsample/norm", O.conv2d(x, w[f"block/{bi}/downsample/conv/kernel"], None, 2, 1, "same"))
+    return endpoints

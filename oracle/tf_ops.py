@@ -385,3 +385,62 @@ def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7):
     a = torch.softmax(a, dim=-1)
     a = torch.clamp(a, eps, 1.0 - eps)
     return (a @ vh).permute(0, 2, 1, 3).reshape(N, H, W, Cv)
+
+
+# ------------------------------------------------------------------------------------------------------
+# layers/dcn_v3/op.py:16-109 + utils.py:14-209, transcribed op for op (tensor form), quirks included:
+# ref is stacked [y, x] while grid / offset / the sampler use [x, y]; weights come from the clipped corners.
+# ------------------------------------------------------------------------------------------------------
+def dcnv3_op(x, offset, mask, kernel_size=(3, 3), strides=(1, 1), padding="SAME", dilation_rate=(1, 1), groups=4, group_channels=16,
+             offset_scale=1.0):
+    kh, kw = kernel_size
+    dh, dw = dilation_rate
+    sh, sw = strides
+    ph, pw = (kh // 2, kw // 2) if padding.upper() == "SAME" else (0, 0)
+    x = F.pad(x, (0, 0, pw, pw, ph, ph))
+    N, Hin, Win, C = x.shape
+    _, Ho, Wo, _ = offset.shape
+    dt_ = x.dtype
+    # get_reference_points (utils.py:14-58)
+    H_out = (Hin - (dh * (kh - 1) + 1)) // sh + 1
+    W_out = (Win - (dw * (kw - 1) + 1)) // sw + 1
+    y_start = (dh * (kh - 1)) // 2 + 0.5
+    x_start = (dw * (kw - 1)) // 2 + 0.5
+    ys = torch.linspace(y_start, y_start + (H_out - 1) * sh, H_out, dtype=dt_) / Hin
+    xs = torch.linspace(x_start, x_start + (W_out - 1) * sw, W_out, dtype=dt_) / Win
+    ref_y, ref_x = torch.meshgrid(ys, xs, indexing="ij")
+    ref = torch.stack([ref_y.reshape(-1), ref_x.reshape(-1)], dim=-1).reshape(1, H_out, W_out, 1, 2)
+    # generate_dilation_grids (utils.py:65-103)
+    lx = torch.linspace(-((dw * (kw - 1)) // 2), -((dw * (kw - 1)) // 2) + (kw - 1) * dw, kw, dtype=dt_)
+    ly = torch.linspace(-((dh * (kh - 1)) // 2), -((dh * (kh - 1)) // 2) + (kh - 1) * dh, kh, dtype=dt_)
+    gx, gy = torch.meshgrid(lx, ly, indexing="ij")
+    grid = torch.stack([gx / Win, gy / Hin], dim=-1).reshape(-1, 1, 2).repeat(1, groups, 1).permute(1, 0, 2)
+    grid = grid.reshape(1, 1, 1, groups * kh * kw, 2)
+    P_ = kh * kw
+    spatial_norm = torch.tensor([Win, Hin], dtype=dt_).reshape(1, 1, 1, 2).repeat(1, 1, 1, groups * P_)
+    loc = (ref + grid * offset_scale).reshape(1, Ho, Wo, groups * P_ * 2)
+    loc = loc + offset * offset_scale / spatial_norm
+    grids = 2 * loc - 1
+    xg = x.reshape(N, Hin, Win, groups, group_channels).permute(0, 3, 1, 2, 4).reshape(N * groups, Hin, Win, group_channels)
+    grids = grids.reshape(N, Ho * Wo, groups, P_, 2).permute(3, 0, 2, 1, 4).reshape(P_, N * groups, Ho * Wo, 2)
+    m = mask.reshape(N, Ho * Wo, groups, P_).permute(3, 0, 2, 1).reshape(P_, N * groups, Ho * Wo, 1)
+    # dcnv3_bilinear_sampler (utils.py:110-209)
+    max_y, max_x = Hin - 1, Win - 1
+    gx_, gy_ = grids[..., 0], grids[..., 1]
+    px = 0.5 * ((gx_ + 1.0) * float(max_x - 1))
+    py = 0.5 * ((gy_ + 1.0) * float(max_y - 1))
+    x0 = torch.floor(px).long()
+    y0 = torch.floor(py).long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0, x1 = x0.clamp(0, max_x), x1.clamp(0, max_x)
+    y0, y1 = y0.clamp(0, max_y), y1.clamp(0, max_y)
+    dx0, dx1 = px - x0.to(dt_), x1.to(dt_) - px
+    dy0, dy1 = py - y0.to(dt_), y1.to(dt_) - py
+    wa, wb, wc, wd = dx1 * dy1, dx1 * dy0, dx0 * dy1, dx0 * dy0
+    B = N * groups
+    bidx = torch.arange(B).reshape(1, B, 1).expand(P_, B, Ho * Wo)
+    out = 0
+    for (yy, xx, ww) in ((y0, x0, wa), (y1, x0, wb), (y0, x1, wc), (y1, x1, wd)):
+        out = out + xg[bidx, yy, xx] * ww.unsqueeze(-1)            # [P, B, HW, Cg]
+    out = (out * m).sum(dim=0)                                      # [B, HW, Cg]
+    return out.reshape(N, groups, Ho, Wo, group_channels).permute(0, 2, 3, 1, 4).reshape(N, Ho, Wo, groups * group_channels)
