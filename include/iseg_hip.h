@@ -296,6 +296,10 @@ int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int64_t rows_in
                      iseg_stream_t stream);
 /* backbones/swin.py:134-142: bias[h,i,j] = table[index[i,j], h]; gradient dtable[k,h] (+)= sum_{index[i,j]==k} dbias[h,i,j]
  * (dbias rows have stride ld) */
+/* out[c] (+)= sum_r x[r*ldx + c] for a short, very wide matrix (the [windows, heads*T*ld] score gradients -> bias gradient) */
+size_t iseg_colsum_wide_workspace_bytes(int64_t rows, int64_t cols);
+int iseg_colsum_wide(const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, int accumulate, int dtype, void* ws,
+                     size_t ws_bytes, iseg_stream_t stream);
 int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bias, int heads, int TT, iseg_stream_t stream);
 int iseg_relpos_bias_scatter_grad(const float* dbias, int ld, const int32_t* index, float* dtable, int entries, int heads, int T,
                                   int accumulate, iseg_stream_t stream);

@@ -1,8 +1,11 @@
 """core_model.py of the reference: SegModelInferenceConfig :24-47, SegBase :51-326 (inference entry points),
 SegFoundation :329-605 (loss / loss-weight / metric plumbing, inputs_process)."""
 import numpy as np
+import torch
 
+from . import functional as F
 from .core_inference import inference_fn
+from .utils.common import get_scaled_size, resize_image
 from .losses.catecrossentropy_ignore_label import catecrossentropy_ignore_label_loss
 from .metrics.utils import SegMetricBuilder
 from .nn import Layer
@@ -36,7 +39,51 @@ class SegBase(Layer):
 
     def predict_step(self, data):
         x = data[0] if isinstance(data, (tuple, list)) else data
-        return self.inference(x, training=False)
+        return self.inference_with_multi_scales(x, training=False, **self.inference_configs.to_dict())
+
+    # -- multi-scale / flip test-time augmentation (:128-326) --------------------------------------------------
+    def inference_with_scale_inputs_process(self, inputs, training=False, scale_rate=1.0, flip=False, resize_method="bilinear"):
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        if flip:
+            x = F.flip_left_right(x)
+        sizes = get_scaled_size(x, scale_rate, pad_mode=1)
+        if x.dtype != torch.float32:
+            x = F.cast_to(x, torch.float32)
+        return resize_image(x, sizes, method=resize_method)
+
+    def inference_with_scale(self, inputs, training=False, scale_rate=1.0, flip=False, resize_method="bilinear"):
+        first = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        original_size = [int(first.shape[1]), int(first.shape[2])]
+        x = self.inference_with_scale_inputs_process(inputs, training=training, scale_rate=scale_rate, flip=flip,
+                                                     resize_method=resize_method)
+        sizes = [int(x.shape[1]), int(x.shape[2])]
+        window = self.inference_sliding_window_size
+        if window is not None:
+            window = (min(int(window[0]), sizes[0]), min(int(window[1]), sizes[1]))
+        logits = inference_fn(x, model=self, num_class=self.num_class, training=training, sliding_window_crop_size=window)
+        logits = resize_image(logits, original_size, method=resize_method)
+        if flip:
+            logits = F.flip_left_right(logits)
+        return logits
+
+    def inference_with_multi_scales(self, inputs, training=False, scale_rates=[1.0], flip=False, use_cpu_cache=False,
+                                    resize_method="bilinear"):
+        """sum over scales (and over the mirrored image when flip) of the logits resized back to the input size, divided by the
+        number of passes; use_cpu_cache is accepted for signature parity -- 288 GB of HBM never needs the host round trip"""
+        from . import kernels as K
+
+        divide_factor = len(scale_rates) * (2 if flip else 1)
+        total = None
+        for mirrored in ([False, True] if flip else [False]):
+            x = F.flip_left_right(inputs) if mirrored else inputs
+            part = None
+            for rate in scale_rates:
+                logits = self.inference_with_scale(x, training=training, scale_rate=float(rate), flip=False, resize_method=resize_method)
+                part = logits if part is None else K.axpby(part, logits, 1.0, 1.0)
+            if mirrored:
+                part = F.flip_left_right(part)
+            total = part if total is None else K.axpby(total, part, 1.0, 1.0)
+        return K.axpby(total, None, 1.0 / divide_factor, 0.0)
 
 
 class SegFoundation(SegBase):

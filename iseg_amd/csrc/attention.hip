@@ -149,6 +149,27 @@ __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __rest
     }
 }
 
+// column sums of a short, very wide matrix (rows = windows, cols = heads*T*ld score entries): lanes along the columns,
+// row chunks along grid.y, partials [chunks][cols] reduced afterwards in chunk order
+template <class T>
+__global__ __launch_bounds__(256) void colsum_wide_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t rows, int64_t cols,
+                                                                  float* __restrict__ partials) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t rpc = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += to_f32(x[r * ldx + c]);
+    partials[(int64_t)blockIdx.y * cols + c] = s;
+}
+
+static inline int wide_chunks(int64_t rows) {
+    int64_t c = ceil_div64(rows, 32);
+    if (c > 64) c = 64;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
 static inline unsigned row_blocks(int64_t rows) {
     int64_t b = ceil_div64(rows, 4);
     if (b > 256 * 32) b = 256 * 32;
@@ -236,6 +257,28 @@ extern "C" int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int6
                                (float*)y, rows_out, C);
     }
     return iseg_check_launch("iseg_gather_rows");
+}
+
+extern "C" size_t iseg_colsum_wide_workspace_bytes(int64_t rows, int64_t cols) {
+    return (size_t)wide_chunks(rows) * (size_t)cols * sizeof(float);
+}
+
+extern "C" int iseg_colsum_wide(const void* x, int64_t ldx, int64_t rows, int64_t cols, float* out, int accumulate, int dtype, void* ws,
+                                size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(x && out && rows > 0 && cols > 0 && ldx >= cols, "iseg_colsum_wide: bad arguments");
+    const int chunks = wide_chunks(rows);
+    const size_t need = (size_t)chunks * (size_t)cols * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_colsum_wide: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const dim3 grid((unsigned)ceil_div64(cols, 256), chunks);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((colsum_wide_partial_kernel<bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, rows, cols, (float*)ws);
+    else
+        hipLaunchKernelGGL((colsum_wide_partial_kernel<float>), grid, dim3(256), 0, stream, (const float*)x, ldx, rows, cols, (float*)ws);
+    launch_reduce_rows((const float*)ws, chunks, cols, 0, 1, cols, out, nullptr, cols, 0, 1.f, accumulate, stream);
+    return iseg_check_launch("iseg_colsum_wide");
 }
 
 extern "C" int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bias, int heads, int TT, hipStream_t stream) {

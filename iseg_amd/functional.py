@@ -930,7 +930,7 @@ class _AttentionFn(Function):
         K.softmax_rows_bwd(P, dP, B * heads * T, T, Tp)
         if ctx.bias_table is not None and ctx.bias_table.requires_grad:
             dbias = torch.empty(heads * T * Tp, dtype=torch.float32, device=qkv.device)
-            K.colsum(dP, heads * T * Tp, 0, 1, B, heads * T * Tp, dbias)
+            K.colsum_wide(dP.reshape(B, heads * T * Tp), dbias)
             K.relpos_bias_scatter_grad(dbias, Tp, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True)
             dist.grads_ready(ctx.bias_table)
         for b0, b1 in _attn_chunks(B, heads):
@@ -1210,3 +1210,19 @@ def scale_channels(x, gamma):
     if nn.dry_run():
         return _dry(x.shape, x)
     return _ScaleChannelsFn.apply(x, gamma)
+
+
+_FLIP_CACHE = {}
+
+
+def flip_left_right(x):
+    """tf.image.flip_left_right on [N,H,W,C]: a row permutation (its own inverse)"""
+    N, H, W, C = x.shape
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    key = (N, H, W, str(x.device))
+    if key not in _FLIP_CACHE:
+        base = torch.arange(N * H, dtype=torch.int32).reshape(-1, 1) * W
+        _FLIP_CACHE[key] = (base + torch.arange(W - 1, -1, -1, dtype=torch.int32).reshape(1, -1)).reshape(-1).to(x.device)
+    idx = _FLIP_CACHE[key]
+    return permute_rows(x, idx, idx, tuple(x.shape))

@@ -39,3 +39,65 @@ def convnext_tiny_aspp(num_class=21, output_stride=32, build_input_size=(512, 51
     model.head = ASPPHead(256, output_stride=output_stride, dropout_rate=dropout_rate)
     model.build_with_dummy()
     return model
+
+
+class FPNHead(Layer):
+    """BASELINE config 3: FeaturePyramidNetwork(skip_conv_filters = C_top)(endpoints[1:]) -> finest level (OS4)
+    -> ConvNormAct(256, 1x1)."""
+
+    def __init__(self, top_filters, filters=256, name="fpn_head"):
+        super().__init__(name=name)
+        from .layers.fpn import FeaturePyramidNetwork
+
+        self.fpn = FeaturePyramidNetwork(skip_conv_filters=top_filters, name=f"{self.name}/fpn")
+        self.end_conv = ConvNormAct(filters, (1, 1), name=f"{self.name}/end_conv")
+
+    def call(self, inputs, training=None):
+        levels = self.fpn(list(inputs)[1:], training=training)
+        return self.end_conv(levels[0], training=training)
+
+
+class SimpleDecoderHead(Layer):
+    """BASELINE config 4: ViT returns one endpoint; SimpleDecoder(48, 256)((e, ConvNormAct(256, 1x1)(e)))."""
+
+    def __init__(self, filters=256, low_level_filters=48, name="decoder_head"):
+        super().__init__(name=name)
+        from .layers.simpledecoder import SimpleDecoder
+
+        self.high_conv = ConvNormAct(filters, (1, 1), name=f"{self.name}/high_conv")
+        self.decoder = SimpleDecoder(low_level_filters, filters, name=f"{self.name}/decoder")
+
+    def call(self, inputs, training=None):
+        e = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        return self.decoder((e, self.high_conv(e, training=training)), training=training)
+
+
+def _managed(backbone_name, head, num_class, output_stride, build_input_size, backbone_custom_fn=None):
+    model = SegManaged(backbone_name=backbone_name, backbone_custom_fn=backbone_custom_fn, output_stride=output_stride,
+                       num_class=num_class, build_input_size=build_input_size, name="seg")
+    model.head = head
+    model.build_with_dummy()
+    return model
+
+
+def resnet50_aspp(num_class=21, output_stride=32, build_input_size=(256, 256), dropout_rate=0.1):
+    """BASELINE config 1: ResNet-50 (slim/beta) + ASPP"""
+    return _managed("resnet50", ASPPHead(256, output_stride=output_stride, dropout_rate=dropout_rate), num_class, output_stride,
+                    build_input_size)
+
+
+def swin_tiny_fpn(num_class=21, build_input_size=(512, 512)):
+    """BASELINE config 3: Swin-T + FPN"""
+    return _managed("swin_tiny_224", FPNHead(top_filters=768), num_class, 32, build_input_size)
+
+
+def vit_base_simple_decoder(num_class=21, build_input_size=(512, 512)):
+    """BASELINE config 4: ViT-B/16 + SimpleDecoder (evaluated with sliding-window inference)"""
+    return _managed("vit_base", SimpleDecoderHead(), num_class, 16, build_input_size)
+
+
+def intern_image_base_aspp(num_class=21, build_input_size=(512, 512), dropout_rate=0.1):
+    """BASELINE config 5: InternImage-B (DCNv3) + ASPP"""
+    from .backbones import intern_image  # noqa: F401  (registers intern_image_base)
+
+    return _managed("intern_image_base", ASPPHead(256, output_stride=32, dropout_rate=dropout_rate), num_class, 32, build_input_size)

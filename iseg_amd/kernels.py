@@ -642,3 +642,14 @@ def scale_cols(x2d, colscale):
     y = torch.empty_like(x2d)
     _hip.check(_hip.lib().iseg_scale_cols(ptr(x2d), ptr(colscale), ptr(y), rows, Cc, dt(x2d), stream()), "iseg_scale_cols")
     return y
+
+
+def colsum_wide(x2d, out, accumulate=False):
+    """out[c] (+)= sum_r x2d[r, c] for few rows and very many columns"""
+    _require_cuda(x2d, out)
+    rows, cols = x2d.shape
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_colsum_wide_workspace_bytes(rows, cols), x2d.device)
+    _hip.check(L.iseg_colsum_wide(ptr(x2d), x2d.stride(0), rows, cols, ptr(out), int(accumulate), dt(x2d), ptr(ws), wsb, stream()),
+               "iseg_colsum_wide")
+    return out

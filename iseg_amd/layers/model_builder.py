@@ -77,3 +77,72 @@ class CommonEndBlock(Layer):
         x = self.logits_conv(x)
         x = resize_image(x, orginal_inputs.shape[1:3])
         return F.cast_to(x, torch.float32)
+
+
+class SepConvBnReLU(Layer):
+    """layers/model_builder.py:118-171: depthwise conv (no bias) -> [BN] -> activation -> [pointwise ConvNormAct]"""
+
+    def __init__(self, filters, kernel_size, apply_bn=True, dilation_rate=1, activation="relu", apply_pointwise=True,
+                 apply_pointwise_bn=True, name=None):
+        super().__init__(name=name)
+        from .base_layers import DepthwiseConv2D
+
+        self.use_bn = apply_bn
+        self.activation = get_activation(activation)
+        self.apply_pointwise = apply_pointwise
+        self.depthwise_conv = DepthwiseConv2D(kernel_size, padding="same", dilation_rate=dilation_rate, use_bias=False,
+                                              name=f"{self.name}/depthwise_conv")
+        if self.use_bn:
+            self.depthwise_bn = normalization(name=f"{self.name}/depthwise_bn")
+        if self.apply_pointwise:
+            self.pointwise_conv = ConvNormAct(filters, use_bn=apply_pointwise_bn, activation=activation, name=f"{self.name}/pointwise_conv")
+
+    def call(self, inputs, training=None):
+        x = self.depthwise_conv(inputs)
+        act = self.activation
+        if self.use_bn:
+            fuse = act is F.relu and hasattr(self.depthwise_bn, "moving_mean")
+            x = self.depthwise_bn(x, training=training, fused_relu=True) if fuse else self.depthwise_bn(x, training=training)
+            if fuse:
+                act = None
+        if act is not None:
+            x = act(x)
+        if self.apply_pointwise:
+            x = self.pointwise_conv(x, training=training)
+        return x
+
+
+class NormConvAct(Layer):
+    """layers/model_builder.py:175-250: [LN | GN | BN | RMSN] -> Conv2D(padding same, activation)"""
+
+    def __init__(self, filters=256, kernel_size=1, dilation_rate=(1, 1), use_norm=True, norm_type="ln", ln_epsilon=1e-6, activation="gelu",
+                 conv_kernel_initializer="glorot_uniform", dropout_rate=0, trainable=True, use_bias=True, groups=1, name=None):
+        super().__init__(trainable=trainable, name=name)
+        from .. import static_strings as ss
+        from .base_layers import BatchNormalization, LayerNormalization
+        from .groupnorm import GroupNormalization
+        from .rmsnorm import RMSNormalization
+
+        self.ln = None
+        if use_norm:
+            if norm_type == ss.BN:
+                self.ln = BatchNormalization(trainable=trainable, epsilon=ln_epsilon, synchronized=True, name=f"{self.name}_bn")
+            elif norm_type in (ss.LN, ss.GN):
+                if groups == 1:
+                    self.ln = LayerNormalization(trainable=trainable, epsilon=ln_epsilon, name=f"{self.name}_ln")
+                elif groups > 1:
+                    self.ln = GroupNormalization(groups=groups, axis=-1, epsilon=ln_epsilon, trainable=trainable, name=f"{self.name}_ln")
+                else:
+                    raise ValueError(f"Invalid groups value: {groups}")
+            elif norm_type == ss.RMSN:
+                self.ln = RMSNormalization(epsilon=ln_epsilon, trainable=trainable, name=f"{self.name}_rmsn")
+            else:
+                raise ValueError(f"Invalid norm_type: {norm_type}")
+        self.conv = Conv2D(filters, kernel_size, padding="same", use_bias=use_bias, kernel_initializer=conv_kernel_initializer,
+                           dilation_rate=dilation_rate, trainable=trainable, activation=activation, name=f"{self.name}_conv")
+
+    def call(self, inputs, training=None):
+        x = inputs
+        if self.ln is not None:
+            x = self.ln(x, training=training) if hasattr(self.ln, "moving_mean") else self.ln(x)
+        return self.conv(x)

@@ -407,3 +407,49 @@ def intern_image_forward(w, x, depths, groups, post_norm, dp_factors=None):
         if bi < len(depths) - 1:
             x = ln(f"block/{bi}/downsample/norm", O.conv2d(x, w[f"block/{bi}/downsample/conv/kernel"], None, 2, 1, "same"))
     return endpoints
+
+
+# ------------------------------------------------------------------------------------------------------
+# model-level compositions of iseg_amd/heads.py and the inference drivers of core_inference.py:230-304, core_model.py:170-326
+# ------------------------------------------------------------------------------------------------------
+def resnet_aspp_forward(w, x, training=False, output_stride=32, head="aspp_head", seg="seg", new_stats=None):
+    ends = resnet_forward(w, x, output_stride=output_stride, training=training, new_stats=new_stats)
+    mult = max(32 // output_stride, 1)
+    feat = aspp(w, f"{head}/aspp", ends[-1], training, rates=tuple(r * mult for r in (3, 6, 9)), new_stats=new_stats)
+    feat = conv_norm_act(w, f"{head}/end_conv", feat, training, new_stats=new_stats)
+    small = O.conv2d(feat, w[f"{seg}/logits_conv/kernel"], w[f"{seg}/logits_conv/bias"], 1, 1, "same")
+    return {"endpoints": ends, "logits": O.resize_bilinear(small, (x.shape[1], x.shape[2]))}
+
+
+def sliding_window_inference(fn, x, window):
+    """core_inference.py:230-304: windows at get_sliding_start_indexs positions, logits zero-padded back and summed, divided by
+    the per-pixel visit count"""
+    N, H, W, _ = x.shape
+    wh, ww = min(window[0], H), min(window[1], W)
+    total, count = None, torch.zeros(H, W, dtype=x.dtype)
+    for t in O.sliding_start_indexs(H, wh):
+        for l in O.sliding_start_indexs(W, ww):
+            logits = fn(x[:, t:t + wh, l:l + ww])
+            if total is None:
+                total = torch.zeros(N, H, W, logits.shape[-1], dtype=x.dtype)
+            total[:, t:t + wh, l:l + ww] += logits
+            count[t:t + wh, l:l + ww] += 1
+    return total / count.reshape(1, H, W, 1)
+
+
+def multi_scale_inference(fn, x, scale_rates=(1.0,), flip=False):
+    """core_model.py:231-326 with get_scaled_size(pad_mode=1) (utils/common.py:159-188)"""
+    def scaled(h, rate):
+        t = int(rate * h)
+        return t + 1 if (t % 2 == 0 and h % 2 != 0) else t
+
+    H, W = x.shape[1], x.shape[2]
+    total = 0
+    for mirrored in ([False, True] if flip else [False]):
+        xi = torch.flip(x, dims=(2,)) if mirrored else x
+        part = 0
+        for r in scale_rates:
+            xs = O.resize_bilinear(xi, (scaled(H, r), scaled(W, r)))
+            part = part + O.resize_bilinear(fn(xs), (H, W))
+        total = total + (torch.flip(part, dims=(2,)) if mirrored else part)
+    return total / (len(scale_rates) * (2 if flip else 1))

@@ -1,0 +1,110 @@
+"""The BASELINE configurations beyond the flagship, through the same public entry points (heads.* -> SegManaged -> TrainableModel):
+cfg1 ResNet-50 + ASPP (full parity vs the oracle, it is the reference's own CPU-runnable case), cfg3 Swin-T + FPN, cfg4 ViT-B/16 +
+SimpleDecoder, cfg5 InternImage-B + ASPP (full architectures, one bf16 optimisation run each), and the inference drivers
+(sliding window, multi-scale + flip) on the flagship model vs the oracle."""
+import pytest
+import torch
+
+from oracle import models as OM
+from oracle import tf_ops as O
+from tests.util_models import randomize_parameters
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_policy():
+    from iseg_amd import nn
+
+    yield
+    nn.set_compute_dtype(torch.float32)
+
+
+def _prep(model, seed=0):
+    from iseg_amd.param_store import ParamStore
+
+    model._iseg_store = ParamStore(list(model.parameters()))
+    randomize_parameters(model, seed)
+    return model
+
+
+def test_cfg1_resnet50_aspp_fp32_logits_argmax_and_loss(cuda):
+    from iseg_amd import heads, nn
+    from iseg_amd.data import synthetic_batch
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(heads.resnet50_aspp(build_input_size=(96, 96), dropout_rate=0.0))
+    x, y = synthetic_batch(2, 96, 96, seed=4)
+    with torch.no_grad():
+        logits = model(x.cuda(), training=False)[0]
+    ref = OM.resnet_aspp_forward(OM.export_weights(model), x.double(), training=False)["logits"]
+    assert logits.dtype == torch.float32 and tuple(logits.shape) == (2, 96, 96, 21)
+    assert (logits.cpu().double() - ref).abs().max().item() < 1e-3
+    assert torch.equal(logits.argmax(-1).cpu(), O.argmax_first(ref))
+    from iseg_amd.losses.catecrossentropy_ignore_label import catecrossentropy_ignore_label_loss
+
+    got = float(catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, batch_size=2)(y.cuda(), logits).mean())
+    assert abs(got - OM.mean_ce_loss(ref, y).item()) < 1e-4
+
+
+@pytest.mark.parametrize("factory,size", [("resnet50_aspp", 128), ("swin_tiny_fpn", 96), ("vit_base_simple_decoder", 96),
+                                          ("intern_image_base_aspp", 96)])
+def test_full_architectures_train_in_bf16(cuda, factory, size):
+    from iseg_amd import heads, nn
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.trainer import TrainableModel
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    model = _prep(getattr(heads, factory)(build_input_size=(size, size)), seed=1)
+    x, y = synthetic_batch(2, size, size, seed=21)
+    opt = get_optimizer(Strategy(one_device=True), initial_lr=5e-4, epoch_steps=100, train_epoch=1, optimizer="adamw")
+    tm = TrainableModel(model, optimizer=opt, loss=model.custom_losses(21, 255, 2), loss_weights=model.custom_losses_weights(),
+                        metrics=model.custom_metrics(21, 255))
+    losses = [float(tm.train_step(x.cuda(), y.cuda())[0]) for _ in range(6)]
+    assert all(l == l and l < 50 for l in losses), losses
+    assert min(losses[3:]) < losses[0], losses
+    with torch.no_grad():
+        logits = model(x.cuda(), training=False)[0]
+    assert tuple(logits.shape) == (2, size, size, 21) and torch.isfinite(logits).all()
+
+
+def _flagship(size):
+    from iseg_amd import nn
+    from iseg_amd.heads import convnext_tiny_aspp
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    return _prep(convnext_tiny_aspp(build_input_size=size, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0), seed=2)
+
+
+def test_sliding_window_inference_matches_oracle(cuda):
+    """BASELINE config 4's driver: 80x104 image, 64x64 window -> 2x2 overlapping windows, count-normalised"""
+    from iseg_amd.core_inference import inference_with_sliding_window
+    from iseg_amd.data import synthetic_batch
+
+    model = _flagship((64, 64))
+    x, _ = synthetic_batch(2, 80, 104, seed=6)
+    with torch.no_grad():
+        got = inference_with_sliding_window(x.cuda(), model, training=False, windows_size=(64, 64))
+    w = OM.export_weights(model)
+    ref = OM.sliding_window_inference(lambda t: OM.convnext_aspp_forward(w, t, training=False)["logits"], x.double(), (64, 64))
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert (got.cpu().double() - ref).abs().max().item() < 1e-3
+    assert torch.equal(got.argmax(-1).cpu(), O.argmax_first(ref))
+
+
+def test_multi_scale_flip_inference_matches_oracle(cuda):
+    from iseg_amd.data import synthetic_batch
+
+    model = _flagship((64, 64))
+    x, _ = synthetic_batch(1, 65, 96, seed=8)          # odd height: get_scaled_size(pad_mode=1) keeps odd sizes odd
+    with torch.no_grad():
+        got = model.inference_with_multi_scales(x.cuda(), training=False, scale_rates=[0.5, 1.0, 1.5], flip=True)
+    w = OM.export_weights(model)
+    ref = OM.multi_scale_inference(lambda t: OM.convnext_aspp_forward(w, t, training=False)["logits"], x.double(), (0.5, 1.0, 1.5), True)
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 65, 96, 21)
+    assert (got.cpu().double() - ref).abs().max().item() < 1e-3
