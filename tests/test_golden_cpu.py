@@ -1,0 +1,68 @@
+"""tests/golden/oracle_ops.npz pins the oracle: the torch restatement must reproduce the committed vectors bit-for-bit-ish
+(1e-12), and the independent numpy-loop restatement (oracle/np_loops.py) must agree with them too."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import models as OM
+from oracle import np_loops as NL
+from oracle import tf_ops as O
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_ops.npz"))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a, dtype=np.float64))
+
+
+def same(a, b, tol=1e-12):
+    assert np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max() <= tol
+
+
+def test_oracle_reproduces_golden_vectors():
+    same(O.conv2d(t(G["conv_x"]), t(G["conv_k"]), t(G["conv_b"]), 1, 2, "same").numpy(), G["conv_s1d2"])
+    same(O.conv2d(t(G["conv_x"]), t(G["conv_k"]), t(G["conv_b"]), 2, 1, "same").numpy(), G["conv_s2d1"])
+    yd = O.depthwise_conv2d(t(G["dw_x"]), t(G["dw_k"]), None, 1, 1, "same")
+    same(yd.numpy(), G["dw_y"])
+    same(O.layer_norm(yd, t(G["ln_gamma"]), t(G["ln_beta"]), 1e-6).numpy(), G["ln_y"])
+    same(O.gelu(yd).numpy(), G["gelu_y"])
+    same(O.resize_bilinear(t(G["resize_x"]), (13, 9)).numpy(), G["resize_y"])
+    assert np.array_equal(O.resize_nearest(torch.from_numpy(G["nearest_x"].astype(np.int64)), (4, 9)).numpy(), G["nearest_y"])
+    labels = torch.from_numpy(G["ce_labels"].astype(np.int64))
+    same(O.softmax_ce_ignore(labels, t(G["ce_logits"]), 21, 255).numpy(), G["ce_px"])
+    pred = O.argmax_first(t(G["ce_logits"]))
+    assert np.array_equal(pred.numpy(), G["argmax"])
+    same(O.confusion_matrix(labels.reshape(-1), pred.reshape(-1), 21, 255).numpy(), G["confusion"])
+    same(O.group_norm(t(G["gn_x"]), None, None, 3, 1e-3).numpy(), G["gn_y"])
+    same(O.rms_norm(t(G["gn_x"]), t(np.zeros(12)), 1e-6).numpy(), G["rms_y"])
+    same(O.max_pool_same(t(G["pool_x"]), 3, 2).numpy(), G["maxpool_3s2"])
+    same(O.avg_pool_same(t(G["pool_x"]), 2, 2).numpy(), G["avgpool_2s2"])
+    same(O.resize_bicubic(t(G["bicubic_x"]), (6, 5)).numpy(), G["bicubic_y"])
+    same(O.dcnv3_op(t(G["dcn_x"]), t(G["dcn_off"]), t(G["dcn_mask"]), (3, 3), (1, 1), "SAME", (1, 1), 2, 4, 1.0).numpy(), G["dcn_y"])
+    assert np.array_equal(OM.swin_attention_mask(19, 23, 7, 3).numpy().astype(np.float32), G["swin_mask_19x23"])
+    assert np.array_equal(OM._rel_index(7).numpy(), G["swin_rel_index"])
+    assert list(O.sliding_start_indexs(640, 512)) == list(G["sliding_640_512"])
+    assert list(O.sliding_start_indexs(1024, 512)) == list(G["sliding_1024_512"])
+    lr = [O.warmup_poly_decay(s, 1e-2, 30000, end_lr=0.0, warmup_steps=1500, warmup_lr=0.0, power=1.0) for s in (0, 500, 1000, 1500, 2000, 29999)]
+    same(lr, G["poly_lr"])
+
+
+def test_numpy_loop_restatement_agrees_with_golden_vectors():
+    same(NL.conv2d_same(G["conv_x"], G["conv_k"], G["conv_b"], (1, 1), (2, 2)), G["conv_s1d2"], 1e-10)
+    same(NL.conv2d_same(G["conv_x"], G["conv_k"], G["conv_b"], (2, 2), (1, 1)), G["conv_s2d1"], 1e-10)
+    same(NL.resize_bilinear(G["resize_x"], (13, 9)), G["resize_y"], 1e-12)
+    same(NL.layer_norm(G["dw_y"], G["ln_gamma"], G["ln_beta"], 1e-6), G["ln_y"], 1e-10)
+    same(NL.softmax_ce_ignore(G["ce_labels"], G["ce_logits"], 21, 255), G["ce_px"], 1e-10)
+
+
+def test_golden_closed_forms():
+    # values that can be checked by hand, independent of any code under oracle/
+    assert abs(G["poly_lr"][1] - 1e-2 * 500 / 1500) < 1e-12 and abs(G["poly_lr"][3] - 1e-2) < 1e-12
+    assert abs(G["poly_lr"][4] - 1e-2 * (1 - 500 / 28500)) < 1e-12
+    assert G["swin_rel_index"][0, 0] == 84 and G["swin_rel_index"].max() == 168
+    ignored = (G["ce_labels"] == 255).reshape(-1)
+    px = G["ce_px"].reshape(-1)
+    assert np.all(px[ignored] == 0.0) and np.all(px[~ignored] > 0.0)
+    assert list(G["sliding_640_512"]) == [0, 128]
+    assert G["confusion"].sum() == (~ignored).sum()
