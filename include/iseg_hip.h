@@ -303,6 +303,10 @@ int iseg_colsum_wide(const void* x, int64_t ldx, int64_t rows, int64_t cols, flo
 int iseg_relpos_bias_gather(const float* table, const int32_t* index, float* bias, int heads, int TT, iseg_stream_t stream);
 int iseg_relpos_bias_scatter_grad(const float* dbias, int ld, const int32_t* index, float* dtable, int entries, int heads, int T,
                                   int accumulate, iseg_stream_t stream);
+/* the same gradient when `index` is the canonical square-window table of backbones/swin.py:93-104 (window side ws, T = ws*ws,
+ * (2ws-1)^2 entries): displacement-enumerating kernel, no table scan */
+int iseg_relpos_bias_scatter_grad_window(const float* dbias, int ld, float* dtable, int ws, int heads, int accumulate,
+                                         iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * layers/dcn_v3/op.py:16-109 dcnv3_op + utils.py:14-209 (reference points, dilation grids, bilinear sampler), restated

@@ -97,6 +97,7 @@ SIGNATURES = {
     "iseg_clip_fwd": (_i, [_p, _p, _l, _f, _f, _i, _p]),
     "iseg_clip_bwd": (_i, [_p, _p, _p, _l, _f, _f, _i, _p]),
     "iseg_gather_rows": (_i, [_p, _p, _p, _l, _l, _i, _i, _p]),
+    "iseg_relpos_bias_scatter_grad_window": (_i, [_p, _i, _p, _i, _i, _i, _p]),
     "iseg_colsum_wide_workspace_bytes": (_z, [_l, _l]),
     "iseg_colsum_wide": (_i, [_p, _l, _l, _l, _p, _i, _i, _p, _z, _p]),
     "iseg_relpos_bias_gather": (_i, [_p, _p, _p, _i, _i, _p]),

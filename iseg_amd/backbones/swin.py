@@ -124,7 +124,8 @@ class WindowAttention(Layer):
         windows = 1 if attention_mask is None else attention_mask.shape[0]
         x = F.attention_packed(qkv, self.num_heads, C, C, self.scale, bias_table=self.relative_position_bias_table,
                                bias_index=self.relative_position_index, mask=attention_mask, windows=windows,
-                               dropout_rate=self.attn_drop, training=bool(training))
+                               dropout_rate=self.attn_drop, training=bool(training),
+                               bias_window=self.window_size[0] if self.window_size[0] == self.window_size[1] else 0)
         x = self.project(x)
         return self.project_dropout(x, training=training)
 

@@ -32,6 +32,9 @@ def get_sliding_window_slices_paddings_list(stride_h, stride_w, inputs_height, i
     return slices, paddings, count
 
 
+_PLAN_CACHE = {}
+
+
 def _first_logits(out):
     if isinstance(out, (list, tuple)):
         return out[0]
@@ -44,18 +47,39 @@ def inference_with_sliding_window(inputs, model, training=False, windows_size=(7
     x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
     H, W = int(x.shape[1]), int(x.shape[2])
     stride_h, stride_w = min(int(windows_size[0]), H), min(int(windows_size[1]), W)
-    slices, paddings, count = get_sliding_window_slices_paddings_list(stride_h, stride_w, H, W)
+    # static geometry: tiling, count map and its reciprocal (on the device) are built once per (H, W, window, batch)
+    key = (stride_h, stride_w, H, W, int(x.shape[0]), str(x.device))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        slices, _, count = get_sliding_window_slices_paddings_list(stride_h, stride_w, H, W)
+        inv_count = (1.0 / count.to(torch.float32)).reshape(-1).repeat(x.shape[0]).to(x.device)
+        plan = _PLAN_CACHE[key] = (slices, inv_count)
+    slices, inv = plan
     acc = None
-    for (t, b, l, r) in slices:
-        crop = x[:, t:b, l:r, :].contiguous()
-        logits = _first_logits(model(crop, training=training))
+    N = x.shape[0]
+    # The reference runs one forward per window (tf.while_loop, :262-293).  With training=False every layer is per-sample
+    # (BatchNorm uses its moving statistics), so all windows -- which share one size -- go through ONE forward as a batch of
+    # len(slices) * N crops: identical arithmetic per crop, 1/len(slices) of the kernel launches, 4x taller GEMMs at cfg4.
+    # training=True keeps the sequential order (batch statistics would otherwise mix windows).
+    same_size = len({(b - t, r - l) for (t, b, l, r) in slices}) == 1
+    if not training and same_size and len(slices) > 1:
+        crops = torch.cat([x[:, t:b, l:r, :] for (t, b, l, r) in slices], dim=0).contiguous()
+        all_logits = _first_logits(model(crops, training=False))
+        per_window = [all_logits[i * N:(i + 1) * N] for i in range(len(slices))]
+    else:
+        per_window = None
+    for i, (t, b, l, r) in enumerate(slices):
+        if per_window is not None:
+            logits = per_window[i]
+        else:
+            crop = x[:, t:b, l:r, :].contiguous()
+            logits = _first_logits(model(crop, training=training))
         C = logits.shape[-1]
         if acc is None:
-            acc = torch.zeros((x.shape[0], H, W, C), dtype=torch.float32, device=x.device)
+            acc = torch.zeros((N, H, W, C), dtype=torch.float32, device=x.device)
         # results += pad(logits): zero-pad-and-add == accumulate into the window's slice of the full-size buffer
-        for n in range(x.shape[0]):
+        for n in range(N):
             K.add2d(logits[n].reshape(b - t, (r - l) * C), (r - l) * C, acc[n, t:b, l:r, :], W * C, b - t, (r - l) * C)
-    inv = (1.0 / count.to(torch.float32)).reshape(-1).repeat(x.shape[0]).to(x.device)
     return K.scale_rows(acc.reshape(-1, acc.shape[-1]), inv).reshape(acc.shape)
 
 

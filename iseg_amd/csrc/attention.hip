@@ -149,6 +149,26 @@ __global__ __launch_bounds__(256) void relpos_scatter_kernel(const float* __rest
     }
 }
 
+// Same gradient for the canonical square-window index of backbones/swin.py:93-104 (index[i][j] = (yi-yj+ws-1)*(2ws-1) + (xi-xj+ws-1)):
+// entry k = (dy, dx) collects the <= ws*ws pairs with that displacement, enumerated directly instead of scanning all T*T pairs
+// (162 us -> a few us per call at T = 49).  The host checks the index table against the formula before choosing this kernel.
+__global__ __launch_bounds__(256) void relpos_scatter_ws_kernel(const float* __restrict__ dbias, int ld, float* __restrict__ dtable,
+                                                                int ws, int heads, int accumulate) {
+    const int side = 2 * ws - 1, T = ws * ws;
+    const int total = side * side * heads;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int k = i / heads, h = i % heads;
+        const int dy = k / side - (ws - 1), dx = k % side - (ws - 1);
+        float s = 0.f;
+        for (int yi = max(0, dy); yi < min(ws, ws + dy); ++yi)
+            for (int xi = max(0, dx); xi < min(ws, ws + dx); ++xi) {
+                const int a = yi * ws + xi, b = (yi - dy) * ws + (xi - dx);
+                s += dbias[((int64_t)h * T + a) * ld + b];
+            }
+        dtable[i] = accumulate ? dtable[i] + s : s;
+    }
+}
+
 // column sums of a short, very wide matrix (rows = windows, cols = heads*T*ld score entries): lanes along the columns,
 // row chunks along grid.y, partials [chunks][cols] reduced afterwards in chunk order
 template <class T>
@@ -257,6 +277,14 @@ extern "C" int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int6
                                (float*)y, rows_out, C);
     }
     return iseg_check_launch("iseg_gather_rows");
+}
+
+extern "C" int iseg_relpos_bias_scatter_grad_window(const float* dbias, int ld, float* dtable, int ws, int heads, int accumulate,
+                                                    hipStream_t stream) {
+    ISEG_REQUIRE(dbias && dtable && ws > 0 && heads > 0 && ld >= ws * ws, "iseg_relpos_bias_scatter_grad_window: bad arguments");
+    const int total = (2 * ws - 1) * (2 * ws - 1) * heads;
+    hipLaunchKernelGGL(relpos_scatter_ws_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, dbias, ld, dtable, ws, heads, accumulate);
+    return iseg_check_launch("iseg_relpos_bias_scatter_grad_window");
 }
 
 extern "C" size_t iseg_colsum_wide_workspace_bytes(int64_t rows, int64_t cols) {

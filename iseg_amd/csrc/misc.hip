@@ -39,19 +39,36 @@ template <class T>
 __global__ __launch_bounds__(256) void finite_minmax_kernel(const T* __restrict__ x, int64_t n, float nan_value,
                                                             unsigned* __restrict__ mm) {
     float lo = FLT_MAX, hi = -FLT_MAX;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float v = to_f32(x[i]);
+    auto take = [&](float v) {
         if (v != v) v = nan_value;          // replace_nan
         if (isinf(v)) v = 0.f;              // replace_inf: inf -> 0 before the global min / max
         lo = fminf(lo, v);
         hi = fmaxf(hi, v);
+    };
+    const int64_t n8 = ((uintptr_t)x % 16 == 0) ? n / 8 : 0;   // 16-byte (bf16) / 32-byte (fp32) vector body, scalar tail
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) take(v[u]);
     }
+    for (int64_t i = n8 * 8 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) take(to_f32(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo = fminf(lo, __shfl_xor(lo, o, 64));
         hi = fmaxf(hi, __shfl_xor(hi, o, 64));
     }
+    // one pair of atomics per workgroup (the grid is capped at a few thousand workgroups): per-wave atomics on two addresses
+    // serialised 400 k requests at 25 M elements (379 us measured)
+    __shared__ float slo[4], shi[4];
     if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
         atomicMin(&mm[0], f2ord(lo));
         atomicMax(&mm[1], f2ord(hi));
     }
@@ -61,19 +78,35 @@ template <class T>
 __global__ __launch_bounds__(256) void sanitize_apply_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float nan_value,
                                                              const unsigned* __restrict__ mm) {
     const float lo = ord2f(mm[0]), hi = ord2f(mm[1]);
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float v = to_f32(x[i]);
+    auto fix = [&](float v) {
         if (v != v) v = nan_value;
-        v = fminf(fmaxf(v, lo), hi);        // tf.clip_by_value(x, min, max)
-        y[i] = from_f32<T>(v);
+        return fminf(fmaxf(v, lo), hi);     // tf.clip_by_value(x, min, max)
+    };
+    const int64_t n8 = (((uintptr_t)x | (uintptr_t)y) % 16 == 0) ? n / 8 : 0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8];
+        load8<T>(x + i * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = fix(v[u]);
+        store8<T>(y + i * 8, v);
     }
+    for (int64_t i = n8 * 8 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = from_f32<T>(fix(to_f32(x[i])));
 }
 
 // gradient: tf.where(is_nan) blocks NaN positions, clip_by_value passes min <= x <= max (finite values always are)
 template <class T>
 __global__ __launch_bounds__(256) void sanitize_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                            int64_t n) {
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t n8 = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0) ? n / 8 : 0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float v[8], d[8];
+        load8<T>(x + i * 8, v);
+        load8<T>(dy + i * 8, d);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = ((v[u] == v[u]) && !isinf(v[u])) ? d[u] : 0.f;
+        store8<T>(dx + i * 8, d);
+    }
+    for (int64_t i = n8 * 8 + blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float v = to_f32(x[i]);
         const bool pass = (v == v) && !isinf(v);
         dx[i] = pass ? dy[i] : from_f32<T>(0.f);

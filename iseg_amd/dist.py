@@ -39,6 +39,9 @@ def init(backend=None):
         backend = os.environ.get("ISEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank())
+        from . import kernels
+
+        kernels._DEVICE_INDEX[0] = None      # the launch path caches the device index (kernels.stream)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     td.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)

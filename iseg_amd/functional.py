@@ -866,7 +866,7 @@ def _attn_chunks(B, heads):
 
 class _AttentionFn(Function):
     @staticmethod
-    def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed):
+    def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed, bias_window=0):
         B, T, ld = qkv.shape
         assert ld == 2 * Cq + Cv
         qkv = _c(qkv)
@@ -898,7 +898,7 @@ class _AttentionFn(Function):
             K.gemm(Pd[b0 * heads:b1 * heads], vv[b0:b1], O[b0:b1], T, dv, T, lda=Tp, ldb=ld, ldd=Cv, a_kcontig=1, b_kcontig=0,
                    batch=nb, batch_inner=heads, sa=(heads * T * Tp, T * Tp), sb=(T * ld, dv), sd=(T * Cv, dv))
         ctx.cfg = (heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp)
-        ctx.bias_table, ctx.bias_index = bias_table, bias_index
+        ctx.bias_table, ctx.bias_index, ctx.bias_window = bias_table, bias_index, bias_window
         ctx.save_for_backward(qkv, P, Pd if Pd is not P else None)
         return O
 
@@ -931,7 +931,8 @@ class _AttentionFn(Function):
         if ctx.bias_table is not None and ctx.bias_table.requires_grad:
             dbias = torch.empty(heads * T * Tp, dtype=torch.float32, device=qkv.device)
             K.colsum_wide(dP.reshape(B, heads * T * Tp), dbias)
-            K.relpos_bias_scatter_grad(dbias, Tp, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True)
+            K.relpos_bias_scatter_grad(dbias, Tp, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True,
+                                       window=ctx.bias_window)
             dist.grads_ready(ctx.bias_table)
         for b0, b1 in _attn_chunks(B, heads):
             nb = (b1 - b0) * heads
@@ -941,11 +942,11 @@ class _AttentionFn(Function):
                    batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
             K.gemm(dP[z0:z1], qv[b0:b1], dkv[b0:b1], T, dq, T, lda=Tp, ldb=ld, ldd=ld, a_kcontig=0, b_kcontig=0, alpha=scale,
                    batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=None, mask=None, windows=1, clip=None,
-                     dropout_rate=0.0, training=False):
+                     dropout_rate=0.0, training=False, bias_window=0):
     """qkv [B, T, 2*Cq + Cv] (columns [q | k | v], each split into `heads` contiguous head slices) -> [B, T, Cv].
     bias_table [entries, heads] fp32 parameter + bias_index int32 [T*T]; mask fp32 [windows, T, T] (sample b uses mask
     b % windows); clip = (lo, hi) on the probabilities."""
@@ -956,7 +957,7 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
         raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
     rate = float(dropout_rate) if training else 0.0
     return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip,
-                              rate, next_seed() if rate > 0 else 0)
+                              rate, next_seed() if rate > 0 else 0, int(bias_window))
 
 
 class _GatherRowsFn(Function):

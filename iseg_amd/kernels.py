@@ -24,8 +24,17 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_DEVICE_INDEX = [None]
+
+
 def stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream on this process's device.  torch.cuda.current_stream() re-derives the device
+    through is_available() -> os.getenv on every call (measured 70 us per launch on the GPU box: 20 of the 41 ms of a batch-1
+    ViT inference step were spent there); one process drives one GPU, so the index is resolved once."""
+    idx = _DEVICE_INDEX[0]
+    if idx is None:
+        idx = _DEVICE_INDEX[0] = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(idx)
 
 
 def _require_cuda(*ts):
@@ -308,6 +317,12 @@ def col2im(dcol, N, H, W, Cc, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo):
 
 
 def colsum(x, ldx, batch_stride, batch, rows, Cc, out, scale=1.0, accumulate=False):
+    if Cc > 8192 and batch == 1 and scale == 1.0:
+        # few rows, very wide (token-axis sums, score gradients): the LDS-staged kernel would need C floats of LDS per workgroup
+        L = _hip.lib()
+        ws, wsb = workspace(L.iseg_colsum_wide_workspace_bytes(rows, Cc), x.device)
+        _hip.check(L.iseg_colsum_wide(ptr(x), ldx, rows, Cc, ptr(out), int(accumulate), dt(x), ptr(ws), wsb, stream()), "iseg_colsum_wide")
+        return out
     need = _hip.lib().iseg_colsum_workspace_bytes(batch, rows, Cc)
     ws, wsb = workspace(need, x.device)
     _hip.call("iseg_colsum", ptr(x), ldx, batch_stride, batch, rows, Cc, ptr(out), scale, int(accumulate), dt(x), ptr(ws), wsb,
@@ -585,8 +600,13 @@ def relpos_bias_gather(table, index, heads, T):
     return bias
 
 
-def relpos_bias_scatter_grad(dbias, ld, index, dtable, heads, T, accumulate=True):
+def relpos_bias_scatter_grad(dbias, ld, index, dtable, heads, T, accumulate=True, window=0):
+    """window = ws > 0 asserts that `index` is the canonical ws x ws table (backbones/swin.py:93-104): fast kernel"""
     _require_cuda(dbias, index, dtable)
+    if window > 0 and window * window == T and dtable.shape[0] == (2 * window - 1) ** 2:
+        _hip.check(_hip.lib().iseg_relpos_bias_scatter_grad_window(ptr(dbias), ld, ptr(dtable), window, heads, int(accumulate), stream()),
+                   "iseg_relpos_bias_scatter_grad_window")
+        return dtable
     _hip.check(_hip.lib().iseg_relpos_bias_scatter_grad(ptr(dbias), ld, ptr(index), ptr(dtable), dtable.shape[0], heads, T, int(accumulate),
                                                        stream()), "iseg_relpos_bias_scatter_grad")
     return dtable
