@@ -90,6 +90,101 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// Register-resident variants: a row is read once and written once.  LPR lanes share a row (64 / LPR rows per wave: rows of 9
+// (DCNv3 mask) or 49 (Swin window) no longer leave most of a wave idle), lane l holds columns l, l + LPR, ... (EPL of them).
+template <class T, int LPR, int EPL>
+__global__ __launch_bounds__(256) void softmax_fwd_reg_kernel(const T* __restrict__ s, T* __restrict__ p, int64_t rows, int Tq, int cols,
+                                                              int ld, const float* __restrict__ bias, int heads,
+                                                              const float* __restrict__ mask, int nW, float clip_lo, float clip_hi) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane % LPR, sub = lane / LPR;
+    const bool clip = clip_hi > clip_lo;
+    for (int64_t r = (blockIdx.x * 4ll + (threadIdx.x >> 6)) * RPW + sub; r < rows; r += (int64_t)gridDim.x * 4 * RPW) {
+        const int64_t z = r / Tq;
+        const int i = (int)(r % Tq);
+        const T* sr = s + r * ld;
+        T* pr = p + r * ld;
+        const float* br = bias ? bias + ((int64_t)(z % heads) * Tq + i) * cols : nullptr;
+        const float* mr = mask ? mask + ((int64_t)((z / heads) % nW) * Tq + i) * cols : nullptr;
+        float v[EPL];
+        float mx = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = l + k * LPR;
+            v[k] = -FLT_MAX;
+            if (j < cols) {
+                float t = to_f32(sr[j]);
+                if (br) t += br[j];
+                if (mr) t += mr[j];
+                v[k] = t;
+                mx = fmaxf(mx, t);
+            }
+        }
+#pragma unroll
+        for (int o = LPR >> 1; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            v[k] = (l + k * LPR < cols) ? __expf(v[k] - mx) : 0.f;
+            sum += v[k];
+        }
+        sum = group_sum(sum, LPR);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = l + k * LPR;
+            if (j < ld) {
+                float out = v[k] * inv;
+                if (clip && j < cols) out = fminf(fmaxf(out, clip_lo), clip_hi);
+                pr[j] = from_f32<T>(j < cols ? out : 0.f);
+            }
+        }
+    }
+}
+
+template <class T, int LPR, int EPL>
+__global__ __launch_bounds__(256) void softmax_bwd_reg_kernel(const T* __restrict__ p, const T* __restrict__ dp, T* __restrict__ ds,
+                                                              int64_t rows, int cols, int ld, float clip_lo, float clip_hi) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane % LPR, sub = lane / LPR;
+    const bool clip = clip_hi > clip_lo;
+    for (int64_t r = (blockIdx.x * 4ll + (threadIdx.x >> 6)) * RPW + sub; r < rows; r += (int64_t)gridDim.x * 4 * RPW) {
+        const T* pr = p + r * ld;
+        const T* dr = dp + r * ld;
+        T* or_ = ds + r * ld;
+        float pv[EPL], g[EPL];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = l + k * LPR;
+            pv[k] = g[k] = 0.f;
+            if (j < cols) {
+                pv[k] = to_f32(pr[j]);
+                g[k] = to_f32(dr[j]);
+                if (clip && !(pv[k] > clip_lo && pv[k] < clip_hi)) g[k] = 0.f;
+                dot = fmaf(g[k], pv[k], dot);
+            }
+        }
+        dot = group_sum(dot, LPR);
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            const int j = l + k * LPR;
+            if (j < ld) or_[j] = from_f32<T>(j < cols ? pv[k] * (g[k] - dot) : 0.f);
+        }
+    }
+}
+
+// picks (LPR, EPL) for a row length; returns false when the row does not fit the register variants (ld > 64 * 32)
+template <class F16, class F64x2, class F64x8, class F64x32>
+static bool softmax_dispatch(int ld, F16 f16, F64x2 f64x2, F64x8 f64x8, F64x32 f64x32) {
+    if (ld <= 16) f16();
+    else if (ld <= 128) f64x2();
+    else if (ld <= 512) f64x8();
+    else if (ld <= 2048) f64x32();
+    else return false;
+    return true;
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void clip_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float lo, float hi) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -212,6 +307,19 @@ extern "C" int iseg_softmax_rows_fwd(const void* scores, void* probs, int64_t pr
     ISEG_REQUIRE((!bias && !mask) || heads > 0, "iseg_softmax_rows_fwd: bias / mask need the head count");
     ISEG_REQUIRE(!mask || windows > 0, "iseg_softmax_rows_fwd: mask needs the window count");
     const int64_t rows = problems * Tq;
+    const int hd = heads > 0 ? heads : 1, nw = windows > 0 ? windows : 1;
+#define SM_FWD(T, LPR, EPL)                                                                                                          \
+    hipLaunchKernelGGL((softmax_fwd_reg_kernel<T, LPR, EPL>), dim3(row_blocks(ceil_div64(rows, 64 / LPR))), dim3(256), 0, stream,    \
+                       (const T*)scores, (T*)probs, rows, Tq, cols, ld, bias, hd, mask, nw, clip_lo, clip_hi)
+    bool done;
+    if (dtype == ISEG_BF16)
+        done = softmax_dispatch(ld, [&] { SM_FWD(bf16_t, 16, 1); }, [&] { SM_FWD(bf16_t, 64, 2); }, [&] { SM_FWD(bf16_t, 64, 8); },
+                                [&] { SM_FWD(bf16_t, 64, 32); });
+    else
+        done = softmax_dispatch(ld, [&] { SM_FWD(float, 16, 1); }, [&] { SM_FWD(float, 64, 2); }, [&] { SM_FWD(float, 64, 8); },
+                                [&] { SM_FWD(float, 64, 32); });
+#undef SM_FWD
+    if (done) return iseg_check_launch("iseg_softmax_rows_fwd");
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const bf16_t*)scores,
                            (bf16_t*)probs, rows, Tq, cols, ld, bias, heads > 0 ? heads : 1, mask, windows > 0 ? windows : 1, clip_lo,
@@ -226,6 +334,18 @@ extern "C" int iseg_softmax_rows_fwd(const void* scores, void* probs, int64_t pr
 extern "C" int iseg_softmax_rows_bwd(const void* probs, const void* dprobs, void* dscores, int64_t rows, int cols, int ld, float clip_lo,
                                      float clip_hi, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(probs && dprobs && dscores && rows > 0 && cols > 0 && ld >= cols, "iseg_softmax_rows_bwd: bad arguments");
+#define SM_BWD(T, LPR, EPL)                                                                                                          \
+    hipLaunchKernelGGL((softmax_bwd_reg_kernel<T, LPR, EPL>), dim3(row_blocks(ceil_div64(rows, 64 / LPR))), dim3(256), 0, stream,    \
+                       (const T*)probs, (const T*)dprobs, (T*)dscores, rows, cols, ld, clip_lo, clip_hi)
+    bool done;
+    if (dtype == ISEG_BF16)
+        done = softmax_dispatch(ld, [&] { SM_BWD(bf16_t, 16, 1); }, [&] { SM_BWD(bf16_t, 64, 2); }, [&] { SM_BWD(bf16_t, 64, 8); },
+                                [&] { SM_BWD(bf16_t, 64, 32); });
+    else
+        done = softmax_dispatch(ld, [&] { SM_BWD(float, 16, 1); }, [&] { SM_BWD(float, 64, 2); }, [&] { SM_BWD(float, 64, 8); },
+                                [&] { SM_BWD(float, 64, 32); });
+#undef SM_BWD
+    if (done) return iseg_check_launch("iseg_softmax_rows_bwd");
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(row_blocks(rows)), dim3(256), 0, stream, (const bf16_t*)probs,
                            (const bf16_t*)dprobs, (bf16_t*)dscores, rows, cols, ld, clip_lo, clip_hi);
