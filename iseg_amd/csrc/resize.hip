@@ -73,6 +73,74 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const TI* __re
     }
 }
 
+// Large up-sampling of small maps (logits 16x16x21 -> 512x512x21 at cfg2: 88 MB written): the generic kernel above spends its
+// time in per-element integer division by C, lerp_of and four dependent global gathers (170 us measured, 0.5 TB/s).  Here the two
+// source rows (fp32) and the per-column lerp table sit in LDS, (ox, c) advance incrementally, and the arithmetic keeps TF's order.
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_lds_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int Hi, int Wi,
+                                                                      int Ho, int Wo, int C, float sy, float sx) {
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    const int src_len = Wi * C;
+    float* top = rsm;                                   // [Wi*C]
+    float* bot = rsm + src_len;                         // [Wi*C]
+    int* xlo = reinterpret_cast<int*>(rsm + 2 * src_len);   // [Wo] element offsets lo*C
+    int* xhi = xlo + Wo;                                // [Wo] element offsets hi*C
+    float* xt = reinterpret_cast<float*>(xhi + Wo);     // [Wo]
+    for (int ox = threadIdx.x; ox < Wo; ox += 256) {
+        const Lerp lx = lerp_of(ox, sx, Wi);
+        xlo[ox] = lx.lo * C;
+        xhi[ox] = lx.hi * C;
+        xt[ox] = lx.t;
+    }
+    const int rowlen = Wo * C;
+    const bool vec = (rowlen % 4 == 0);
+    const int dq = 1024 / C, dr = 1024 % C;
+    for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
+        const int n = row / Ho, oy = row - n * Ho;
+        const Lerp ly = lerp_of(oy, sy, Hi);
+        const TI* gt = x + ((int64_t)n * Hi + ly.lo) * src_len;
+        const TI* gb = x + ((int64_t)n * Hi + ly.hi) * src_len;
+        __syncthreads();   // previous row consumed (and the lerp table written, first time round)
+        for (int i = threadIdx.x; i < src_len; i += 256) {
+            top[i] = to_f32(gt[i]);
+            bot[i] = to_f32(gb[i]);
+        }
+        __syncthreads();
+        TO* out = y + (int64_t)row * rowlen;
+        int e0 = threadIdx.x * 4;
+        int ox = e0 / C, c = e0 - ox * C;
+        for (; e0 < rowlen; e0 += 1024) {
+            float v[4];
+            int oxx = ox, cc = c;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = 0.f;
+                if (e0 + u < rowlen) {
+                    const int lo = xlo[oxx] + cc, hi = xhi[oxx] + cc;
+                    const float t = xt[oxx];
+                    const float tl = top[lo], tr = top[hi], bl = bot[lo], br = bot[hi];
+                    const float tp = tl + (tr - tl) * t;
+                    const float bt = bl + (br - bl) * t;
+                    v[u] = tp + (bt - tp) * ly.t;
+                }
+                if (++cc >= C) {
+                    cc = 0;
+                    ++oxx;
+                }
+            }
+            if (vec) store4<TO>(out + e0, v);
+            else
+                for (int u = 0; u < 4 && e0 + u < rowlen; ++u) out[e0 + u] = from_f32<TO>(v[u]);
+            ox += dq;
+            c += dr;
+            if (c >= C) {
+                c -= C;
+                ++ox;
+            }
+        }
+    }
+}
+
 // transposed interpolation weights of forward destination d onto source j
 __device__ __forceinline__ float bwd_weight(int d, int j, float scale, int J) {
     const Lerp l = lerp_of(d, scale, J);
@@ -96,10 +164,19 @@ __device__ __forceinline__ void bwd_range(int j, int J, int Dn, float inv, int& 
 template <class TI>
 __global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restrict__ dy, float* __restrict__ tmp, int rows, int Wo,
                                                                int Wi, int C, float sx) {
-    extern __shared__ __attribute__((aligned(16))) float srow[];  // [Wo*C]
+    extern __shared__ __attribute__((aligned(16))) float srow[];  // [Wo*C], then the destination table lo[Wo], hi[Wo], t[Wo]
     const int rowlen = Wo * C;
     const float inv = 1.0f / sx;
     constexpr int V = 16 / sizeof(TI);
+    int* xlo = reinterpret_cast<int*>(srow + rowlen);
+    int* xhi = xlo + Wo;
+    float* xt = reinterpret_cast<float*>(xhi + Wo);
+    for (int d = threadIdx.x; d < Wo; d += 256) {
+        const Lerp l = lerp_of(d, sx, Wi);
+        xlo[d] = l.lo;
+        xhi[d] = l.hi;
+        xt[d] = l.t;
+    }
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
         const TI* src = dy + (int64_t)row * rowlen;
         __syncthreads();
@@ -114,16 +191,24 @@ __global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restr
             for (int i = threadIdx.x; i < rowlen; i += 256) srow[i] = to_f32(src[i]);
         }
         __syncthreads();
-        for (int o = threadIdx.x; o < Wi * C; o += 256) {
-            const int ix = o / C, c = o - ix * C;
-            int d0, d1;
-            bwd_range(ix, Wi, Wo, inv, d0, d1);
+        // four lanes share one output (ix, c): each walks every fourth destination of the range with the (lo, hi, t) table
+        // from LDS, partial sums meet through two shuffles (same fixed order every run)
+        for (int o0 = 0; o0 < Wi * C; o0 += 64) {
+            const int o = o0 + (threadIdx.x >> 2), part = threadIdx.x & 3;
             float acc = 0.f;
-            for (int d = d0; d <= d1; ++d) {
-                const float w = bwd_weight(d, ix, sx, Wi);
-                if (w != 0.f) acc = fmaf(w, srow[d * C + c], acc);
+            if (o < Wi * C) {
+                const int ix = o / C, c = o - ix * C;
+                int d0, d1;
+                bwd_range(ix, Wi, Wo, inv, d0, d1);
+                for (int d = d0 + part; d <= d1; d += 4) {
+                    const float t = xt[d], v = srow[d * C + c];
+                    if (xlo[d] == ix) acc = fmaf(1.f - t, v, acc);
+                    if (xhi[d] == ix) acc = fmaf(t, v, acc);
+                }
             }
-            tmp[(int64_t)row * Wi * C + o] = acc;
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (part == 0 && o < Wi * C) tmp[(int64_t)row * Wi * C + o] = acc;
         }
     }
 }
@@ -190,6 +275,22 @@ extern "C" int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, in
 #define RS(TI, TO)                                                                                                                    \
     hipLaunchKernelGGL((resize_bilinear_fwd_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TI*)x, (TO*)y, N, Hi, \
                        Wi, Ho, Wo, C, sy, sx)
+    const size_t lds = ((size_t)2 * Wi * C + (size_t)3 * Wo) * sizeof(float);
+    if (lds <= 48 * 1024 && (int64_t)Wo * C >= 1024) {   // small source rows, long output rows: LDS-resident sources
+#define RSL(TI, TO)                                                                                                                   \
+    hipLaunchKernelGGL((resize_bilinear_fwd_lds_kernel<TI, TO>), dim3((unsigned)blocks), dim3(256), lds, stream, (const TI*)x, (TO*)y, \
+                       N, Hi, Wi, Ho, Wo, C, sy, sx)
+        if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RSL(float, float);
+        else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RSL(bf16_t, float);
+        else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RSL(bf16_t, bf16_t);
+        else if (in_dtype == ISEG_F32 && out_dtype == ISEG_BF16) RSL(float, bf16_t);
+        else {
+            iseg_set_error("iseg_resize_bilinear_fwd: bad dtypes");
+            return ISEG_ERR_ARG;
+        }
+#undef RSL
+        return iseg_check_launch("iseg_resize_bilinear_fwd");
+    }
     if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RS(float, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RS(bf16_t, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RS(bf16_t, bf16_t);
@@ -221,7 +322,7 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     // X pass: [N*Ho, Wo, C] -> [N*Ho, Wi, C]
     const int64_t t1 = (int64_t)N * Ho * Wi * C;
-    const size_t row_bytes = (size_t)Wo * C * sizeof(float);
+    const size_t row_bytes = ((size_t)Wo * C + (size_t)3 * Wo) * sizeof(float);   // gradient row + destination lerp table
     if (row_bytes <= 64 * 1024 && (int64_t)N * Ho < (1ll << 31)) {
         int64_t blocks = (int64_t)N * Ho;
         if (blocks > 256 * 8) blocks = 256 * 8;
