@@ -238,6 +238,74 @@ __global__ void resize_bwd_axis_kernel(const TI* __restrict__ in, TO* __restrict
     }
 }
 
+// 8-element (channel) vector forms of the two generic kernels for C % 8 == 0 (FPN x2 up-sampling of 768-channel maps): index
+// math and interpolation weights once per 8 channels, 16-byte (bf16) / 32-byte (fp32) accesses.
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void resize_bilinear_fwd_vec_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int Hi, int Wi,
+                                                                      int Ho, int Wo, int C, float sy, float sx) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        int64_t r = i / C8;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const Lerp ly = lerp_of(oy, sy, Hi), lx = lerp_of(ox, sx, Wi);
+        const TI* top = x + ((int64_t)n * Hi + ly.lo) * Wi * C + c;
+        const TI* bot = x + ((int64_t)n * Hi + ly.hi) * Wi * C + c;
+        float tl[8], tr[8], bl[8], br[8], v[8];
+        load8<TI>(top + (int64_t)lx.lo * C, tl);
+        load8<TI>(top + (int64_t)lx.hi * C, tr);
+        load8<TI>(bot + (int64_t)lx.lo * C, bl);
+        load8<TI>(bot + (int64_t)lx.hi * C, br);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float tp = tl[u] + (tr[u] - tl[u]) * lx.t;
+            const float bt = bl[u] + (br[u] - bl[u]) * lx.t;
+            v[u] = tp + (bt - tp) * ly.t;
+        }
+        store8<TO>(y + i * 8, v);
+    }
+}
+
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void resize_bwd_axis_vec_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t O, int Dn, int J,
+                                                                  int64_t Q, float scale, const TO* __restrict__ add) {
+    const int64_t Q8 = Q / 8;
+    const int64_t total = O * J * Q8;
+    const float inv = 1.0f / scale;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t q = (i % Q8) * 8;
+        const int j = (int)((i / Q8) % J);
+        const int64_t o = i / (Q8 * J);
+        int d0, d1;
+        bwd_range(j, J, Dn, inv, d0, d1);
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        const TI* p = in + o * Dn * Q + q;
+        for (int d = d0; d <= d1; ++d) {
+            const float w = bwd_weight(d, j, scale, J);
+            if (w != 0.f) {
+                float v[8];
+                load8<TI>(p + (int64_t)d * Q, v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += w * v[u];
+            }
+        }
+        const int64_t e = (o * J + j) * Q + q;
+        if (add) {
+            float a[8];
+            load8<TO>(add + e, a);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += a[u];
+        }
+        store8<TO>(out + e, acc);
+    }
+}
+
 // tf.image.resize nearest (v2, half-pixel): src = min(floor((dst+0.5)*in/out), in-1)   -- labels, int32
 __global__ void resize_nearest_i32_kernel(const int32_t* __restrict__ x, int32_t* __restrict__ y, int N, int Hi, int Wi, int Ho,
                                           int Wo, int C, float sy, float sx) {
@@ -291,6 +359,22 @@ extern "C" int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, in
 #undef RSL
         return iseg_check_launch("iseg_resize_bilinear_fwd");
     }
+    if (C % 8 == 0 && ((uintptr_t)x | (uintptr_t)y) % 16 == 0) {
+        const unsigned vb = cap_blocks((int64_t)N * Ho * Wo * (C / 8));
+#define RSV(TI, TO)                                                                                                                  \
+    hipLaunchKernelGGL((resize_bilinear_fwd_vec_kernel<TI, TO>), dim3(vb), dim3(256), 0, stream, (const TI*)x, (TO*)y, N, Hi, Wi, Ho, \
+                       Wo, C, sy, sx)
+        if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RSV(float, float);
+        else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RSV(bf16_t, float);
+        else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RSV(bf16_t, bf16_t);
+        else if (in_dtype == ISEG_F32 && out_dtype == ISEG_BF16) RSV(float, bf16_t);
+        else {
+            iseg_set_error("iseg_resize_bilinear_fwd: bad dtypes");
+            return ISEG_ERR_ARG;
+        }
+#undef RSV
+        return iseg_check_launch("iseg_resize_bilinear_fwd");
+    }
     if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RS(float, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RS(bf16_t, float);
     else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RS(bf16_t, bf16_t);
@@ -332,6 +416,12 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
         else
             hipLaunchKernelGGL((resize_bwd_x_lds_kernel<float>), dim3((unsigned)blocks), dim3(256), row_bytes, stream, (const float*)dy,
                                tmp, N * Ho, Wo, Wi, C, sx);
+    } else if (C % 8 == 0 && (uintptr_t)dy % 16 == 0 && dy_dtype == ISEG_BF16) {
+        hipLaunchKernelGGL((resize_bwd_axis_vec_kernel<bf16_t, float>), dim3(cap_blocks(t1 / 8)), dim3(256), 0, stream, (const bf16_t*)dy,
+                           tmp, (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
+    } else if (C % 8 == 0 && (uintptr_t)dy % 16 == 0) {
+        hipLaunchKernelGGL((resize_bwd_axis_vec_kernel<float, float>), dim3(cap_blocks(t1 / 8)), dim3(256), 0, stream, (const float*)dy,
+                           tmp, (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
     } else if (dy_dtype == ISEG_BF16) {
         hipLaunchKernelGGL((resize_bwd_axis_kernel<bf16_t, float>), dim3(cap_blocks(t1)), dim3(256), 0, stream, (const bf16_t*)dy,
                            tmp, (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
@@ -341,7 +431,14 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
     }
     // Y pass: [N, Ho, Wi*C] -> [N, Hi, Wi*C]
     const int64_t t2 = (int64_t)N * Hi * Wi * C;
-    if (dx_dtype == ISEG_BF16)
+    const bool vec_y = ((int64_t)Wi * C) % 8 == 0 && ((uintptr_t)dx | (uintptr_t)dx_add) % 16 == 0;
+    if (vec_y && dx_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((resize_bwd_axis_vec_kernel<float, bf16_t>), dim3(cap_blocks(t2 / 8)), dim3(256), 0, stream, (const float*)tmp,
+                           (bf16_t*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const bf16_t*)dx_add);
+    else if (vec_y)
+        hipLaunchKernelGGL((resize_bwd_axis_vec_kernel<float, float>), dim3(cap_blocks(t2 / 8)), dim3(256), 0, stream, (const float*)tmp,
+                           (float*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const float*)dx_add);
+    else if (dx_dtype == ISEG_BF16)
         hipLaunchKernelGGL((resize_bwd_axis_kernel<float, bf16_t>), dim3(cap_blocks(t2)), dim3(256), 0, stream, (const float*)tmp,
                            (bf16_t*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const bf16_t*)dx_add);
     else

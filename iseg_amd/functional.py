@@ -87,10 +87,12 @@ class _DenseFn(Function):
         dy2 = _c(dy).reshape(-1, N)
         if ctx.act in (K.ACT_GELU, K.ACT_RELU):
             dy2 = K.act_bwd(dy2, aux, ctx.act)
-        if b is not None and b.requires_grad:
-            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b).reshape(-1), accumulate=True)
+        want_b = b is not None and b.requires_grad
         if W.requires_grad:
-            K.dense_wgrad(x2, dy2, _grad(W).reshape(Kd, N))
+            # the bias gradient rides the weight-gradient GEMM (virtual ones-row) whenever the last 128-row tile has a spare row
+            K.dense_wgrad(x2, dy2, _grad(W).reshape(Kd, N), bias_grad=(_grad(b).reshape(-1) if want_b else None))
+        elif want_b:
+            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b).reshape(-1), accumulate=True)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.dense_dgrad(dy2, nn.w(W).reshape(Kd, N)).reshape(*dy.shape[:-1], Kd)
