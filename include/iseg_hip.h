@@ -326,6 +326,24 @@ size_t iseg_mul_colsum_workspace_bytes(int64_t rows, int C);
 int iseg_mul_colsum(const void* a, const void* b, int64_t rows, int C, float* out, int accumulate, int dtype, void* ws,
                     size_t ws_bytes, iseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused window attention (backbones/swin.py:117-167 WindowAttention.call between the qkv and proj Dense layers):
+ *   out[b,:,h] = softmax(scale * q k^T + bias[h] + mask[b % mask_windows]) v    for qkv [windows, T, 3*heads*32] bf16
+ * bias [heads,T,T] fp32 (iseg_relpos_bias_gather) and mask [mask_windows,T,T] fp32 (or NULL) are first folded into one padded
+ * additive table (iseg_window_attention_table).  One wavefront per (window, head), MFMA
+ * for all five products, nothing of size T x T in HBM.  Supported: bf16, head_dim 32, T <= 64 (iseg_window_attention_supported).
+ * Backward recomputes the probabilities; dbias [heads,T,T] fp32 is overwritten (sum over windows, fixed order).
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_window_attention_supported(int T, int head_dim, int dtype);
+/* table[w][h][64][64] fp32 = bias[h] + mask[w] inside T x T, -FLT_MAX outside (w < mask_windows; one window when mask is NULL) */
+int iseg_window_attention_table(const float* bias, const float* mask, float* table, int T, int heads, int mask_windows,
+                                iseg_stream_t stream);
+int iseg_window_attention_fwd(const void* qkv, const float* table, void* out, int64_t windows, int T, int heads, int table_windows,
+                              float scale, int dtype, iseg_stream_t stream);
+size_t iseg_window_attention_bwd_workspace_bytes(int64_t windows, int T, int heads);
+int iseg_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dbias, int64_t windows, int T,
+                              int heads, int table_windows, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,8 @@ sequence of libiseg_hip.so calls.  Parameter gradients are written by the kernel
 (a view of the flat gradient buffer, see param_store.py) -- the Functions return None for parameters, so autograd
 never runs an accumulation kernel of its own for them.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -873,6 +875,15 @@ class _AttentionFn(Function):
         assert ld == 2 * Cq + Cv
         qkv = _c(qkv)
         dq, dv = Cq // heads, Cv // heads
+        ctx.fused = (bias_table is not None and Cq == Cv and clip is None and drop_rate <= 0 and
+                     K.window_attention_supported(T, dq, qkv.dtype) and os.environ.get("ISEG_WINATTN", "1") != "0")
+        if ctx.fused:      # Swin window attention: one wavefront per (window, head), probabilities never leave the CU
+            bias = K.relpos_bias_gather(bias_table.data, bias_index, heads, T)
+            ctx.cfg = (heads, Cq, Cv, scale, windows, clip, drop_rate, seed, 0)
+            ctx.bias_table, ctx.bias_index, ctx.bias_window = bias_table, bias_index, bias_window
+            table = K.window_attention_table(bias, mask, heads, T)
+            ctx.save_for_backward(qkv, table)
+            return K.window_attention_fwd(qkv, table, heads, scale)
         Tp = (T + 7) // 8 * 8
         dev, dtp = qkv.device, qkv.dtype
         P = torch.empty((B * heads, T, Tp), dtype=dtp, device=dev)
@@ -906,6 +917,16 @@ class _AttentionFn(Function):
 
     @staticmethod
     def backward(ctx, dO):
+        if ctx.fused:
+            qkv, table = ctx.saved_tensors
+            heads, _, _, scale = ctx.cfg[:4]
+            T = qkv.shape[1]
+            dqkv, dbias = K.window_attention_bwd(qkv, table, _c(dO), heads, scale)
+            if ctx.bias_table.requires_grad:
+                K.relpos_bias_scatter_grad(dbias, T, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True,
+                                           window=ctx.bias_window)
+                dist.grads_ready(ctx.bias_table)
+            return (dqkv,) + (None,) * 12
         qkv, P, Pd = ctx.saved_tensors
         heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp = ctx.cfg
         B, T, ld = qkv.shape

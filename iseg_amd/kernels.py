@@ -673,3 +673,40 @@ def colsum_wide(x2d, out, accumulate=False):
     _hip.check(L.iseg_colsum_wide(ptr(x2d), x2d.stride(0), rows, cols, ptr(out), int(accumulate), dt(x2d), ptr(ws), wsb, stream()),
                "iseg_colsum_wide")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused window attention (csrc/winattn.hip)
+# ---------------------------------------------------------------------------------------------------------
+def window_attention_supported(T, head_dim, dtype):
+    return dtype == torch.bfloat16 and bool(_hip.lib().iseg_window_attention_supported(int(T), int(head_dim), BF16))
+
+
+def window_attention_table(bias, mask, heads, T):
+    """[mask windows (1 without mask), heads, 64, 64] fp32 additive table: bias + mask inside T x T, -FLT_MAX outside"""
+    _require_cuda(bias)
+    nW = mask.shape[0] if mask is not None else 1
+    table = torch.empty((nW, heads, 64, 64), dtype=torch.float32, device=bias.device)
+    _hip.check(_hip.lib().iseg_window_attention_table(ptr(bias), ptr(mask), ptr(table), T, heads, nW, stream()), "iseg_window_attention_table")
+    return table
+
+
+def window_attention_fwd(qkv, table, heads, scale):
+    _require_cuda(qkv, table)
+    B, T, ld = qkv.shape
+    out = torch.empty((B, T, ld // 3), dtype=qkv.dtype, device=qkv.device)
+    _hip.check(_hip.lib().iseg_window_attention_fwd(ptr(qkv), ptr(table), ptr(out), B, T, heads, table.shape[0], float(scale), dt(qkv), stream()),
+               "iseg_window_attention_fwd")
+    return out
+
+
+def window_attention_bwd(qkv, table, dout, heads, scale):
+    _require_cuda(qkv, table, dout)
+    B, T, ld = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.empty((heads, T, T), dtype=torch.float32, device=qkv.device)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_window_attention_bwd_workspace_bytes(B, T, heads), qkv.device)
+    _hip.check(L.iseg_window_attention_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dbias), B, T, heads, table.shape[0], float(scale),
+                                           dt(qkv), ptr(ws), wsb, stream()), "iseg_window_attention_bwd")
+    return dqkv, dbias

@@ -253,3 +253,51 @@ def test_swin_small(cuda, dtype):
         _check_grads(swin, w, 5e-4 if dtype == torch.float32 else 8e-2, l2=dtype != torch.float32)
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("heads,B,ws,masked", [(6, 5, 7, False), (3, 18, 7, True), (12, 4, 5, False), (2, 7, 8, True)])
+def test_fused_window_attention_matches_materialised_route_and_oracle(cuda, heads, B, ws, masked):
+    """csrc/winattn.hip (bf16, head_dim 32, T = ws*ws <= 64) against the fp64 oracle and against the strided-batch GEMM route
+    (ISEG_WINATTN=0) on the same inputs: forward, dqkv and the relative-position-bias gradient"""
+    import os
+
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import relative_position_index
+
+    nn.set_compute_dtype(torch.bfloat16)
+    try:
+        d, T = 32, ws * ws
+        C = heads * d
+        nW = 1
+        mask = None
+        if masked:
+            nW = 3 if B % 3 == 0 else 1
+            mask = torch.where(rnd((nW, T, T), 9) > 0.3, torch.tensor(-100.0, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64)).float()
+        index = torch.from_numpy(relative_position_index((ws, ws)).reshape(-1)).cuda()
+        results = {}
+        for mode in ("1", "0"):
+            os.environ["ISEG_WINATTN"] = mode
+            table = torch.nn.Parameter((rnd(((2 * ws - 1) ** 2, heads), 3) * 0.5).float().cuda())
+            qkv, qkvr = q(rnd((B, T, 3 * C), 1), torch.bfloat16)
+            dy, dyr = q(rnd((B, T, C), 2), torch.bfloat16)
+            qkv.requires_grad_(True)
+            y = F.attention_packed(qkv, heads, C, C, d ** -0.5, bias_table=table, bias_index=index, mask=None if mask is None else mask.cuda(),
+                                   windows=nW, bias_window=ws)
+            y.backward(dy)
+            results[mode] = (y.detach().cpu().double(), qkv.grad.cpu().double(), table.grad.cpu().double())
+        qkvr.requires_grad_(True)
+        tr = table.detach().cpu().double().requires_grad_(True)
+        bias_r = tr[index.cpu().long()].reshape(T, T, heads).permute(2, 0, 1)
+        yr = _ref_attention(qkvr, heads, C, d ** -0.5, bias_r, None if mask is None else mask.double())
+        yr.backward(dyr)
+        for mode in ("1", "0"):
+            y, g, gt = results[mode]
+            assert (y - yr.detach()).norm() / yr.detach().norm() < 1.5e-2, mode
+            assert (g - qkvr.grad).norm() / qkvr.grad.norm() < 3e-2, mode
+            assert (gt - tr.grad).norm() / tr.grad.norm() < 3e-2, mode
+        # the two HIP routes agree with each other more tightly than either does with fp64
+        assert (results["1"][0] - results["0"][0]).abs().max() < 4e-2 * results["0"][0].abs().max()
+    finally:
+        os.environ.pop("ISEG_WINATTN", None)
+        nn.set_compute_dtype(torch.float32)
