@@ -344,6 +344,15 @@ size_t iseg_window_attention_bwd_workspace_bytes(int64_t windows, int T, int hea
 int iseg_window_attention_bwd(const void* qkv, const float* table, const void* dout, void* dqkv, float* dbias, int64_t windows, int T,
                               int heads, int table_windows, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Forward-only global self-attention for inference (keras MultiHeadAttention of backbones/vit.py:142-147,166 under
+ * core_inference.py's sliding windows): out[b,:,h] = softmax(scale * q k^T) v for packed qkv [batch, T, 3*heads*64] bf16.
+ * Online softmax over key tiles of 64: no T x T tensor in HBM.  Supported: bf16, head_dim 64, any T.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_attention_fwd_supported(int head_dim, int dtype);
+int iseg_attention_fwd(const void* qkv, void* out, int64_t batch, int T, int heads, int head_dim, float scale, int dtype,
+                       iseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -979,6 +979,11 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
     if mask is not None and (_MAX_GRID_Z // heads) % windows != 0 and qkv.shape[0] * heads > _MAX_GRID_Z:
         raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
     rate = float(dropout_rate) if training else 0.0
+    if (bias_table is None and mask is None and clip is None and rate <= 0 and Cq == Cv and
+            not (torch.is_grad_enabled() and qkv.requires_grad) and K.attention_fwd_supported(Cq // heads, qkv.dtype) and
+            os.environ.get("ISEG_FLASHATTN", "1") != "0"):
+        # inference: online-softmax kernel, no T x T tensor (the training route keeps the probabilities for its backward)
+        return K.attention_fwd(_c(qkv), int(heads), float(scale))
     return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip,
                               rate, next_seed() if rate > 0 else 0, int(bias_window))
 

@@ -678,6 +678,20 @@ def colsum_wide(x2d, out, accumulate=False):
 # ---------------------------------------------------------------------------------------------------------
 # fused window attention (csrc/winattn.hip)
 # ---------------------------------------------------------------------------------------------------------
+def attention_fwd_supported(head_dim, dtype):
+    return dtype == torch.bfloat16 and bool(_hip.lib().iseg_attention_fwd_supported(int(head_dim), BF16))
+
+
+def attention_fwd(qkv, heads, scale):
+    """forward-only global attention on packed [q|k|v] (inference): [B, T, 3C] -> [B, T, C]"""
+    B, T, ld = qkv.shape
+    C = ld // 3
+    out = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
+    _hip.check(_hip.lib().iseg_attention_fwd(ptr(qkv), ptr(out), B, T, heads, C // heads, float(scale), dt(qkv), stream()),
+               "iseg_attention_fwd")
+    return out
+
+
 def window_attention_supported(T, head_dim, dtype):
     return dtype == torch.bfloat16 and bool(_hip.lib().iseg_window_attention_supported(int(T), int(head_dim), BF16))
 

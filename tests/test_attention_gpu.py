@@ -301,3 +301,37 @@ def test_fused_window_attention_matches_materialised_route_and_oracle(cuda, head
     finally:
         os.environ.pop("ISEG_WINATTN", None)
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("heads,B,T", [(12, 2, 1025), (3, 4, 64), (2, 3, 1), (4, 1, 197), (1, 5, 130)])
+def test_inference_flash_attention_matches_materialised_route_and_oracle(cuda, heads, B, T):
+    """csrc/flashattn.hip (bf16, head_dim 64, forward only) against the fp64 oracle and the GEMM + softmax route (ISEG_FLASHATTN=0):
+    ragged last key / query tiles (T % 64 in {1, 0, 5, 2}), a single token, the ViT-B/16 512x512 window (T = 1025)"""
+    import os
+
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+
+    nn.set_compute_dtype(torch.bfloat16)
+    try:
+        d = 64
+        C = heads * d
+        qkv, qkvr = q(rnd((B, T, 3 * C), 11) * 1.5, torch.bfloat16)
+        out = {}
+        with torch.no_grad():
+            for mode in ("1", "0"):
+                os.environ["ISEG_FLASHATTN"] = mode
+                out[mode] = F.attention_packed(qkv, heads, C, C, d ** -0.5).cpu().double()
+        yr = _ref_attention(qkvr, heads, C, d ** -0.5)
+        assert torch.isfinite(out["1"]).all()
+        for mode in ("1", "0"):
+            assert (out[mode] - yr).norm() / yr.norm() < 1.5e-2, mode
+        assert (out["1"] - out["0"]).abs().max() < 4e-2 * out["0"].abs().max()
+        # a training call (grad required) keeps the materialised route and its backward
+        qkv.requires_grad_(True)
+        os.environ["ISEG_FLASHATTN"] = "1"
+        y = F.attention_packed(qkv, heads, C, C, d ** -0.5)
+        assert y.grad_fn is not None
+    finally:
+        os.environ.pop("ISEG_FLASHATTN", None)
+        nn.set_compute_dtype(torch.float32)
