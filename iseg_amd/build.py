@@ -31,7 +31,7 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_impl.h"), os.path.join(ROOT, "include", "iseg_hip.h")]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(ROOT, "include", "iseg_hip.h")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

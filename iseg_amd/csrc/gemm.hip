@@ -15,7 +15,7 @@
 #include "common.h"
 #include "iseg_hip.h"
 
-#include "gemm_impl.h"
+#include "gemm_dma.h"
 
 using namespace iseg_mm;
 
@@ -25,6 +25,13 @@ int long_k_tile() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_BK");
         return (e && atoi(e) == 64) ? 64 : 128;
+    }();
+    return v;
+}
+int dma_mode() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_DMA");
+        return e ? atoi(e) : 1;
     }();
     return v;
 }
@@ -122,6 +129,8 @@ int choose_split(const iseg_gemm_args* g, int tile) {
     if (g->split_k > 0) return g->split_k;
     const int64_t tiles = ceil_div64(g->M, tile) * ceil_div64(g->N, tile);
     if (tiles >= 256 || g->K < 2048 || g->batch > 1) return 1;
+    // the LDS-DMA pipeline keeps several K-tiles in flight per workgroup: half-filled grids are better left unsplit
+    if (g->in_dtype == ISEG_BF16 && tiles >= 96 && iseg_mm::dma_mode() && iseg_mm::dma_eligible(g, 128)) return 1;
     int64_t want = ceil_div64(512, tiles);
     const int64_t maxs = g->K / 512 > 0 ? g->K / 512 : 1;
     if (want > maxs) want = maxs;

@@ -1,0 +1,234 @@
+// Second bf16 main loop: LDS-DMA pipeline (global_load_lds_dwordx4) for problems whose A and B are both K-contiguous and 16-byte
+// aligned, with the reduction range a multiple of 64, N a multiple of 8 and no operand transform (dgrads, attention products).
+// Differences from gemm_bf16_kernel (gemm_impl.h):
+//   * operand tiles go HBM -> LDS without passing through registers: no staging VGPRs, no ds_write pass, so a wavefront owns a
+//     64x64 output tile (16 accumulator fragments; 8 ds_read_b128 per 16 MFMAs = 512 LDS bytes per MFMA instead of 768);
+//   * a ring of NS LDS stages: with NS = 2 tile t+1's DMA is issued before tile t is waited for (two barriers per K-step, two
+//     workgroups per CU); with NS >= 3, NS-1 tiles are in flight and ONE barrier per K-step does both jobs.  Waits are COUNTED
+//     s_waitcnt vmcnt and the barriers raw s_barrier (a __syncthreads() would drain the DMA in flight);
+//   * the LDS image of a tile is unpadded [row][64] bf16 (128-B rows; one DMA instruction = 8 rows = 1 KiB, lane-linear) with
+//     the 16-B chunk index XOR-ed by a 3-bit key of the row: applied on the per-lane SOURCE address and again on the ds_read_b128
+//     address, it makes every 16-lane read group ({0-3,12-15,20-27}, ...) cover all 64 banks;
+//   * B is the first MFMA operand and its fragment rows are permuted, so the accumulator holds the TRANSPOSED product with eight
+//     consecutive output columns per lane: the fused epilogue (epi_finish8 of gemm_impl.h: same operations, split-K slabs and
+//     strided batch) runs on 16-byte vectors straight from registers -- no LDS transpose, no barrier after the main loop;
+//   * rows past M / N are clamped to the last valid row on the source side (their products are never stored).
+// Measured (tools/kbench_gemm_ref.py, plain epilogue): dgrad M=16384 N=1536 K=384 43.5 -> 35.2 us, M=16384 N=384 K=1536
+// 44.6 -> 32.1 us, M=4096 N=4096 K=1024 59.9 -> 43.0 us; end to end the flagship gains 0.5 % (its dgrads are epilogue-bound).
+#pragma once
+#include "gemm_impl.h"
+
+namespace iseg_mm {
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// swizzle key of a B-tile row (see the fragment read below: a 16-lane read group holds rows {x, 8+x, 16+x, 24+x} + const, x = 0..3)
+__device__ __forceinline__ int b_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int WM, int WN, int NS, class TO>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                                     int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
+                                                                     int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
+                                                                     float* __restrict__ slabs, Epi epi, int vecD) {
+    constexpr int NW = WM * WN;
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int PIECES = (BM + BN) / 8;      // 1-KiB DMA pieces (8 rows x 128 B) per stage
+    constexpr int PPW = PIECES / NW;           // pieces each wavefront issues per stage
+    static_assert(PIECES % NW == 0, "stage pieces must divide over the wavefronts");
+    constexpr int STAGE = (BM + BN) * 128;     // bytes
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // NS * STAGE bytes
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    if (gridDim.z > 1) {
+        A += epi.off_a(blockIdx.z);
+        B += epi.off_b(blockIdx.z);
+        D += epi.off_d(blockIdx.z);
+    }
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tile_n = t % tiles_n, tile_m = t / tiles_n;
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
+    const int nk = (int)((kend - kbeg) / 64);
+
+    // per-lane DMA sources: piece p of this wavefront covers stage rows 8*(wid + p*NW) .. +7 (A rows first, then B rows);
+    // lane l fills LDS slot (row l>>3, chunk l&7) with source chunk (l&7) ^ (l>>3)
+    const bf16_t* src[PPW];
+    {
+        const int rsub = lane >> 3;
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const int r = (wid + p * NW) * 8 + rsub;
+            if (r < BM) {
+                int64_t row = m0 + r;
+                row = row < M ? row : M - 1;
+                src[p] = A + row * lda + kbeg + ((lane & 7) ^ (r & 7)) * 8;
+            } else {
+                const int rb = r - BM;
+                int64_t row = n0 + rb;
+                row = row < N ? row : N - 1;
+                src[p] = B + row * ldb + kbeg + ((lane & 7) ^ b_key(rb)) * 8;
+            }
+        }
+    }
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)src[p], (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
+            src[p] += 64;
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Fragment addresses.  A: row (lane & 15) of 16-row block i, chunk (4*ks + (lane >> 4)) ^ (row & 7).
+    // B: fragment j of the wave tile takes the rows 32*(j >> 1) + 8*(c >> 2) + 4*(j & 1) + (c & 3), c = lane & 15, and is the FIRST
+    // MFMA operand, so the accumulator is the transposed product: lane (g, c) ends up with output row 16*i + c and, over the four
+    // registers of fragments (2h, 2h+1), the eight CONSECUTIVE columns 32*h + 8*g .. + 7 -- the epilogue stores 16-B vectors
+    // straight from registers (four lanes = 64 contiguous bytes of a row), no LDS transpose.
+    const int g = lane >> 4, c15 = lane & 15;
+    const int a_sw = (g ^ (lane & 7)) * 16;      // ks = 0; ks = 1 flips bit 6 of the byte offset (chunk ^ 4)
+    const int a_off = (wm * 64 + c15) * 128;
+    const int b_row0 = wn * 64 + 8 * (c15 >> 2) + (c15 & 3);
+    const int b_sw = (g ^ b_key(b_row0)) * 16;   // + 32*(j >> 1) + 4*(j & 1) leaves the key (bits 0,1,3 of the row) unchanged
+    const int b_off = BM * 128 + b_row0 * 128;
+
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE + a_off;
+        const char* sb = smem + stage * STAGE + b_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 2048 + (a_sw ^ (ks * 64)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * 128 + (b_sw ^ (ks * 64)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (NS == 2) {
+        issue(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            if (kt + 1 < nk) {
+                issue(stage ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // tile kt landed; tile kt+1 stays in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();      // every wavefront's pieces of tile kt are in LDS
+            asm volatile("" ::: "memory");
+            compute(stage);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // every wavefront is done reading this stage before tile kt+2's DMA overwrites it
+            asm volatile("" ::: "memory");
+        }
+    } else {
+        // ring of NS stages, NS-1 tiles in flight, ONE barrier per K-step: the barrier of step kt proves both that tile kt has
+        // landed for everyone and that everyone is past the fragment reads of tile kt-1, whose stage tile kt+NS-1 then takes
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nk) issue(p);
+        int stage = 0, fill = (NS - 1) % NS;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int ahead = nk - 1 - kt;      // tiles issued after tile kt that may stay in flight (capped at NS-2)
+            if (ahead >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+            else if (NS > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NS - 1 < nk) issue(fill);
+            compute(stage);
+            stage = stage + 1 == NS ? 0 : stage + 1;
+            fill = fill + 1 == NS ? 0 : fill + 1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // the epilogue slab overwrites the ring
+        asm volatile("" ::: "memory");
+    }
+    // ---- epilogue from registers: per 16-row block, two 8-column vectors per lane (N % 8 == 0 and aligned operands are
+    // eligibility conditions, so there is no scalar path) ----
+    const bool split = slabs != nullptr;
+    float* const slab = split ? slabs + (int64_t)blockIdx.y * M * N : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + c15;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t n = n0 + wn * 64 + 32 * h + 8 * g;
+            if (m < M && n < N) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = acc[i][2 * h + (u >> 2)][u & 3];
+                if (split) {
+                    float* dst = slab + m * N + n;
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v);
+                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(v + 4);
+                } else {
+                    EpiPrefetch<TO> pf;
+                    pf.load(epi, m, n, D, ldd);
+                    epi_finish8<TO>(epi, v, pf, m, n, D, ldd);
+                }
+            }
+        }
+    }
+}
+
+// eligibility of a problem for the DMA pipeline (checked on the host)
+inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
+    if (!g->a_kcontig || !g->b_kcontig || g->a_act != ISEG_ACT_NONE || g->colsum_out) return false;
+    if (g->K % 64 != 0 || kps % 64 != 0 || g->K < 128 || g->N % 8 != 0 || g->N < 64 || g->M < 64) return false;
+    if (((uintptr_t)g->A % 16) || ((uintptr_t)g->B % 16) || g->lda % 8 || g->ldb % 8) return false;
+    if (((uintptr_t)g->D % 16) || g->ldd % 8) return false;
+    if (g->residual && (((uintptr_t)g->residual % 16) || g->ldr % 8)) return false;
+    if (g->aux && (((uintptr_t)g->aux % 16) || g->ldaux % 8)) return false;
+    if (g->pre_out && (((uintptr_t)g->pre_out % 16) || g->ldp % 8)) return false;
+    if ((g->bias && (uintptr_t)g->bias % 16) || (g->colscale && (uintptr_t)g->colscale % 16)) return false;
+    if (g->batch > 1 && (g->sa_outer % 8 || g->sa_inner % 8 || g->sb_outer % 8 || g->sb_inner % 8 || g->sd_outer % 8 || g->sd_inner % 8))
+        return false;
+    return true;
+}
+
+template <int WM, int WN, int NS, class TO>
+void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
+    constexpr int BM = WM * 64, BN = WN * 64;
+    const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
+    const int ntiles = tiles_m * tiles_n;
+    const int vecD = 1;
+    const int batch = g->batch > 1 ? g->batch : 1;
+    dim3 grid(ntiles, nsplit, batch);
+    constexpr int lds = NS * (BM + BN) * 128;
+    static const bool raised = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   lds) == hipSuccess;
+    }();
+    (void)raised;
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda, (const bf16_t*)g->B,
+                       g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
+}
+
+int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default)
+
+template <class TO>
+void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
+    // tile choice (measured on MI355X, tools/kbench_gemm_ref.py): 256 x 128 with a 3-deep ring (one workgroup of 8 wavefronts per
+    // CU) once it fills most CUs -- it reads each B panel half as often; otherwise 128 x 128, two workgroups per CU with two stages
+    // when there are enough tiles, one workgroup with the deeper ring when the grid is thin
+    const int64_t tiles256 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), tiles128 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128);
+    if (g->N <= 64) launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s);                                // 128 x 64
+    else if (tiles256 * nsplit >= 192) launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s);             // 256 x 128
+    else if (tiles128 * nsplit >= 384) launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s);             // 128 x 128, 2 per CU
+    else launch_dma<2, 2, 3, TO>(g, epi, nsplit, kps, slabs, s);                                           // 128 x 128, deeper ring
+}
+
+}  // namespace iseg_mm

@@ -308,6 +308,86 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, i
     }
 }
 
+// ---- epilogue: accumulators -> per-wave LDS slab (fp32) -> 8-column coalesced rows ----
+// Shared by both main loops.  `smem` must be free (every wave past its last fragment read) and hold WM*WN*32*(FN*16+4) floats.
+template <int WM, int WN, int FM, int FN, class TO>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[FM][FN], char* smem, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
+                                              int64_t m0, int64_t n0, int wm, int wn, int wid, int lane, float* __restrict__ slabs,
+                                              const Epi& epi, bool ones_row, int vecD) {
+    constexpr int TM = FM * 16, TN = FN * 16;
+    constexpr int EPI_ROWS = 32;
+    constexpr int EPI_STRIDE = TN + 4;
+    float* const ew = reinterpret_cast<float*>(smem) + wid * EPI_ROWS * EPI_STRIDE;
+    const bool split = slabs != nullptr;
+    const int64_t slab_rows = M + (ones_row ? 1 : 0);
+    float* const slab = split ? slabs + (int64_t)blockIdx.y * slab_rows * N : nullptr;
+    constexpr int PASSES = (TM + EPI_ROWS - 1) / EPI_ROWS;
+    constexpr int FPP = EPI_ROWS / 16;  // fragments (in M) per pass
+    constexpr int CPR = TN / 8;         // 8-column groups per row
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+        for (int fi = 0; fi < FPP; ++fi) {
+            const int i = ps * FPP + fi;
+            if (i < FM) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ew[(fi * 16 + (lane >> 4) * 4 + r) * EPI_STRIDE + j * 16 + (lane & 15)] = acc[i][j][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the slab is wave-private and LDS ops of a wave complete in order
+        // all of this pass's rows: LDS reads and global operand loads first (kept packed), then the arithmetic and the stores
+        constexpr int ITERS = (EPI_ROWS * CPR + 63) / 64;
+        constexpr int PF = 1;  // rows whose operands are in flight together (2 was measured: no gain, costs occupancy)
+#pragma unroll
+        for (int g0 = 0; g0 < ITERS; g0 += PF) {
+            float v[PF][8];
+            EpiPrefetch<TO> pf[PF];
+            int64_t mm[PF], nn[PF];
+            int kind[PF];  // 0 skip, 1 split slab, 2 vector epilogue, 3 scalar epilogue
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int c = lane + (g0 + q) * 64;
+                const int rr = c / CPR, cc = (c % CPR) * 8;
+                mm[q] = m0 + wm * TM + ps * EPI_ROWS + rr;
+                nn[q] = n0 + wn * TN + cc;
+                kind[q] = 0;
+                if (g0 + q < ITERS && c < EPI_ROWS * CPR && ps * EPI_ROWS + rr < TM && mm[q] < slab_rows && nn[q] < N) {
+                    const float* src = ew + rr * EPI_STRIDE + cc;
+                    *reinterpret_cast<float4*>(v[q]) = *reinterpret_cast<const float4*>(src);
+                    *reinterpret_cast<float4*>(v[q] + 4) = *reinterpret_cast<const float4*>(src + 4);
+                    kind[q] = split ? 1 : (mm[q] == M ? 4 : ((vecD && nn[q] + 8 <= N) ? 2 : 3));
+                    if (kind[q] == 2) pf[q].load(epi, mm[q], nn[q], D, ldd);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int64_t m = mm[q], n = nn[q];
+                if (kind[q] == 1) {
+                    float* dst = slab + m * N + n;
+                    if (n + 8 <= N && (N % 4 == 0)) {
+                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v[q]);
+                        *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(v[q] + 4);
+                    } else {
+                        for (int u = 0; u < 8 && n + u < N; ++u) dst[u] = v[q][u];
+                    }
+                } else if (kind[q] == 2) {
+                    epi_finish8<TO>(epi, v[q], pf[q], m, n, D, ldd);
+                } else if (kind[q] == 3) {
+                    for (int u = 0; u < 8 && n + u < N; ++u)
+                        D[m * ldd + n + u] = from_f32<TO>(epi_apply<TO>(epi, v[q][u], m, n + u, D, ldd));
+                } else if (kind[q] == 4) {  // the ones-row: column sums of B
+                    for (int u = 0; u < 8 && n + u < N; ++u)
+                        epi.colsum_out[n + u] = v[q][u] + (epi.colsum_accumulate ? epi.colsum_out[n + u] : 0.f);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <int WM, int WN, int FM, int FN, bool AKC, bool BKC, int BK, class TO>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                                  const bf16_t* __restrict__ B, int64_t ldb, TO* __restrict__ D,
@@ -389,76 +469,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         }
     }
 
-    // ---- epilogue: accumulators -> per-wave LDS slab (fp32) -> 8-column coalesced rows ----
-    float* const ew = reinterpret_cast<float*>(smem) + wid * EPI_ROWS * EPI_STRIDE;
-    const bool split = slabs != nullptr;
-    const int64_t slab_rows = M + (ones_row ? 1 : 0);
-    float* const slab = split ? slabs + (int64_t)blockIdx.y * slab_rows * N : nullptr;
-    constexpr int PASSES = (TM + EPI_ROWS - 1) / EPI_ROWS;
-    constexpr int FPP = EPI_ROWS / 16;  // fragments (in M) per pass
-    constexpr int CPR = TN / 8;         // 8-column groups per row
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-#pragma unroll
-        for (int fi = 0; fi < FPP; ++fi) {
-            const int i = ps * FPP + fi;
-            if (i < FM) {
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ew[(fi * 16 + (lane >> 4) * 4 + r) * EPI_STRIDE + j * 16 + (lane & 15)] = acc[i][j][r];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the slab is wave-private and LDS ops of a wave complete in order
-        // all of this pass's rows: LDS reads and global operand loads first (kept packed), then the arithmetic and the stores
-        constexpr int ITERS = (EPI_ROWS * CPR + 63) / 64;
-        constexpr int PF = 1;  // rows whose operands are in flight together (2 was measured: no gain, costs occupancy)
-#pragma unroll
-        for (int g0 = 0; g0 < ITERS; g0 += PF) {
-            float v[PF][8];
-            EpiPrefetch<TO> pf[PF];
-            int64_t mm[PF], nn[PF];
-            int kind[PF];  // 0 skip, 1 split slab, 2 vector epilogue, 3 scalar epilogue
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int c = lane + (g0 + q) * 64;
-                const int rr = c / CPR, cc = (c % CPR) * 8;
-                mm[q] = m0 + wm * TM + ps * EPI_ROWS + rr;
-                nn[q] = n0 + wn * TN + cc;
-                kind[q] = 0;
-                if (g0 + q < ITERS && c < EPI_ROWS * CPR && ps * EPI_ROWS + rr < TM && mm[q] < slab_rows && nn[q] < N) {
-                    const float* src = ew + rr * EPI_STRIDE + cc;
-                    *reinterpret_cast<float4*>(v[q]) = *reinterpret_cast<const float4*>(src);
-                    *reinterpret_cast<float4*>(v[q] + 4) = *reinterpret_cast<const float4*>(src + 4);
-                    kind[q] = split ? 1 : (mm[q] == M ? 4 : ((vecD && nn[q] + 8 <= N) ? 2 : 3));
-                    if (kind[q] == 2) pf[q].load(epi, mm[q], nn[q], D, ldd);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int64_t m = mm[q], n = nn[q];
-                if (kind[q] == 1) {
-                    float* dst = slab + m * N + n;
-                    if (n + 8 <= N && (N % 4 == 0)) {
-                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v[q]);
-                        *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(v[q] + 4);
-                    } else {
-                        for (int u = 0; u < 8 && n + u < N; ++u) dst[u] = v[q][u];
-                    }
-                } else if (kind[q] == 2) {
-                    epi_finish8<TO>(epi, v[q], pf[q], m, n, D, ldd);
-                } else if (kind[q] == 3) {
-                    for (int u = 0; u < 8 && n + u < N; ++u)
-                        D[m * ldd + n + u] = from_f32<TO>(epi_apply<TO>(epi, v[q][u], m, n + u, D, ldd));
-                } else if (kind[q] == 4) {  // the ones-row: column sums of B
-                    for (int u = 0; u < 8 && n + u < N; ++u)
-                        epi.colsum_out[n + u] = v[q][u] + (epi.colsum_accumulate ? epi.colsum_out[n + u] : 0.f);
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, ones_row, vecD);
 }
 
 // experiment knob (read once)

@@ -400,3 +400,51 @@ def test_argmax_confusion_first_max_and_ignore(cuda):
     assert torch.equal(cm.cpu().reshape(C, C).double(), want_cm)
     k.argmax_confusion(z.cuda(), y.cuda(), 255, cm=cm)  # accumulates
     assert torch.equal(cm.cpu().reshape(C, C).double(), 2 * want_cm)
+
+
+@pytest.mark.parametrize("M,N,Kd,split", [(300, 64, 256, 0),        # 128 x 64 tile, 4-deep ring, ragged M
+                                         (1000, 136, 128, 0),      # 128 x 128 thin grid (3-deep ring), ragged M and N % 128 != 0
+                                         (7000, 384, 192, 0),      # 128 x 128, two workgroups per CU (2 stages)
+                                         (16384, 512, 128, 0),     # 256 x 128 tile
+                                         (25000, 264, 320, 0),     # 256 x 128, ragged both ways
+                                         (640, 128, 2048, 4)])     # split-K slabs from the DMA kernel
+def test_gemm_dma_pipeline_matches_oracle_and_register_staged_kernel(cuda, M, N, Kd, split):
+    """csrc/gemm_dma.h (bf16, A and B K-contiguous, K % 64 == 0): every tile variant, ragged edges, the fused epilogues, fp32
+    accumulate output and split-K slabs against the fp64 oracle"""
+    k = K()
+    dt = torch.bfloat16
+    a, ar = q(rnd((M, Kd), 1), dt)
+    b, br = q(rnd((N, Kd), 2, Kd ** -0.5), dt)
+    bias = rnd((N,), 3).float()
+    cs = (rnd((N,), 4) * 0.5 + 1.0).float()
+    res, resr = q(rnd((M, N), 5), dt)
+    aux, auxr = q(rnd((M, N), 6), dt)
+    out = torch.empty((M, N), dtype=dt, device="cuda")
+    k.gemm(a, b, out, M, N, Kd, lda=Kd, ldb=Kd, ldd=N, a_kcontig=1, b_kcontig=1, split_k=split)
+    close(out, ar @ br.T, dt, "plain")
+    k.gemm(a, b, out, M, N, Kd, lda=Kd, ldb=Kd, ldd=N, a_kcontig=1, b_kcontig=1, bias=bias.cuda(), colscale=cs.cuda(), residual=res, ldr=N,
+           act=k.ACT_GELU, split_k=split)
+    want = O.gelu(ar @ br.T + bias.double()) * cs.double() + resr
+    close(out, want, dt, "bias+gelu+colscale+residual")
+    k.gemm(a, b, out, M, N, Kd, lda=Kd, ldb=Kd, ldd=N, a_kcontig=1, b_kcontig=1, act=k.ACT_GELU_GRAD, aux=aux, ldaux=N, split_k=split)
+    hh = auxr.clone().requires_grad_(True)
+    O.gelu(hh).backward(ar @ br.T)
+    close(out, hh.grad, dt, "gelu'")
+    o32 = torch.full((M, N), 0.25, dtype=torch.float32, device="cuda")
+    k.gemm(a, b, o32, M, N, Kd, lda=Kd, ldb=Kd, ldd=N, a_kcontig=1, b_kcontig=1, accumulate=True, alpha=0.5, split_k=split)
+    close(o32, 0.5 * (ar @ br.T) + 0.25, torch.float32, "fp32 accumulate", f32_tol=2e-5)
+
+
+def test_gemm_dma_pipeline_strided_batch(cuda):
+    k = K()
+    dt = torch.bfloat16
+    Bz, H, T, d = 3, 4, 200, 128
+    C = H * d
+    qkv, qr = q(rnd((Bz, T, 2 * C), 7), dt)
+    P = torch.empty((Bz * H, T, T), dtype=dt, device="cuda")
+    ld = 2 * C
+    k.gemm(qkv[:, :, :C], qkv[:, :, C:], P, T, T, d, lda=ld, ldb=ld, ldd=T, a_kcontig=1, b_kcontig=1, alpha=0.125, batch=Bz * H,
+           batch_inner=H, sa=(T * ld, d), sb=(T * ld, d), sd=(H * T * T, T * T))
+    qh = qr[:, :, :C].reshape(Bz, T, H, d).permute(0, 2, 1, 3)
+    kh = qr[:, :, C:].reshape(Bz, T, H, d).permute(0, 2, 1, 3)
+    close(P.reshape(Bz, H, T, T), 0.125 * (qh @ kh.transpose(-1, -2)), dt, "batched q k^T")

@@ -3,7 +3,7 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from iseg_amd import kernels as K  # noqa: E402
 
 B, T, H, D = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (4, 1025, 12, 64)))
