@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 tools/micro/l2bw.hip -o tools/micro/l2bw   (the binary is git-ignored)
 // Read-bandwidth ceiling by footprint (L2 / Infinity Cache / HBM): every workgroup streams the same `bytes`-sized buffer with 16-B
 // loads, starting at a different offset.  Used to decide whether the GEMM's tile re-reads (L2 -> CU traffic) are what bound it.
 #include <hip/hip_runtime.h>
