@@ -45,6 +45,7 @@ typedef struct ihipStream_t* iseg_stream_t; /* == hipStream_t */
 #define ISEG_ACT_GELU 2      /* keras.activations.gelu, exact erf (backbones/convnext.py:53) */
 #define ISEG_ACT_GELU_GRAD 3 /* v *= gelu'(aux)  : backward of ISEG_ACT_GELU, aux = saved pre-activation */
 #define ISEG_ACT_RELU_GRAD 4 /* v  = aux > 0 ? v : 0 */
+#define ISEG_ACT_MUL_AUX 5   /* v *= aux : backward of ISEG_ACT_GELU when the forward saved gelu'(pre) (pre_deriv = 1) */
 
 int iseg_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf_h; returns its length */
@@ -58,7 +59,7 @@ size_t iseg_last_error(char* buf_h, size_t n);
  * autodiff transposes (dgrad: a_kcontig=1,b_kcontig=1 on the Keras kernel as stored; wgrad: a_kcontig=0,b_kcontig=0).
  *   a_kcontig=1: A(m,k) = A[m*lda + k]      a_kcontig=0: A(m,k) = A[k*lda + m]
  *   b_kcontig=1: B(k,n) = B[n*ldb + k]      b_kcontig=0: B(k,n) = B[k*ldb + n]   (Keras [in,out])
- * Epilogue, in this order:  v = alpha*acc ; v += bias[n] ; pre_out[m,n] = v ; act ; v *= colscale[n] ;
+ * Epilogue, in this order:  v = alpha*acc ; v += bias[n] ; pre_out[m,n] = v (or gelu'(v), pre_deriv) ; act ; v *= colscale[n] ;
  *   v *= rowscale[m / rows_per_group] ; v += residual[m,n] ; v += D[m,n] if accumulate ; D[m,n] = v.
  * residual / aux / pre_out have the OUTPUT dtype.  in_dtype bf16 -> MFMA path; f32 -> fp32 FMA (parity) path.
  * split_k: 0 = automatic (skinny outputs with a long reduction are split and reduced in slab order:
@@ -81,7 +82,7 @@ typedef struct iseg_gemm_args {
     int64_t rows_per_group;
     const void* residual; /* [M, ldr] or NULL */
     int64_t ldr;
-    const void* aux; /* [M, ldaux], needed by ISEG_ACT_*_GRAD */
+    const void* aux; /* [M, ldaux], needed by ISEG_ACT_*_GRAD and ISEG_ACT_MUL_AUX */
     int64_t ldaux;
     void* pre_out; /* [M, ldp] or NULL: pre-activation saved for backward */
     int64_t ldp;
@@ -102,6 +103,9 @@ typedef struct iseg_gemm_args {
        alpha / accumulate epilogue and are never split along K. */
     int batch, batch_inner;
     int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
+    int pre_deriv; /* 1 (needs act = ISEG_ACT_GELU and pre_out): pre_out receives gelu'(pre-activation) instead of the pre-activation --
+                      the forward epilogue has Phi(v) and exp(-v^2/2) in hand anyway, and the backward GEMM's epilogue becomes one
+                      multiply (ISEG_ACT_MUL_AUX) instead of re-evaluating erf per element (50 us of VALU per 100 M elements) */
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);

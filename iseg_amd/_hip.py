@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libiseg_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
 
 
 class HipLibraryMissing(RuntimeError):
@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("batch", C.c_int), ("batch_inner", C.c_int),
         ("sa_outer", C.c_int64), ("sa_inner", C.c_int64), ("sb_outer", C.c_int64), ("sb_inner", C.c_int64),
         ("sd_outer", C.c_int64), ("sd_inner", C.c_int64),
+        ("pre_deriv", C.c_int),
     ]
 
 

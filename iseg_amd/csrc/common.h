@@ -205,6 +205,14 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// gelu(x) and gelu'(x) from one Phi / exp evaluation (forward epilogue that saves the derivative for the backward pass)
+__device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
+    float e;
+    const float cdf = norm_cdf_fast(x, e);
+    y = x * cdf;
+    dy = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 // exact-erf GELU, as keras.activations.gelu(approximate=False)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -159,11 +159,15 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     ISEG_REQUIRE(g->out_dtype == ISEG_F32 || g->out_dtype == ISEG_BF16, "iseg_gemm: bad out_dtype %d", g->out_dtype);
     ISEG_REQUIRE(!(g->in_dtype == ISEG_F32 && g->out_dtype == ISEG_BF16), "iseg_gemm: f32 inputs need f32 output");
     ISEG_REQUIRE(!g->rowscale || g->rows_per_group > 0, "iseg_gemm: rowscale needs rows_per_group");
-    ISEG_REQUIRE((g->act != ISEG_ACT_GELU_GRAD && g->act != ISEG_ACT_RELU_GRAD) || g->aux, "iseg_gemm: act needs aux");
+    ISEG_REQUIRE((g->act != ISEG_ACT_GELU_GRAD && g->act != ISEG_ACT_RELU_GRAD && g->act != ISEG_ACT_MUL_AUX) || g->aux,
+                 "iseg_gemm: act needs aux");
+    ISEG_REQUIRE(g->act >= ISEG_ACT_NONE && g->act <= ISEG_ACT_MUL_AUX, "iseg_gemm: bad act %d", g->act);
+    ISEG_REQUIRE(!g->pre_deriv || (g->act == ISEG_ACT_GELU && g->pre_out), "iseg_gemm: pre_deriv needs act = GELU and pre_out");
     ISEG_REQUIRE(g->a_act == ISEG_ACT_NONE || g->a_act == ISEG_ACT_GELU, "iseg_gemm: a_act must be NONE or GELU");
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
-            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner};
+            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
+            g->pre_deriv};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);
@@ -247,7 +251,8 @@ extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_byt
     const int eff_split = (int)ceil_div64(g->K, kps);
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
-            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner};
+            g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
+            g->pre_deriv};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);

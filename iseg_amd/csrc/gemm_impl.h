@@ -35,6 +35,7 @@ struct Epi {
     // strided batch: problem z = blockIdx.z
     int batch_inner;
     int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
+    int pre_deriv;          // pre_out receives gelu'(pre) instead of pre (act == GELU)
     __device__ __forceinline__ int64_t off_a(int z) const { return (z / batch_inner) * sa_outer + (z % batch_inner) * sa_inner; }
     __device__ __forceinline__ int64_t off_b(int z) const { return (z / batch_inner) * sb_outer + (z % batch_inner) * sb_inner; }
     __device__ __forceinline__ int64_t off_d(int z) const { return (z / batch_inner) * sd_outer + (z % batch_inner) * sd_inner; }
@@ -44,11 +45,12 @@ template <class TO>
 __device__ __forceinline__ float epi_apply(const Epi& e, float acc, int64_t m, int64_t n, const TO* D, int64_t ldd) {
     float v = acc * e.alpha;
     if (e.bias) v += e.bias[n];
-    if (e.pre_out) reinterpret_cast<TO*>(e.pre_out)[m * e.ldp + n] = from_f32<TO>(v);
+    if (e.pre_out) reinterpret_cast<TO*>(e.pre_out)[m * e.ldp + n] = from_f32<TO>(e.pre_deriv ? gelu_erf_grad(v) : v);
     if (e.act == ISEG_ACT_RELU) v = fmaxf(v, 0.f);
     else if (e.act == ISEG_ACT_GELU) v = gelu_erf(v);
     else if (e.act == ISEG_ACT_GELU_GRAD) v *= gelu_erf_grad(to_f32(reinterpret_cast<const TO*>(e.aux)[m * e.ldaux + n]));
     else if (e.act == ISEG_ACT_RELU_GRAD) v = to_f32(reinterpret_cast<const TO*>(e.aux)[m * e.ldaux + n]) > 0.f ? v : 0.f;
+    else if (e.act == ISEG_ACT_MUL_AUX) v *= to_f32(reinterpret_cast<const TO*>(e.aux)[m * e.ldaux + n]);
     if (e.colscale) v *= e.colscale[n];
     if (e.rowscale) v *= e.rowscale[m / e.rows_per_group];
     if (e.residual) v += to_f32(reinterpret_cast<const TO*>(e.residual)[m * e.ldr + n]);
@@ -67,14 +69,32 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += b[i];
     }
-    if (e.pre_out) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
     constexpr bool FAST = sizeof(TO) == 2;  // bf16 storage: approximation error << output rounding; fp32 parity path: libm erf
+    if (e.pre_out && !e.pre_deriv) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
     if (e.act == ISEG_ACT_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     } else if (e.act == ISEG_ACT_GELU) {
+        if (e.pre_out && e.pre_deriv) {
+            float d[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) {
+                if (FAST) gelu_fast_both(v[i], v[i], d[i]);
+                else {
+                    d[i] = gelu_erf_grad(v[i]);
+                    v[i] = gelu_erf(v[i]);
+                }
+            }
+            store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+        }
+    } else if (e.act == ISEG_ACT_MUL_AUX) {
+        float a[8];
+        load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= a[i];
     } else if (e.act == ISEG_ACT_GELU_GRAD) {
         float a[8];
         load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
@@ -133,7 +153,8 @@ template <> struct Raw8<float> {
 template <class TO> struct EpiPrefetch {
     Raw8<TO> aux, res, old;
     __device__ __forceinline__ void load(const Epi& e, int64_t m, int64_t n, const TO* D, int64_t ldd) {
-        if (e.act == ISEG_ACT_GELU_GRAD || e.act == ISEG_ACT_RELU_GRAD) aux.load(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n);
+        if (e.act == ISEG_ACT_GELU_GRAD || e.act == ISEG_ACT_RELU_GRAD || e.act == ISEG_ACT_MUL_AUX)
+            aux.load(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n);
         if (e.residual) res.load(reinterpret_cast<const TO*>(e.residual) + m * e.ldr + n);
         if (e.accumulate) old.load(D + m * ldd + n);
     }
@@ -151,13 +172,29 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += b[i];
     }
-    if (e.pre_out) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
+    if (e.pre_out && !e.pre_deriv) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
     if (e.act == ISEG_ACT_RELU) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
     } else if (e.act == ISEG_ACT_GELU) {
+        if (e.pre_out && e.pre_deriv) {      // Phi(v) and exp(-v^2/2) serve both gelu(v) and gelu'(v)
+            float d[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) {
+                if (FAST) gelu_fast_both(v[i], v[i], d[i]);
+                else {
+                    d[i] = gelu_erf_grad(v[i]);
+                    v[i] = gelu_erf(v[i]);
+                }
+            }
+            store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+        }
+    } else if (e.act == ISEG_ACT_MUL_AUX) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= pf.aux.get(i);
     } else if (e.act == ISEG_ACT_GELU_GRAD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_fast_grad(pf.aux.get(i)) : gelu_erf_grad(pf.aux.get(i));

@@ -574,8 +574,10 @@ class _ConvNeXtBlockFn(Function):
         # measured on MI355X (tools/kbench_gemm.py): writing both h and g = gelu(h) from the pw1 epilogue (175+83+117 us at
         # stage 0 for pw1/pw2/wgrad2) beats writing h only and re-deriving gelu(h) while staging the A operand of pw2 and of
         # the pw2 weight gradient (83+147+185 us): the transform sits on the load->LDS critical path.  a_act stays available.
+        # h holds gelu'(pre-activation), not the pre-activation: the pw1 epilogue has Phi and exp(-v^2/2) in hand for gelu anyway, and
+        # the backward epilogue then costs one multiply instead of an erf per element (+50 us of VALU per 100 M elements, measured)
         h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
-        g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h)
+        g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
         out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
                           rows_per_group=H * W, residual=xc.reshape(M, C))
         ctx.p, ctx.dil, ctx.pad = p, dil, pad
@@ -605,7 +607,7 @@ class _ConvNeXtBlockFn(Function):
             K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
             w2eff = nn.w(p.w2)
         del g
-        dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_GELU_GRAD, aux=h)            # [M,4C] = (dbr @ W2g^T) * gelu'(h)
+        dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_MUL_AUX, aux=h)              # [M,4C] = (dbr @ W2g^T) * gelu'(pre), h = gelu'(pre)
         del h
         K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))      # db1 rides the wgrad GEMM (virtual ones-row) when C % 128 != 0
         dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                    # [M,C]

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _hip
-from ._hip import F32, BF16, ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, GemmArgs  # noqa: F401
+from ._hip import F32, BF16, ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX, GemmArgs  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -107,7 +107,7 @@ class KernelTimer:
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
          accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False, batch=1, batch_inner=1,
-         sa=(0, 0), sb=(0, 0), sd=(0, 0)):
+         sa=(0, 0), sb=(0, 0), sd=(0, 0), pre_deriv=False):
     """batch > 1: problem z uses X + (z // batch_inner) * sX[0] + (z % batch_inner) * sX[1] (element strides)"""
     _require_cuda(A, B, D)
     if A.dtype != B.dtype:
@@ -125,6 +125,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.act, g.alpha, g.accumulate, g.split_k, g.a_act = act, alpha, int(accumulate), split_k, a_act
     g.colsum_out, g.colsum_accumulate = ptr(colsum_out), int(colsum_accumulate)
     g.batch, g.batch_inner = int(batch), int(batch_inner)
+    g.pre_deriv = int(bool(pre_deriv))
     (g.sa_outer, g.sa_inner), (g.sb_outer, g.sb_inner), (g.sd_outer, g.sd_inner) = sa, sb, sd
     for t in (residual, aux, pre_out):
         if t is not None and t.dtype != D.dtype:
@@ -149,8 +150,9 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
 
 
 def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=None, pre_out=None, colscale=None,
-              rowscale=None, rows_per_group=0, residual=None, a_act=ACT_NONE):
-    """x2d [M,K] (row stride x2d.stride(0)) @ W [K,N] (Keras Dense / 1x1 conv kernel)."""
+              rowscale=None, rows_per_group=0, residual=None, a_act=ACT_NONE, pre_deriv=False):
+    """x2d [M,K] (row stride x2d.stride(0)) @ W [K,N] (Keras Dense / 1x1 conv kernel).  pre_deriv: pre_out receives gelu'(pre-activation)
+    (act must be GELU); the matching backward epilogue is ACT_MUL_AUX."""
     M, K = x2d.shape
     N = W.shape[1]
     if out is None:
@@ -158,7 +160,7 @@ def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=
     return gemm(x2d, W, out, M, N, K, lda=x2d.stride(0), ldb=W.stride(0), ldd=ldd or out.stride(0), a_kcontig=1, b_kcontig=0,
                 bias=bias, act=act, pre_out=pre_out, ldp=(pre_out.stride(0) if pre_out is not None else 0), colscale=colscale,
                 rowscale=rowscale, rows_per_group=rows_per_group, residual=residual,
-                ldr=(residual.stride(0) if residual is not None else 0), a_act=a_act)
+                ldr=(residual.stride(0) if residual is not None else 0), a_act=a_act, pre_deriv=pre_deriv)
 
 
 def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, rows_per_group=0, residual=None, accumulate=False):

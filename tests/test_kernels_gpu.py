@@ -91,6 +91,19 @@ def test_gemm_dgrad_and_gelu_grad(cuda, dtype, M, N, Kd):
     close(dx, hh.grad, dtype, "dgrad*gelu'")
     dx = k.dense_dgrad(dy, w, act=k.ACT_RELU_GRAD, aux=h)
     close(dx, (dyr @ wr.T) * (hr > 0), dtype, "dgrad*relu'")
+    # forward epilogue that saves gelu'(pre) (pre_deriv) + the one-multiply backward epilogue (ACT_MUL_AUX)
+    x, xr = q(rnd((M, N), 5), dtype)
+    w1, w1r = q(rnd((N, Kd), 6, N ** -0.5), dtype)
+    b1 = (rnd((Kd,), 7) * 0.2).float()
+    d = torch.empty((M, Kd), dtype=dtype, device="cuda")
+    y = k.dense_fwd(x, w1, b1.cuda(), act=k.ACT_GELU, pre_out=d, pre_deriv=True)
+    pre = (xr @ w1r + b1.double()).requires_grad_(True)
+    yo = O.gelu(pre)
+    yo.backward(torch.ones_like(yo))
+    close(y, yo, dtype, "gelu fwd with saved derivative")
+    close(d, pre.grad, dtype, "saved gelu'")
+    dx = k.dense_dgrad(dy, w, act=k.ACT_MUL_AUX, aux=d)
+    close(dx, (dyr @ wr.T) * d.detach().cpu().double(), dtype, "dgrad * saved gelu'")
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -178,7 +191,7 @@ def test_layernorm_fwd_bwd(cuda, dtype, rows, C):
 
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape,Kk,dil", [((2, 13, 17, 96), 7, 1), ((1, 16, 16, 768), 7, 2), ((2, 9, 9, 192), 7, 1), ((1, 20, 11, 64), 3, 1),
+@pytest.mark.parametrize("shape,Kk,dil", [((2, 13, 17, 96), 7, 1), ((1, 40, 70, 32), 7, 1), ((1, 16, 16, 768), 7, 2), ((2, 9, 9, 192), 7, 1), ((1, 20, 11, 64), 3, 1),
                                          ((1, 8, 8, 112), 3, 2), ((1, 33, 5, 384), 5, 1)])
 def test_dwconv_fwd_bwd(cuda, dtype, shape, Kk, dil):
     k = K()

@@ -39,6 +39,17 @@ for C, M in SHAPES:
          lambda: torch.matmul(h, w2, out=y2), M, C, 4 * C, 2),
         ("pw2 dgrad NT", lambda: K.gemm(x, w2, y1, M, 4 * C, C, lda=C, ldb=C, ldd=4 * C, a_kcontig=1, b_kcontig=1),
          lambda: torch.matmul(x, w2.t(), out=y1), M, 4 * C, C, 2),
+        ("pw2 dgrad+gelu' NT", lambda: K.gemm(x, w2, y1, M, 4 * C, C, lda=C, ldb=C, ldd=4 * C, a_kcontig=1, b_kcontig=1, act=K.ACT_GELU_GRAD,
+                                          aux=h, ldaux=4 * C),
+         lambda: torch.matmul(x, w2.t(), out=y1), M, 4 * C, C, 2),
+        ("pw2 dgrad+relu' NT", lambda: K.gemm(x, w2, y1, M, 4 * C, C, lda=C, ldb=C, ldd=4 * C, a_kcontig=1, b_kcontig=1, act=K.ACT_RELU_GRAD,
+                                          aux=h, ldaux=4 * C),
+         lambda: torch.matmul(x, w2.t(), out=y1), M, 4 * C, C, 2),
+        ("pw1 fwd+gelu NN", lambda: K.gemm(x, w1, y1, M, 4 * C, C, lda=C, ldb=4 * C, ldd=4 * C, a_kcontig=1, b_kcontig=0, act=K.ACT_GELU),
+         lambda: torch.matmul(x, w1, out=y1), M, 4 * C, C, 2),
+        ("pw1 fwd+gelu+pre NN", lambda: K.gemm(x, w1, y1, M, 4 * C, C, lda=C, ldb=4 * C, ldd=4 * C, a_kcontig=1, b_kcontig=0, act=K.ACT_GELU,
+                                              pre_out=h, ldp=4 * C),
+         lambda: torch.matmul(x, w1, out=y1), M, 4 * C, C, 2),
         ("pw1 dgrad NT", lambda: K.gemm(h, w1, y2, M, C, 4 * C, lda=4 * C, ldb=4 * C, ldd=C, a_kcontig=1, b_kcontig=1),
          lambda: torch.matmul(h, w1.t(), out=y2), M, C, 4 * C, 2),
         ("pw1 wgrad TN", lambda: K.gemm(x, h, gw, C, 4 * C, M, lda=C, ldb=4 * C, ldd=4 * C, a_kcontig=0, b_kcontig=0),
