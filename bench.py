@@ -78,8 +78,11 @@ def _gemm_group_model(key):
 def _kernel_label(key):
     _, akc, bkc, M, N, K = key[:6]
     split = key[12]
+    variant = key[13] if len(key) > 13 else 0
     orient = {(1, 0): "forward x[M,K] @ kernel[K,N]", (1, 1): "dgrad dy[M,K] @ kernel[N,K]^T", (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
-    return f"iseg_mm::gemm_bf16_kernel ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''})"
+    name = "iseg_mm::gemm_bf16_kernel" if not variant else \
+        "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages"}[variant]
+    return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''})"
 
 
 def pick_dominant(report):

@@ -109,6 +109,9 @@ typedef struct iseg_gemm_args {
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
+/* which main loop iseg_gemm runs for this problem (profiling labels): 0 = register-staged gemm_bf16_kernel / fp32 kernel,
+   1..4 = LDS-DMA pipeline gemm_bf16_dma_kernel with tile 128x64 / 256x128 / 128x128 (2 stages) / 128x128 (3 stages) */
+int iseg_gemm_variant(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
 int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
 int iseg_gemm_reduce(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);

@@ -146,6 +146,14 @@ extern "C" int iseg_gemm_splits(const iseg_gemm_args* g) {
     return choose_split(g, g->in_dtype == ISEG_BF16 ? 128 : 64);
 }
 
+extern "C" int iseg_gemm_variant(const iseg_gemm_args* g) {
+    if (!g || g->in_dtype != ISEG_BF16) return 0;
+    const int nsplit = iseg_gemm_splits(g);
+    const int64_t kps = nsplit > 1 ? ceil_div64(ceil_div64(g->K, nsplit), 128) * 128 : g->K;
+    if (!iseg_mm::dma_mode() || !iseg_mm::dma_eligible(g, kps)) return 0;
+    return iseg_mm::dma_variant(g, (int)ceil_div64(g->K, kps));
+}
+
 extern "C" size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* g) {
     const int s = iseg_gemm_splits(g);
     return s > 1 ? (size_t)s * (size_t)(g->M + (g->colsum_out ? 1 : 0)) * (size_t)g->N * sizeof(float) : 0;

@@ -219,16 +219,26 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
 
 int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default)
 
+// 1: 128 x 64 (4-deep ring)   2: 256 x 128 (8 wavefronts, 3-deep ring)   3: 128 x 128, two workgroups per CU (2 stages)
+// 4: 128 x 128, one workgroup per CU with the 3-deep ring.  Measured on MI355X (tools/kbench_gemm_ref.py): 256 x 128 once it fills
+// most CUs -- it reads each B panel half as often; otherwise 128 x 128, two per CU when there are enough tiles, the deeper ring when
+// the grid is thin.
+inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
+    const int64_t tiles256 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), tiles128 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128);
+    if (g->N <= 64) return 1;
+    if (tiles256 * nsplit >= 192) return 2;
+    if (tiles128 * nsplit >= 384) return 3;
+    return 4;
+}
+
 template <class TO>
 void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
-    // tile choice (measured on MI355X, tools/kbench_gemm_ref.py): 256 x 128 with a 3-deep ring (one workgroup of 8 wavefronts per
-    // CU) once it fills most CUs -- it reads each B panel half as often; otherwise 128 x 128, two workgroups per CU with two stages
-    // when there are enough tiles, one workgroup with the deeper ring when the grid is thin
-    const int64_t tiles256 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), tiles128 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128);
-    if (g->N <= 64) launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s);                                // 128 x 64
-    else if (tiles256 * nsplit >= 192) launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s);             // 256 x 128
-    else if (tiles128 * nsplit >= 384) launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s);             // 128 x 128, 2 per CU
-    else launch_dma<2, 2, 3, TO>(g, epi, nsplit, kps, slabs, s);                                           // 128 x 128, deeper ring
+    switch (dma_variant(g, nsplit)) {
+        case 1: launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s); break;
+        case 2: launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
+        case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
+        default: launch_dma<2, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
+    }
 }
 
 }  // namespace iseg_mm

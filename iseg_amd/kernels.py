@@ -140,7 +140,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     timer = KERNEL_TIMER[0]
     if timer is not None:
         timer.begin(("gemm", int(a_kcontig), int(b_kcontig), int(M), int(N), int(K), int(act), pre_out is not None, residual is not None,
-                     aux is not None, A.dtype, D.dtype, need > 0) + ((int(batch),) if batch > 1 else ()))
+                     aux is not None, A.dtype, D.dtype, need > 0, int(L.iseg_gemm_variant(C.byref(g)))) + ((int(batch),) if batch > 1 else ()))
     _hip.check(L.iseg_gemm(C.byref(g), ptr(ws), wsb, stream()), "iseg_gemm")
     if timer is not None:
         timer.end()
