@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int TW = 4;
+constexpr int BWSEG = 32;  // widest W segment the register-batched weight-gradient path holds
 
 template <class T, int CV> __device__ __forceinline__ void loadv(const T* p, float* out);
 template <> __device__ __forceinline__ void loadv<float, 8>(const float* p, float* out) { load8<float>(p, out); }
@@ -349,7 +350,49 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
             const bool row_ok = (unsigned)ih < (unsigned)H;
             const T* dyr = dy + (((int64_t)n * H + h) * W) * C + c0;
             const T* xr = x + (((int64_t)n * H + (row_ok ? ih : 0)) * W) * C + c0;
-            if (DIL1) {
+            if (DIL1 && sizeof(T) == 2 && CV == 4 && wseg <= BWSEG) {
+                // Small planes (W <= 32, stages 3-4 of ConvNeXt): the whole row segment is requested up front as packed 8-byte
+                // pixels (<= 38 + 32 loads in flight per lane) and the window slides over registers.  With one x and one dy load per
+                // pixel inside the sliding loop every step waited a full L2 round trip: 81 us per launch at 16x32x32x384.
+                uint2 xraw[BWSEG + K - 1], draw[BWSEG];
+                const int cnt = we - ws;
+#pragma unroll
+                for (int t = 0; t < BWSEG + K - 1; ++t) {
+                    const int iw = ws - pad_l + t;
+                    const bool ok = row_ok && t < cnt + K - 1 && (unsigned)iw < (unsigned)W;
+                    const uint2 v = *reinterpret_cast<const uint2*>(xr + (int64_t)min(max(iw, 0), W - 1) * C);
+                    xraw[t] = ok ? v : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int t = 0; t < BWSEG; ++t) {
+                    const bool ok = t < cnt;
+                    const uint2 v = *reinterpret_cast<const uint2*>(dyr + (int64_t)(ok ? ws + t : ws) * C);
+                    draw[t] = ok ? v : make_uint2(0u, 0u);
+                }
+                auto unpack = [](const uint2& r, float* o) {
+                    o[0] = __uint_as_float(r.x << 16);
+                    o[1] = __uint_as_float(r.x & 0xffff0000u);
+                    o[2] = __uint_as_float(r.y << 16);
+                    o[3] = __uint_as_float(r.y & 0xffff0000u);
+                };
+                float win[K][CV];
+#pragma unroll
+                for (int j = 0; j < K - 1; ++j) unpack(xraw[j], win[j]);
+#pragma unroll
+                for (int t = 0; t < BWSEG; ++t) {
+                    unpack(xraw[t + K - 1], win[(t + K - 1) % K]);
+                    float d[CV];
+                    unpack(draw[t], d);
+                    if (kh == 0) {
+#pragma unroll
+                        for (int u = 0; u < CV; ++u) accb[u] += d[u];
+                    }
+#pragma unroll
+                    for (int j = 0; j < K; ++j)
+#pragma unroll
+                        for (int u = 0; u < CV; ++u) acc[j][u] = fmaf(win[(t + j) % K][u], d[u], acc[j][u]);
+                }
+            } else if (DIL1) {
                 float win[K][CV];
 #pragma unroll
                 for (int j = 0; j < K - 1; ++j) load_px<T, CV, true>(xr, ws - pad_l + j, W, C, row_ok, win[j]);
@@ -592,9 +635,11 @@ static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     g.wseg = W <= 32 ? W : 32;
     const int nseg = (W + g.wseg - 1) / g.wseg;
     const int64_t items = (int64_t)N * H * nseg;
-    // aim at ~1024 blocks in total: enough waves to hide L2 latency, small enough partial buffers
-    int64_t target = 1024 / g.slabs;
-    if (target < 64) target = 64;
+    // aim at ~1024 blocks in total: enough waves to hide L2 latency, small enough partial buffers.  The register-batched bf16 path
+    // (W <= 32) keeps ~70 loads in flight per lane by itself and runs 2 waves per SIMD: ~512 blocks = one resident round
+    const bool batched = elem == 2 && g.cv == 4 && dil == 1 && g.wseg <= BWSEG;
+    int64_t target = (batched ? env_int("ISEG_DW_BW_BLOCKS", 512) : 1024) / g.slabs;
+    if (target < (batched ? 8 : 64)) target = batched ? 8 : 64;
     int64_t ipl = ceil_div64(items, (int64_t)g.rt * target);
     if (ipl < 1) ipl = 1;
     g.ipl = (int)ipl;
