@@ -673,12 +673,21 @@ int launch_fwd(const void* x, const float* w, const float* bias, const void* add
 }
 
 static int use_lds() { static int v = env_int("ISEG_DW_LDS", 1); return v != 0; }
-static int fwd_lds_groups() { static int v = env_int("ISEG_DW_LDS_GROUPS", 6); return v < 1 ? 1 : (v > 16 ? 16 : v); }
+// channel groups (of 8) per workgroup slab; 0 = automatic.  Measured at the four ConvNeXt-T stages (16 images, us per launch):
+//   groups      2      3      4      6      8
+//   128x128x96  79.8   89.8   69.8   79.8   79.9
+//   64x64x192   36.1   53.6   39.4   49.8   49.2
+//   32x32x384   19.0   29.8   20.5   30.8   28.9
+//   16x16x768   14.3   14.4   14.9   15.9   15.8
+// Power-of-two slabs give square-ish pixel tiles (32x16 / 16x16: halo amplification 1.6 / 1.9 instead of 2.2 at 10x16) and keep
+// all 256 lanes busy; the widest planes prefer 64-byte pixel pieces (4 groups) for their L2 -> L1 line use.
+static int fwd_lds_groups() { static int v = env_int("ISEG_DW_LDS_GROUPS", 0); return v < 0 ? 0 : (v > 16 ? 16 : v); }
 
 template <class T, int K>
 bool launch_fwd_lds(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int dil,
                     int pad_t, int pad_l, int flip, hipStream_t s) {
-    const int gs = groups_per_slab(C, 8, fwd_lds_groups());
+    const int want = fwd_lds_groups() ? fwd_lds_groups() : ((int64_t)H * W >= 128 * 128 ? 4 : 2);
+    const int gs = groups_per_slab(C, 8, want);
     const int TH = (256 / gs) / (TWB / TW);
     if (TH < 1) return false;
     const int halo = (K - 1) * dil;
