@@ -597,7 +597,8 @@ static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w()) {
         // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes.  Small planes (W <= 32: one tile spans the row) take
         // the widest slab whose lane rows still cover the whole image height, so one tile = one image plane.
-        int gs = groups_per_slab(C, 8, 6);
+        static const int max_groups = env_int("ISEG_DW_BW_LDS_GROUPS", 3);   // measured 1..6 at 128x128x96 / 64x64x192: 163/107, 155/101, 137/88, 141/99, 144/92 us
+        int gs = groups_per_slab(C, 8, max_groups);
         if (W <= BWW) {
             gs = 1;
             for (int cand = 6; cand >= 1; --cand)
