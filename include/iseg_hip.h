@@ -359,6 +359,17 @@ int iseg_window_attention_bwd(const void* qkv, const float* table, const void* d
 int iseg_attention_fwd_supported(int head_dim, int dtype);
 int iseg_attention_fwd(const void* qkv, void* out, int64_t batch, int T, int heads, int head_dim, float scale, int dtype,
                        iseg_stream_t stream);
+/* Training pair of the same kernel family (same support set).  The forward additionally returns, per (sample, head, token) and
+ * padded to a multiple of 64 tokens (iseg_attention_lse_elems floats), log2 of the softmax denominator in the kernel's exp2 domain;
+ * the backward recomputes the probabilities from qkv and that vector, tile by tile (dQ kernel over key tiles, dK/dV kernel over
+ * query tiles: no atomics, fixed summation order).  dqkv has the layout of qkv and is overwritten; workspace = one float per
+ * lse element. */
+size_t iseg_attention_lse_elems(int64_t batch, int T, int heads);
+int iseg_attention_fwd_train(const void* qkv, void* out, float* lse2, int64_t batch, int T, int heads, int head_dim, float scale,
+                             int dtype, iseg_stream_t stream);
+size_t iseg_attention_bwd_workspace_bytes(int64_t batch, int T, int heads);
+int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, void* dqkv, int64_t batch, int T,
+                       int heads, int head_dim, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -112,6 +112,10 @@ SIGNATURES = {
     "iseg_window_attention_supported": (_i, [_i, _i, _i]),
     "iseg_attention_fwd_supported": (_i, [_i, _i]),
     "iseg_attention_fwd": (_i, [_p, _p, _l, _i, _i, _i, _f, _i, _p]),
+    "iseg_attention_lse_elems": (_z, [_l, _i, _i]),
+    "iseg_attention_fwd_train": (_i, [_p, _p, _p, _l, _i, _i, _i, _f, _i, _p]),
+    "iseg_attention_bwd_workspace_bytes": (_z, [_l, _i, _i]),
+    "iseg_attention_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _f, _i, _p, _z, _p]),
     "iseg_window_attention_table": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "iseg_window_attention_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _f, _i, _p]),
     "iseg_window_attention_bwd_workspace_bytes": (_z, [_l, _i, _i]),

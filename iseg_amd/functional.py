@@ -870,6 +870,25 @@ def _attn_chunks(B, heads):
     return [(b0, min(B, b0 + per)) for b0 in range(0, B, per)]
 
 
+class _FlashAttentionFn(Function):
+    """global self-attention without bias / mask / clip / dropout, head_dim 64, bf16 (ViT, MHSA): online-softmax forward that keeps
+    one log-sum-exp float per row, backward kernels that recompute the probabilities (csrc/flashattn.hip); no T x T tensor"""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        qkv = _c(qkv)
+        out, lse = K.attention_fwd_train(qkv, heads, scale)
+        ctx.cfg = (heads, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dO):
+        qkv, out, lse = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        return K.attention_bwd(qkv, out, _c(dO), lse, heads, scale), None, None
+
+
 class _AttentionFn(Function):
     @staticmethod
     def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed, bias_window=0):
@@ -982,10 +1001,11 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
         raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
     rate = float(dropout_rate) if training else 0.0
     if (bias_table is None and mask is None and clip is None and rate <= 0 and Cq == Cv and
-            not (torch.is_grad_enabled() and qkv.requires_grad) and K.attention_fwd_supported(Cq // heads, qkv.dtype) and
-            os.environ.get("ISEG_FLASHATTN", "1") != "0"):
-        # inference: online-softmax kernel, no T x T tensor (the training route keeps the probabilities for its backward)
-        return K.attention_fwd(_c(qkv), int(heads), float(scale))
+            K.attention_fwd_supported(Cq // heads, qkv.dtype) and os.environ.get("ISEG_FLASHATTN", "1") != "0"):
+        # online-softmax kernels, no T x T tensor: forward only for inference, the recomputing forward / backward pair for training
+        if not (torch.is_grad_enabled() and qkv.requires_grad):
+            return K.attention_fwd(_c(qkv), int(heads), float(scale))
+        return _FlashAttentionFn.apply(qkv, int(heads), float(scale))
     return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip,
                               rate, next_seed() if rate > 0 else 0, int(bias_window))
 

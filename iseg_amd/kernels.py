@@ -694,6 +694,29 @@ def attention_fwd(qkv, heads, scale):
     return out
 
 
+def attention_fwd_train(qkv, heads, scale):
+    """attention_fwd that also returns the per-row log2-sum-exp vector the backward kernels recompute the probabilities from"""
+    B, T, ld = qkv.shape
+    C = ld // 3
+    L = _hip.lib()
+    out = torch.empty((B, T, C), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(int(L.iseg_attention_lse_elems(B, T, heads)), dtype=torch.float32, device=qkv.device)
+    _hip.check(L.iseg_attention_fwd_train(ptr(qkv), ptr(out), ptr(lse), B, T, heads, C // heads, float(scale), dt(qkv), stream()),
+               "iseg_attention_fwd_train")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, heads, scale):
+    B, T, ld = qkv.shape
+    C = ld // 3
+    L = _hip.lib()
+    dqkv = torch.empty_like(qkv)
+    ws, wsb = workspace(L.iseg_attention_bwd_workspace_bytes(B, T, heads), qkv.device)
+    _hip.check(L.iseg_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, T, heads, C // heads, float(scale), dt(qkv),
+                                    ptr(ws), wsb, stream()), "iseg_attention_bwd")
+    return dqkv
+
+
 def window_attention_supported(T, head_dim, dtype):
     return dtype == torch.bfloat16 and bool(_hip.lib().iseg_window_attention_supported(int(T), int(head_dim), BF16))
 

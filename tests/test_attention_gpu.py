@@ -327,11 +327,27 @@ def test_inference_flash_attention_matches_materialised_route_and_oracle(cuda, h
         for mode in ("1", "0"):
             assert (out[mode] - yr).norm() / yr.norm() < 1.5e-2, mode
         assert (out["1"] - out["0"]).abs().max() < 4e-2 * out["0"].abs().max()
-        # a training call (grad required) keeps the materialised route and its backward
-        qkv.requires_grad_(True)
-        os.environ["ISEG_FLASHATTN"] = "1"
-        y = F.attention_packed(qkv, heads, C, C, d ** -0.5)
-        assert y.grad_fn is not None
+        # training: the recomputing forward / backward pair against fp64 and against the materialised route
+        dy, dyr = q(rnd((B, T, C), 12), torch.bfloat16)
+        grads = {}
+        for mode in ("1", "0"):
+            os.environ["ISEG_FLASHATTN"] = mode
+            qg = qkv.detach().clone().requires_grad_(True)
+            y = F.attention_packed(qg, heads, C, C, d ** -0.5)
+            assert y.grad_fn is not None
+            y.backward(dy)
+            grads[mode] = (y.detach().cpu().double(), qg.grad.cpu().double())
+        qr = qkvr.clone().requires_grad_(True)
+        yr2 = _ref_attention(qr, heads, C, d ** -0.5)
+        yr2.backward(dyr)
+        for mode in ("1", "0"):
+            assert (grads[mode][0] - yr).norm() / yr.norm() < 1.5e-2, mode
+            assert torch.isfinite(grads[mode][1]).all(), mode
+            assert (grads[mode][1] - qr.grad).norm() / qr.grad.norm() < 3e-2, mode
+        for k3, name in enumerate(("dq", "dk", "dv")):      # per slice, so a wrong small slice cannot hide behind a large one
+            a = grads["1"][1][..., k3 * C:(k3 + 1) * C]
+            r = qr.grad[..., k3 * C:(k3 + 1) * C]
+            assert (a - r).norm() <= 3e-2 * max(r.norm(), 1e-3 * qr.grad.norm()), name      # T = 1: dq and dk are exactly zero
     finally:
         os.environ.pop("ISEG_FLASHATTN", None)
         nn.set_compute_dtype(torch.float32)
