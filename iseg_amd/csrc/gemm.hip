@@ -131,7 +131,10 @@ int choose_split(const iseg_gemm_args* g, int tile) {
     if (tiles >= 256 || g->K < 2048 || g->batch > 1) return 1;
     // the LDS-DMA pipeline keeps several K-tiles in flight per workgroup: half-filled grids are better left unsplit
     if (g->in_dtype == ISEG_BF16 && tiles >= 96 && iseg_mm::dma_mode() && iseg_mm::dma_eligible(g, 128)) return 1;
-    int64_t want = ceil_div64(512, tiles);
+    // two 128x128 workgroups fit a CU: the grid must stay within ONE resident round of 512 (measured: 42 splits of a 12-tile
+    // weight gradient = 504 workgroups 61.5 us, 43 splits = 516 workgroups 74.7 us)
+    int64_t want = 512 / tiles;
+    if (want < 1) want = 1;
     const int64_t maxs = g->K / 512 > 0 ? g->K / 512 : 1;
     if (want > maxs) want = maxs;
     if (want > 512) want = 512;
