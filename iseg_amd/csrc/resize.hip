@@ -181,11 +181,22 @@ __global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restr
         const TI* src = dy + (int64_t)row * rowlen;
         __syncthreads();
         if (rowlen % V == 0 && ((int64_t)row * rowlen) % V == 0) {
-            for (int i = threadIdx.x; i < rowlen / V; i += 256) {
-                float v[V];
-                Vec16<TI>::load(src + i * V, v);
+            constexpr int NB = 4;      // loads issued together per lane (one per trip left ~11 dependent round trips per row)
+            for (int base = threadIdx.x; base < rowlen / V; base += 256 * NB) {
+                float v[NB][V];
 #pragma unroll
-                for (int u = 0; u < V; ++u) srow[i * V + u] = v[u];
+                for (int q = 0; q < NB; ++q) {
+                    const int i = base + q * 256;
+                    if (i < rowlen / V) Vec16<TI>::load(src + i * V, v[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    const int i = base + q * 256;
+                    if (i < rowlen / V) {
+#pragma unroll
+                        for (int u = 0; u < V; ++u) srow[i * V + u] = v[q][u];
+                    }
+                }
             }
         } else {
             for (int i = threadIdx.x; i < rowlen; i += 256) srow[i] = to_f32(src[i]);
@@ -200,7 +211,25 @@ __global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restr
                 const int ix = o / C, c = o - ix * C;
                 int d0, d1;
                 bwd_range(ix, Wi, Wo, inv, d0, d1);
-                for (int d = d0 + part; d <= d1; d += 4) {
+                // four destinations per trip, their LDS reads issued together (the loop is bound by LDS latency, not by bandwidth)
+                int d = d0 + part;
+                for (; d + 12 <= d1; d += 16) {
+                    float t[4], v[4];
+                    int lo[4], hi[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        t[q] = xt[d + 4 * q];
+                        v[q] = srow[(d + 4 * q) * C + c];
+                        lo[q] = xlo[d + 4 * q];
+                        hi[q] = xhi[d + 4 * q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (lo[q] == ix) acc = fmaf(1.f - t[q], v[q], acc);
+                        if (hi[q] == ix) acc = fmaf(t[q], v[q], acc);
+                    }
+                }
+                for (; d <= d1; d += 4) {
                     const float t = xt[d], v = srow[d * C + c];
                     if (xlo[d] == ix) acc = fmaf(1.f - t, v, acc);
                     if (xhi[d] == ix) acc = fmaf(t, v, acc);
