@@ -368,10 +368,9 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[FM][FN], char* smem, 
             const int i = ps * FPP + fi;
             if (i < FM) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ew[(fi * 16 + (lane >> 4) * 4 + r) * EPI_STRIDE + j * 16 + (lane & 15)] = acc[i][j][r];
+                for (int j = 0; j < FN; ++j)      // transposed accumulators: row = lane & 15, four consecutive columns per lane
+                    *reinterpret_cast<float4*>(ew + (fi * 16 + (lane & 15)) * EPI_STRIDE + j * 16 + (lane >> 4) * 4) =
+                        make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             }
         }
         __builtin_amdgcn_wave_barrier();  // the slab is wave-private and LDS ops of a wave complete in order
@@ -495,7 +494,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    // B fragment first: the accumulator holds the transposed product, i.e. lane (g, c) owns output row 16*i + c and
+                    // columns 16*j + 4*g .. + 3 -- the epilogue slab is then filled with 16-byte rows instead of scattered dwords
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
         __syncthreads();  // every wave is done reading the tile (also fences the epilogue's reuse of the LDS)
         if (more) {
