@@ -594,7 +594,9 @@ static int bw_lds_min_w() { static int v = env_int("ISEG_DW_BW_LDS_MINW", 48); r
 static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     BwGeom g;
     g.lds = 0;
-    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w()) {
+    // bf16 takes the register-batched kernel below at every plane size (measured at 64x64x192: 69 us vs 88 us for the LDS tiles, equal
+    // at 128x128x96); the LDS-tiled variant serves fp32 storage
+    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w() && elem != 2) {
         // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes.  Small planes (W <= 32: one tile spans the row) take
         // the widest slab whose lane rows still cover the whole image height, so one tile = one image plane.
         static const int max_groups = env_int("ISEG_DW_BW_LDS_GROUPS", 3);   // measured 1..6 at 128x128x96 / 64x64x192: 163/107, 155/101, 137/88, 141/99, 144/92 us
