@@ -119,8 +119,6 @@ class SegFoundation(SegBase):
         self.model_class_weights = class_weights
         if use_ohem:
             raise NotImplementedError("OHEM is marked 'WIP DO NOT USE' in the reference (losses/ohem.py:6) and is out of scope")
-        if use_focal_loss:
-            raise NotImplementedError("focal variant of the CE loss is outside this round's hot path")
 
     def inputs_process(self, image, label):
         is_label_collection = isinstance(label, (list, tuple, dict))
@@ -165,8 +163,10 @@ class SegFoundation(SegBase):
         common_kwargs = {"num_class": num_class, "ignore_label": ignore_label, "batch_size": batch_size, "reduction": reduction,
                          "class_weights": class_weights}
 
-        def default_ce_loss(post_func):
-            return catecrossentropy_ignore_label_loss(post_compute_fn=post_func, **common_kwargs, **kwargs)
+        def default_ce_loss(post_func):      # core_model.py:498-505 of the reference
+            return catecrossentropy_ignore_label_loss(post_compute_fn=post_func, use_focal_loss=self.use_focal_loss,
+                                                      focal_loss_gamma=self.focal_loss_gamma, focal_loss_alpha=self.focal_loss_alpha,
+                                                      **common_kwargs, **kwargs)
 
         if self.custom_main_loss_fn is not None:
             loss_dict = {self._index_to_output_key(0): self.custom_main_loss_fn(**common_kwargs, **kwargs)}

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
                                                          const float* __restrict__ class_w, int64_t P, int C, int ignore,
                                                          float* __restrict__ loss_px, float* __restrict__ block_sums,
                                                          float* __restrict__ dlogits, float grad_scale,
-                                                         const float* __restrict__ grad_px, int pix) {
+                                                         const float* __restrict__ grad_px, int pix, int focal, float f_alpha,
+                                                         float f_gamma) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [pix][C]
     __shared__ float wsum[4];
     const int64_t p0 = (int64_t)blockIdx.x * pix;
@@ -62,13 +63,34 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict
             se += e;
         }
         const float lse = mx + __logf(se);
-        // -sum_c onehot_c * log_softmax_c : zero row when y is out of range
-        my_loss = in_range ? w * (lse - zy) : 0.f;
-        if (loss_px) loss_px[p0 + threadIdx.x] = my_loss;
-        if (dlogits) {
-            const float g = w * grad_scale * (grad_px ? grad_px[p0 + threadIdx.x] : 1.f);
-            const float inv = in_range ? g / se : 0.f;
-            for (int c = 0; c < C; ++c) z[c] = z[c] * inv - ((c == y) ? g : 0.f);
+        if (!focal) {
+            // -sum_c onehot_c * log_softmax_c : zero row when y is out of range
+            my_loss = in_range ? w * (lse - zy) : 0.f;
+            if (loss_px) loss_px[p0 + threadIdx.x] = my_loss;
+            if (dlogits) {
+                const float g = w * grad_scale * (grad_px ? grad_px[p0 + threadIdx.x] : 1.f);
+                const float inv = in_range ? g / se : 0.f;
+                for (int c = 0; c < C; ++c) z[c] = z[c] * inv - ((c == y) ? g : 0.f);
+            }
+        } else {
+            // keras CategoricalFocalCrossentropy(from_logits): p = clip(softmax_y, 1e-7, 1 - 1e-7),
+            // loss = alpha * (1 - p)^gamma * (-log p); the clip passes no gradient outside its range
+            const float py = in_range ? z[y] / se : 1.f;
+            const float pc = fminf(fmaxf(py, 1e-7f), 1.f - 1e-7f);
+            const float om = 1.f - pc;
+            const float mod = __powf(om, f_gamma);
+            const float lg = __logf(pc);
+            my_loss = in_range ? w * f_alpha * mod * (-lg) : 0.f;
+            if (loss_px) loss_px[p0 + threadIdx.x] = my_loss;
+            if (dlogits) {
+                const float g = w * grad_scale * (grad_px ? grad_px[p0 + threadIdx.x] : 1.f);
+                const bool live = in_range && py > 1e-7f && py < 1.f - 1e-7f;
+                // dL/dp = alpha * (gamma (1-p)^(gamma-1) log p - (1-p)^gamma / p);   dp/dz_c = p (delta_cy - p_c)
+                const float dldp = live ? f_alpha * (f_gamma * (mod / om) * lg - mod / pc) : 0.f;
+                const float k = g * dldp * py;
+                const float inv = 1.f / se;
+                for (int c = 0; c < C; ++c) z[c] = k * (((c == y) ? 1.f : 0.f) - z[c] * inv);
+            }
         }
     }
     if (block_sums) {
@@ -156,30 +178,47 @@ extern "C" size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C) {
     return (size_t)ceil_div64(P, pixels_per_block(C)) * sizeof(float);
 }
 
-extern "C" int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
+static int launch_softmax_ce(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
                                       int ignore_label, float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits,
                                       float grad_scale, const float* grad_px, void* ws, size_t ws_bytes,
-                                      hipStream_t stream) {
-    ISEG_REQUIRE(logits && labels && P > 0 && C > 0, "iseg_softmax_ce_ignore: bad arguments");
-    ISEG_REQUIRE(C <= 640, "iseg_softmax_ce_ignore: num_class %d > 640 unsupported", C);
+                                      hipStream_t stream, int focal, float f_alpha, float f_gamma, const char* who) {
+    ISEG_REQUIRE(logits && labels && P > 0 && C > 0, "%s: bad arguments", who);
+    ISEG_REQUIRE(C <= 640, "%s: num_class %d > 640 unsupported", who, C);
     const int pix = pixels_per_block(C);
     const int64_t blocks = ceil_div64(P, pix);
     float* bs = nullptr;
     if (loss_sum) {
         const size_t need = (size_t)blocks * sizeof(float);
         if (!ws || ws_bytes < need) {
-            iseg_set_error("iseg_softmax_ce_ignore: needs %zu workspace bytes, got %zu", need, ws_bytes);
+            iseg_set_error("%s: needs %zu workspace bytes, got %zu", who, need, ws_bytes);
             return ISEG_ERR_WORKSPACE;
         }
         bs = (float*)ws;
     }
     const size_t lds = (size_t)pix * C * sizeof(float);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, class_w, P, C,
-                       ignore_label, loss_px, bs, dlogits, grad_scale, grad_px, pix);
+                       ignore_label, loss_px, bs, dlogits, grad_scale, grad_px, pix, focal, f_alpha, f_gamma);
     if (loss_sum)
         hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, (const float*)bs, (int)blocks, loss_sum,
                            loss_sum_scale);
-    return iseg_check_launch("iseg_softmax_ce_ignore");
+    return iseg_check_launch(who);
+}
+
+extern "C" int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
+                                      int ignore_label, float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits,
+                                      float grad_scale, const float* grad_px, void* ws, size_t ws_bytes,
+                                      hipStream_t stream) {
+    return launch_softmax_ce(logits, labels, class_w, P, C, ignore_label, loss_px, loss_sum, loss_sum_scale, dlogits, grad_scale, grad_px,
+                             ws, ws_bytes, stream, 0, 0.f, 0.f, "iseg_softmax_ce_ignore");
+}
+
+extern "C" int iseg_softmax_focal_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C,
+                                            int ignore_label, float alpha, float gamma, float* loss_px, float* loss_sum,
+                                            float loss_sum_scale, float* dlogits, float grad_scale, const float* grad_px, void* ws,
+                                            size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(gamma >= 0.f, "iseg_softmax_focal_ce_ignore: gamma must be >= 0");
+    return launch_softmax_ce(logits, labels, class_w, P, C, ignore_label, loss_px, loss_sum, loss_sum_scale, dlogits, grad_scale, grad_px,
+                             ws, ws_bytes, stream, 1, alpha, gamma, "iseg_softmax_focal_ce_ignore");
 }
 
 extern "C" int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P, int C, int ignore_label,

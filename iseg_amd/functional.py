@@ -639,38 +639,38 @@ class _SoftmaxCEPerPixelFn(Function):
     """returns the per-position loss vector [N*H*W] exactly like the reference's weighted_loss (Reduction.NONE)"""
 
     @staticmethod
-    def forward(ctx, logits, labels, num_class, ignore_label, class_w):
+    def forward(ctx, logits, labels, num_class, ignore_label, class_w, focal=None):
         z = _c(logits).reshape(-1, num_class)
         if z.dtype != torch.float32:
             z = K.cast(z, torch.float32)
         y = _c(labels).reshape(-1)
         if y.dtype != torch.int32:
             y = y.to(torch.int32)
-        px, _, _ = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=True)
-        ctx.args = (num_class, ignore_label, class_w)
-        ctx.in_dtype = logits.dtype
+        px, _, _ = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=True, focal=focal)
+        ctx.args = (num_class, ignore_label, class_w, focal)
+        ctx.in_dtype, ctx.in_shape = logits.dtype, logits.shape
         ctx.save_for_backward(z, y)
         return px
 
     @staticmethod
     def backward(ctx, dpx):
         z, y = ctx.saved_tensors
-        num_class, ignore_label, class_w = ctx.args
+        num_class, ignore_label, class_w, focal = ctx.args
         gp = _c(dpx)
         if gp.dtype != torch.float32:
             gp = K.cast(gp, torch.float32)
         _, _, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_grad=True, grad_scale=1.0,
-                                       grad_px=gp)
+                                       grad_px=gp, focal=focal)
         if dz.dtype != ctx.in_dtype:
             dz = K.cast(dz, ctx.in_dtype)
-        return dz.reshape(-1, num_class), None, None, None, None
+        return dz.reshape(ctx.in_shape), None, None, None, None, None
 
 
 class _SoftmaxCEMeanFn(Function):
     """mean over ALL positions (Keras' reduction of the NONE loss): loss and d(loss)/d(logits) in one fused pass"""
 
     @staticmethod
-    def forward(ctx, logits, labels, num_class, ignore_label, class_w, weight):
+    def forward(ctx, logits, labels, num_class, ignore_label, class_w, weight, focal=None):
         z = _c(logits).reshape(-1, num_class)
         if z.dtype != torch.float32:
             z = K.cast(z, torch.float32)
@@ -680,7 +680,7 @@ class _SoftmaxCEMeanFn(Function):
         P = z.shape[0]
         want_grad = ctx.needs_input_grad[0]
         _, s, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_sum=True, sum_scale=weight / P,
-                                       want_grad=want_grad, grad_scale=weight / P)
+                                       want_grad=want_grad, grad_scale=weight / P, focal=focal)
         ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
         ctx.save_for_backward(dz)
         return s.reshape(())
@@ -694,7 +694,7 @@ class _SoftmaxCEMeanFn(Function):
             dz = K.scale_dev(dz, _c(dloss).reshape(1).to(torch.float32))
         if dz.dtype != ctx.in_dtype:
             dz = K.cast(dz, ctx.in_dtype)
-        return dz.reshape(ctx.shape), None, None, None, None, None
+        return dz.reshape(ctx.shape), None, None, None, None, None, None
 
 
 _UNIT_LOSS_GRAD = [False]
@@ -711,12 +711,12 @@ class unit_loss_grad:
         _UNIT_LOSS_GRAD[0] = self.prev
 
 
-def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None):
-    return _SoftmaxCEPerPixelFn.apply(logits, labels, num_class, ignore_label, class_w)
+def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None, focal=None):
+    return _SoftmaxCEPerPixelFn.apply(logits, labels, num_class, ignore_label, class_w, focal)
 
 
-def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0):
-    return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight))
+def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0, focal=None):
+    return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight), focal)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -12,8 +12,8 @@ from .. import nn
 def catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, class_weights=None, batch_size=2, reduction=False,
                                        pre_compute_fn=None, post_compute_fn=None, from_logits=True, use_focal_loss=False,
                                        focal_loss_gamma=2.0, focal_loss_alpha=0.25):
-    if use_focal_loss:
-        raise NotImplementedError("focal variant (losses/categorical_focal_crossentropy_loss.py) is outside this round's hot path")
+    # use_focal_loss: keras CategoricalFocalCrossentropy(alpha, gamma, from_logits) replaces the plain CE (:27-37)
+    focal = (float(focal_loss_alpha), float(focal_loss_gamma)) if use_focal_loss else None
     if not from_logits:
         raise NotImplementedError("from_logits=False is not used by the reference's training path")
     cw = None
@@ -25,7 +25,7 @@ def catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, class_wei
         local_batch_size = y_pred.shape[0]
         if pre_compute_fn is not None:
             y_true, y_pred = pre_compute_fn(y_true, y_pred)
-        loss_value = F.softmax_ce_per_pixel(y_pred, y_true, num_class, ignore_label, cw)
+        loss_value = F.softmax_ce_per_pixel(y_pred, y_true, num_class, ignore_label, cw, focal)
         if post_compute_fn is not None:
             loss_value = post_compute_fn(None, y_pred, loss_value, local_batch_size)
         if reduction:
@@ -35,7 +35,7 @@ def catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, class_wei
     def fused_mean(y_true, y_pred, weight=1.0):
         if pre_compute_fn is not None:
             y_true, y_pred = pre_compute_fn(y_true, y_pred)
-        return F.softmax_ce_mean(y_pred, y_true, num_class, ignore_label, cw, weight)
+        return F.softmax_ce_mean(y_pred, y_true, num_class, ignore_label, cw, weight, focal)
 
     weighted_loss.fused_mean = fused_mean if (post_compute_fn is None and not reduction) else None
     return weighted_loss

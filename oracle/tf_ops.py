@@ -168,6 +168,29 @@ def softmax_ce_ignore(y_true, logits, num_class=21, ignore_label=255, class_weig
     return -(onehot * logp).sum(-1) * w
 
 
+def softmax_focal_ce_ignore(y_true, logits, num_class=21, ignore_label=255, class_weights=None, alpha=0.25, gamma=2.0):
+    """use_focal_loss branch of losses/catecrossentropy_ignore_label.py:27-37: keras.losses.CategoricalFocalCrossentropy(alpha, gamma,
+    from_logits=True, reduction=NONE) applied to the same one-hot rows and sample weights.  Keras' formula (the reference's
+    losses/categorical_focal_crossentropy_loss.py is a copy of it): softmax -> renormalise -> clip to [1e-7, 1 - 1e-7] ->
+    sum_c alpha * (1 - p_c)^gamma * (-onehot_c * log p_c)."""
+    z = logits.reshape(-1, num_class)
+    y = y_true.reshape(-1).to(torch.int64)
+    w = (y != ignore_label).to(z.dtype)
+    if ignore_label == 0:
+        y = y - 1
+    in_range = (y >= 0) & (y < num_class)
+    yc = y.clamp(0, num_class - 1)
+    onehot = F.one_hot(yc, num_class).to(z.dtype) * in_range.unsqueeze(-1).to(z.dtype)
+    if class_weights is not None and len(class_weights) > 0:
+        cw = torch.as_tensor(class_weights, dtype=z.dtype)
+        w = w * (onehot * cw.unsqueeze(0)).sum(-1)
+    p = torch.softmax(z, dim=-1)
+    p = p / p.sum(-1, keepdim=True)
+    p = torch.clamp(p, 1e-7, 1.0 - 1e-7)
+    cce = -onehot * torch.log(p)
+    return (alpha * torch.pow(1.0 - p, gamma) * cce).sum(-1) * w
+
+
 def argmax_first(logits):
     """tf.argmax: first maximal index."""
     z = logits.detach().cpu().numpy()

@@ -396,6 +396,32 @@ def test_softmax_ce_ignore(cuda, C, ignore, use_w):
     assert (px.cpu()[y == ignore] == 0).all()
 
 
+@pytest.mark.parametrize("C,ignore,use_w,alpha,gamma", [(21, 255, False, 0.25, 2.0), (21, 255, True, 1.0, 2.0), (19, 0, True, 0.5, 1.5),
+                                                        (4, 255, False, 0.25, 0.0)])
+def test_softmax_focal_ce_ignore(cuda, C, ignore, use_w, alpha, gamma):
+    """use_focal_loss branch (keras CategoricalFocalCrossentropy from logits): loss, its mean and d(loss)/d(logits)"""
+    k = K()
+    P = 3 * 29 * 31
+    z = (rnd((P, C), 11) * 3).float()
+    g = torch.Generator().manual_seed(6)
+    y = torch.randint(0, C if ignore != 0 else C + 1, (P,), generator=g, dtype=torch.int32)
+    y[torch.rand(P, generator=g) < 0.1] = ignore
+    cw = (torch.rand(C, generator=g) + 0.5) if use_w else None
+    zz = z.double().requires_grad_(True)
+    lo = O.softmax_focal_ce_ignore(y, zz, C, ignore, cw, alpha, gamma)
+    scale = 0.41 / P
+    (lo.sum() * scale).backward()
+    px, sm, dz = k.softmax_ce_ignore(z.cuda(), y.cuda(), ignore, class_w=None if cw is None else cw.cuda(), want_px=True, want_sum=True,
+                                     sum_scale=1.0 / P, want_grad=True, grad_scale=scale, focal=(alpha, gamma))
+    close(px, lo, torch.float32, "focal loss px", f32_tol=2e-5)
+    assert abs(sm.item() - lo.mean().item()) <= 2e-5 * max(1.0, abs(lo.mean().item()))
+    close(dz, zz.grad, torch.float32, "focal dlogits", f32_tol=5e-5)
+    assert (px.cpu()[y == ignore] == 0).all()
+    if gamma == 0.0 and not use_w:      # gamma = 0: alpha * plain cross-entropy (away from the clip)
+        plain = O.softmax_ce_ignore(y, z.double(), C, ignore, None)
+        close(px, alpha * plain, torch.float32, "gamma 0 = scaled CE", f32_tol=2e-5)
+
+
 def test_argmax_confusion_first_max_and_ignore(cuda):
     k = K()
     C, P = 21, 10007

@@ -174,3 +174,17 @@ def test_same_pooling_edges():
 def test_replace_nan_or_inf_semantics():
     x = torch.tensor([1.0, float("nan"), float("inf"), -2.0, float("-inf")], dtype=torch.float64)
     assert O.replace_nan_or_inf(x, 0.0).tolist() == [1.0, 0.0, 1.0, -2.0, -2.0]
+
+
+def test_focal_ce_known_answer():
+    """keras CategoricalFocalCrossentropy docstring example (from probabilities): y_true [[0,1,0],[0,0,1]],
+    y_pred [[0.05,0.95,0],[0.1,0.8,0.1]], alpha 0.25, gamma 2 -> [3.2058331e-05, 4.6627346e-01]; fed here as logits = log p"""
+    import numpy as np
+    import torch
+
+    from oracle import tf_ops as O
+
+    p = torch.tensor([[0.05, 0.95, 1e-30], [0.1, 0.8, 0.1]], dtype=torch.float64)
+    y = torch.tensor([1, 2], dtype=torch.int32)
+    got = O.softmax_focal_ce_ignore(y, torch.log(p), 3, 255, None, 0.25, 2.0).numpy()
+    assert np.allclose(got, [3.2058331e-05, 4.6627346e-01], rtol=2e-6)
