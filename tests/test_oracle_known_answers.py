@@ -188,3 +188,35 @@ def test_focal_ce_known_answer():
     y = torch.tensor([1, 2], dtype=torch.int32)
     got = O.softmax_focal_ce_ignore(y, torch.log(p), 3, 255, None, 0.25, 2.0).numpy()
     assert np.allclose(got, [3.2058331e-05, 4.6627346e-01], rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------
+# values PUBLISHED in the TensorFlow / Keras API documentation (docstring examples) -- the only reference outputs
+# available without running TensorFlow; they pin the oracle's loss, metric and activation restatements
+# ------------------------------------------------------------------------------------------------------
+def test_keras_categorical_crossentropy_docstring_values():
+    """keras.losses.CategoricalCrossentropy: y_true [[0,1,0],[0,0,1]], y_pred [[0.05,0.95,0],[0.1,0.8,0.1]] ->
+    reduction NONE [0.0513, 2.303], mean 1.177, sample_weight [0.3, 0.7] -> 0.814, SUM 2.354"""
+    p = torch.tensor([[0.05, 0.95, 1e-30], [0.1, 0.8, 0.1]], dtype=torch.float64)
+    y = torch.tensor([1, 2], dtype=torch.int32)
+    px = O.softmax_ce_ignore(y, torch.log(p), 3, 255)
+    assert px.tolist() == pytest.approx([0.0513, 2.303], abs=5e-4)
+    assert px.mean().item() == pytest.approx(1.177, abs=5e-4)
+    assert px.sum().item() == pytest.approx(2.354, abs=5e-4)
+    assert (px * torch.tensor([0.3, 0.7])).mean().item() == pytest.approx(0.814, abs=5e-4)
+
+
+def test_keras_mean_iou_docstring_values():
+    """keras.metrics.MeanIoU(num_classes=2): y_true [0,0,1,1], y_pred [0,1,0,1] -> 0.33333334;
+    with sample_weight [0.3,0.3,0.3,0.1] -> 0.23809525 (cm = [[0.3,0.3],[0.3,0.1]])"""
+    cm = O.confusion_matrix(torch.tensor([0, 0, 1, 1]), torch.tensor([0, 1, 0, 1]), 2, 255)
+    assert O.per_class_iou(cm)[1].item() == pytest.approx(0.33333334, abs=1e-7)
+    cmw = torch.tensor([[0.3, 0.3], [0.3, 0.1]], dtype=torch.float64)
+    assert O.per_class_iou(cmw)[1].item() == pytest.approx(0.23809525, abs=1e-7)
+
+
+def test_tf_nn_gelu_docstring_values():
+    """tf.nn.gelu([-3,-1,0,1,3]) (approximate=False) -> [-0.00404951, -0.15865529, 0., 0.8413447, 2.9959507]"""
+    x = torch.tensor([-3.0, -1.0, 0.0, 1.0, 3.0], dtype=torch.float64)
+    # the documented values are float32 results (TF's fp32 erf): they sit within 5e-7 of the exact form
+    assert O.gelu(x).tolist() == pytest.approx([-0.00404951, -0.15865529, 0.0, 0.8413447, 2.9959507], abs=5e-7)
