@@ -284,8 +284,11 @@ int iseg_pool2d_fwd(const void* x, void* y, int N, int H, int W, int C, int kh, 
                     int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
 /* relu(a + b), n % 8 == 0: residual join of backbones/resnet_blocks.py:106-107,202-203 */
 int iseg_add_relu(const void* a, const void* b, void* y, int64_t n, int dtype, iseg_stream_t stream);
+/* max mode with C % 8 == 0 runs two vector passes through a one-byte-per-output-element winner table (workspace); everything else
+   takes the one-pass gather kernel and needs no workspace (ws may be NULL when iseg_pool2d_bwd_workspace_bytes returns 0) */
+size_t iseg_pool2d_bwd_workspace_bytes(int N, int Ho, int Wo, int C, int mode);
 int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int pad_t,
-                    int pad_l, int Ho, int Wo, int mode, int dtype, iseg_stream_t stream);
+                    int pad_l, int Ho, int Wo, int mode, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Attention pieces around the strided-batch GEMMs (iseg_gemm with batch > 1):

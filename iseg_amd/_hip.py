@@ -122,7 +122,8 @@ SIGNATURES = {
     "iseg_window_attention_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _f, _i, _p, _z, _p]),
     "iseg_add_relu": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_pool2d_fwd": (_i, [_p, _p] + [_i] * 14 + [_p]),
-    "iseg_pool2d_bwd": (_i, [_p, _p, _p] + [_i] * 14 + [_p]),
+    "iseg_pool2d_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "iseg_pool2d_bwd": (_i, [_p, _p, _p] + [_i] * 14 + [_p, _z, _p]),
     "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_resize_bilinear_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "iseg_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

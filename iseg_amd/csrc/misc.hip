@@ -343,6 +343,86 @@ __global__ __launch_bounds__(256) void pool2d_bwd_kernel(const T* __restrict__ x
     }
 }
 
+// Max-pool gradient in two vector passes (C % 8 == 0, one byte of workspace per output element): pass 1 records, per window and
+// channel, the row-major index of its FIRST maximal cell (TF MaxPoolGrad's tie rule); pass 2 lets every input cell look up the
+// <= ceil(kh/sh)*ceil(kw/sw) windows that cover it and take their gradient where the recorded index is its own.  8 channels per lane,
+// 16-byte loads.  The one-pass kernel above re-derives the winner of every covering window per input element from scalar loads
+// (36 two-byte loads per element for the 3x3/s2 ResNet stem pool: 388 us on 16x128x128x128).
+template <class T>
+__global__ __launch_bounds__(256) void pool_argmax_kernel(const T* __restrict__ x, unsigned char* __restrict__ idx, int N, int H, int W,
+                                                          int C, int kh, int kw, int sh, int sw, int pt, int pl, int Ho, int Wo) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        const int ow = (int)(t % Wo);
+        t /= Wo;
+        const int oh = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float best[8];
+        unsigned int bi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            best[u] = -FLT_MAX;
+            bi[u] = 255u;
+        }
+        for (int a = 0; a < kh; ++a) {
+            const int yh = oh * sh - pt + a;
+            if ((unsigned)yh >= (unsigned)H) continue;
+            for (int b = 0; b < kw; ++b) {
+                const int yw = ow * sw - pl + b;
+                if ((unsigned)yw >= (unsigned)W) continue;
+                float v[8];
+                load8<T>(x + (((int64_t)n * H + yh) * W + yw) * C + c8 * 8, v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (bi[u] == 255u || v[u] > best[u]) {      // strict: the first maximal cell keeps the window
+                        best[u] = v[u];
+                        bi[u] = (unsigned)(a * kw + b);
+                    }
+            }
+        }
+        uint2 packed;
+        packed.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+        packed.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+        *reinterpret_cast<uint2*>(idx + i * 8) = packed;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void pool_max_bwd_idx_kernel(const unsigned char* __restrict__ idx, const T* __restrict__ dy,
+                                                               T* __restrict__ dx, int N, int H, int W, int C, int kh, int kw, int sh,
+                                                               int sw, int pt, int pl, int Ho, int Wo) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)N * H * W * C8;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c8 = (int)(i % C8);
+        int64_t t = i / C8;
+        const int iw = (int)(t % W);
+        t /= W;
+        const int ih = (int)(t % H);
+        const int n = (int)(t / H);
+        const int oh_lo = max(0, (ih + pt - kh + 1 + sh - 1) / sh), oh_hi = min(Ho - 1, (ih + pt) / sh);
+        const int ow_lo = max(0, (iw + pl - kw + 1 + sw - 1) / sw), ow_hi = min(Wo - 1, (iw + pl) / sw);
+        float g[8] = {};
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const unsigned cell = (unsigned)((ih - (oh * sh - pt)) * kw + (iw - (ow * sw - pl)));
+                const int64_t o = (((int64_t)n * Ho + oh) * Wo + ow) * C8 + c8;
+                const uint2 packed = *reinterpret_cast<const uint2*>(idx + o * 8);
+                float d[8];
+                load8<T>(dy + o * 8, d);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned w = ((u < 4 ? packed.x : packed.y) >> (8 * (u & 3))) & 255u;
+                    if (w == cell) g[u] += d[u];
+                }
+            }
+        store8<T>(dx + i * 8, g);
+    }
+}
+
 // residual join of the ResNet bottleneck: relu(a + b)   (backbones/resnet_blocks.py:106-107,202-203)
 template <class T>
 __global__ __launch_bounds__(256) void add_relu_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int64_t n8) {
@@ -490,13 +570,40 @@ extern "C" int iseg_pool2d_fwd(const void* x, void* y, int N, int H, int W, int 
     return iseg_check_launch("iseg_pool2d_fwd");
 }
 
+extern "C" size_t iseg_pool2d_bwd_workspace_bytes(int N, int Ho, int Wo, int C, int mode) {
+    return (mode == 0 && C % 8 == 0) ? (size_t)N * Ho * Wo * C : 0;      // one winner index per window and channel
+}
+
 extern "C" int iseg_pool2d_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int kh, int kw, int sh, int sw,
-                               int pad_t, int pad_l, int Ho, int Wo, int mode, int dtype, hipStream_t stream) {
+                               int pad_t, int pad_l, int Ho, int Wo, int mode, int dtype, void* ws, size_t ws_bytes,
+                               hipStream_t stream) {
     ISEG_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "iseg_pool2d_bwd: bad arguments");
     ISEG_REQUIRE(mode == 0 || mode == 1, "iseg_pool2d_bwd: mode %d (0 = max, 1 = avg)", mode);
     ISEG_REQUIRE(kh > 0 && kw > 0 && sh > 0 && sw > 0 && pad_t >= 0 && pad_l >= 0 && pad_t < kh && pad_l < kw,
                  "iseg_pool2d_bwd: bad window geometry");
     const int64_t total = (int64_t)N * H * W * C;
+    const size_t need = iseg_pool2d_bwd_workspace_bytes(N, Ho, Wo, C, mode);
+    const bool aligned = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0 && ((uintptr_t)ws & 7) == 0;
+    if (need > 0 && kh * kw < 255 && aligned) {
+        if (!ws || ws_bytes < need) {
+            iseg_set_error("iseg_pool2d_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        unsigned char* idx = (unsigned char*)ws;
+        const int64_t n_out = (int64_t)N * Ho * Wo * (C / 8), n_in = total / 8;
+        if (dtype == ISEG_BF16) {
+            hipLaunchKernelGGL((pool_argmax_kernel<bf16_t>), dim3(ew_blocks(n_out)), dim3(256), 0, stream, (const bf16_t*)x, idx, N, H, W, C,
+                               kh, kw, sh, sw, pad_t, pad_l, Ho, Wo);
+            hipLaunchKernelGGL((pool_max_bwd_idx_kernel<bf16_t>), dim3(ew_blocks(n_in)), dim3(256), 0, stream, idx, (const bf16_t*)dy,
+                               (bf16_t*)dx, N, H, W, C, kh, kw, sh, sw, pad_t, pad_l, Ho, Wo);
+        } else {
+            hipLaunchKernelGGL((pool_argmax_kernel<float>), dim3(ew_blocks(n_out)), dim3(256), 0, stream, (const float*)x, idx, N, H, W, C,
+                               kh, kw, sh, sw, pad_t, pad_l, Ho, Wo);
+            hipLaunchKernelGGL((pool_max_bwd_idx_kernel<float>), dim3(ew_blocks(n_in)), dim3(256), 0, stream, idx, (const float*)dy,
+                               (float*)dx, N, H, W, C, kh, kw, sh, sw, pad_t, pad_l, Ho, Wo);
+        }
+        return iseg_check_launch("iseg_pool2d_bwd");
+    }
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((pool2d_bwd_kernel<bf16_t>), dim3(ew_blocks(total)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy,
                            (bf16_t*)dx, N, H, W, C, kh, kw, sh, sw, pad_t, pad_l, Ho, Wo, mode);

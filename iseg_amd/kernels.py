@@ -542,8 +542,10 @@ def pool2d_bwd(x, dy, kh, kw, sh, sw, pt, pl, mode):
     N, H, W, Cc = x.shape
     Ho, Wo = dy.shape[1], dy.shape[2]
     dx = torch.empty_like(x)
-    _hip.check(_hip.lib().iseg_pool2d_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode, dt(x), stream()),
-               "iseg_pool2d_bwd")
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_pool2d_bwd_workspace_bytes(N, Ho, Wo, Cc, mode), x.device)
+    _hip.check(L.iseg_pool2d_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, Cc, kh, kw, sh, sw, pt, pl, Ho, Wo, mode, dt(x), ptr(ws), wsb,
+                                 stream()), "iseg_pool2d_bwd")
     return dx
 
 
