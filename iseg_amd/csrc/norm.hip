@@ -203,7 +203,23 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     for (int c = tc; c < nchunks; c += tpc) {
         float s[8] = {}, q[8] = {};
         if (active) {
-            for (int64_t r = (int64_t)blockIdx.x * rpi + tr; r < rows; r += (int64_t)gridDim.x * rpi) {
+            // eight rows per trip with their loads issued together (one dependent load per trip waits a memory round trip per row)
+            int64_t r = (int64_t)blockIdx.x * rpi + tr;
+            const int64_t rstep = (int64_t)gridDim.x * rpi;
+            constexpr int UB = 8;
+            for (; r + (UB - 1) * rstep < rows; r += UB * rstep) {
+                float v[UB][8];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) load8<T>(x + (r + k * rstep) * ldx + c * 8, v[k]);
+#pragma unroll
+                for (int k = 0; k < UB; ++k)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        s[u] += v[k][u];
+                        q[u] += v[k][u] * v[k][u];
+                    }
+            }
+            for (; r < rows; r += rstep) {
                 float v[8];
                 load8<T>(x + r * ldx + c * 8, v);
 #pragma unroll
@@ -286,7 +302,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             float m[8], rs[8];
             load8<float>(mean + c * 8, m);
             load8<float>(rstd + c * 8, rs);
-            for (int64_t r = (int64_t)blockIdx.x * rpi + tr; r < rows; r += (int64_t)gridDim.x * rpi) {
+            int64_t r = (int64_t)blockIdx.x * rpi + tr;
+            const int64_t rstep = (int64_t)gridDim.x * rpi;
+            constexpr int UB = 4;      // four rows per trip, all of their loads issued together
+            for (; r + (UB - 1) * rstep < rows; r += UB * rstep) {
+                float d[UB][8], xv[UB][8], yv[UB][8];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    load8<T>(dy + (r + k * rstep) * lddy + c * 8, d[k]);
+                    load8<T>(x + (r + k * rstep) * ldx + c * 8, xv[k]);
+                    if (relu) load8<T>(y + (r + k * rstep) * ldy + c * 8, yv[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < UB; ++k)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float dv = (relu && !(yv[k][u] > 0.f)) ? 0.f : d[k][u];
+                        s[u] += dv;
+                        q[u] += dv * (xv[k][u] - m[u]) * rs[u];
+                    }
+            }
+            for (; r < rows; r += rstep) {
                 float d[8], xv[8];
                 load8<T>(dy + r * lddy + c * 8, d);
                 load8<T>(x + r * ldx + c * 8, xv);
