@@ -95,6 +95,8 @@ class Mlp(Layer):
         self.dropout = Dropout(dropout_rate, name=f"{name}/dropout")
 
     def call(self, inputs, training=None):
+        if self.fc1.built and self.fc2.built and (self.dropout.rate == 0.0 or not training):
+            return F.mlp_gelu(inputs, self.fc1.kernel, self.fc1.bias, self.fc2.kernel, self.fc2.bias)     # one tape node
         x = self.fc1(inputs)                     # Dense + exact-erf GELU in the GEMM epilogue
         x = self.dropout(x, training=training)
         x = self.fc2(x)

@@ -102,6 +102,54 @@ class _DenseFn(Function):
         return dx, None, None, None, None
 
 
+class _MlpGeluFn(Function):
+    """Dense -> exact GELU -> Dense of the transformer MLPs (backbones/swin.py:17-43 Mlp, backbones/vit.py:66-113 MLPBlock,
+    backbones/intern_image/mlp_layer.py:48-59) as one tape node: the first GEMM's epilogue writes gelu(h) and gelu'(h), the second
+    GEMM's data gradient multiplies by the saved derivative in its epilogue -- no elementwise activation-gradient pass."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2):
+        C, Hd = W1.shape[-2], W1.shape[-1]
+        N = W2.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        need_grad = any(ctx.needs_input_grad)
+        d = torch.empty((x2.shape[0], Hd), dtype=x2.dtype, device=x2.device) if need_grad else None
+        g = K.dense_fwd(x2, nn.w(W1), b1.data if b1 is not None else None, act=K.ACT_GELU, pre_out=d, pre_deriv=need_grad)
+        y = K.dense_fwd(g, nn.w(W2), b2.data if b2 is not None else None)
+        ctx.params = (W1, b1, W2, b2)
+        ctx.save_for_backward(x2, g if need_grad else None, d)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, d = ctx.saved_tensors
+        W1, b1, W2, b2 = ctx.params
+        N = W2.shape[-1]
+        dy2 = _c(dy).reshape(-1, N)
+        if W2.requires_grad:
+            K.dense_wgrad(g, dy2, _grad(W2), bias_grad=(_grad(b2) if b2 is not None and b2.requires_grad else None))
+        elif b2 is not None and b2.requires_grad:
+            K.colsum(dy2, N, 0, 1, dy2.shape[0], N, _grad(b2), accumulate=True)
+        dh = K.dense_dgrad(dy2, nn.w(W2), act=K.ACT_MUL_AUX, aux=d)            # (dy W2^T) * gelu'(h)
+        if W1.requires_grad:
+            K.dense_wgrad(x2, dh, _grad(W1), bias_grad=(_grad(b1) if b1 is not None and b1.requires_grad else None))
+        elif b1 is not None and b1.requires_grad:
+            K.colsum(dh, dh.shape[1], 0, 1, dh.shape[0], dh.shape[1], _grad(b1), accumulate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.dense_dgrad(dh, nn.w(W1)).reshape(*dy.shape[:-1], W1.shape[-2])
+        dist.grads_ready(W1, b1, W2, b2)
+        return dx, None, None, None, None
+
+
+def mlp_gelu(x, W1, b1, W2, b2):
+    """dense(gelu(dense(x, W1, b1)), W2, b2) with no dropout in between"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry((*x.shape[:-1], W2.shape[-1]), x)
+    return _MlpGeluFn.apply(x, W1, b1, W2, b2)
+
+
 def dense(x, W, b=None, act=K.ACT_NONE, kshape=None):
     """kshape=(in, out) re-interprets a higher-rank kernel (keras MultiHeadAttention: [C, heads, d] / [heads, d, C]) as [in, out]"""
     _check_act_dtype(x)

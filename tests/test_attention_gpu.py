@@ -351,3 +351,35 @@ def test_inference_flash_attention_matches_materialised_route_and_oracle(cuda, h
     finally:
         os.environ.pop("ISEG_FLASHATTN", None)
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_fused_gelu_mlp_matches_unfused_layers_and_oracle(cuda, dtype):
+    """F.mlp_gelu (one tape node: gelu and gelu' from the first GEMM's epilogue, the second GEMM's data gradient multiplies by the
+    saved derivative) against fp64 autograd, through the Swin Mlp layer that selects it when dropout is inactive"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import Mlp
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        shape = (3, 37, 64)
+        layer = Mlp(64, hidden_features=256, name="mlp")
+        _setup(layer, torch.empty(shape, dtype=dtype, device="cuda"))
+        assert layer.fc1.built and layer.fc2.built
+        x = rnd(shape, 1).to(dtype)
+        xg = x.cuda().requires_grad_(True)
+        y = layer(xg, training=True)
+        assert type(y.grad_fn).__name__.startswith("_MlpGeluFn")
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(layer).items()}
+        xr = x.double().requires_grad_(True)
+        h = xr @ w["mlp/fc1/kernel"] + w["mlp/fc1/bias"]
+        yr = O.gelu(h) @ w["mlp/fc2/kernel"] + w["mlp/fc2/bias"]
+        assert _rel(y, yr.detach()) < (2e-5 if dtype == torch.float32 else 2e-2)
+        dy = rnd(shape, 2).to(dtype)
+        y.backward(dy.cuda())
+        yr.backward(dy.double())
+        assert _rel(xg.grad, xr.grad) < (2e-4 if dtype == torch.float32 else 4e-2)
+        _check_grads(layer, w, 2e-4 if dtype == torch.float32 else 5e-2, l2=dtype != torch.float32)
+    finally:
+        nn.set_compute_dtype(torch.float32)
