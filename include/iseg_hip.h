@@ -231,6 +231,11 @@ size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C);
 int iseg_softmax_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C, int ignore_label,
                            float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits, float grad_scale,
                            const float* grad_px, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* iseg_softmax_ce_ignore that also performs iseg_argmax_confusion on the same logits / labels (cm[y*C + argmax] += 1 for kept,
+ * in-range labels; first maximal index): the training step's loss and running-mIoU update in ONE pass over the logits */
+int iseg_softmax_ce_confusion(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C, int ignore_label,
+                              float* loss_px, float* loss_sum, float loss_sum_scale, float* dlogits, float grad_scale,
+                              const float* grad_px, uint64_t* cm, void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* focal variant (use_focal_loss of losses/catecrossentropy_ignore_label.py:27-37 = keras CategoricalFocalCrossentropy, from_logits):
  * p = clip(softmax(logits)[y], 1e-7, 1 - 1e-7);  loss = w * alpha * (1 - p)^gamma * (-log p);  same outputs and masking rules */
 int iseg_softmax_focal_ce_ignore(const float* logits, const int32_t* labels, const float* class_w, int64_t P, int C, int ignore_label,

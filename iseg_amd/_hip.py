@@ -130,6 +130,7 @@ SIGNATURES = {
     "iseg_resize_nearest_i32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_softmax_ce_workspace_bytes": (_z, [_l, _i]),
     "iseg_softmax_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
+    "iseg_softmax_ce_confusion": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _p, _p, _z, _p]),
     "iseg_softmax_focal_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),

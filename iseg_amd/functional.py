@@ -718,7 +718,7 @@ class _SoftmaxCEMeanFn(Function):
     """mean over ALL positions (Keras' reduction of the NONE loss): loss and d(loss)/d(logits) in one fused pass"""
 
     @staticmethod
-    def forward(ctx, logits, labels, num_class, ignore_label, class_w, weight, focal=None):
+    def forward(ctx, logits, labels, num_class, ignore_label, class_w, weight, focal=None, cm=None):
         z = _c(logits).reshape(-1, num_class)
         if z.dtype != torch.float32:
             z = K.cast(z, torch.float32)
@@ -728,7 +728,7 @@ class _SoftmaxCEMeanFn(Function):
         P = z.shape[0]
         want_grad = ctx.needs_input_grad[0]
         _, s, dz = K.softmax_ce_ignore(z, y, ignore_label, class_w=class_w, want_px=False, want_sum=True, sum_scale=weight / P,
-                                       want_grad=want_grad, grad_scale=weight / P, focal=focal)
+                                       want_grad=want_grad, grad_scale=weight / P, focal=focal, cm=cm)
         ctx.shape, ctx.in_dtype = logits.shape, logits.dtype
         ctx.save_for_backward(dz)
         return s.reshape(())
@@ -742,7 +742,7 @@ class _SoftmaxCEMeanFn(Function):
             dz = K.scale_dev(dz, _c(dloss).reshape(1).to(torch.float32))
         if dz.dtype != ctx.in_dtype:
             dz = K.cast(dz, ctx.in_dtype)
-        return dz.reshape(ctx.shape), None, None, None, None, None, None
+        return dz.reshape(ctx.shape), None, None, None, None, None, None, None
 
 
 _UNIT_LOSS_GRAD = [False]
@@ -763,8 +763,9 @@ def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None, 
     return _SoftmaxCEPerPixelFn.apply(logits, labels, num_class, ignore_label, class_w, focal)
 
 
-def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0, focal=None):
-    return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight), focal)
+def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0, focal=None, cm=None):
+    """cm: int64 [C*C] confusion matrix that the same kernel pass updates with argmax(logits) (running mIoU of the train step)"""
+    return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight), focal, cm)
 
 
 # ---------------------------------------------------------------------------------------------------------

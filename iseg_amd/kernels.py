@@ -438,8 +438,9 @@ def scale_dev(x, s_dev):
 
 
 def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px=True, want_sum=False, sum_scale=1.0,
-                      want_grad=False, grad_scale=1.0, grad_px=None, focal=None):
-    """focal = (alpha, gamma) selects keras' CategoricalFocalCrossentropy instead of the plain cross-entropy"""
+                      want_grad=False, grad_scale=1.0, grad_px=None, focal=None, cm=None):
+    """focal = (alpha, gamma) selects keras' CategoricalFocalCrossentropy instead of the plain cross-entropy; cm (int64 [C*C]) also
+    accumulates the confusion matrix of argmax(logits) in the same pass (plain cross-entropy only)"""
     _require_cuda(logits2d, labels1d)
     P, Cc = logits2d.shape
     dev = logits2d.device
@@ -448,7 +449,12 @@ def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px
     dlogits = torch.empty_like(logits2d) if want_grad else None
     need = _hip.lib().iseg_softmax_ce_workspace_bytes(P, Cc) if want_sum else 0
     ws, wsb = workspace(need, dev)
-    if focal is not None:
+    if cm is not None:
+        if focal is not None:
+            raise ValueError("softmax_ce_ignore: cm rides the plain cross-entropy kernel only")
+        _hip.call("iseg_softmax_ce_confusion", ptr(logits2d), ptr(labels1d), ptr(class_w), P, Cc, ignore_label, ptr(loss_px), ptr(loss_sum),
+                  sum_scale, ptr(dlogits), grad_scale, ptr(grad_px), ptr(cm), ptr(ws), wsb, stream())
+    elif focal is not None:
         _hip.call("iseg_softmax_focal_ce_ignore", ptr(logits2d), ptr(labels1d), ptr(class_w), P, Cc, ignore_label, float(focal[0]),
                   float(focal[1]), ptr(loss_px), ptr(loss_sum), sum_scale, ptr(dlogits), grad_scale, ptr(grad_px), ptr(ws), wsb, stream())
     else:

@@ -32,10 +32,12 @@ def catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, class_wei
             loss_value = loss_value.sum() / batch_size      # tf.nn.compute_average_loss
         return loss_value
 
-    def fused_mean(y_true, y_pred, weight=1.0):
+    def fused_mean(y_true, y_pred, weight=1.0, cm=None):
         if pre_compute_fn is not None:
             y_true, y_pred = pre_compute_fn(y_true, y_pred)
-        return F.softmax_ce_mean(y_pred, y_true, num_class, ignore_label, cw, weight, focal)
+        return F.softmax_ce_mean(y_pred, y_true, num_class, ignore_label, cw, weight, focal, cm)
 
     weighted_loss.fused_mean = fused_mean if (post_compute_fn is None and not reduction) else None
+    # the trainer may let the loss kernel also update a MeanIOU confusion matrix built for the same classes / ignore label
+    weighted_loss.confusion_spec = (num_class, ignore_label) if (pre_compute_fn is None and focal is None) else None
     return weighted_loss

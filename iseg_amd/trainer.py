@@ -67,6 +67,25 @@ class TrainableModel:
     def __call__(self, x, training=False):
         return self.model(x, training=training)
 
+    def _fusable_confusion(self, fn, i, y_true, out):
+        """the MeanIOU confusion matrix of output i when the loss kernel can update it itself: exactly one SegMetricWrapper(MeanIOU)
+        without pre-compute hooks, same class count / ignore label as the loss, labels already at the logits size (no nearest resize)"""
+        from .metrics.mean_iou import MeanIOU
+        from .metrics.seg_metric_wrapper import SegMetricWrapper
+
+        spec = getattr(fn, "confusion_spec", None)
+        ms = self._metrics_for(i)
+        if not self.update_metrics or spec is None or len(ms) != 1:
+            return None
+        m = ms[0]
+        if not isinstance(m, SegMetricWrapper) or m._pre_compute_fn_list or not isinstance(m.metric, MeanIOU):
+            return None
+        if (m.num_class, m.ignore_label) != spec or out.dim() != 4 or out.shape[-1] != m.num_class:
+            return None
+        if tuple(y_true.shape[1:3]) != tuple(out.shape[1:3]) or y_true.shape[0] != out.shape[0]:
+            return None
+        return m.metric.total_cm
+
     # ---- the hot loop ---------------------------------------------------------------------------------------
     def train_step(self, x, y):
         ys = y if isinstance(y, (tuple, list)) else None
@@ -78,13 +97,19 @@ class TrainableModel:
         if not isinstance(outputs, (list, tuple)):
             outputs = [outputs]
         losses = []
+        fused_metric_outputs = set()
         for i, out in enumerate(outputs):
             fn = self._loss_fn(i)
             yt = ys[i] if ys is not None else y
             w = self._weight(i)
             fused = getattr(fn, "fused_mean", None)
             if fused is not None:
-                losses.append(fused(yt, out, w))
+                cm = self._fusable_confusion(fn, i, yt, out)
+                if cm is not None:
+                    fused_metric_outputs.add(i)
+                    losses.append(fused(yt, out, w, cm=cm))      # loss, its gradient and the running-mIoU update in one pass
+                else:
+                    losses.append(fused(yt, out, w))
             else:
                 lv = fn(yt, out)
                 losses.append(lv.float().mean() * w)
@@ -97,6 +122,8 @@ class TrainableModel:
         if self.update_metrics:
             with torch.no_grad():
                 for i, out in enumerate(outputs):
+                    if i in fused_metric_outputs:
+                        continue
                     yt = ys[i] if ys is not None else y
                     for m in self._metrics_for(i):
                         m.update_state(yt, out.detach())

@@ -173,3 +173,52 @@ def test_bf16_forward_close_and_training_decreases_loss(cuda):
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
     res = tm.metric_results()
     assert 0.0 <= res["output_1_IOU"] <= 1.0
+
+
+def test_loss_kernel_updates_the_running_miou_exactly_like_the_separate_pass(cuda):
+    """trainer: when loss and metric agree on classes / ignore label and the labels are at the logits size, the CE kernel also fills the
+    MeanIOU confusion matrix (iseg_softmax_ce_confusion); the matrix must equal the one of the separate argmax pass bit for bit"""
+    from iseg_amd import kernels as K
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.trainer import TrainableModel
+
+    model = _setup(torch.float32, drop_path=0.0)
+    x, y = synthetic_batch(2, 64, 64, seed=21)
+    opt = get_optimizer(Strategy(one_device=True), initial_lr=1e-3, epoch_steps=100, train_epoch=1, optimizer="adamw")
+    losses = model.custom_losses(21, 255, 2)
+    tm = TrainableModel(model, optimizer=opt, loss=losses, loss_weights=model.custom_losses_weights(), metrics=model.custom_metrics(21, 255))
+    fn = tm._loss_fn(0)
+    assert getattr(fn, "confusion_spec", None) == (21, 255)
+    with torch.no_grad():
+        logits = model(x.cuda(), training=True)[0]      # same weights, same batch statistics as the step below
+    want = torch.zeros(21 * 21, dtype=torch.int64, device="cuda")
+    K.argmax_confusion(logits.reshape(-1, 21).float().contiguous(), y.cuda().reshape(-1).to(torch.int32), 255, cm=want)
+    tm.reset_metrics()
+    tm.train_step(x.cuda(), y.cuda())
+    got = tm._metrics_for(0)[0].metric.total_cm
+    assert int(got.sum()) == int((y != 255).sum())
+    assert torch.equal(got.cpu(), want.cpu())
+
+
+@pytest.mark.parametrize("C,ignore", [(21, 255), (150, 255), (19, 0)])
+def test_softmax_ce_confusion_kernel(cuda, C, ignore):
+    from iseg_amd import kernels as K
+
+    P = 4 * 33 * 29
+    g = torch.Generator().manual_seed(9)
+    z = (torch.randn(P, C, generator=g) * 2).float()
+    z[::5, 2] = z[::5].max(-1).values      # ties: the first maximal index wins
+    y = torch.randint(0, C if ignore != 0 else C + 1, (P,), generator=g, dtype=torch.int32)
+    y[torch.rand(P, generator=g) < 0.1] = ignore
+    cm = torch.zeros(C * C, dtype=torch.int64, device="cuda")
+    px, sm, dz = K.softmax_ce_ignore(z.cuda(), y.cuda(), ignore, want_px=True, want_sum=True, sum_scale=1.0 / P, want_grad=True,
+                                     grad_scale=1.0 / P, cm=cm)
+    px0, sm0, dz0 = K.softmax_ce_ignore(z.cuda(), y.cuda(), ignore, want_px=True, want_sum=True, sum_scale=1.0 / P, want_grad=True,
+                                        grad_scale=1.0 / P)
+    assert torch.equal(px, px0) and torch.equal(dz, dz0) and torch.equal(sm, sm0)
+    want = torch.zeros(C * C, dtype=torch.int64, device="cuda")
+    yy, ig = (y - 1, -1) if ignore == 0 else (y, ignore)      # metrics/seg_metric_wrapper.py:56-59
+    K.argmax_confusion(z.cuda(), yy.cuda(), ig, cm=want)
+    assert torch.equal(cm.cpu(), want.cpu())
