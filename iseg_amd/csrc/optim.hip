@@ -24,24 +24,39 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
                                                     const float* __restrict__ seg_wd, const float* __restrict__ hp, float b1,
                                                     float b2, float eps, int64_t nblocks) {
     const float lr = hp[0], corr = hp[1], gscale = hp[2], clipv = hp[3];
-    for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    // one wavefront per 256-element block (the segment granularity of the flat parameter buffer), four elements per lane: 16-byte
+    // loads / stores, the segment lookup is wave-uniform
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t b = (int64_t)blockIdx.x * 4 + wv; b < nblocks; b += (int64_t)gridDim.x * 4) {
         const int seg = seg_of_block[b];
         if (seg < 0) continue;  // padding block
         const float lr_mult = seg_lr_mult[seg], wd = seg_wd[seg];
-        const int64_t i = b * 256 + threadIdx.x;
-        float wi = w[i];
-        float gi = scrub_nan(g[i]) * gscale;
-        if (clipv > 0.f) gi = fminf(fmaxf(gi, -clipv), clipv);
-        wi -= wi * wd * lr;
-        float mi = m[i], vi = v[i];
-        mi += (gi - mi) * (1.f - b1);
-        vi += (gi * gi - vi) * (1.f - b2);
+        const int64_t i = b * 256 + lane * 4;
+        float4 w4 = *reinterpret_cast<const float4*>(w + i);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + i);
+        float4 m4 = *reinterpret_cast<const float4*>(m + i);
+        float4 v4 = *reinterpret_cast<const float4*>(v + i);
+        float wi[4] = {w4.x, w4.y, w4.z, w4.w}, mi[4] = {m4.x, m4.y, m4.z, m4.w}, vi[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float gr[4] = {g4.x, g4.y, g4.z, g4.w};
         const float alpha = lr * lr_mult * corr;
-        wi -= (mi * alpha) / (sqrtf(vi) + eps);
-        w[i] = wi;
-        m[i] = mi;
-        v[i] = vi;
-        if (w_bf16) w_bf16[i] = (bf16_t)wi;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float gi = scrub_nan(gr[u]) * gscale;
+            if (clipv > 0.f) gi = fminf(fmaxf(gi, -clipv), clipv);
+            wi[u] -= wi[u] * wd * lr;
+            mi[u] += (gi - mi[u]) * (1.f - b1);
+            vi[u] += (gi * gi - vi[u]) * (1.f - b2);
+            wi[u] -= (mi[u] * alpha) / (sqrtf(vi[u]) + eps);
+        }
+        *reinterpret_cast<float4*>(w + i) = make_float4(wi[0], wi[1], wi[2], wi[3]);
+        *reinterpret_cast<float4*>(m + i) = make_float4(mi[0], mi[1], mi[2], mi[3]);
+        *reinterpret_cast<float4*>(v + i) = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        if (w_bf16) {
+            bf16x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = (bf16_t)wi[u];
+            *reinterpret_cast<bf16x4*>(w_bf16 + i) = o;
+        }
     }
 }
 
