@@ -34,7 +34,64 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 storage (parity mode); the headline number is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="rendezvous + one all-reduce only (gloo when there is no GPU): tests the --gpus N self-launch path on CPU")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not touched the GPU (no HIP call,
+    no torch.cuda.is_available()), the children are fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (never an
+    exec of a process that initialised the GPU).  Rank 0 inherits stdout and prints the JSON line; the exit code is non-zero when any
+    rank fails."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if not args.check_launch and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} but this node exposes {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def joined_ranks(device):
+    """the number of ranks that actually take part in collectives: an all-reduce of ones, not the environment's word for it"""
+    from iseg_amd import dist
+
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce_sum(one)
+    return int(round(float(one.item())))
+
+
+def check_launch(args):
+    from iseg_amd import dist
+
+    use_gpu = torch.cuda.device_count() >= max(args.gpus, 1) and torch.cuda.is_available()
+    dist.init(backend=None if use_gpu else "gloo")
+    n = joined_ranks(torch.device("cuda", dist.local_rank()) if use_gpu else torch.device("cpu"))
+    if n != args.gpus:
+        print(f"bench.py: {n} ranks joined, --gpus {args.gpus}", file=sys.stderr)
+        sys.exit(3)
+    dist.barrier()
+    if dist.rank() == 0:
+        print(json.dumps({"metric": "launch_check", "n_gpus": n, "backend": torch.distributed.get_backend() if n > 1 else "none"}))
+    if dist.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 def build_trainer(args):
@@ -177,13 +234,23 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    env_world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and env_world == 0:
+        sys.exit(self_launch(args))
+    if env_world not in (0, args.gpus) or (args.gpus == 1 and env_world > 1):
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}", file=sys.stderr)
+        sys.exit(2)
+    if args.check_launch:
+        return check_launch(args)
     from iseg_amd import dist
     from iseg_amd.data import synthetic_batch
 
     strategy, model, trainer = build_trainer(args)
-    rank, world = dist.rank(), dist.world_size()
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}", file=sys.stderr)
+    rank = dist.rank()
+    world = joined_ranks(torch.device("cuda", dist.local_rank()))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined the process group", file=sys.stderr)
+        sys.exit(3)
     x, y = synthetic_batch(args.batch, args.size, args.size, seed=100 + rank)
     x, y = x.cuda(), y.cuda()
     from iseg_amd import kernels as K

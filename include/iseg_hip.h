@@ -384,6 +384,18 @@ size_t iseg_attention_bwd_workspace_bytes(int64_t batch, int T, int heads);
 int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse2, void* dqkv, int64_t batch, int T,
                        int heads, int head_dim, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused ConvNeXt MLP (backbones/convnext.py:51-63 Block.call: pwconv1 -> act (exact GELU) -> pwconv2 -> gamma -> drop_path ->
+ * + input) for the wide stages, bf16 storage, C = 96 / 192 (iseg_convnext_mlp_supported):
+ *     out[m][:] = residual[m][:] + rowscale[m / rows_per_group] * gamma[:] * (gelu(y2[m][:] @ W1 + b1) @ W2 + b2)
+ * y2 = LayerNorm output [M, C]; W1 [C, 4C] and W2 [4C, C] are the Keras Dense kernels as stored (bf16 shadow copies); gamma
+ * (layer scale) and rowscale (per-sample drop-path factor) may be NULL.  The [M, 4C] hidden tensor never reaches HBM.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_convnext_mlp_supported(int C, int dtype);
+int iseg_convnext_mlp_fwd(const void* y2, const void* W1, const float* b1, const void* W2, const float* b2, const float* gamma,
+                          const float* rowscale, int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype,
+                          iseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

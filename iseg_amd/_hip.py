@@ -134,6 +134,8 @@ SIGNATURES = {
     "iseg_softmax_focal_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
+    "iseg_convnext_mlp_supported": (_i, [_i, _i]),
+    "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _l, _p]),
 }
 

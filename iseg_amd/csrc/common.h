@@ -213,6 +213,32 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
     dy = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// Cheapest GELU that is still far below bf16 rounding (used by the fused ConvNeXt MLP kernels, whose hidden tile never leaves the
+// CU and is rounded to bf16 as the next MFMA operand): Phi(x) ~ sigmoid(x * (a0 + a1 x^2 + a2 x^4)), coefficients from a minimax
+// fit of x * Phi(x) on [-8, 8] (tools/fit_gelu_sigmoid.py): |gelu error| <= 2.6e-5, |gelu' error| <= 1.1e-4 (bf16 half-ulp at 1 is
+// 2e-3).  One v_exp_f32 + one v_rcp_f32 + 7 plain VALU per element instead of the ~27 issue slots of the erfc form above.
+// The polynomial's x^4 coefficient is negative, so x^2 is clamped at 64 (|x| > 8: sigmoid is saturated either way).
+#define ISEG_GELU_SIG_A0 1.5950157270240881f
+#define ISEG_GELU_SIG_A1 0.07401132728640801f
+#define ISEG_GELU_SIG_A2 (-0.0007030389408329068f)
+__device__ __forceinline__ float gelu_sig(float x) {
+    const float x2 = fminf(x * x, 64.f);
+    constexpr float L = -1.4426950408889634f;      // -log2(e): sigmoid(u) = 1 / (1 + exp2(-u * log2 e))
+    const float p = fmaf(fmaf(ISEG_GELU_SIG_A2 * L, x2, ISEG_GELU_SIG_A1 * L), x2, ISEG_GELU_SIG_A0 * L);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+    return x * s;
+}
+// gelu(x) and d/dx of the SAME approximation: s + x s (1 - s) (a0 + 3 a1 x^2 + 5 a2 x^4)
+__device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
+    const float x2 = fminf(x * x, 64.f);
+    constexpr float L = -1.4426950408889634f;
+    const float p = fmaf(fmaf(ISEG_GELU_SIG_A2 * L, x2, ISEG_GELU_SIG_A1 * L), x2, ISEG_GELU_SIG_A0 * L);
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
+    const float dp = fmaf(fmaf(5.f * ISEG_GELU_SIG_A2, x2, 3.f * ISEG_GELU_SIG_A1), x2, ISEG_GELU_SIG_A0);
+    y = x * s;
+    dy = fmaf(y * dp, 1.0f - s, s);
+}
+
 // exact-erf GELU, as keras.activations.gelu(approximate=False)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -33,11 +33,15 @@ class Dataset:
 
         return Dataset(gen)
 
-    def shuffle(self, buffer_size, seed=0):
+    def shuffle(self, buffer_size, seed=0, reshuffle_each_iteration=True):
+        """tf.data semantics: every new iteration (each epoch of a following .repeat()) draws a different order"""
         src = self
+        epoch = [0]
 
         def gen():
-            rng = random.Random(seed)
+            rng = random.Random(seed * 1000003 + epoch[0])
+            if reshuffle_each_iteration:
+                epoch[0] += 1
             buf = []
             for item in src:
                 buf.append(item)

@@ -28,13 +28,26 @@ def local_rank():
     return int(os.environ.get("LOCAL_RANK", "0"))
 
 
+def _forced():
+    """ISEG_DIST_SINGLE_RANK_COLLECTIVES=1: a world of ONE rank still creates the process group and issues every collective (SyncBN
+    messages, async gradient buckets, broadcasts).  A 1-GPU box can this way drive the real RCCL backend -- stream ordering of the
+    async handles, in-place reduction of flat-buffer slices -- that otherwise only an 8-GPU node would touch."""
+    return os.environ.get("ISEG_DIST_SINGLE_RANK_COLLECTIVES", "0") == "1"
+
+
+def active():
+    """True when collectives have to be issued"""
+    return is_initialized() and (td.get_world_size() > 1 or _forced())
+
+
 def init(backend=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
     if is_initialized():
         return
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1:
+    if ws <= 1 and not _forced():
         return
+    os.environ.setdefault("RANK", "0")
     if backend is None:
         backend = os.environ.get("ISEG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
@@ -48,18 +61,18 @@ def init(backend=None):
 
 
 def all_reduce_sum(t, async_op=False):
-    if world_size() > 1:
+    if active():
         return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
     return None
 
 
 def broadcast(t, src=0):
-    if world_size() > 1:
+    if active():
         td.broadcast(t, src)
 
 
 def barrier():
-    if world_size() > 1:
+    if active():
         td.barrier()
 
 
@@ -83,33 +96,61 @@ class GradReducer:
         if cnt:
             last = store.segments[-1]
             self.buckets.append((lo, last[1] + store.padded(last[2]), cnt))
+        self.uses = None       # id(param) -> ready() calls per step, learnt from the first step
         self.reset()
 
     def reset(self):
-        self.pending = [b[2] for b in self.buckets]
+        self.seen = {}                                  # id(param) -> ready() calls this step
+        self.launched = [False] * len(self.buckets)
         self.handles = []
+        if self.uses is None:
+            self.pending = None                         # first step: nothing is launched before finish()
+        else:
+            self.pending = [0] * len(self.buckets)      # parameters of the bucket that still owe a gradient contribution
+            for pid, n in self.uses.items():
+                if n > 0:
+                    self.pending[self.bucket_of[pid]] += 1
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        self.launched[b] = True
+        self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
 
     def ready(self, *params):
-        if world_size() <= 1:
+        """called by an operator's backward once the kernels that write these parameters' gradients are enqueued.  A parameter
+        used k times in the forward pass (a layer applied twice, a shared table) reports k times; the bucket goes out when every
+        parameter in it has reported as often as it did in the first step, which only counts (static graphs: the count is the
+        same every step).  A report for a bucket that is already on the wire would mean a silently wrong sum, so it raises."""
+        if not active():
             return
         for p in params:
             if p is None:
                 continue
-            b = self.bucket_of.get(id(p))
+            pid = id(p)
+            b = self.bucket_of.get(pid)
             if b is None:
                 continue
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                lo, hi, _ = self.buckets[b]
-                self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
+            c = self.seen[pid] = self.seen.get(pid, 0) + 1
+            if self.launched[b]:
+                raise RuntimeError(f"GradReducer: gradient of {getattr(p, 'iseg_name', '?')} reported after its bucket was all-reduced "
+                                   "(the model used it more often than in the first step); call relearn() after changing the graph")
+            if self.pending is not None and c == self.uses.get(pid, 0):
+                self.pending[b] -= 1
+                if self.pending[b] == 0:
+                    self._launch(b)
+
+    def relearn(self):
+        self.uses = None
+        self.reset()
 
     def finish(self):
         """launch whatever was not triggered by ready() and make the compute stream wait for all buckets"""
-        if world_size() > 1:
-            for b, left in enumerate(self.pending):
-                if left > 0:
-                    lo, hi, _ = self.buckets[b]
-                    self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
+        if active():
+            if self.uses is None:
+                self.uses = dict(self.seen)
+            for b in range(len(self.buckets)):
+                if not self.launched[b]:
+                    self._launch(b)
             for h in self.handles:
                 if h is not None:
                     h.wait()

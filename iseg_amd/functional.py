@@ -343,7 +343,7 @@ class _BatchNormTrainFn(Function):
             K.axpby(sums[C:], _grad(ctx.gamma), 1.0, 1.0, out=_grad(ctx.gamma))
         dist.grads_ready(ctx.gamma, ctx.beta)
         n_total = rows
-        if ctx.sync and dist.world_size() > 1:
+        if ctx.sync and dist.active():
             sums = sums.clone()
             dist.all_reduce_sum(sums)
             n_total = rows * dist.world_size()
@@ -450,8 +450,9 @@ _RNG_COUNTER = [0]
 
 
 def next_seed():
+    """one stream per (global seed, data-parallel rank, draw): replicas must not share dropout / drop-path masks on their shards"""
     _RNG_COUNTER[0] += 1
-    return (nn.seed() * 0x9E3779B97F4A7C15 + _RNG_COUNTER[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return (nn.seed() * 0x9E3779B97F4A7C15 + _RNG_COUNTER[0] * 0xD1B54A32D192ED03 + dist.rank() * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 class _DropoutFn(Function):

@@ -71,19 +71,36 @@ class ModelHelper:
         if dist.rank() != 0:
             return None
         os.makedirs(self.checkpoint_dir, exist_ok=True)
-        path = os.path.join(self.checkpoint_dir, f"id-{time.strftime('%Y%m%d-%H%M%S')}.{POSTFIX}")
+        # the reference's names have one-second resolution (modelhelper.py:201-213); two saves inside one second must not
+        # overwrite each other, so a per-helper counter follows the time stamp (lexicographic order = save order)
+        self._save_count = getattr(self, "_save_count", 0) + 1
+        path = os.path.join(self.checkpoint_dir, f"id-{time.strftime('%Y%m%d-%H%M%S')}-{self._save_count:06d}.{POSTFIX}")
+        while os.path.exists(path):
+            self._save_count += 1
+            path = os.path.join(self.checkpoint_dir, f"id-{time.strftime('%Y%m%d-%H%M%S')}-{self._save_count:06d}.{POSTFIX}")
         torch.save({k: v.detach().cpu() for k, v in self._named_tensors().items()}, path)
         ckpts = self.list_checkpoints()
         for old in ckpts[:-self.max_to_keep] if self.max_to_keep > 0 else []:
             os.remove(old)
         return path
 
-    def restore_checkpoint(self):
+    def restore_checkpoint(self, skip_mismatch=False):
+        """newest checkpoint -> model.  Every variable of the model must be found with its shape (and every stored tensor must
+        have a home) unless skip_mismatch=True, in which case the unmatched names are reported and left untouched."""
         ckpts = self.list_checkpoints()
         if not ckpts:
             return None
         state = torch.load(ckpts[-1], map_location="cpu")
         mine = self._named_tensors()
+        missing = [k for k in mine if k not in state]
+        unexpected = [k for k in state if k not in mine]
+        mismatched = [k for k in state if k in mine and tuple(mine[k].shape) != tuple(state[k].shape)]
+        if missing or unexpected or mismatched:
+            msg = (f"checkpoint {ckpts[-1]}: {len(missing)} model variables not in the file {missing[:5]}, {len(unexpected)} stored "
+                   f"tensors without a variable {unexpected[:5]}, {len(mismatched)} shape mismatches {mismatched[:5]}")
+            if not skip_mismatch:
+                raise ValueError(msg + " (pass skip_mismatch=True to load the rest)")
+            print("WARNING: " + msg)
         for k, v in state.items():
             if k in mine and tuple(mine[k].shape) == tuple(v.shape):
                 mine[k].copy_(v)

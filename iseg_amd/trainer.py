@@ -32,7 +32,7 @@ class TrainableModel:
         if self.store is None or [id(p) for p in self.store.params] != [id(p) for p in _unique(params)]:
             self.store = ParamStore(params)
             model._iseg_store = self.store
-        if dist.world_size() > 1:
+        if dist.active():
             self.store.broadcast_from_rank0()
             for b in model.buffers():
                 dist.broadcast(b, 0)

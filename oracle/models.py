@@ -453,3 +453,29 @@ def multi_scale_inference(fn, x, scale_rates=(1.0,), flip=False):
             part = part + O.resize_bilinear(fn(xs), (H, W))
         total = total + (torch.flip(part, dims=(2,)) if mirrored else part)
     return total / (len(scale_rates) * (2 if flip else 1))
+
+
+# ------------------------------------------------------------------------------------------------------
+# N optimisation steps of CoreTrain's hot loop (core_train.py:141-152) restated on the oracle: forward (batch statistics) ->
+# mean ignore-label CE -> autograd backward -> Keras AdamW (optimizers/modern/adamw.py:13-74) with the poly-decay schedule ->
+# moving-statistics update.  Used by smoke() and tests/test_model_gpu.py as the loss-curve checker.
+# ------------------------------------------------------------------------------------------------------
+def convnext_aspp_adamw_curve(w, x, y, steps, trainable, lr_fn, wd_of, eps=1e-7, beta1=0.9, beta2=0.999, output_stride=32):
+    """w: weight dict (updated in place); trainable: names of the optimised variables; lr_fn(step) -> lr; wd_of(name) -> weight decay.
+    Returns the list of losses, one per step (the loss BEFORE that step's update, like Keras logs it)."""
+    state = {k: (torch.zeros_like(w[k]), torch.zeros_like(w[k])) for k in trainable}
+    curve = []
+    for step in range(steps):
+        wr = {k: (v.clone().requires_grad_(True) if k in state else v) for k, v in w.items()}
+        new_stats = {}
+        out = convnext_aspp_forward(wr, x.to(next(iter(w.values())).dtype), training=True, output_stride=output_stride, new_stats=new_stats)
+        loss = mean_ce_loss(out["logits"], y)
+        loss.backward()
+        curve.append(loss.item())
+        lr = lr_fn(step)
+        for k in trainable:
+            m, v = state[k]
+            nw, nm, nv = O.adamw_step(w[k], wr[k].grad, m, v, step + 1, lr, 1.0, wd_of(k), beta1=beta1, beta2=beta2, eps=eps)
+            w[k], state[k] = nw.detach(), (nm, nv)
+        w.update(new_stats)
+    return curve

@@ -39,13 +39,37 @@ def _worker(rank, world, port, q):
     # bucketed reducer: tiny buckets so that several are in flight
     red = dist.GradReducer(st, bucket_bytes=8 << 10)
     assert len(red.buckets) > 3
+    params = list(reversed(st.params))              # backward order
+    shared = params[0]                              # a parameter the "model" uses twice per step (reports twice)
+    b_shared = red.bucket_of[id(shared)]
+    want = float(sum(range(1, world + 1)))
+    ok_red = True
+    for step in range(3):
+        for p in st.params:
+            p.grad.fill_(float(rank + 1))
+        red.ready(shared)
+        # step 0 only counts uses; later the bucket of `shared` must wait for the second report even when all others are in
+        red.ready(*params[1: len(params) // 2])
+        ok_red = ok_red and not red.launched[b_shared]
+        if step > 0:
+            ok_red = ok_red and any(red.launched)   # buckets completed during "backward" are already on the wire
+        red.ready(shared)
+        if step > 0:
+            ok_red = ok_red and red.launched[b_shared]
+        red.finish()                                # sweeps the buckets whose parameters never reported
+        ok_red = ok_red and all(bool((p.grad == want).all()) for p in st.params)
+    # a report that arrives after its bucket went out must raise, not corrupt the sum
     for p in st.params:
         p.grad.fill_(float(rank + 1))
-    params = list(reversed(st.params))
-    red.ready(*params[: len(params) // 2])           # half signalled during "backward", the rest swept by finish()
+    red.ready(shared)
+    red.ready(*params[1: len(params) // 2])
+    red.ready(shared)
+    try:
+        red.ready(shared)
+        ok_red = False
+    except RuntimeError:
+        pass
     red.finish()
-    want = float(sum(range(1, world + 1)))
-    ok_red = all(bool((p.grad == want).all()) for p in st.params)
     # packed SyncBN message: [sum, sumsq, count]
     x = torch.arange(8, dtype=torch.float32).reshape(4, 2) + 10 * rank
     packed = torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([4.0])])

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _step(rank, world, port, q, size, batch):
+def _step(rank, world, port, q, size, batch, rccl_single=False):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +27,11 @@ def _step(rank, world, port, q, size, batch):
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                           ISEG_DIST_BACKEND="gloo")
     else:
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ISEG_DIST_BACKEND"):
             os.environ.pop(k, None)
+        if rccl_single:     # one rank, every collective issued for real on the RCCL backend
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                              ISEG_DIST_SINGLE_RANK_COLLECTIVES="1", ISEG_DIST_BACKEND="nccl")
     from iseg_amd import dist, nn
     from iseg_amd.core_optimizer import get_optimizer
     from iseg_amd.data import synthetic_batch
@@ -38,7 +41,9 @@ def _step(rank, world, port, q, size, batch):
     from tests.util_models import randomize_parameters
 
     nn.set_compute_dtype(torch.float32)
-    strat = Strategy(one_device=(world == 1))
+    strat = Strategy(one_device=(world == 1 and not rccl_single))
+    if rccl_single:
+        assert dist.active() and torch.distributed.get_backend() == "nccl" and dist.world_size() == 1
     model = convnext_tiny_aspp(num_class=21, build_input_size=size, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0)
     randomize_parameters(model, 0)
     opt = get_optimizer(strat, initial_lr=1e-3, epoch_steps=10, train_epoch=1, optimizer="sgd", sgd_momentum_rate=0.9)
@@ -54,17 +59,19 @@ def _step(rank, world, port, q, size, batch):
     out = {p.iseg_name: p.detach().cpu().numpy().copy() for p in model.parameters()}
     out.update({b.iseg_name: b.detach().cpu().numpy().copy() for b in model.buffers() if hasattr(b, "iseg_name")})
     miou = tm.metric_results()["output_1_IOU"]
+    if rccl_single:
+        assert tm.reducer.uses, "the reducer never saw a gradient report"
     q.put((rank, world, losses, out, miou))
-    if world > 1:
+    if world > 1 or rccl_single:
         dist.barrier()
         torch.distributed.destroy_process_group()
 
 
-def _run(world, size, batch):
+def _run(world, size, batch, rccl_single=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_step, args=(r, world, port, q, size, batch)) for r in range(world)]
+    procs = [ctx.Process(target=_step, args=(r, world, port, q, size, batch, rccl_single)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -89,3 +96,19 @@ def test_two_ranks_equal_one_rank_full_batch(cuda):
         assert abs(avg - single[2][step]) < 1e-4 * max(1.0, abs(single[2][step]))
     for k in double[0][3]:
         assert (double[0][3][k] == double[1][3][k]).all(), f"ranks diverged on {k}"
+
+
+def test_rccl_backend_single_rank_collectives_are_identity(cuda):
+    """the `nccl` (= RCCL) branch of dist.py on real hardware: one rank, but the process group exists and EVERY collective of the step
+    is issued -- weight / buffer broadcast, packed SyncBN all-reduces on the compute stream, the asynchronous gradient buckets launched
+    from inside backward on RCCL's stream and waited for before the optimizer.  A sum over one rank is the identity, so weights, moving
+    statistics and losses after two steps must equal the collective-free run (up to the last-bit noise of the in-block LDS float atomics
+    in the parameter-gradient reductions); a missing stream dependency shows up as a gross difference."""
+    size, batch = (64, 64), 4
+    plain = _run(1, size, batch)[0]
+    rccl = _run(1, size, batch, rccl_single=True)[0]
+    for a, b in zip(plain[2], rccl[2]):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(a)), (plain[2], rccl[2])
+    for k in plain[3]:
+        d = float(abs(plain[3][k] - rccl[3][k]).max())
+        assert d <= 1e-5 * max(float(abs(plain[3][k]).max()), 1e-3), (k, d)
