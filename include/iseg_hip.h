@@ -388,13 +388,24 @@ int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const
  * Fused ConvNeXt MLP (backbones/convnext.py:51-63 Block.call: pwconv1 -> act (exact GELU) -> pwconv2 -> gamma -> drop_path ->
  * + input) for the wide stages, bf16 storage, C = 96 / 192 (iseg_convnext_mlp_supported):
  *     out[m][:] = residual[m][:] + rowscale[m / rows_per_group] * gamma[:] * (gelu(y2[m][:] @ W1 + b1) @ W2 + b2)
- * y2 = LayerNorm output [M, C]; W1 [C, 4C] and W2 [4C, C] are the Keras Dense kernels as stored (bf16 shadow copies); gamma
- * (layer scale) and rowscale (per-sample drop-path factor) may be NULL.  The [M, 4C] hidden tensor never reaches HBM.
+ * y2 = LayerNorm output [M, C].  The [M, 4C] hidden tensor never reaches HBM in the forward pass and is recomputed by the backward
+ * chain.  The kernels stream the weights as bf16 *tiled* images (the byte order of their LDS ring stages):
+ *   iseg_convnext_mlp_prep      fp32 Keras kernels W1 [C, 4C], W2 [4C, C] (+ layer scale gamma [C] or NULL) -> fw_tiled
+ *                               (iseg_convnext_mlp_tiled_bytes(C, 0) bytes) and, when bw_tiled != NULL, bw_tiled (.. (C, 1) bytes; it
+ *                               holds W1, W2 * gamma and W1 again in the orders the backward products read them); once per step
+ *   iseg_convnext_mlp_fwd       the formula above; gamma / rowscale (per-sample drop-path factor) may be NULL
+ *   iseg_convnext_mlp_bwd       dbr [M, C] = rowscale * d(out)  ->  g [M, 4C] = gelu(h), dh [M, 4C] = (dbr @ (W2 gamma)^T) * gelu'(h)
+ *                               (the operands of the two weight-gradient GEMMs) and dy2 [M, C] = dh @ W1^T
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_convnext_mlp_supported(int C, int dtype);
-int iseg_convnext_mlp_fwd(const void* y2, const void* W1, const float* b1, const void* W2, const float* b2, const float* gamma,
+size_t iseg_convnext_mlp_tiled_bytes(int C, int backward);
+int iseg_convnext_mlp_prep(const float* W1, const float* W2, const float* gamma, void* fw_tiled, void* bw_tiled, int C,
+                           iseg_stream_t stream);
+int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1, const float* b2, const float* gamma,
                           const float* rowscale, int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype,
                           iseg_stream_t stream);
+int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled, const float* b1, void* g, void* dh, void* dy2,
+                          int64_t M, int C, int dtype, iseg_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -135,7 +135,10 @@ SIGNATURES = {
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
     "iseg_convnext_mlp_supported": (_i, [_i, _i]),
-    "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
+    "iseg_convnext_mlp_tiled_bytes": (_z, [_i, _i]),
+    "iseg_convnext_mlp_prep": (_i, [_p, _p, _p, _p, _p, _i, _p]),
+    "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
+    "iseg_convnext_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _l, _p]),
 }
 
@@ -150,6 +153,12 @@ def lib():
             raise HipLibraryMissing(
                 f"{LIB_PATH} not found: build it with `python -m iseg_amd.build` (hipcc --offload-arch=gfx950). "
                 "iseg_amd has no CPU or torch fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1; the process must hold ONE HIP runtime, and the device
+        # pointers this library receives come from torch's.  Loading torch first makes the dynamic linker resolve our DT_NEEDED
+        # entries (same SONAMEs) to the copies torch already mapped; the other order leaves two runtimes in the process and every
+        # launch from here fails with "no ROCm-capable device is detected" (seen when build() and smoke() shared one process).
+        import torch  # noqa: F401
+
         dll = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(dll, name)

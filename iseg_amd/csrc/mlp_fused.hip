@@ -2,23 +2,36 @@
 //     out = x + rowscale[sample] * gamma * (gelu(y2 @ W1 + b1) @ W2 + b2)
 // for the wide, shallow stages (C = 96 / 192; M = 262144 / 65536 rows at the flagship size), where the [M, 4C] hidden tensor is
 // 4x the activation and the un-fused pair of GEMMs is a pure HBM stream (two writes and two reads of 200 MB per block at stage 0).
-// Here the hidden tile never leaves the CU.
+// Here the hidden tile never leaves the CU in the forward pass, and the backward pass recomputes it.
 //
 // Everything is computed TRANSPOSED so that the first product's accumulator is directly the second product's MFMA operand
 // (v_mfma_f32_32x32x16_bf16: the accumulator has its column on the lane and its rows in the 16 registers; a following MFMA that
 // sums over those rows takes registers 8s..8s+7 as the B fragment of k-step s, no lane movement, no LDS):
-//     H^T[hid][m] = W1^T[hid][c] . y2^T[c][m]        A = W1 slab (transposed LDS read), B = y2 rows (registers, loaded once)
+//     H^T[hid][m] = W1^T[hid][c] . y2^T[c][m]        A = W1 slab, B = y2 rows (registers, loaded once)
 //     G^T        = gelu(H^T + b1)                     in registers, rounded to bf16
-//     O^T[c][m] += W2^T[c][hid] . G^T[hid][m]         A = W2 slab (transposed LDS read), B = G^T
-// A wavefront owns 32 rows (m) and ALL C output channels (C/32 accumulator blocks); a workgroup = 8 wavefronts = 256 rows.  The
-// weights stream through a 3-stage LDS ring in slabs of 32 hidden units (global_load_lds_dwordx4, counted vmcnt, one raw s_barrier
-// per stage -- the ring protocol of gemm_dma.h).  Both weight images are stored [k][32 MN] with 64-byte rows: a transposed read
-// (ds_read_b64_tr_b16) of one 32-lane half covers 4 rows x 64 B = all 64 banks once, so no swizzle is needed:
-//     W1 slab  [c = 0..C-1][32 hid]                    straight 64-byte pieces of the Keras [C][4C] kernel rows
-//     W2 slab  [cb = 0..C/32-1][32 hid][32 c]          64-byte pieces of the Keras [4C][C] kernel rows, regrouped by the DMA
-// Per slab and wavefront: C/16 + C/16 MFMAs (32 cycles each) and 16 gelu evaluations per lane (gelu_sig: ~44 issue cycles each)
-// -> VALU-bound at C = 96, balanced at C = 192; two wavefronts per SIMD let one's gelu overlap the other's MFMAs.
-// The backward kernels (below) recompute H^T from y2 instead of reading a saved [M, 4C] tensor.
+//     O^T[c][m] += W2^T[c][hid] . G^T[hid][m]         A = W2 slab, B = G^T
+// A wavefront owns 32 rows (m) and ALL C output channels (C/32 accumulator blocks).  The weights stream through a 3-stage LDS ring
+// in slabs of 32 hidden units (global_load_lds_dwordx4, counted vmcnt, one raw s_barrier per stage -- the ring protocol of
+// gemm_dma.h).
+//
+// Weight images.  A tiny per-step kernel (iseg_convnext_mlp_prep) rewrites the fp32 master kernels as bf16 *tiled* copies that are
+// byte-for-byte the LDS images, slab after slab, so a ring stage is ONE contiguous run of 1-KiB pieces (piece p, lane l <- 16 bytes at
+// p * 1024 + 16 l: perfectly coalesced DMA, no per-lane address math) and every A fragment is ONE plain ds_read_b128 of
+// [row (lane & 31)][k-half (lane >> 5)] from a [32 rows][16 k] piece -- a wavefront reads 1 KiB contiguous, conflict-free:
+//     A1 (H = y2 W1):            [kk < C/16][32 hid][16 c]            value W1[16 kk + k][hid]
+//     A2 (O = G W2):             [cb < C/32][s < 2][32 c][16 k*]      value W2[hid(s, k*)][32 cb + c]
+//     A3 (dG = dbr (W2 gamma)^T):[kk < C/16][32 hid][16 c]            value W2[hid][16 kk + k] * gamma[16 kk + k]
+//     A4 (dy2 = dH W1^T):        [cb < C/32][s < 2][32 c][16 k*]      value W1[32 cb + c][hid(s, k*)]
+// k* is the accumulator's register order: position 8 h + j of k-step s is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3) of the slab.
+// (Plain C++ loads matter: hipcc orders a ds_read *builtin* behind every LDS-DMA in flight with s_waitcnt vmcnt(0) -- it carries no
+// alias information -- which drained the ring on every stage in the first version of this file, built on ds_read_b64_tr_b16.)
+// RING NOTE: inside the ring loop every LDS read must be a bf16x8 load like the fragments.  A float4-typed read of the bias copy made
+// hipcc put s_waitcnt vmcnt(0) in front of it (it may alias the LDS-DMA as far as its alias info goes), draining the ring every
+// stage; tools/check_mlp_isa.py greps the ISA for that.
+// Forward buffer FW = [slab][A1 | A2] (C * 128 bytes per slab), backward buffer BW = [slab][A1 | A3 | A4] (C * 192 bytes).
+//
+// Per slab and wavefront: C/16 + C/16 MFMAs (32 cycles each) and 16 gelu evaluations per lane -> VALU-bound at C = 96, balanced at
+// C = 192; two wavefronts per SIMD let one's gelu overlap the other's MFMAs.
 #include "common.h"
 #include "iseg_hip.h"
 
@@ -27,50 +40,60 @@ namespace {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
-
-// A fragment (32 rows x 16 k) of v_mfma_f32_32x32x16_bf16 from a [k][32 MN] image with 64-byte rows: lane (r = l & 31, h = l >> 5)
-// needs k = 8h + j (j = 0..7) of MN row r.  One ds_read_b64_tr_b16 hands each lane 4 consecutive k rows of its column; `a0` is the
-// lane's address for the first four, `second` the byte distance to the next four.
-__device__ __forceinline__ bf16x8 tr_frag(const char* a0, int second) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(a0 + second));
-    bf16x8 f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f[i] = lo[i];
-        f[4 + i] = hi[i];
-    }
-    return f;
-}
 
 constexpr int MLP_NS = 3;                 // ring stages
 constexpr int OUT_SLAB = 32 * 36 * 4;     // per-wavefront epilogue slab: 32 rows x (32 + 4 pad) floats
 
-template <int C, int SUB> struct MlpGeom {
+// NIMG images of C * 64 bytes per 32-hidden-unit slab, SUB slabs per ring stage, WAVES wavefronts of 32 rows.  Pieces of a stage are
+// dealt round-robin over the wavefronts; when PIECES % WAVES != 0 the first NHI wavefronts issue one piece more, and each wavefront
+// counts its own DMAs in the vmcnt wait.
+template <int C, int SUB, int WAVES, int NIMG> struct MlpGeom {
     static constexpr int HID = 4 * C, KK = C / 16, CB = C / 32;
-    static constexpr int SLAB = 2 * C * 64;            // bytes per 32 hidden units: W1 image (C*64), then W2 image (C*64)
+    static constexpr int IMG = C * 64;
+    static constexpr int SLAB = NIMG * IMG;
     static constexpr int STAGE = SUB * SLAB;
-    static constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8;
+    static constexpr int PIECES = STAGE / 1024;
+    static constexpr int PLO = PIECES / WAVES, NHI = PIECES % WAVES, PHI = PLO + (NHI ? 1 : 0);
     static constexpr int NST = HID / (32 * SUB);
-    static constexpr int RING = MLP_NS * STAGE > 8 * OUT_SLAB ? MLP_NS * STAGE : 8 * OUT_SLAB;
+    static constexpr int RING = MLP_NS * STAGE > WAVES * OUT_SLAB ? MLP_NS * STAGE : WAVES * OUT_SLAB;
     static constexpr int LDS = RING + HID * 4;         // + b1 as floats
-    static_assert(C % 32 == 0 && PIECES % 8 == 0 && HID % (32 * SUB) == 0, "geometry");
+    static_assert(C % 32 == 0 && STAGE % 1024 == 0 && HID % (32 * SUB) == 0 && PLO >= 1 && NST >= MLP_NS - 1, "geometry");
 };
 
+__device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// One ring stage = PIECES consecutive KiB of the tiled weight buffer; wavefront `wid` moves pieces wid, wid + WAVES, ...
+template <class G, int WAVES> struct RingFeeder {
+    const char* src;      // this lane's 16 bytes of the wavefront's first piece of the next stage to issue
+    int wid;
+    __device__ __forceinline__ RingFeeder(const void* tiled, int wid_, int lane) : src((const char*)tiled + wid_ * 1024 + lane * 16), wid(wid_) {}
+    __device__ __forceinline__ void issue(char* smem, int stage) {
+        char* dst = smem + stage * G::STAGE + wid * 1024;
+#pragma unroll
+        for (int i = 0; i < G::PLO; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(src + i * WAVES * 1024), (lds_void_ptr)(dst + i * WAVES * 1024), 16, 0, 0);
+        if (G::NHI && wid < G::NHI)
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)(src + G::PLO * WAVES * 1024), (lds_void_ptr)(dst + G::PLO * WAVES * 1024), 16, 0, 0);
+        src += G::STAGE;
+    }
+};
+
+
+#define MLP_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
 template <int C, int SUB>
-__global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W1,
-                                                               const float* __restrict__ b1, const bf16_t* __restrict__ W2,
-                                                               const float* __restrict__ b2, const float* __restrict__ gamma,
-                                                               const float* __restrict__ rowscale, int64_t rows_per_group,
-                                                               const bf16_t* __restrict__ R, bf16_t* __restrict__ O, int64_t M) {
-    using G = MlpGeom<C, SUB>;
-    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, SLAB = G::SLAB, STAGE = G::STAGE, PPW = G::PPW, NST = G::NST, NS = MLP_NS;
+__global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const void* __restrict__ FW,
+                                                               const float* __restrict__ b1, const float* __restrict__ b2,
+                                                               const float* __restrict__ gamma, const float* __restrict__ rowscale,
+                                                               int64_t rows_per_group, const bf16_t* __restrict__ R, bf16_t* __restrict__ O,
+                                                               int64_t M) {
+    using G = MlpGeom<C, SUB, 8, 2>;
+    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = MLP_NS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const b1s = reinterpret_cast<float*>(smem + G::RING);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r = lane & 31, h = lane >> 5, q = (lane >> 2) & 3;
+    const int r = lane & 31, h = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.x * 256 + wid * 32;
 
     // ---- B operand of the first product: this wavefront's 32 rows of y2, all C channels, straight from global memory ----
@@ -83,31 +106,11 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
         for (int kk = 0; kk < KK; ++kk) yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
     }
     for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+    // the loads above must have landed before the ring starts (keeps the compiler's own vmcnt bookkeeping out of the loop)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(yf[kk]));
 
-    // ---- DMA sources: piece pi = wid + 8 i of a stage; 1 KiB = 16 image rows of 64 B, lane l fills (row l >> 2, 16-B chunk l & 3) ----
-    const bf16_t* src[PPW];
-    int step[PPW], dst[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int pi = wid + 8 * i;
-        const int sub = pi / (C / 8), qq = pi % (C / 8);
-        dst[i] = sub * SLAB + qq * 1024;
-        if (qq < C / 16) {      // W1 image rows c = 16 qq .. + 15
-            src[i] = W1 + (int64_t)(16 * qq + (lane >> 2)) * HID + 32 * sub + 8 * (lane & 3);
-            step[i] = 32 * SUB;
-        } else {                // W2 image rows R = (cb, hid): piece covers half a 32x32 block
-            const int Rr = 16 * (qq - C / 16) + (lane >> 2);
-            src[i] = W2 + (int64_t)(32 * sub + (Rr & 31)) * C + 32 * (Rr >> 5) + 8 * (lane & 3);
-            step[i] = 32 * SUB * C;
-        }
-    }
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)src[i], (lds_void_ptr)(smem + stage * STAGE + dst[i]), 16, 0, 0);
-            src[i] += step[i];
-        }
-    };
+    RingFeeder<G, 8> feed(FW, wid, lane);
 
     f32x16 acc[CB];
 #pragma unroll
@@ -115,21 +118,19 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[cb][j] = 0.f;
 
-    const int colb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    const int base1 = (8 * h + q) * 64 + colb;      // first product: k rows 16 kk + 8 h + {q, q + 4}
-    const int base2 = (4 * h + q) * 64 + colb;      // second product: k rows 16 s + 4 h + {q, q + 8}  (the accumulator's register order)
+    const int fo = r * 32 + h * 16;      // this lane's fragment inside a [32 rows][16 k] piece
 
     auto compute = [&](int stage, int kt) {
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
-            const char* img1 = smem + stage * STAGE + sub * SLAB;
-            const char* img2 = img1 + C * 64;
+            const char* img1 = smem + stage * STAGE + sub * SLAB + fo;
+            const char* img2 = img1 + IMG;
             f32x16 hacc;
             {
                 const float* bb = b1s + 32 * (kt * SUB + sub) + 4 * h;      // register 4 i + u is hidden row 8 i + 4 h + u
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float4 v = *reinterpret_cast<const float4*>(bb + 8 * i);
+                    const float4 v = __builtin_bit_cast(float4, lds_frag(reinterpret_cast<const char*>(bb + 8 * i)));      // (typed like the fragments: see RING NOTE)
                     hacc[4 * i] = v.x;
                     hacc[4 * i + 1] = v.y;
                     hacc[4 * i + 2] = v.z;
@@ -137,8 +138,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(img1 + kk * 1024 + base1, 256), yf[kk], hacc, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img1 + kk * 1024), yf[kk], hacc, 0, 0, 0);
             bf16x8 gf[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) gf[j >> 3][j & 7] = (bf16_t)gelu_sig(hacc[j]);
@@ -146,22 +146,25 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(img2 + cb * 2048 + s * 1024 + base2, 512), gf[s], acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img2 + (2 * cb + s) * 1024), gf[s], acc[cb], 0, 0, 0);
         }
     };
 
     // ---- ring: NS - 1 stages in flight, one barrier per stage (gemm_dma.h) ----
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p)
-        if (p < NST) issue(p);
+    for (int p = 0; p < NS - 1; ++p) feed.issue(smem, p);
     int stage = 0, fill = NS - 1;
     for (int kt = 0; kt < NST; ++kt) {
-        if (NST - 1 - kt >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NST - 1 - kt >= NS - 2) {
+            if (G::NHI && wid < G::NHI) MLP_WAIT((NS - 2) * G::PHI);
+            else MLP_WAIT((NS - 2) * G::PLO);
+        } else {
+            MLP_WAIT(0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + NS - 1 < NST) issue(fill);
+        if (kt + NS - 1 < NST) feed.issue(smem, fill);
         compute(stage, kt);
         stage = stage + 1 == NS ? 0 : stage + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
@@ -207,34 +210,284 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward chain of the same MLP.  Nothing [M, 4C]-shaped was saved by the forward pass: the pre-activation is recomputed from y2, and
+//     H^T  = W1^T . y2^T + b1            G^T = gelu(H^T),  G'^T = gelu'(H^T)                       (as in the forward kernel)
+//     dG^T = (W2 gamma)[hid][c] . dbr^T  A = A3, B = dbr rows (registers)
+//     dH^T = dG^T o G'^T                 in registers, rounded to bf16 = B operand of
+//     dy2^T[c][m] += W1[c][hid] . dH^T   A = A4
+// G and dH leave the CU once, as bf16 [M, 4C] operands of the two weight-gradient GEMMs (Z = G^T dbr, dW1 = y2^T dH); dy2 [M, C] goes to
+// the LayerNorm backward.  The accumulator layout (hidden units 8 i + 4 h + u in register 4 i + u of lane half h) is turned into 16-byte
+// row pieces by one v_permlane32_swap per packed dword (lane halves exchange their odd / even groups).
+// WAVES = 8 (C = 96, two wavefronts per SIMD share 256 registers each) or 4 (C = 192: y2 and dbr fragments + dy2 accumulators = 192
+// registers, one wavefront per SIMD).
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v;
+    v[0] = (bf16_t)lo;
+    v[1] = (bf16_t)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// accumulator registers (hidden unit 8 i + 4 h + u in v[4 i + u]) -> the lane's two 16-byte row pieces: hidden units 8 h .. 8 h + 7 and
+// 16 + 8 h .. 16 + 8 h + 7 of row (lane & 31)
+__device__ __forceinline__ void acc_to_row_pieces(const float* v, uint4& p0, uint4& p1) {
+    uint32_t d[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+    // groups i = 0, 1 (dwords 0..3) and i = 2, 3 (dwords 4..7): swap the upper half's group k with the lower half's group k + 1
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            auto sw = __builtin_amdgcn_permlane32_swap(d[4 * pr + w], d[4 * pr + 2 + w], false, false);
+            d[4 * pr + w] = sw[0];
+            d[4 * pr + 2 + w] = sw[1];
+        }
+    p0 = make_uint4(d[0], d[1], d[2], d[3]);
+    p1 = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+template <int C, int SUB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ D,
+                                                                      const void* __restrict__ BW, const float* __restrict__ b1,
+                                                                      bf16_t* __restrict__ Gout, bf16_t* __restrict__ DHout,
+                                                                      bf16_t* __restrict__ DY, int64_t M) {
+    using G = MlpGeom<C, SUB, WAVES, 3>;
+    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = MLP_NS;
+    constexpr int STORES = 4 * SUB;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* const b1s = reinterpret_cast<float*>(smem + G::RING);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * (32 * WAVES) + wid * 32;
+    const bool active = m0 < M;             // wave-uniform: an inactive wavefront still feeds the ring and joins every barrier
+
+    bf16x8 yf[KK], df[KK];
+    {
+        int64_t row = m0 + r;
+        row = row < M ? row : M - 1;
+        const bf16_t* yp = Y + row * C + 8 * h;
+        const bf16_t* dp = D + row * C + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
+            df[kk] = *reinterpret_cast<const bf16x8*>(dp + 16 * kk);
+        }
+    }
+    for (int i = tid; i < HID; i += 64 * WAVES) b1s[i] = b1[i];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(yf[kk]), "v"(df[kk]));
+
+    RingFeeder<G, WAVES> feed(BW, wid, lane);
+
+    f32x16 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[cb][j] = 0.f;
+
+    const int fo = r * 32 + h * 16;
+    // this lane's 16-byte pieces of row m0 + r of G / dH: hidden units 8 h .. + 7 and 16 + 8 h .. + 7 of the current slab
+    const bool row_ok = m0 + r < M;
+    const int64_t row_o = (row_ok ? m0 + r : 0) * HID + 8 * h;
+
+    auto compute = [&](int stage, int kt) {
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            const char* img1 = smem + stage * STAGE + sub * SLAB + fo;
+            const char* img3 = img1 + IMG;
+            const char* img4 = img1 + 2 * IMG;
+            f32x16 hacc, dacc;
+            {
+                const float* bb = b1s + 32 * (kt * SUB + sub) + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 v = __builtin_bit_cast(float4, lds_frag(reinterpret_cast<const char*>(bb + 8 * i)));      // (typed like the fragments: see RING NOTE)
+                    hacc[4 * i] = v.x;
+                    hacc[4 * i + 1] = v.y;
+                    hacc[4 * i + 2] = v.z;
+                    hacc[4 * i + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dacc[j] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img1 + kk * 1024), yf[kk], hacc, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img3 + kk * 1024), df[kk], dacc, 0, 0, 0);
+            float gv[16], dv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float gd;
+                gelu_sig_both(hacc[j], gv[j], gd);
+                dv[j] = dacc[j] * gd;
+            }
+            bf16x8 hf[2];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) hf[j >> 3][j & 7] = (bf16_t)dv[j];
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img4 + (2 * cb + s) * 1024), hf[s], acc[cb], 0, 0, 0);
+            uint4 g0, g1, d0, d1;
+            acc_to_row_pieces(gv, g0, g1);
+            acc_to_row_pieces(dv, d0, d1);
+            if (row_ok) {
+                const int64_t o = row_o + 32 * (kt * SUB + sub);
+                *reinterpret_cast<uint4*>(Gout + o) = g0;
+                *reinterpret_cast<uint4*>(Gout + o + 16) = g1;
+                *reinterpret_cast<uint4*>(DHout + o) = d0;
+                *reinterpret_cast<uint4*>(DHout + o + 16) = d1;
+            }
+        }
+    };
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) feed.issue(smem, p);
+    int stage = 0, fill = NS - 1;
+    for (int kt = 0; kt < NST; ++kt) {
+        // in flight behind this wait: the next stage's DMAs and (active wavefronts) the previous stage's G / dH stores
+        if (NST - 1 - kt >= NS - 2) {
+            if (active) {
+                if (G::NHI && wid < G::NHI) MLP_WAIT((NS - 2) * G::PHI + STORES);
+                else MLP_WAIT((NS - 2) * G::PLO + STORES);
+            } else {
+                if (G::NHI && wid < G::NHI) MLP_WAIT((NS - 2) * G::PHI);
+                else MLP_WAIT((NS - 2) * G::PLO);
+            }
+        } else {
+            MLP_WAIT(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + NS - 1 < NST) feed.issue(smem, fill);
+        if (active) compute(stage, kt);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // ---- dy2^T blocks -> per-wavefront LDS slab -> bf16 rows ----
+    float* const slab = reinterpret_cast<float*>(smem + wid * OUT_SLAB);
+    const int er = lane >> 1, eh = lane & 1;
+    const int64_t m = m0 + er;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(slab + r * 36 + 8 * i + 4 * h) = make_float4(acc[cb][4 * i], acc[cb][4 * i + 1], acc[cb][4 * i + 2], acc[cb][4 * i + 3]);
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(slab + er * 36 + 16 * eh + 4 * i);
+            v[4 * i] = t.x;
+            v[4 * i + 1] = t.y;
+            v[4 * i + 2] = t.z;
+            v[4 * i + 3] = t.w;
+        }
+        if (m < M) {
+            const int c0 = 32 * cb + 16 * eh;
+            store8<bf16_t>(DY + m * C + c0, v);
+            store8<bf16_t>(DY + m * C + c0 + 8, v + 8);
+        }
+    }
+}
+
+// fp32 master kernels -> the tiled bf16 images (see the header comment).  One thread per image element.
+__global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ gamma,
+                                         bf16_t* __restrict__ FW, bf16_t* __restrict__ BW, int C) {
+    const int HID = 4 * C, per_img = C * 32, nslab = HID / 32;
+    const int nfw = nslab * 2 * per_img, nbw = BW ? nslab * 3 * per_img : 0;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfw + nbw; e += gridDim.x * blockDim.x) {
+        const bool bw = e >= nfw;
+        const int i = bw ? e - nfw : e, nimg = bw ? 3 : 2;
+        const int slab = i / (nimg * per_img), rem = i % (nimg * per_img);
+        const int img = rem / per_img, x = rem % per_img;
+        const int piece = x / 512, y = x % 512, rr = y / 16, kq = y % 16, hh = kq / 8, j = kq % 8;
+        // image kinds: 0 = A1, 1 = A2 (forward) ; 0 = A1, 1 = A3, 2 = A4 (backward)
+        const int kind = bw ? (img == 0 ? 1 : img + 2) : img + 1;      // 1 = A1, 2 = A2, 3 = A3, 4 = A4
+        float v;
+        if (kind == 1 || kind == 3) {
+            const int hid = 32 * slab + rr, c = 16 * piece + kq;
+            v = kind == 1 ? W1[(int64_t)c * HID + hid] : W2[(int64_t)hid * C + c] * (gamma ? gamma[c] : 1.f);
+        } else {
+            const int cb = piece / 2, s = piece % 2;
+            const int c = 32 * cb + rr, hid = 32 * slab + 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+            v = kind == 2 ? W2[(int64_t)hid * C + c] : W1[(int64_t)c * HID + hid];
+        }
+        (bw ? BW : FW)[i] = (bf16_t)v;
+    }
+}
+
 template <int C, int SUB>
-int launch_mlp_fwd(const void* y2, const void* W1, const float* b1, const void* W2, const float* b2, const float* gamma, const float* rowscale,
+int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float* b2, const float* gamma, const float* rowscale,
                    int64_t rows_per_group, const void* residual, void* out, int64_t M, hipStream_t s) {
-    using G = MlpGeom<C, SUB>;
+    using G = MlpGeom<C, SUB, 8, 2>;
     static const bool raised = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_fwd_kernel<C, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    G::LDS) == hipSuccess;
     }();
     (void)raised;
     const int grid = (int)ceil_div64(M, 256);
-    hipLaunchKernelGGL((convnext_mlp_fwd_kernel<C, SUB>), dim3(grid), dim3(512), G::LDS, s, (const bf16_t*)y2, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2,
-                       gamma, rowscale, rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M);
+    hipLaunchKernelGGL((convnext_mlp_fwd_kernel<C, SUB>), dim3(grid), dim3(512), G::LDS, s, (const bf16_t*)y2, FW, b1, b2, gamma, rowscale,
+                       rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M);
     return iseg_check_launch("iseg_convnext_mlp_fwd");
+}
+
+template <int C, int SUB, int WAVES>
+int launch_mlp_bwd(const void* y2, const void* dbr, const void* BW, const float* b1, void* g, void* dh, void* dy2, int64_t M, hipStream_t s) {
+    using G = MlpGeom<C, SUB, WAVES, 3>;
+    static const bool raised = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
+    }();
+    (void)raised;
+    const int grid = (int)ceil_div64(M, 32 * WAVES);
+    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, (const bf16_t*)dbr, BW, b1,
+                       (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M);
+    return iseg_check_launch("iseg_convnext_mlp_bwd");
 }
 
 }  // namespace
 
 extern "C" int iseg_convnext_mlp_supported(int C, int dtype) { return dtype == ISEG_BF16 && (C == 96 || C == 192) ? 1 : 0; }
 
-extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* W1, const float* b1, const void* W2, const float* b2, const float* gamma,
+extern "C" size_t iseg_convnext_mlp_tiled_bytes(int C, int backward) { return (size_t)(backward ? 3 : 2) * 4 * C * C * 2; }
+
+extern "C" int iseg_convnext_mlp_prep(const float* W1, const float* W2, const float* gamma, void* fw_tiled, void* bw_tiled, int C,
+                                      hipStream_t stream) {
+    ISEG_REQUIRE(W1 && W2 && fw_tiled && C > 0 && C % 32 == 0, "iseg_convnext_mlp_prep: bad arguments");
+    const int total = (bw_tiled ? 5 : 2) * 4 * C * C;
+    hipLaunchKernelGGL(convnext_mlp_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, W1, W2, gamma, (bf16_t*)fw_tiled,
+                       (bf16_t*)bw_tiled, C);
+    return iseg_check_launch("iseg_convnext_mlp_prep");
+}
+
+extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1, const float* b2, const float* gamma,
                                      const float* rowscale, int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype,
                                      hipStream_t stream) {
     ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_fwd: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
-    ISEG_REQUIRE(y2 && W1 && b1 && W2 && b2 && residual && out && M > 0, "iseg_convnext_mlp_fwd: null operand or empty problem");
+    ISEG_REQUIRE(y2 && fw_tiled && b1 && b2 && residual && out && M > 0, "iseg_convnext_mlp_fwd: null operand or empty problem");
     ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_fwd: rowscale needs rows_per_group > 0");
-    ISEG_REQUIRE(((uintptr_t)y2 % 16 == 0) && ((uintptr_t)W1 % 16 == 0) && ((uintptr_t)W2 % 16 == 0) && ((uintptr_t)residual % 16 == 0) &&
-                     ((uintptr_t)out % 16 == 0) && ((uintptr_t)b1 % 16 == 0),
+    ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1) & 15) == 0,
                  "iseg_convnext_mlp_fwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_fwd<96, 2>(y2, W1, b1, W2, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
-    return launch_mlp_fwd<192, 1>(y2, W1, b1, W2, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    if (C == 96) return launch_mlp_fwd<96, 2>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    return launch_mlp_fwd<192, 1>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+}
+
+extern "C" int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled, const float* b1, void* g, void* dh, void* dy2,
+                                     int64_t M, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_bwd: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(y2 && dbr && bw_tiled && b1 && g && dh && dy2 && M > 0, "iseg_convnext_mlp_bwd: null operand or empty problem");
+    ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dbr | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)g | (uintptr_t)dh | (uintptr_t)dy2) & 15) == 0,
+                 "iseg_convnext_mlp_bwd: operands must be 16-byte aligned");
+    if (C == 96) return launch_mlp_bwd<96, 2, 8>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
+    return launch_mlp_bwd<192, 1, 4>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
 }

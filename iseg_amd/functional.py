@@ -625,10 +625,18 @@ class _ConvNeXtBlockFn(Function):
         # the pw2 weight gradient (83+147+185 us): the transform sits on the load->LDS critical path.  a_act stays available.
         # h holds gelu'(pre-activation), not the pre-activation: the pw1 epilogue has Phi and exp(-v^2/2) in hand for gelu anyway, and
         # the backward epilogue then costs one multiply instead of an erf per element (+50 us of VALU per 100 M elements, measured)
-        h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
-        g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
-        out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=(p.gamma.data if p.gamma is not None else None), rowscale=dp_mask,
-                          rows_per_group=H * W, residual=xc.reshape(M, C))
+        gam = p.gamma.data if p.gamma is not None else None
+        ctx.fused = K.convnext_mlp_supported(C, xc.dtype)
+        if ctx.fused:
+            # wide stages (C = 96 / 192, bf16): the [M, 4C] hidden tile stays on the CU (csrc/mlp_fused.hip) and the backward pass
+            # recomputes it, so nothing [M, 4C]-shaped is kept; `bw` holds the tiled weight images the backward chain streams
+            fw, bw = K.convnext_mlp_prep(p.w1.data, p.w2.data, gam, backward=grad)
+            out = K.convnext_mlp_fwd(y2, fw, p.b1.data, p.b2.data, gam, dp_mask, H * W, xc.reshape(M, C))
+            h, g = bw, None
+        else:
+            h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
+            g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
+            out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
         ctx.p, ctx.dil, ctx.pad = p, dil, pad
         ctx.save_for_backward(xc, y1, y2, mean, rstd, h, g if grad else None, dp_mask)
         return out.reshape(N, H, W, C)
@@ -646,20 +654,26 @@ class _ConvNeXtBlockFn(Function):
         # --- pw2 + layer scale: everything from Z = g^T dbr and S = colsum(dbr), no pass over [M,C] for gamma
         S = torch.empty(C, dtype=torch.float32, device=xc.device)
         K.colsum(dbr, C, 0, 1, M, C, S)
+        dy2 = None
+        if ctx.fused:
+            # h is the tiled weight buffer here: g = gelu(pre), dh = (dbr @ (W2 gamma)^T) * gelu'(pre), dy2 = dh @ W1^T in one launch
+            g, dh, dy2 = K.convnext_mlp_bwd(y2, dbr, h, p.b1.data)
         if p.gamma is not None:
             Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
             K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr
             K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
-            w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
+            w2eff = None if ctx.fused else K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
         else:
             K.dense_wgrad(g, dbr, _grad(p.w2))
             K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
             w2eff = nn.w(p.w2)
         del g
-        dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_MUL_AUX, aux=h)              # [M,4C] = (dbr @ W2g^T) * gelu'(pre), h = gelu'(pre)
+        if not ctx.fused:
+            dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_MUL_AUX, aux=h)          # [M,4C] = (dbr @ W2g^T) * gelu'(pre), h = gelu'(pre)
         del h
         K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))      # db1 rides the wgrad GEMM (virtual ones-row) when C % 128 != 0
-        dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                    # [M,C]
+        if not ctx.fused:
+            dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                # [M,C]
         del dh
         dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
         dy1 = dy1.reshape(N, H, W, C)

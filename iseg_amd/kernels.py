@@ -194,6 +194,44 @@ def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE, b
 # ---------------------------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------------------------
+def convnext_mlp_supported(C, dtype):
+    """the fused ConvNeXt MLP kernels (csrc/mlp_fused.hip) cover bf16 storage at C = 96 / 192"""
+    return bool(_hip.lib().iseg_convnext_mlp_supported(int(C), _DT[dtype])) if dtype in _DT else False
+
+
+def convnext_mlp_prep(W1, W2, gamma, backward=True):
+    """fp32 Keras kernels -> the tiled bf16 images the fused kernels stream (once per step and block); returns (fw_tiled, bw_tiled)"""
+    _require_cuda(W1, W2)
+    Cc = W1.shape[0]
+    L = _hip.lib()
+    fw = torch.empty(L.iseg_convnext_mlp_tiled_bytes(Cc, 0) // 2, dtype=torch.bfloat16, device=W1.device)
+    bw = torch.empty(L.iseg_convnext_mlp_tiled_bytes(Cc, 1) // 2, dtype=torch.bfloat16, device=W1.device) if backward else None
+    _hip.call("iseg_convnext_mlp_prep", ptr(W1), ptr(W2), ptr(gamma), ptr(fw), ptr(bw), Cc, stream())
+    return fw, bw
+
+
+def convnext_mlp_fwd(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out=None):
+    """out = residual + rowscale[m // rows_per_group] * gamma * (gelu(y2 @ W1 + b1) @ W2 + b2); the [M, 4C] hidden tile stays on the CU"""
+    _require_cuda(y2, fw_tiled, residual)
+    M, Cc = y2.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=y2.dtype, device=y2.device)
+    _hip.call("iseg_convnext_mlp_fwd", ptr(y2), ptr(fw_tiled), ptr(b1), ptr(b2), ptr(gamma), ptr(rowscale), int(rows_per_group),
+              ptr(residual), ptr(out), M, Cc, dt(y2), stream())
+    return out
+
+
+def convnext_mlp_bwd(y2, dbr, bw_tiled, b1):
+    """backward chain with the hidden tile recomputed: returns (g = gelu(h), dh = (dbr @ (W2 gamma)^T) * gelu'(h), dy2 = dh @ W1^T)"""
+    _require_cuda(y2, dbr, bw_tiled)
+    M, Cc = y2.shape
+    g = torch.empty((M, 4 * Cc), dtype=y2.dtype, device=y2.device)
+    dh = torch.empty((M, 4 * Cc), dtype=y2.dtype, device=y2.device)
+    dy2 = torch.empty((M, Cc), dtype=y2.dtype, device=y2.device)
+    _hip.call("iseg_convnext_mlp_bwd", ptr(y2), ptr(dbr), ptr(bw_tiled), ptr(b1), ptr(g), ptr(dh), ptr(dy2), M, Cc, dt(y2), stream())
+    return g, dh, dy2
+
+
 def layernorm_fwd(x2d, gamma, beta, eps, save_stats=True):
     _require_cuda(x2d)
     rows, Cc = x2d.shape

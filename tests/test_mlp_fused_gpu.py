@@ -1,0 +1,131 @@
+"""Fused ConvNeXt MLP kernels (csrc/mlp_fused.hip; reference backbones/convnext.py:51-63): the hidden [M, 4C] tile never reaches
+HBM.  Checked against the fp64 restatement and against the un-fused GEMM pair on the same bf16 inputs."""
+import pytest
+import torch
+
+from oracle import tf_ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(M, C, seed, scale_w=1.0):
+    g = torch.Generator().manual_seed(seed)
+    y2 = torch.randn(M, C, generator=g)
+    res = torch.randn(M, C, generator=g)
+    W1 = torch.randn(C, 4 * C, generator=g) * (scale_w / C ** 0.5)
+    W2 = torch.randn(4 * C, C, generator=g) * (scale_w / (4 * C) ** 0.5)
+    b1 = torch.randn(4 * C, generator=g) * 0.3
+    b2 = torch.randn(C, generator=g) * 0.3
+    gamma = torch.rand(C, generator=g) + 0.5
+    return y2, res, W1, b1, W2, b2, gamma
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M,groups", [(256, 1), (1000, 4), (4096 + 37, 3), (33, 1)])
+@pytest.mark.parametrize("use_gamma,use_rs", [(True, True), (False, False)])
+def test_convnext_mlp_fwd_matches_oracle(cuda, C, M, groups, use_gamma, use_rs):
+    from iseg_amd import kernels as K
+
+    y2, res, W1, b1, W2, b2, gamma = _inputs(M, C, 11 + C + M)
+    bf = torch.bfloat16
+    y2b, resb, W1b, W2b = (t.to(bf) for t in (y2, res, W1, W2))
+    rpg = -(-M // groups)
+    rs = (torch.arange(groups, dtype=torch.float32) * 0.25 + 0.5) if use_rs else None
+    # the prep kernel rounds the fp32 masters to bf16 itself: hand it the already-rounded values so both sides see the same weights
+    fw, _ = K.convnext_mlp_prep(W1b.float().cuda(), W2b.float().cuda(), None, backward=False)
+    out = K.convnext_mlp_fwd(y2b.cuda(), fw, b1.cuda(), b2.cuda(), gamma.cuda() if use_gamma else None,
+                             rs.cuda() if use_rs else None, rpg if use_rs else 0, resb.cuda())
+    assert K.convnext_mlp_supported(C, bf)
+    # fp64 restatement on the bf16-rounded operands (the hidden tile is rounded to bf16 before the second product, as in the kernel)
+    h = y2b.double() @ W1b.double() + b1.double()
+    gl = O.gelu(h).to(bf).double()
+    z = gl @ W2b.double() + b2.double()
+    if use_gamma:
+        z = z * gamma.double()
+    if use_rs:
+        z = z * rs.double()[torch.arange(M) // rpg][:, None]
+    ref = resb.double() + z
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item() / 4), err
+    # same inputs through the un-fused pair of GEMMs (bf16 outputs): the two must agree to bf16 rounding
+    g2 = K.dense_fwd(y2b.cuda(), W1b.cuda(), b1.cuda(), act=K.ACT_GELU)
+    un = K.dense_fwd(g2, W2b.cuda(), b2.cuda(), colscale=gamma.cuda() if use_gamma else None, rowscale=rs.cuda() if use_rs else None,
+                     rows_per_group=rpg if use_rs else 0, residual=resb.cuda())
+    d = (out.float() - un.float()).abs().max().item()
+    assert d < 6e-2, d
+
+
+def test_convnext_mlp_rejects_other_shapes(cuda):
+    from iseg_amd import _hip, kernels as K
+
+    assert not K.convnext_mlp_supported(384, torch.bfloat16)
+    assert not K.convnext_mlp_supported(96, torch.float32)
+    t = torch.zeros(64, 384, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(_hip.HipCallError):
+        K.convnext_mlp_fwd(t, t, t, t, None, None, 0, t)
+    with pytest.raises(_hip.HipCallError):
+        K.convnext_mlp_bwd(t, t, t, t)
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M", [256, 1000, 4096 + 37, 33])
+def test_convnext_mlp_bwd_chain_matches_oracle(cuda, C, M):
+    """g, dh and dy2 of the recomputing backward kernel against fp64 autograd through the same bf16-rounded operands"""
+    from iseg_amd import kernels as K
+
+    y2, dbr, W1, b1, W2, b2, gamma = _inputs(M, C, 5 + C + M)
+    bf = torch.bfloat16
+    y2b, dbrb = y2.to(bf), dbr.to(bf)
+    _, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda(), backward=True)
+    g, dh, dy2 = K.convnext_mlp_bwd(y2b.cuda(), dbrb.cuda(), bw, b1.cuda())
+    W1b = W1.to(bf).double()
+    W2e = (W2 * gamma).to(bf).double()
+    h = (y2b.double() @ W1b + b1.double()).requires_grad_(True)
+    gr = O.gelu(h)
+    (dgelu,) = torch.autograd.grad(gr.sum(), h)
+    dg_ref = dbrb.double() @ W2e.t()
+    dh_ref = dg_ref * dgelu
+    dy2_ref = dh_ref.to(bf).double() @ W1b.t()
+
+    def rel(a, b):
+        return (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-8)
+
+    assert rel(g, gr.detach()) < 1e-2, rel(g, gr.detach())
+    assert rel(dh, dh_ref) < 1.5e-2, rel(dh, dh_ref)
+    assert rel(dy2, dy2_ref) < 1.5e-2, rel(dy2, dy2_ref)
+
+
+def test_convnext_mlp_prep_images(cuda):
+    """the tiled images hold exactly the bf16-rounded kernels in the documented order (csrc/mlp_fused.hip header)"""
+    from iseg_amd import kernels as K
+
+    C = 96
+    g = torch.Generator().manual_seed(3)
+    W1 = torch.randn(C, 4 * C, generator=g)
+    W2 = torch.randn(4 * C, C, generator=g)
+    gamma = torch.rand(C, generator=g) + 0.5
+    fw, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda())
+    fw, bw = fw.cpu().float(), bw.cpu().float()
+    per = C * 32
+    fw = fw.reshape(4 * C // 32, 2, per)
+    bw = bw.reshape(4 * C // 32, 3, per)
+    bf = torch.bfloat16
+    for slab in (0, 5, 11):
+        a1 = fw[slab, 0].reshape(C // 16, 32, 16)      # [kk][hid][c]
+        want = W1.to(bf).float()[:, 32 * slab:32 * slab + 32].t().reshape(32, C // 16, 16).permute(1, 0, 2)
+        assert torch.equal(a1, want)
+        assert torch.equal(bw[slab, 0].reshape(C // 16, 32, 16), want)
+        a3 = bw[slab, 1].reshape(C // 16, 32, 16)
+        want3 = (W2 * gamma).to(bf).float()[32 * slab:32 * slab + 32, :].reshape(32, C // 16, 16).permute(1, 0, 2)
+        assert torch.equal(a3, want3)
+        # A2 / A4: [cb][s][c][kpos], kpos = 8 h + j  <->  hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3)
+        kpos = torch.arange(16)
+        hh, j = kpos // 8, kpos % 8
+        for s_ in range(2):
+            hid = 32 * slab + 16 * s_ + 8 * (j // 4) + 4 * hh + (j % 4)
+            a2 = fw[slab, 1].reshape(C // 32, 2, 32, 16)[:, s_]
+            want2 = W2.to(bf).float()[hid, :].t().reshape(C // 32, 32, 16)
+            assert torch.equal(a2, want2)
+            a4 = bw[slab, 2].reshape(C // 32, 2, 32, 16)[:, s_]
+            want4 = W1.to(bf).float()[:, hid].reshape(C // 32, 32, 16)
+            assert torch.equal(a4, want4)
