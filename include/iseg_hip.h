@@ -385,6 +385,30 @@ int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const
                        int heads, int head_dim, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the matrix cores: keras.layers.Conv2D(filters, k, strides, padding="same", dilation_rate,
+ * groups, use_bias) as built by layers/model_builder.py:54-64 (ConvNormAct.conv), layers/aspp.py:41-52 (dilated 3x3 branches),
+ * backbones/resnet_blocks.py:175-205, backbones/convnext.py:72-75,255-257 (2x2/s2 or dilated downsample), layers/simpledecoder.py:21-36.
+ * x [N,H,W,Cin], w [KH,KW,Cin/groups,Cout] (Keras layout, bf16 shadow), y [N,Ho,Wo,Cout]; pt / pl = TF "same" top / left padding
+ * (the halo is zero chunks of the gathered operand -- no padded copy, no [pixels, KH*KW*Cin] column buffer, no col2im scatter).
+ * bf16 storage, channels per group multiples of 8 (iseg_conv2d_igemm_supported); fp32 parity runs keep iseg_im2col + iseg_gemm.
+ *   fwd         y = conv(x, w) (+ bias)
+ *   bwd_data    dx = conv^T(dy, w)          gather form, deterministic
+ *   bwd_weight  dw (+)= x^T * dy per tap    fp32 [KH,KW,Cin/groups,Cout], fixed-order split-K slabs
+ * Workspace (split-K slabs): iseg_conv2d_igemm_workspace_bytes(geom, pass) with pass 0 fwd, 1 bwd_data, 2 bwd_weight.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct iseg_conv_geom {
+    int N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, groups;
+} iseg_conv_geom;
+int iseg_conv2d_igemm_supported(const iseg_conv_geom* geom_h, int dtype);
+size_t iseg_conv2d_igemm_workspace_bytes(const iseg_conv_geom* geom_h, int pass);
+int iseg_conv2d_igemm_fwd(const void* x, const void* w, const float* bias, void* y, const iseg_conv_geom* geom_h, int dtype, void* ws,
+                          size_t ws_bytes, iseg_stream_t stream);
+int iseg_conv2d_igemm_bwd_data(const void* dy, const void* w, void* dx, const iseg_conv_geom* geom_h, int dtype, void* ws, size_t ws_bytes,
+                               iseg_stream_t stream);
+int iseg_conv2d_igemm_bwd_weight(const void* x, const void* dy, float* dw, int accumulate, const iseg_conv_geom* geom_h, int dtype, void* ws,
+                                 size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Fused ConvNeXt MLP (backbones/convnext.py:51-63 Block.call: pwconv1 -> act (exact GELU) -> pwconv2 -> gamma -> drop_path ->
  * + input) for the wide stages, bf16 storage, C = 96 / 192 (iseg_convnext_mlp_supported):
  *     out[m][:] = residual[m][:] + rowscale[m / rows_per_group] * gamma[:] * (gelu(y2[m][:] @ W1 + b1) @ W2 + b2)

@@ -42,6 +42,10 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "Cin", "Cout", "KH", "KW", "sh", "sw", "dh", "dw", "pt", "pl", "Ho", "Wo", "groups")]
+
+
 _p, _i, _l, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/iseg_hip.h declares (tests/test_abi.py checks it)
@@ -134,6 +138,11 @@ SIGNATURES = {
     "iseg_softmax_focal_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
+    "iseg_conv2d_igemm_supported": (_i, [C.POINTER(ConvGeom), _i]),
+    "iseg_conv2d_igemm_workspace_bytes": (_z, [C.POINTER(ConvGeom), _i]),
+    "iseg_conv2d_igemm_fwd": (_i, [_p, _p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),
+    "iseg_conv2d_igemm_bwd_data": (_i, [_p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),
+    "iseg_conv2d_igemm_bwd_weight": (_i, [_p, _p, _p, _i, C.POINTER(ConvGeom), _i, _p, _z, _p]),
     "iseg_convnext_mlp_supported": (_i, [_i, _i]),
     "iseg_convnext_mlp_tiled_bytes": (_z, [_i, _i]),
     "iseg_convnext_mlp_prep": (_i, [_p, _p, _p, _p, _p, _i, _p]),

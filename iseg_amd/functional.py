@@ -159,7 +159,7 @@ def dense(x, W, b=None, act=K.ACT_NONE, kshape=None):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# Conv2D (groups=1) through im2col + GEMM;   kernel [kh,kw,Cin,Cout]
+# Conv2D;   kernel [kh,kw,Cin/groups,Cout]
 # ---------------------------------------------------------------------------------------------------------
 def _conv_geometry(H, W, kh, kw, strides, dilation, padding):
     sh, sw = strides
@@ -181,24 +181,39 @@ def _conv_geometry(H, W, kh, kw, strides, dilation, padding):
 
 
 class _Conv2dFn(Function):
+    """Three routes: (1) 1x1 / stride 1 / one group on the activation as it lies = a plain GEMM; (2) bf16 storage with channels per
+    group that are multiples of 8 = implicit GEMM on the matrix cores (csrc/conv_igemm.hip: the patch matrix is gathered while the
+    operand tile is staged, the data gradient is a gather over dy -- no column buffer, no col2im); (3) everything else (the fp32 parity
+    mode, Cin = 3 stems) = im2col + GEMM + col2im, group by group."""
+
     @staticmethod
-    def forward(ctx, x, W, b, strides, dilation, padding):
-        kh, kw, Cin, Cout = W.shape
-        N, H, Wd, _ = x.shape
+    def forward(ctx, x, W, b, strides, dilation, padding, groups):
+        kh, kw, Cin_g, Cout = W.shape
+        N, H, Wd, Cin = x.shape
+        if Cin != Cin_g * groups or Cout % groups != 0:
+            raise ValueError(f"Conv2D: kernel {tuple(W.shape)} does not fit {Cin} input channels in {groups} groups")
         Ho, Wo, pt, pl = _conv_geometry(H, Wd, kh, kw, strides, dilation, padding)
         cdt = nn.compute_dtype()
-        pointwise = kh == 1 and kw == 1 and strides == (1, 1)
         xc = _c(x)
-        if pointwise and xc.dtype == cdt and Cin % 8 == 0:
-            col = xc.reshape(-1, Cin)
+        geom = K.conv_geom(N, H, Wd, Cin, Cout, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo, groups)
+        direct = kh == 1 and kw == 1 and strides == (1, 1) and groups == 1 and xc.dtype == cdt and Cin % 8 == 0
+        igemm = (not direct) and xc.dtype == cdt and K.conv2d_igemm_supported(geom, cdt)
+        M = N * Ho * Wo
+        if direct:
+            y = torch.empty((M, Cout), dtype=cdt, device=x.device)
+            K.gemm(xc.reshape(-1, Cin), nn.w(W).reshape(Cin, Cout), y, M, Cout, Cin, lda=Cin, ldb=Cout, ldd=Cout, a_kcontig=1, b_kcontig=0,
+                   bias=(b.data if b is not None else None))
+        elif igemm:
+            y = K.conv2d_igemm_fwd(xc, nn.w(W), b.data if b is not None else None, geom)
         else:
-            col = K.im2col(xc, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo, cdt)
-        Kd = kh * kw * Cin
-        y = torch.empty((N * Ho * Wo, Cout), dtype=cdt, device=x.device)
-        K.gemm(col, nn.w(W).reshape(Kd, Cout), y, N * Ho * Wo, Cout, Kd, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=1,
-               b_kcontig=0, bias=(b.data if b is not None else None))
+            y = torch.empty((M, Cout), dtype=cdt, device=x.device)
+            Kd, og = kh * kw * Cin_g, Cout // groups
+            for g in range(groups):
+                col = K.im2col(_group_slice(xc, g, Cin_g, groups), kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo, cdt)
+                K.gemm(col, nn.w(W).reshape(Kd, Cout)[:, g * og:], y[:, g * og:], M, og, Kd, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=1,
+                       b_kcontig=0, bias=(b.data[g * og:(g + 1) * og] if b is not None else None))
         ctx.W, ctx.b = W, b
-        ctx.geom = (N, H, Wd, Cin, kh, kw, strides, dilation, pt, pl, Ho, Wo, pointwise)
+        ctx.geom, ctx.route = geom, (direct, igemm)
         ctx.x_dtype = x.dtype
         ctx.save_for_backward(xc)
         return y.reshape(N, Ho, Wo, Cout)
@@ -206,43 +221,72 @@ class _Conv2dFn(Function):
     @staticmethod
     def backward(ctx, dy):
         (xc,) = ctx.saved_tensors
-        W, b = ctx.W, ctx.b
-        N, H, Wd, Cin, kh, kw, strides, dilation, pt, pl, Ho, Wo, pointwise = ctx.geom
-        Cout = W.shape[-1]
-        Kd = kh * kw * Cin
+        W, b, g_ = ctx.W, ctx.b, ctx.geom
+        direct, igemm = ctx.route
+        N, H, Wd, Cin, Cout, kh, kw, groups = g_.N, g_.H, g_.W, g_.Cin, g_.Cout, g_.KH, g_.KW, g_.groups
+        Ho, Wo, pt, pl = g_.Ho, g_.Wo, g_.pt, g_.pl
+        st, di = (g_.sh, g_.sw), (g_.dh, g_.dw)
+        Cin_g, og = Cin // groups, Cout // groups
+        Kd = kh * kw * Cin_g
         cdt = nn.compute_dtype()
         M = N * Ho * Wo
         dy2 = _c(dy).reshape(M, Cout)
         if b is not None and b.requires_grad:
             K.colsum(dy2, Cout, 0, 1, M, Cout, _grad(b), accumulate=True)
-        direct = pointwise and xc.dtype == cdt and Cin % 8 == 0
-        if W.requires_grad:
-            col = xc.reshape(-1, Cin) if direct else K.im2col(xc, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl,
-                                                              Ho, Wo, cdt)
-            K.gemm(col, dy2, _grad(W).reshape(Kd, Cout), Kd, Cout, M, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=0, b_kcontig=0,
-                   accumulate=True)
-            del col
+        need_dx = ctx.needs_input_grad[0]
         dx = None
-        if ctx.needs_input_grad[0]:
-            Wc = nn.w(W).reshape(Kd, Cout)
-            if direct:
-                dx = K.dense_dgrad(dy2, Wc).reshape(N, H, Wd, Cin)
-            else:
-                ldc = (Kd + 7) // 8 * 8
-                dcol = torch.empty((M, ldc), dtype=cdt, device=dy.device)
-                K.gemm(dy2, Wc, dcol, M, Kd, Cout, lda=Cout, ldb=Cout, ldd=ldc, a_kcontig=1, b_kcontig=1)
-                dx = K.col2im(dcol, N, H, Wd, Cin, kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo)
-                if dx.dtype != ctx.x_dtype:
-                    dx = K.cast(dx, ctx.x_dtype)
+        if direct:
+            if W.requires_grad:
+                K.gemm(xc.reshape(-1, Cin), dy2, _grad(W).reshape(Cin, Cout), Cin, Cout, M, lda=Cin, ldb=Cout, ldd=Cout, a_kcontig=0, b_kcontig=0,
+                       accumulate=True)
+            if need_dx:
+                dx = K.dense_dgrad(dy2, nn.w(W).reshape(Cin, Cout)).reshape(N, H, Wd, Cin)
+        elif igemm:
+            dy4 = dy2.reshape(N, Ho, Wo, Cout)
+            if W.requires_grad:
+                K.conv2d_igemm_bwd_weight(xc, dy4, _grad(W), g_, accumulate=True)
+            if need_dx:
+                dx = K.conv2d_igemm_bwd_data(dy4, nn.w(W), g_)
+        else:
+            if need_dx:
+                dx = torch.empty((N, H, Wd, Cin), dtype=cdt, device=dy.device)
+            ldc = (Kd + 7) // 8 * 8
+            for g in range(groups):
+                dyg = dy2[:, g * og:]
+                if W.requires_grad:
+                    col = K.im2col(_group_slice(xc, g, Cin_g, groups), kh, kw, st[0], st[1], di[0], di[1], pt, pl, Ho, Wo, cdt)
+                    K.gemm(col, dyg, _grad(W).reshape(Kd, Cout)[:, g * og:], Kd, og, M, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=0,
+                           b_kcontig=0, accumulate=True)
+                    del col
+                if need_dx:
+                    dcol = torch.empty((M, ldc), dtype=cdt, device=dy.device)
+                    K.gemm(dyg, nn.w(W).reshape(Kd, Cout)[:, g * og:], dcol, M, Kd, og, lda=Cout, ldb=Cout, ldd=ldc, a_kcontig=1, b_kcontig=1)
+                    dxg = K.col2im(dcol, N, H, Wd, Cin_g, kh, kw, st[0], st[1], di[0], di[1], pt, pl, Ho, Wo)
+                    if groups == 1:
+                        dx = dxg
+                    else:
+                        K.copy2d(dxg.reshape(-1, Cin_g), Cin_g, dx.reshape(-1, Cin)[:, g * Cin_g:], Cin, N * H * Wd, Cin_g)
+        if dx is not None and dx.dtype != ctx.x_dtype:
+            dx = K.cast(dx, ctx.x_dtype)
         dist.grads_ready(W, b)
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
-def conv2d(x, W, b=None, strides=(1, 1), dilation=(1, 1), padding="same"):
+def _group_slice(xc, g, Cin_g, groups):
+    """dense NHWC copy of one channel group (the im2col kernel reads dense tensors); groups == 1 is the tensor itself"""
+    if groups == 1:
+        return xc
+    N, H, W, Cin = xc.shape
+    out = torch.empty((N, H, W, Cin_g), dtype=xc.dtype, device=xc.device)
+    K.copy2d(xc.reshape(-1, Cin)[:, g * Cin_g:], Cin, out.reshape(-1, Cin_g), Cin_g, N * H * W, Cin_g)
+    return out
+
+
+def conv2d(x, W, b=None, strides=(1, 1), dilation=(1, 1), padding="same", groups=1):
     if nn.dry_run():
         Ho, Wo, _, _ = _conv_geometry(x.shape[1], x.shape[2], W.shape[0], W.shape[1], tuple(strides), tuple(dilation), padding)
         return _dry((x.shape[0], Ho, Wo, W.shape[-1]), x, nn.compute_dtype())
-    return _Conv2dFn.apply(x, W, b, tuple(strides), tuple(dilation), padding)
+    return _Conv2dFn.apply(x, W, b, tuple(strides), tuple(dilation), padding, int(groups))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -356,6 +356,44 @@ def col2im(dcol, N, H, W, Cc, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo):
     return dx
 
 
+def conv_geom(N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, groups=1):
+    return _hip.ConvGeom(N, H, W, Cin, Cout, KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, groups)
+
+
+def conv2d_igemm_supported(geom, dtype):
+    """implicit-GEMM convolution (csrc/conv_igemm.hip): bf16 storage, channels per group multiples of 8"""
+    return dtype in _DT and bool(_hip.lib().iseg_conv2d_igemm_supported(C.byref(geom), _DT[dtype]))
+
+
+def _conv_ws(geom, which, device):
+    return workspace(_hip.lib().iseg_conv2d_igemm_workspace_bytes(C.byref(geom), which), device)
+
+
+def conv2d_igemm_fwd(x, w, bias, geom):
+    """x [N,H,W,Cin] bf16, w [KH,KW,Cin/groups,Cout] bf16 -> y [N,Ho,Wo,Cout]; the patch matrix is gathered on the fly"""
+    _require_cuda(x, w)
+    y = torch.empty((geom.N, geom.Ho, geom.Wo, geom.Cout), dtype=x.dtype, device=x.device)
+    ws, wsb = _conv_ws(geom, 0, x.device)
+    _hip.call("iseg_conv2d_igemm_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), C.byref(geom), dt(x), ptr(ws), wsb, stream())
+    return y
+
+
+def conv2d_igemm_bwd_data(dy, w, geom):
+    _require_cuda(dy, w)
+    dx = torch.empty((geom.N, geom.H, geom.W, geom.Cin), dtype=dy.dtype, device=dy.device)
+    ws, wsb = _conv_ws(geom, 1, dy.device)
+    _hip.call("iseg_conv2d_igemm_bwd_data", ptr(dy), ptr(w), ptr(dx), C.byref(geom), dt(dy), ptr(ws), wsb, stream())
+    return dx
+
+
+def conv2d_igemm_bwd_weight(x, dy, dw, geom, accumulate=True):
+    """dw [KH,KW,Cin/groups,Cout] fp32 (+)= per-tap x^T dy"""
+    _require_cuda(x, dy, dw)
+    ws, wsb = _conv_ws(geom, 2, x.device)
+    _hip.call("iseg_conv2d_igemm_bwd_weight", ptr(x), ptr(dy), ptr(dw), int(accumulate), C.byref(geom), dt(x), ptr(ws), wsb, stream())
+    return dw
+
+
 def colsum(x, ldx, batch_stride, batch, rows, Cc, out, scale=1.0, accumulate=False):
     if Cc > 8192 and batch == 1 and scale == 1.0:
         # few rows, very wide (token-axis sums, score gradients): the LDS-staged kernel would need C floats of LDS per workgroup

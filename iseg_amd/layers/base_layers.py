@@ -69,8 +69,6 @@ class Conv2D(Layer):
         self.padding = padding.lower()
         self.dilation_rate = _pair(dilation_rate)
         self.groups = int(groups)
-        if self.groups != 1:
-            raise NotImplementedError("grouped Conv2D is outside the ported hot path (use DepthwiseConv2D)")
         self.activation = get_activation(activation)
         self.use_bias = use_bias
         self.kernel_initializer, self.bias_initializer = kernel_initializer, bias_initializer
@@ -78,13 +76,15 @@ class Conv2D(Layer):
 
     def build(self, input_shape):
         cin = int(input_shape[-1])
-        self.kernel = self.add_weight("kernel", (*self.kernel_size, cin, self.filters), self.kernel_initializer)
+        if cin % self.groups != 0 or self.filters % self.groups != 0:
+            raise ValueError(f"Conv2D: {cin} input channels / {self.filters} filters are not divisible by groups={self.groups}")
+        self.kernel = self.add_weight("kernel", (*self.kernel_size, cin // self.groups, self.filters), self.kernel_initializer)
         if self.use_bias:
             self.bias = self.add_weight("bias", (self.filters,), self.bias_initializer)
         self.built = True
 
     def call(self, inputs, training=None):
-        y = F.conv2d(inputs, self.kernel, self.bias, _pair(self.strides), _pair(self.dilation_rate), self.padding)
+        y = F.conv2d(inputs, self.kernel, self.bias, _pair(self.strides), _pair(self.dilation_rate), self.padding, self.groups)
         return y if self.activation is None else self.activation(y)
 
 
