@@ -385,6 +385,23 @@ int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const
                        int heads, int head_dim, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Fused logits tail of the training step: tf.image.resize(bilinear) of the low-resolution logits z [N,Hi,Wi,C] to the label size
+ * (layers/core_model_ext.py:199-256) + the ignore-label cross-entropy mean and its gradient w.r.t. z
+ * (losses/catecrossentropy_ignore_label.py:44-88) + the argmax confusion matrix (metrics/seg_metric_wrapper.py:89-102), in one pass that
+ * never writes the [N,Ho,Wo,C] fp32 logits or their gradient.  Same arithmetic as iseg_resize_bilinear_fwd followed by
+ * iseg_softmax_ce_confusion followed by iseg_resize_bilinear_bwd (TF's lerp order, first-max argmax, zero one-hot row for labels
+ * outside [0,C)), deterministic.  Needs an integer factor (rows even, columns a power of two <= 64) and C <= 32
+ * (iseg_upsample_ce_supported); other shapes take the three separate calls.
+ *   loss_sum[0] = loss_sum_scale * sum_p w_p (logsumexp(l_p) - l_p[y_p]);  dz (same dtype as z, or NULL) = grad_scale * d(sum)/dz;
+ *   cm [C,C] uint64 (or NULL) += counts.
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_upsample_ce_supported(int Hi, int Wi, int Ho, int Wo, int C);
+size_t iseg_upsample_ce_workspace_bytes(int N, int Hi, int Wi, int Ho, int Wo, int C);
+int iseg_upsample_ce(const void* z, int dtype, const int32_t* labels, const float* class_w, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                     int ignore_label, float* loss_sum, float loss_sum_scale, void* dz, float grad_scale, uint64_t* cm, void* ws,
+                     size_t ws_bytes, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution on the matrix cores: keras.layers.Conv2D(filters, k, strides, padding="same", dilation_rate,
  * groups, use_bias) as built by layers/model_builder.py:54-64 (ConvNormAct.conv), layers/aspp.py:41-52 (dilated 3x3 branches),
  * backbones/resnet_blocks.py:175-205, backbones/convnext.py:72-75,255-257 (2x2/s2 or dilated downsample), layers/simpledecoder.py:21-36.

@@ -138,6 +138,9 @@ SIGNATURES = {
     "iseg_softmax_focal_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
+    "iseg_upsample_ce_supported": (_i, [_i, _i, _i, _i, _i]),
+    "iseg_upsample_ce_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "iseg_upsample_ce": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_conv2d_igemm_supported": (_i, [C.POINTER(ConvGeom), _i]),
     "iseg_conv2d_igemm_workspace_bytes": (_z, [C.POINTER(ConvGeom), _i]),
     "iseg_conv2d_igemm_fwd": (_i, [_p, _p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),

@@ -193,6 +193,177 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float* __re
             if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fused logits tail of the training step: bilinear upsample (tf.image.resize, half-pixel centres, TF's lerp order) of the low-resolution
+// logits + ignore-label cross-entropy + its gradient folded back through the resize + argmax / confusion matrix, WITHOUT the
+// [N, Ho, Wo, C] fp32 logits and gradient tensors (88 MB each at 16 x 512 x 512 x 21, four HBM passes in the materialised route:
+// layers/core_model_ext.py:199-256 compute_logits_upsample / compute_final_results, losses/catecrossentropy_ignore_label.py:44-88,
+// metrics/seg_metric_wrapper.py:89-102).
+//
+// For an integer upsampling factor (sy even, sx a power of two <= 64) the output pixels whose two source rows are (b - 1, b) form the
+// band y in [b sy - sy/2, b sy + sy/2), and likewise segments of sx columns.  A wavefront owns one band x 64 columns: a lane keeps its
+// column, so the x-interpolated source rows top[c], bottom[c] - top[c] are computed once and a pixel costs one fma per class; it walks
+// the band's rows accumulating the row-weighted gradient for the two source rows (a0, a1), reduces over the sx lanes of each segment
+// with xor-shuffles, and writes one partial [2 rows][2 columns][C] per (band, segment).  A second tiny kernel adds the <= 4 x 4
+// partials that meet in a source cell in a fixed order (deterministic; no atomics on floats).  Counts go through an LDS histogram.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lerp_src(int dst, float scale, int in_size, int& lo, int& hi, float& t) {      // = resize.hip lerp_of
+    const float src = ((float)dst + 0.5f) * scale - 0.5f;
+    const float f = floorf(src);
+    lo = max((int)f, 0);
+    hi = min((int)ceilf(src), in_size - 1);
+    t = src - f;
+}
+
+template <class TI, int CMAX>
+__global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__ z, const int32_t* __restrict__ labels,
+                                                          const float* __restrict__ class_w, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                                          int sy, int sx, int nwc, int ignore, float grad_scale, float* __restrict__ item_loss,
+                                                          float* __restrict__ partial, unsigned long long* __restrict__ cm) {
+    __shared__ unsigned int hist[CMAX * CMAX];
+    if (cm)
+        for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0u;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nitems = N * (Hi + 1) * nwc;
+    const int item = blockIdx.x * 4 + wid;
+    if (item < nitems) {
+        const int wc = item % nwc, b = (item / nwc) % (Hi + 1), n = item / (nwc * (Hi + 1));
+        const float fy = (float)Hi / (float)Ho, fx = (float)Wi / (float)Wo;
+        const int x = 64 * wc - sx / 2 + lane;
+        const bool xv = x >= 0 && x < Wo;
+        int clo, chi;
+        float tx;
+        lerp_src(xv ? x : 0, fx, Wi, clo, chi, tx);
+        const int rlo = max(b - 1, 0), rhi = min(b, Hi - 1);
+        const int y0 = max(b * sy - sy / 2, 0), y1 = min(b * sy + sy / 2, Ho);
+        float top[CMAX], dif[CMAX], a0[CMAX], a1[CMAX];
+        {
+            const TI* r0 = z + ((int64_t)(n * Hi + rlo) * Wi) * C;
+            const TI* r1 = z + ((int64_t)(n * Hi + rhi) * Wi) * C;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                top[c] = dif[c] = a0[c] = a1[c] = 0.f;
+                if (c < C) {
+                    const float tl = to_f32(r0[clo * C + c]), tr = to_f32(r0[chi * C + c]);
+                    const float bl = to_f32(r1[clo * C + c]), br = to_f32(r1[chi * C + c]);
+                    const float tp = tl + (tr - tl) * tx;
+                    const float bt = bl + (br - bl) * tx;
+                    top[c] = tp;
+                    dif[c] = bt - tp;
+                }
+            }
+        }
+        float loss = 0.f;
+        const int32_t* lab = labels + ((int64_t)n * Ho) * Wo + (xv ? x : 0);
+        for (int y = y0; y < y1; ++y) {
+            int ylo, yhi;
+            float t;
+            lerp_src(y, fy, Hi, ylo, yhi, t);
+            int yl = xv ? lab[(int64_t)y * Wo] : ignore;
+            const bool keep = xv && yl != ignore;
+            if (ignore == 0) yl -= 1;
+            const bool in_range = yl >= 0 && yl < C;
+            float w = keep ? 1.f : 0.f;
+            if (class_w) w *= in_range ? class_w[yl] : 0.f;
+            float v[CMAX];
+            float mx = -3.0e38f;
+            int best = 0;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                v[c] = top[c] + dif[c] * t;
+                if (c < C && v[c] > mx) {      // strict: first maximal index, as tf.argmax
+                    mx = v[c];
+                    best = c;
+                }
+            }
+            if (cm && keep && in_range) atomicAdd(&hist[yl * C + best], 1u);
+            float se = 0.f, zy = 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                if (c == yl) zy = v[c];
+                v[c] = c < C ? __expf(v[c] - mx) : 0.f;
+                se += v[c];
+            }
+            const float lse = mx + __logf(se);
+            loss += in_range ? w * (lse - zy) : 0.f;
+            if (partial) {
+                const float g = w * grad_scale;
+                const float inv = in_range ? g / se : 0.f;
+                const float w1 = t, w0 = 1.f - t;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const float d = v[c] * inv - ((c == yl) ? g : 0.f);
+                    a0[c] = fmaf(w0, d, a0[c]);
+                    a1[c] = fmaf(w1, d, a1[c]);
+                }
+            }
+        }
+        loss = wave_sum(loss);
+        if (lane == 0) item_loss[item] = loss;
+        if (partial) {
+            // [row lo / hi][column lo / hi][c], summed over the sx lanes of this lane's segment (xor butterfly: every lane ends with the sum)
+            const int cseg = (64 * wc + lane) / sx;
+            float* dst = partial + (((int64_t)(n * (Hi + 1) + b) * (Wi + 1) + cseg) * 4) * C;
+            const float wx1 = xv ? tx : 0.f, wx0 = xv ? 1.f - tx : 0.f;
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) {
+                float q00 = wx0 * a0[c], q01 = wx1 * a0[c], q10 = wx0 * a1[c], q11 = wx1 * a1[c];
+                for (int o = sx >> 1; o > 0; o >>= 1) {
+                    q00 += __shfl_xor(q00, o, 64);
+                    q01 += __shfl_xor(q01, o, 64);
+                    q10 += __shfl_xor(q10, o, 64);
+                    q11 += __shfl_xor(q11, o, 64);
+                }
+                if (c < C && (lane & (sx - 1)) == 0 && cseg <= Wi) {
+                    dst[c] = q00;
+                    dst[C + c] = q01;
+                    dst[2 * C + c] = q10;
+                    dst[3 * C + c] = q11;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (cm)
+        for (int i = threadIdx.x; i < C * C; i += 256)
+            if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+
+// dz[n, i, j, c] = the partials of the (band, row-slot) x (segment, column-slot) pairs that address source cell (i, j), in a fixed order
+template <class TI>
+__global__ void upsample_ce_gather_kernel(const float* __restrict__ partial, TI* __restrict__ dz, int N, int Hi, int Wi, int C) {
+    const int64_t total = (int64_t)N * Hi * Wi * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int j = (int)((e / C) % Wi), i = (int)((e / ((int64_t)C * Wi)) % Hi), n = (int)(e / ((int64_t)C * Wi * Hi));
+        // (band, slot) pairs whose source row is i: (i, hi) and (i + 1, lo) always; the clamped edge bands add (0, lo) and (Hi, hi)
+        int bb[4], ys[4], nb = 0;
+        bb[nb] = i, ys[nb++] = 1;
+        bb[nb] = i + 1, ys[nb++] = 0;
+        if (i == 0) bb[nb] = 0, ys[nb++] = 0;
+        if (i == Hi - 1) bb[nb] = Hi, ys[nb++] = 1;
+        int cc[4], xs[4], nc = 0;
+        cc[nc] = j, xs[nc++] = 1;
+        cc[nc] = j + 1, xs[nc++] = 0;
+        if (j == 0) cc[nc] = 0, xs[nc++] = 0;
+        if (j == Wi - 1) cc[nc] = Wi, xs[nc++] = 1;
+        float s = 0.f;
+        for (int u = 0; u < nb; ++u)
+            for (int v = 0; v < nc; ++v)
+                s += partial[((((int64_t)(n * (Hi + 1) + bb[u]) * (Wi + 1) + cc[v]) * 4) + ys[u] * 2 + xs[v]) * C + c];
+        dz[e] = from_f32<TI>(s);
+    }
+}
+
+static inline bool upsample_ce_geometry(int Hi, int Wi, int Ho, int Wo, int C, int& sy, int& sx) {
+    if (Hi <= 0 || Wi <= 0 || Ho % Hi != 0 || Wo % Wi != 0 || C <= 0 || C > 32) return false;
+    sy = Ho / Hi;
+    sx = Wo / Wi;
+    return sy >= 2 && sy % 2 == 0 && sx >= 2 && sx <= 64 && (sx & (sx - 1)) == 0;
+}
+
 }  // namespace
 
 extern "C" size_t iseg_softmax_ce_workspace_bytes(int64_t P, int C) {
@@ -204,7 +375,7 @@ static int launch_softmax_ce(const float* logits, const int32_t* labels, const f
                                       float grad_scale, const float* grad_px, void* ws, size_t ws_bytes,
                                       hipStream_t stream, int focal, float f_alpha, float f_gamma, unsigned long long* cm, const char* who) {
     ISEG_REQUIRE(logits && labels && P > 0 && C > 0, "%s: bad arguments", who);
-    ISEG_REQUIRE(C <= 640, "%s: num_class %d > 640 unsupported", who, C);
+    ISEG_REQUIRE(C <= 256, "%s: num_class %d > 256 unsupported (one 64-pixel tile of fp32 logits must fit 64 KiB of LDS)", who, C);
     const int pix = pixels_per_block(C);
     const int64_t blocks = ceil_div64(P, pix);
     float* bs = nullptr;
@@ -255,7 +426,7 @@ extern "C" int iseg_softmax_focal_ce_ignore(const float* logits, const int32_t* 
 
 extern "C" int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P, int C, int ignore_label,
                                      int32_t* pred_out, unsigned long long* cm, hipStream_t stream) {
-    ISEG_REQUIRE(logits && P > 0 && C > 0 && C <= 640, "iseg_argmax_confusion: bad arguments");
+    ISEG_REQUIRE(logits && P > 0 && C > 0 && C <= 256, "iseg_argmax_confusion: bad arguments (num_class <= 256)");
     ISEG_REQUIRE(!cm || labels, "iseg_argmax_confusion: confusion matrix needs labels");
     const int pix = pixels_per_block(C);
     int64_t blocks = ceil_div64(P, pix);
@@ -265,4 +436,62 @@ extern "C" int iseg_argmax_confusion(const float* logits, const int32_t* labels,
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, logits, labels, P, C, ignore_label,
                        pred_out, cm, pix, use_hist);
     return iseg_check_launch("iseg_argmax_confusion");
+}
+
+extern "C" int iseg_upsample_ce_supported(int Hi, int Wi, int Ho, int Wo, int C) {
+    int sy, sx;
+    return upsample_ce_geometry(Hi, Wi, Ho, Wo, C, sy, sx) ? 1 : 0;
+}
+
+extern "C" size_t iseg_upsample_ce_workspace_bytes(int N, int Hi, int Wi, int Ho, int Wo, int C) {
+    int sy, sx;
+    if (!upsample_ce_geometry(Hi, Wi, Ho, Wo, C, sy, sx)) return 0;
+    const int nwc = ((Wi + 1) * sx + 63) / 64;
+    const size_t items = (size_t)N * (Hi + 1) * nwc;
+    return (items + 3) / 4 * 4 * sizeof(float) + (size_t)N * (Hi + 1) * (Wi + 1) * 4 * C * sizeof(float);
+}
+
+extern "C" int iseg_upsample_ce(const void* z, int dtype, const int32_t* labels, const float* class_w, int N, int Hi, int Wi, int Ho, int Wo,
+                                int C, int ignore_label, float* loss_sum, float loss_sum_scale, void* dz, float grad_scale, uint64_t* cm,
+                                void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(z && labels && loss_sum && N > 0, "iseg_upsample_ce: bad arguments");
+    ISEG_REQUIRE(dtype == ISEG_F32 || dtype == ISEG_BF16, "iseg_upsample_ce: bad dtype %d", dtype);
+    int sy, sx;
+    ISEG_REQUIRE(upsample_ce_geometry(Hi, Wi, Ho, Wo, C, sy, sx),
+                 "iseg_upsample_ce: needs an integer upsampling factor (rows: even; columns: a power of two <= 64) and num_class <= 32; got "
+                 "%dx%d -> %dx%d, %d classes (use iseg_resize_bilinear_fwd + iseg_softmax_ce_ignore)", Hi, Wi, Ho, Wo, C);
+    ISEG_REQUIRE((int64_t)N * Ho * Wo < (1ll << 31), "iseg_upsample_ce: too many pixels");
+    const size_t need = iseg_upsample_ce_workspace_bytes(N, Hi, Wi, Ho, Wo, C);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_upsample_ce: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const int nwc = ((Wi + 1) * sx + 63) / 64;
+    const int items = N * (Hi + 1) * nwc;
+    float* item_loss = (float*)ws;
+    float* partial = dz ? item_loss + (items + 3) / 4 * 4 : nullptr;
+    const int blocks = (items + 3) / 4;
+#define UCE(TI, CMAX)                                                                                                                   \
+    hipLaunchKernelGGL((upsample_ce_kernel<TI, CMAX>), dim3(blocks), dim3(256), 0, stream, (const TI*)z, labels, class_w, N, Hi, Wi, Ho, Wo, C, \
+                       sy, sx, nwc, ignore_label, grad_scale, item_loss, partial, (unsigned long long*)cm)
+    if (dtype == ISEG_BF16) {
+        if (C <= 8) UCE(bf16_t, 8);
+        else if (C <= 24) UCE(bf16_t, 24);
+        else UCE(bf16_t, 32);
+    } else {
+        if (C <= 8) UCE(float, 8);
+        else if (C <= 24) UCE(float, 24);
+        else UCE(float, 32);
+    }
+#undef UCE
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, (const float*)item_loss, items, loss_sum, loss_sum_scale);
+    if (dz) {
+        const int64_t total = (int64_t)N * Hi * Wi * C;
+        const int gb = (int)(ceil_div64(total, 256) < 1024 ? ceil_div64(total, 256) : 1024);
+        if (dtype == ISEG_BF16)
+            hipLaunchKernelGGL((upsample_ce_gather_kernel<bf16_t>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (bf16_t*)dz, N, Hi, Wi, C);
+        else
+            hipLaunchKernelGGL((upsample_ce_gather_kernel<float>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (float*)dz, N, Hi, Wi, C);
+    }
+    return iseg_check_launch("iseg_upsample_ce");
 }

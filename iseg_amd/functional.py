@@ -822,6 +822,81 @@ def softmax_ce_per_pixel(logits, labels, num_class, ignore_label, class_w=None, 
     return _SoftmaxCEPerPixelFn.apply(logits, labels, num_class, ignore_label, class_w, focal)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Deferred logits upsample: inside CoreTrain's step the model hands the low-resolution logits to the loss, and one kernel does
+# bilinear upsample + cross-entropy + its gradient through the resize + the confusion matrix  (layers/core_model_ext.py:199-256,
+# losses/catecrossentropy_ignore_label.py:44-88, metrics/seg_metric_wrapper.py:89-102)
+# ---------------------------------------------------------------------------------------------------------
+_DEFER_UPSAMPLE = [False]
+
+
+class defer_logits_upsample:
+    """while active, SegManaged returns DeferredLogits instead of the bilinear-upsampled fp32 logits"""
+
+    def __enter__(self):
+        self.prev = _DEFER_UPSAMPLE[0]
+        _DEFER_UPSAMPLE[0] = True
+
+    def __exit__(self, *a):
+        _DEFER_UPSAMPLE[0] = self.prev
+
+
+def deferring_logits_upsample():
+    return _DEFER_UPSAMPLE[0]
+
+
+class DeferredLogits:
+    """low-resolution logits [N,h,w,C] + the size tf.image.resize would take them to; quacks like the fp32 [N,H,W,C] tensor as far
+    as shape checks go and turns into it on materialize()"""
+
+    def __init__(self, low, size):
+        self.low, self.size = low, (int(size[0]), int(size[1]))
+        self.dtype = torch.float32
+
+    @property
+    def shape(self):
+        return torch.Size((self.low.shape[0], self.size[0], self.size[1], self.low.shape[3]))
+
+    def dim(self):
+        return 4
+
+    def fusable(self, num_class):
+        N, h, w, Cc = self.low.shape
+        return Cc == num_class and self.low.is_cuda and K.upsample_ce_supported(h, w, self.size[0], self.size[1], Cc)
+
+    def materialize(self):
+        return resize_bilinear(self.low, self.size, out_dtype=torch.float32)
+
+
+class _UpsampleCEMeanFn(Function):
+    @staticmethod
+    def forward(ctx, z, labels, Ho, Wo, ignore_label, class_w, weight, cm):
+        zc = _c(z)
+        y = _c(labels)
+        if y.dtype != torch.int32:
+            y = y.to(torch.int32)
+        P = zc.shape[0] * Ho * Wo
+        s, dz = K.upsample_ce(zc, y, Ho, Wo, ignore_label, class_w=class_w, sum_scale=weight / P, want_grad=ctx.needs_input_grad[0],
+                              grad_scale=weight / P, cm=cm)
+        ctx.in_dtype = z.dtype
+        ctx.save_for_backward(dz)
+        return s.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dz,) = ctx.saved_tensors
+        if not _UNIT_LOSS_GRAD[0]:
+            dz = K.scale_dev(dz, _c(dloss).reshape(1).to(torch.float32))
+        if dz.dtype != ctx.in_dtype:
+            dz = K.cast(dz, ctx.in_dtype)
+        return dz, None, None, None, None, None, None, None
+
+
+def upsample_softmax_ce_mean(deferred, labels, num_class, ignore_label, class_w=None, weight=1.0, cm=None):
+    """mean over ALL positions of the ignore-label CE of the bilinear-upsampled logits; the upsampled tensor is never written"""
+    return _UpsampleCEMeanFn.apply(deferred.low, labels, deferred.size[0], deferred.size[1], int(ignore_label), class_w, float(weight), cm)
+
+
 def softmax_ce_mean(logits, labels, num_class, ignore_label, class_w=None, weight=1.0, focal=None, cm=None):
     """cm: int64 [C*C] confusion matrix that the same kernel pass updates with argmax(logits) (running mIoU of the train step)"""
     return _SoftmaxCEMeanFn.apply(logits, labels, num_class, ignore_label, class_w, float(weight), focal, cm)

@@ -539,6 +539,23 @@ def softmax_ce_ignore(logits2d, labels1d, ignore_label, *, class_w=None, want_px
     return loss_px, loss_sum, dlogits
 
 
+def upsample_ce_supported(Hi, Wi, Ho, Wo, Cc):
+    return bool(_hip.lib().iseg_upsample_ce_supported(int(Hi), int(Wi), int(Ho), int(Wo), int(Cc)))
+
+
+def upsample_ce(z, labels, Ho, Wo, ignore_label, *, class_w=None, sum_scale=1.0, want_grad=True, grad_scale=1.0, cm=None):
+    """fused logits tail (csrc/loss.hip): bilinear upsample of z [N,Hi,Wi,C] to [Ho,Wo] + ignore-label CE sum + d(sum)/dz + confusion
+    matrix, without the full-resolution logits.  returns (loss_sum [1] fp32, dz like z or None)"""
+    _require_cuda(z, labels)
+    N, Hi, Wi, Cc = z.shape
+    loss_sum = torch.empty(1, dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_grad else None
+    ws, wsb = workspace(_hip.lib().iseg_upsample_ce_workspace_bytes(N, Hi, Wi, Ho, Wo, Cc), z.device)
+    _hip.call("iseg_upsample_ce", ptr(z), dt(z), ptr(labels), ptr(class_w), N, Hi, Wi, Ho, Wo, Cc, ignore_label, ptr(loss_sum), sum_scale,
+              ptr(dz), grad_scale, ptr(cm), ptr(ws), wsb, stream())
+    return loss_sum, dz
+
+
 def argmax_confusion(logits2d, labels1d, ignore_label, cm=None, want_pred=False):
     P, Cc = logits2d.shape
     pred = torch.empty(P, dtype=torch.int32, device=logits2d.device) if want_pred else None

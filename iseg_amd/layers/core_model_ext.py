@@ -96,7 +96,8 @@ class SegManaged(SegFoundation):
 
     def compute_final_results(self, logits_list):
         # the Keras-2 branch of the reference (:229-256) is the behavioural truth: list of float32 tensors
-        return [F.cast_to(l, torch.float32) if torch.is_tensor(l) else [F.cast_to(t, torch.float32) for t in l] for l in logits_list]
+        return [l if isinstance(l, F.DeferredLogits) else
+                (F.cast_to(l, torch.float32) if torch.is_tensor(l) else [F.cast_to(t, torch.float32) for t in l]) for l in logits_list]
 
     def call(self, inputs, training=None):
         return self._call_internal(inputs, training=training)
@@ -121,8 +122,11 @@ class SegManaged(SegFoundation):
             return head_results
         logits_list = self.compute_logits_results(head_results)
         # fuse "bilinear upsample + cast to float32" into one pass (resize writes fp32 directly)
-        logits_list = [F.resize_bilinear(l, inputs_size, out_dtype=torch.float32) if (self.logits_upsample_masks is None or
-                                                                                      self.logits_upsample_masks[i]) else l
+        # inside CoreTrain's step (F.defer_logits_upsample) the loss kernel does the upsample itself: hand over the low-resolution logits
+        defer = bool(training) and F.deferring_logits_upsample()
+        logits_list = [(F.DeferredLogits(l, inputs_size) if (defer and torch.is_tensor(l) and l.dim() == 4 and l.is_floating_point())
+                        else F.resize_bilinear(l, inputs_size, out_dtype=torch.float32))
+                       if (self.logits_upsample_masks is None or self.logits_upsample_masks[i]) else l
                        for i, l in enumerate(logits_list)]
         logits_list = self.compute_final_results(logits_list)
         if self.use_dict_outputs:

@@ -37,7 +37,14 @@ def catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, class_wei
             y_true, y_pred = pre_compute_fn(y_true, y_pred)
         return F.softmax_ce_mean(y_pred, y_true, num_class, ignore_label, cw, weight, focal, cm)
 
+    def fused_upsample_mean(y_true, deferred, weight=1.0, cm=None):
+        return F.upsample_softmax_ce_mean(deferred, y_true, num_class, ignore_label, cw, weight, cm)
+
     weighted_loss.fused_mean = fused_mean if (post_compute_fn is None and not reduction) else None
+    # CoreTrain's step may hand the low-resolution logits over (F.DeferredLogits): upsample + loss + gradient + confusion in one kernel
+    weighted_loss.fused_upsample_mean = fused_upsample_mean if (post_compute_fn is None and pre_compute_fn is None and not reduction and
+                                                                focal is None) else None
+    weighted_loss.num_class = num_class
     # the trainer may let the loss kernel also update a MeanIOU confusion matrix built for the same classes / ignore label
     weighted_loss.confusion_spec = (num_class, ignore_label) if (pre_compute_fn is None and focal is None) else None
     return weighted_loss

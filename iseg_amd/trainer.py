@@ -91,17 +91,28 @@ class TrainableModel:
         ys = y if isinstance(y, (tuple, list)) else None
         self.store.zero_grad()
         dist.set_active_reducer(self.reducer)
-        outputs = self.model(x, training=True)
+        with F.defer_logits_upsample():
+            outputs = self.model(x, training=True)
         if isinstance(outputs, dict):
             outputs = list(outputs.values())
-        if not isinstance(outputs, (list, tuple)):
-            outputs = [outputs]
+        outputs = list(outputs) if isinstance(outputs, (list, tuple)) else [outputs]
         losses = []
         fused_metric_outputs = set()
         for i, out in enumerate(outputs):
             fn = self._loss_fn(i)
             yt = ys[i] if ys is not None else y
             w = self._weight(i)
+            if isinstance(out, F.DeferredLogits):
+                # low-resolution logits: one kernel upsamples, takes the loss and its gradient and updates the running mIoU -- when the
+                # loss is the stock ignore-label CE and every metric of this output can ride along; otherwise materialise as usual
+                up = getattr(fn, "fused_upsample_mean", None)
+                cm = self._fusable_confusion(fn, i, yt, out)
+                metrics_ride = (not self.update_metrics) or not self._metrics_for(i) or cm is not None
+                if up is not None and metrics_ride and out.fusable(fn.num_class) and tuple(yt.shape[:3]) == tuple(out.shape[:3]):
+                    fused_metric_outputs.add(i)
+                    losses.append(up(yt, out, w, cm=cm))
+                    continue
+                outputs[i] = out = out.materialize()
             fused = getattr(fn, "fused_mean", None)
             if fused is not None:
                 cm = self._fusable_confusion(fn, i, yt, out)
