@@ -249,13 +249,24 @@ int iseg_argmax_confusion(const float* logits, const int32_t* labels, int64_t P,
  * optimizers/modern/adamw.py:13-74, optimizers/modern/sgd.py:12-51 over the flat parameter buffer.
  * Every tensor is padded to a multiple of 256 elements; seg_of_block[b] = tensor index of 256-element block b
  * (-1 = padding).  hp (device): [lr, sqrt(1-b2^t)/(1-b1^t), grad_scale, clipvalue(<=0 off)].
+ *   AdamW_EXT: g <- NaN->0 (adamw.py:63-74) -> clip -> decoupled decay -> m, v (, v_hat = max(v_hat, v) when vhat != NULL: amsgrad,
+ *              adamw.py:54-57) -> w.       SGD_EXT: no NaN scrub; nesterov as sgd.py:46-49.
+ *   Clipping = Keras' base optimizer (_clip_gradients), which the reference drives through get_optimizer(clipnorm, clipvalue)
+ *   (core_optimizer.py:170-183): clipnorm is PER VARIABLE (tf.clip_by_norm), global_clipnorm over all variables
+ *   (tf.clip_by_global_norm), clipvalue per element; at most one of them is active.  The squared norms come from iseg_grad_sqnorm
+ *   (fixed-order sums: 256-element blocks -> variables -> total; seg_first_block [nseg + 1] = first block of each variable;
+ *   block_ws [nblocks] floats of scratch; seg_l2 / w as in the SGD step or NULL).
  * --------------------------------------------------------------------------------------------------------- */
-int iseg_adamw_step(float* w, const float* g, float* m, float* v, void* w_bf16, const int32_t* seg_of_block,
+int iseg_grad_sqnorm(const float* g, const float* w, const int32_t* seg_of_block, const int32_t* seg_first_block, const float* seg_l2,
+                     const float* hp, int scrub_nan_grads, float* block_ws, float* seg_sq, float* global_sq, int64_t nblocks, int nseg,
+                     iseg_stream_t stream);
+int iseg_adamw_step(float* w, const float* g, float* m, float* v, float* vhat, void* w_bf16, const int32_t* seg_of_block,
                     const float* seg_lr_mult, const float* seg_wd, const float* hp, float beta1, float beta2, float eps,
-                    int64_t nblocks, iseg_stream_t stream);
-int iseg_sgd_momentum_step(float* w, const float* g, float* m, void* w_bf16, const int32_t* seg_of_block,
-                           const float* seg_lr_mult, const float* seg_l2, const float* hp, float momentum, int64_t nblocks,
-                           iseg_stream_t stream);
+                    const float* seg_sq, float clipnorm, const float* global_sq, float global_clipnorm, int64_t nblocks,
+                    iseg_stream_t stream);
+int iseg_sgd_momentum_step(float* w, const float* g, float* m, void* w_bf16, const int32_t* seg_of_block, const float* seg_lr_mult,
+                           const float* seg_l2, const float* hp, float momentum, int nesterov, const float* seg_sq, float clipnorm,
+                           const float* global_sq, float global_clipnorm, int64_t nblocks, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * utils/op_utils.py:43-60 replace_nan_or_inf (layers/fpn.py:52): NaN -> nan_value, then clip to the [min, max] of the

@@ -137,7 +137,8 @@ SIGNATURES = {
     "iseg_softmax_ce_confusion": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _p, _p, _z, _p]),
     "iseg_softmax_focal_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _p, _p, _f, _p, _f, _p, _p, _z, _p]),
     "iseg_argmax_confusion": (_i, [_p, _p, _l, _i, _i, _p, _p, _p]),
-    "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _l, _p]),
+    "iseg_grad_sqnorm": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _i, _p]),
+    "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _f, _p, _f, _l, _p]),
     "iseg_upsample_ce_supported": (_i, [_i, _i, _i, _i, _i]),
     "iseg_upsample_ce_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "iseg_upsample_ce": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _f, _p, _f, _p, _p, _z, _p]),
@@ -151,7 +152,7 @@ SIGNATURES = {
     "iseg_convnext_mlp_prep": (_i, [_p, _p, _p, _p, _p, _i, _p]),
     "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
-    "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _l, _p]),
+    "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, _f, _p, _f, _l, _p]),
 }
 
 _lib = None

@@ -1,63 +1,70 @@
-"""core_optimizer.py of the reference (:18-187): get_optimizer -- scalar-or-list kwargs -> one or several optimizers, poly / cosine
-schedule, sgd / adam / amsgrad / adamw."""
+"""core_optimizer.py of the reference (:18-187): get_optimizer(...) -> one optimizer, or a list of them when any keyword is given as a
+list / tuple (one optimizer per position; scalars are shared), with a poly (WarmUpPolyDecay) or cosine schedule and the
+sgd / adam / amsgrad / adamw families of optimizers/modern."""
+import inspect
+
 from .optimizers import modern as modern_optimizers
 from .optimizers.polydecay import CosineDecay, WarmUpPolyDecay
+
+
+def _schedule(initial_lr, end_lr, steps, warmup_steps, warmup_lr, decay_strategy, poly_decay_power):
+    if decay_strategy == "poly":
+        return WarmUpPolyDecay(initial_lr, steps, end_learning_rate=end_lr, power=poly_decay_power, warmup_steps=warmup_steps,
+                               warmup_learning_rate=warmup_lr)
+    if decay_strategy == "cosine":      # keras CosineDecay: with a warm-up it starts at warmup_lr and targets initial_lr (:139-154)
+        start, target = (warmup_lr, initial_lr) if warmup_steps > 0 else (initial_lr, None)
+        return CosineDecay(start, steps, alpha=float(end_lr) / float(initial_lr), warmup_steps=warmup_steps, warmup_target=target)
+    return initial_lr      # any other strategy keeps the constant rate, as the reference does
+
+
+_FAMILIES = {
+    "sgd": lambda lr, o: modern_optimizers.SGD(learning_rate=lr, momentum=o["sgd_momentum_rate"], clipnorm=o["clipnorm"], clipvalue=o["clipvalue"]),
+    "adam": lambda lr, o: modern_optimizers.AdamW(weight_decay=0.0, learning_rate=lr, amsgrad=False, clipnorm=o["clipnorm"], clipvalue=o["clipvalue"]),
+    "amsgrad": lambda lr, o: modern_optimizers.AdamW(weight_decay=0.0, learning_rate=lr, amsgrad=True, clipnorm=o["clipnorm"], clipvalue=o["clipvalue"]),
+    "adamw": lambda lr, o: modern_optimizers.AdamW(weight_decay=o["adamw_weight_decay"], learning_rate=lr, clipnorm=o["clipnorm"],
+                                                   clipvalue=o["clipvalue"]),
+}
+
+
+def _one_optimizer(o):
+    lr = _schedule(o["initial_lr"], o["end_lr"], o["epoch_steps"] * o["train_epoch"], o["warmup_steps"], o["warmup_lr"], o["decay_strategy"],
+                   o["poly_decay_power"])
+    make = _FAMILIES.get(o["optimizer"])
+    if make is None:
+        raise ValueError(f"Unsupported optimizer {o['optimizer']}")
+    with o["distribute_strategy"].scope():
+        return make(lr, o)
+
+
+def _fan_out(options):
+    """scalars are shared, sequences give one value per optimizer; a one-element sequence counts as a scalar.  Returns None when
+    nothing asks for more than one optimizer, else the list of per-optimizer option dicts."""
+    seqs = {k: list(v) for k, v in options.items() if isinstance(v, (list, tuple))}
+    for k, v in seqs.items():
+        if not v:
+            raise AssertionError(f"empty sequence for optimizer option {k!r}")
+    for k, v in seqs.items():
+        if len(v) == 1:
+            options[k] = v[0]
+    lengths = {len(v) for v in seqs.values() if len(v) > 1}
+    if not lengths:
+        return None
+    if len(lengths) > 1:
+        a, b = sorted(lengths)[:2]
+        raise ValueError(f"kwargs for optimizer must be scaler or list/tuple with same length, found ({a} vs {b})")
+    n = lengths.pop()
+    return [{k: (seqs[k][i] if k in seqs and len(seqs[k]) > 1 else options[k]) for k in options} for i in range(n)]
 
 
 def get_optimizer(distribute_strategy, initial_lr=0.007, end_lr=0.0, epoch_steps=1000, train_epoch=30, warmup_steps=0, warmup_lr=0.0,
                   decay_strategy="poly", poly_decay_power=0.9, optimizer="sgd", sgd_momentum_rate=0.9, adamw_weight_decay=0.0001,
                   clipnorm=None, clipvalue=None):
-    kwargs = {"distribute_strategy": distribute_strategy, "initial_lr": initial_lr, "end_lr": end_lr, "epoch_steps": epoch_steps,
-              "train_epoch": train_epoch, "warmup_steps": warmup_steps, "warmup_lr": warmup_lr, "decay_strategy": decay_strategy,
-              "poly_decay_power": poly_decay_power, "optimizer": optimizer, "sgd_momentum_rate": sgd_momentum_rate,
-              "adamw_weight_decay": adamw_weight_decay, "clipnorm": clipnorm, "clipvalue": clipvalue}
+    names = list(inspect.signature(get_optimizer).parameters)
+    given = locals()
+    options = {k: given[k] for k in names}
     print("Optimizer info : **********************")
-    print({k: v for k, v in kwargs.items() if k != "distribute_strategy"})
-    keys = kwargs.keys()
-    max_list_size = 0
-    for key in keys:
-        value = kwargs[key]
-        if isinstance(value, (list, tuple)):
-            value = list(value)
-            list_size = len(value)
-            kwargs[key] = value
-            assert list_size > 0
-            if list_size == 1:
-                kwargs[key] = value[0]
-            elif list_size >= max_list_size:
-                max_list_size = list_size
-            else:
-                raise ValueError(f"kwargs for optimizer must be scaler or list/tuple with same length, found ({list_size} vs {max_list_size})")
-    if max_list_size <= 1:
-        return _get_optimizer(**kwargs)
-    optimizer_list = []
-    for i in range(max_list_size):
-        sub = {k: (v[i] if isinstance(v, list) else v) for k, v in kwargs.items()}
-        optimizer_list += [_get_optimizer(**sub)]
-    return optimizer_list
-
-
-def _get_optimizer(distribute_strategy, initial_lr=0.007, end_lr=0.0, epoch_steps=1000, train_epoch=30, warmup_steps=0,
-                   warmup_lr=0.003, decay_strategy="poly", poly_decay_power=0.9, optimizer="sgd", sgd_momentum_rate=0.9,
-                   adamw_weight_decay=0.0001, clipnorm=None, clipvalue=None):
-    learning_rate = initial_lr
-    steps = epoch_steps * train_epoch
-    if decay_strategy == "poly":
-        learning_rate = WarmUpPolyDecay(learning_rate, steps, end_learning_rate=end_lr, power=poly_decay_power,
-                                        warmup_steps=warmup_steps, warmup_learning_rate=warmup_lr)
-    elif decay_strategy == "cosine":
-        _initial_lr, warmup_target = learning_rate, None
-        alpha = float(end_lr) / float(learning_rate)
-        if warmup_steps > 0:
-            _initial_lr, warmup_target = warmup_lr, learning_rate
-        learning_rate = CosineDecay(_initial_lr, steps, alpha=alpha, warmup_steps=warmup_steps, warmup_target=warmup_target)
-    with distribute_strategy.scope():
-        if optimizer == "sgd":
-            return modern_optimizers.SGD(learning_rate=learning_rate, momentum=sgd_momentum_rate, clipnorm=clipnorm, clipvalue=clipvalue)
-        if optimizer == "adam":
-            return modern_optimizers.AdamW(weight_decay=0.0, learning_rate=learning_rate, amsgrad=False, clipnorm=clipnorm, clipvalue=clipvalue)
-        if optimizer == "amsgrad":
-            return modern_optimizers.AdamW(weight_decay=0.0, learning_rate=learning_rate, amsgrad=True, clipnorm=clipnorm, clipvalue=clipvalue)
-        if optimizer == "adamw":
-            return modern_optimizers.AdamW(weight_decay=adamw_weight_decay, learning_rate=learning_rate, clipnorm=clipnorm, clipvalue=clipvalue)
-        raise ValueError(f"Unsupported optimizer {optimizer}")
+    print({k: v for k, v in options.items() if k != "distribute_strategy"})
+    each = _fan_out(options)
+    if each is None:
+        return _one_optimizer(options)
+    return [_one_optimizer(o) for o in each]

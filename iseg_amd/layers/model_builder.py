@@ -48,6 +48,36 @@ class ConvNormAct(Layer):
             x = self.dropout(x, training=training)
         return x
 
+    def reset_weights(self):
+        """layers/model_builder.py:100-115: every variable of the block goes back to a fresh draw of its initializer"""
+        _reset_weight(self.conv.kernel, self.conv.kernel_initializer)
+        if self.conv.use_bias:
+            _reset_weight(self.conv.bias, self.conv.bias_initializer)
+        if self.bn is not None:
+            _reset_weight(self.bn.beta, self.bn.beta_initializer)
+            _reset_weight(self.bn.gamma, self.bn.gamma_initializer)
+            _reset_weight(self.bn.moving_mean, self.bn.moving_mean_initializer)
+            _reset_weight(self.bn.moving_variance, self.bn.moving_variance_initializer)
+
+
+_RESET_DRAWS = [0]
+
+
+def _reset_weight(weight, initializer):
+    """weight.assign(initializer(shape, dtype)) on a view of the flat parameter buffer; the bf16 compute copy follows"""
+    from ..nn import init_tensor
+
+    if weight is None:
+        return
+    _RESET_DRAWS[0] += 1      # a new draw each time, like a Keras initializer object without a fixed seed
+    name = f"{getattr(weight, 'iseg_name', 'w')}#reset{_RESET_DRAWS[0]}"
+    fresh = init_tensor(initializer, tuple(weight.shape), name).to(weight.device)
+    with torch.no_grad():
+        (weight.data if isinstance(weight, torch.nn.Parameter) else weight).copy_(fresh)
+        shadow = getattr(weight, "iseg_compute", None)
+        if shadow is not None:
+            shadow.copy_(fresh.to(shadow.dtype))
+
 
 class ImageLevelBlock(Layer):
     def __init__(self, filters=256, pooling_axis=(1, 2), name=None):
@@ -143,6 +173,15 @@ class NormConvAct(Layer):
 
     def call(self, inputs, training=None):
         x = inputs
-        if self.ln is not None:
+        if self.ln is not None:      # (Keras hands the enclosing call's `training` to a nested BatchNormalization)
             x = self.ln(x, training=training) if hasattr(self.ln, "moving_mean") else self.ln(x)
         return self.conv(x)
+
+    def reset_weights(self):
+        """layers/model_builder.py:234-247"""
+        _reset_weight(self.conv.kernel, self.conv.kernel_initializer)
+        if self.conv.use_bias:
+            _reset_weight(self.conv.bias, self.conv.bias_initializer)
+        if self.ln is not None:
+            _reset_weight(getattr(self.ln, "beta", None), getattr(self.ln, "beta_initializer", "zeros"))
+            _reset_weight(getattr(self.ln, "gamma", None), getattr(self.ln, "gamma_initializer", "ones"))

@@ -1,6 +1,7 @@
 """optimizers/modern/{adamw,sgd}.py of the reference: AdamW_EXT.update_step/_clip_gradients (adamw.py:13-74), SGD_EXT.update_step
 (sgd.py:12-51), on top of Keras' optimizer base (decoupled weight decay with `exclude_from_weight_decay(var_names)`,
-`iterations`).  One fused kernel launch over the flat parameter buffer (csrc/optim.hip)."""
+`iterations`, `clipnorm` / `global_clipnorm` / `clipvalue`).  One fused kernel launch over the flat parameter buffer (csrc/optim.hip),
+preceded by the fixed-order norm reduction when a norm clip is configured."""
 import math
 import re
 
@@ -12,11 +13,14 @@ from ..param_store import ParamStore
 
 
 class _FlatOptimizer:
-    def __init__(self, learning_rate, clipnorm=None, clipvalue=None):
+    _scrub_nan = False
+
+    def __init__(self, learning_rate, clipnorm=None, clipvalue=None, global_clipnorm=None):
         self.learning_rate = learning_rate
-        if clipnorm is not None:
-            raise NotImplementedError("clipnorm needs a global-norm reduction; use clipvalue")
-        self.clipvalue = clipvalue
+        if sum(v is not None for v in (clipnorm, clipvalue, global_clipnorm)) > 1:      # Keras' base optimizer refuses the same
+            raise ValueError(f"At most one of `clipnorm`, `clipvalue` and `global_clipnorm` can be set. Received: clipnorm={clipnorm}, "
+                             f"clipvalue={clipvalue}, global_clipnorm={global_clipnorm}.")
+        self.clipnorm, self.clipvalue, self.global_clipnorm = clipnorm, clipvalue, global_clipnorm
         self.iterations = 0
         self._exclude = []
         self.store = None
@@ -42,15 +46,20 @@ class _FlatOptimizer:
     def build(self, store: ParamStore):
         self.store = store
         dev = store.device
-        # step-dependent scalars travel through a ring of pinned-host -> device slots: the async copy of step t must not be
-        # overwritten on the host before the GPU has consumed it, and the host never runs 64 steps ahead of the stream
+        # step-dependent scalars travel through a ring of pinned-host -> device slots.  The async copy of step t must not be overwritten
+        # on the host before the GPU has consumed it: every slot carries the event recorded behind its last copy and is waited for
+        # before it is rewritten (free while the host is less than a ring ahead of the stream)
         self._ring = 64
         self._hp_dev = torch.zeros(self._ring, 4, dtype=torch.float32, device=dev)
         self._hp_host = torch.zeros(self._ring, 4, dtype=torch.float32)
+        self._hp_events = [None] * self._ring
         if dev.type == "cuda":
             self._hp_host = self._hp_host.pin_memory()
         self._slot = 0
         self.hp = self._hp_dev[0]
+        seg_first = [o // 256 for (_, o, _) in store.segments] + [store.nblocks]
+        self._seg_first_block = torch.tensor(seg_first, dtype=torch.int32, device=dev)
+        self._norm_ws = None
         self._build_tables()
 
     def _build_tables(self):
@@ -59,24 +68,51 @@ class _FlatOptimizer:
     def _push_hp(self, vals):
         slot = self._slot
         self._slot = (slot + 1) % self._ring
+        ev = self._hp_events[slot]
+        if ev is not None:
+            ev.synchronize()
         for i, v in enumerate(vals):
             self._hp_host[slot, i] = v
         self.hp = self._hp_dev[slot]
         self.hp.copy_(self._hp_host[slot], non_blocking=True)
+        if self.hp.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hp_events[slot] = ev
+
+    def _clip_tables(self, seg_l2=None):
+        """(seg_sq, clipnorm, global_sq, global_clipnorm) for the step kernel; runs iseg_grad_sqnorm when a norm clip is configured"""
+        cn = float(self.clipnorm) if self.clipnorm and self.clipnorm > 0 else 0.0
+        gn = float(self.global_clipnorm) if self.global_clipnorm and self.global_clipnorm > 0 else 0.0
+        if cn <= 0 and gn <= 0:
+            return None, 0.0, None, 0.0
+        st = self.store
+        if self._norm_ws is None:
+            self._norm_ws = (torch.empty(st.nblocks, dtype=torch.float32, device=st.device),
+                             torch.empty(len(st.segments), dtype=torch.float32, device=st.device),
+                             torch.empty(1, dtype=torch.float32, device=st.device))
+        blk, seg_sq, tot = self._norm_ws
+        _hip.call("iseg_grad_sqnorm", K.ptr(st.flat_g), K.ptr(st.flat_w), K.ptr(st.seg_of_block), K.ptr(self._seg_first_block), K.ptr(seg_l2),
+                  K.ptr(self.hp), int(self._scrub_nan), K.ptr(blk), K.ptr(seg_sq), K.ptr(tot) if gn > 0 else None, st.nblocks,
+                  len(st.segments), K.stream())
+        return (seg_sq if cn > 0 else None), cn, (tot if gn > 0 else None), gn
 
 
 class AdamW(_FlatOptimizer):
+    _scrub_nan = True      # AdamW_EXT._clip_gradients replaces NaN gradients by 0 before clipping (adamw.py:63-74)
+
     def __init__(self, learning_rate=0.001, weight_decay=0.004, beta_1=0.9, beta_2=0.999, epsilon=1e-7, amsgrad=False, clipnorm=None,
-                 clipvalue=None, name="AdamW"):
-        super().__init__(learning_rate, clipnorm, clipvalue)
-        if amsgrad:
-            raise NotImplementedError("amsgrad")
+                 clipvalue=None, global_clipnorm=None, name="AdamW"):
+        super().__init__(learning_rate, clipnorm, clipvalue, global_clipnorm)
+        self.amsgrad = bool(amsgrad)
         self.weight_decay, self.beta_1, self.beta_2, self.epsilon = weight_decay, beta_1, beta_2, epsilon
 
     def _build_tables(self):
         st = self.store
         self.m = getattr(self, "m", None) if getattr(self, "m", None) is not None else torch.zeros_like(st.flat_w)
         self.v = getattr(self, "v", None) if getattr(self, "v", None) is not None else torch.zeros_like(st.flat_w)
+        if self.amsgrad and getattr(self, "vhat", None) is None:
+            self.vhat = torch.zeros_like(st.flat_w)
         lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if p.requires_grad else 0.0 for p in st.params]
         wd = [float(self.weight_decay or 0.0) if (p.requires_grad and self._use_weight_decay(p)) else 0.0 for p in st.params]
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
@@ -87,17 +123,18 @@ class AdamW(_FlatOptimizer):
         t = self.iterations + 1
         corr = math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
         self._push_hp([self.current_lr(), corr, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
-        _hip.call("iseg_adamw_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(self.v), K.ptr(st.flat_bf16),
-                  K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_wd), K.ptr(self.hp), self.beta_1, self.beta_2,
-                  self.epsilon, st.nblocks, K.stream())
+        seg_sq, cn, tot, gn = self._clip_tables()
+        _hip.call("iseg_adamw_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(self.v),
+                  K.ptr(self.vhat) if self.amsgrad else None, K.ptr(st.flat_bf16), K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult),
+                  K.ptr(self.seg_wd), K.ptr(self.hp), self.beta_1, self.beta_2, self.epsilon, K.ptr(seg_sq), cn, K.ptr(tot), gn, st.nblocks,
+                  K.stream())
         self.iterations += 1
 
 
 class SGD(_FlatOptimizer):
-    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, clipnorm=None, clipvalue=None, name="SGD"):
-        super().__init__(learning_rate, clipnorm, clipvalue)
-        if nesterov:
-            raise NotImplementedError("nesterov")
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, clipnorm=None, clipvalue=None, global_clipnorm=None, name="SGD"):
+        super().__init__(learning_rate, clipnorm, clipvalue, global_clipnorm)
+        self.nesterov = bool(nesterov)
         self.momentum = momentum
         self.l2_of = {}      # id(param) -> l2 coefficient, filled by utils.keras_ops.set_weight_decay
 
@@ -112,7 +149,8 @@ class SGD(_FlatOptimizer):
     def apply_gradients(self):
         st = self.store
         self._push_hp([self.current_lr(), 0.0, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
+        seg_sq, cn, tot, gn = self._clip_tables(self.seg_l2)
         _hip.call("iseg_sgd_momentum_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(st.flat_bf16),
-                  K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_l2), K.ptr(self.hp), self.momentum, st.nblocks,
-                  K.stream())
+                  K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_l2), K.ptr(self.hp), self.momentum, int(self.nesterov),
+                  K.ptr(seg_sq), cn, K.ptr(tot), gn, st.nblocks, K.stream())
         self.iterations += 1

@@ -246,20 +246,48 @@ def warmup_poly_decay(step, initial_lr, decay_steps, end_lr=0.0001, warmup_steps
     return slow if step < warmup_steps else lr
 
 
-def adamw_step(w, g, m, v, step, lr, lr_mult=1.0, wd=0.0, beta1=0.9, beta2=0.999, eps=1e-7):
-    """One AdamW_EXT.update_step preceded by Keras' decoupled decay; `step` is 1-based (iterations+1)."""
-    g = torch.where(torch.isnan(g), torch.zeros_like(g), g)
+def clip_gradients(grads, clipnorm=None, global_clipnorm=None, clipvalue=None):
+    """keras optimizer base `_clip_gradients` (the reference hands clipnorm / clipvalue through, core_optimizer.py:170-183):
+    clipnorm -> tf.clip_by_norm per variable (g * c / max(||g||, c)); global_clipnorm -> tf.clip_by_global_norm
+    (g * c * min(1 / ||all g||, 1 / c)); clipvalue -> tf.clip_by_value.  At most one is set."""
+    if clipnorm is not None and clipnorm > 0:
+        return [g * clipnorm / torch.clamp(torch.sqrt((g * g).sum()), min=clipnorm) for g in grads]
+    if global_clipnorm is not None and global_clipnorm > 0:
+        gn = torch.sqrt(sum((g * g).sum() for g in grads))
+        scale = global_clipnorm * torch.minimum(1.0 / gn, torch.tensor(1.0 / global_clipnorm, dtype=gn.dtype))
+        return [g * scale for g in grads]
+    if clipvalue is not None and clipvalue > 0:
+        return [torch.clamp(g, -clipvalue, clipvalue) for g in grads]
+    return list(grads)
+
+
+def scrub_nan(g):
+    """AdamW_EXT._clip_gradients (optimizers/modern/adamw.py:63-74): NaN gradients become 0 before Keras' clipping"""
+    return torch.where(torch.isnan(g), torch.zeros_like(g), g)
+
+
+def adamw_step(w, g, m, v, step, lr, lr_mult=1.0, wd=0.0, beta1=0.9, beta2=0.999, eps=1e-7, vhat=None):
+    """One AdamW_EXT.update_step preceded by Keras' decoupled decay; `step` is 1-based (iterations+1).  vhat (amsgrad, adamw.py:54-57):
+    v_hat = max(v_hat, v) takes v's place in the denominator and is returned as a fourth value."""
+    g = scrub_nan(g)
     w = w - w * wd * lr
     m = m + (g - m) * (1 - beta1)
     v = v + (g * g - v) * (1 - beta2)
     alpha = lr * lr_mult * math.sqrt(1 - beta2 ** step) / (1 - beta1 ** step)
+    if vhat is not None:
+        vhat = torch.maximum(vhat, v)
+        return w - (m * alpha) / (torch.sqrt(vhat) + eps), m, v, vhat
     w = w - (m * alpha) / (torch.sqrt(v) + eps)
     return w, m, v
 
 
-def sgd_step(w, g, m, lr, lr_mult=1.0, momentum=0.9, l2=0.0):
-    g = torch.where(torch.isnan(g), torch.zeros_like(g), g) + 2.0 * l2 * w
+def sgd_step(w, g, m, lr, lr_mult=1.0, momentum=0.9, l2=0.0, nesterov=False):
+    """SGD_EXT.update_step (optimizers/modern/sgd.py:38-51); the keras l2 regulariser of set_weight_decay adds 2 l2 w to the gradient.
+    SGD_EXT does not scrub NaN gradients (only AdamW_EXT overrides _clip_gradients)."""
+    g = g + 2.0 * l2 * w
     m = -g * lr * lr_mult + m * momentum
+    if nesterov:
+        return w + (-g * lr * lr_mult + m * momentum), m
     return w + m, m
 
 
