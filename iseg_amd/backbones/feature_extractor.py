@@ -60,8 +60,20 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
         else:
             backbone((dummy, torch.empty(tuple(label_shape), dtype=torch.float32, device=nn.device())))
     print("Built backbone with shape inputs")
-    if weights_path is not None:
-        from ..saver import load_weights_by_name
+    if weights_path is not None:      # :166-187; `.npz` = a Keras .h5 converted by tools/h5_to_npz.py (h5py is not part of this image)
+        from ..saver import load_h5_weight_by_name
+        from ..utils.keras_ops import load_h5_weight
 
-        load_weights_by_name(backbone, weights_path)
+        stem = weights_path[:-4] if weights_path.endswith(".npz") else weights_path
+        if stem.endswith(".topology.h5") or stem.endswith(".topology"):
+            print(f"Load backbone weights {weights_path} as H5 format (topology-based)")
+            load_h5_weight(backbone, weights_path, by_name=False)
+        elif stem.endswith(".h5") or weights_path.endswith(".npz"):
+            print(f"Load backbone weights {weights_path} as H5 format (name-based)")
+            load_h5_weight_by_name(backbone, weights_path)
+        elif weights_path.endswith(".ckpt") or weights_path.endswith(".keras"):
+            raise NotImplementedError(f"{weights_path}: TensorFlow checkpoint / .keras archives need TensorFlow to read; export the "
+                                      "backbone as .h5 there and convert it with tools/h5_to_npz.py")
+        else:
+            raise ValueError(f"Weights {weights_path} not supported")
     return backbone

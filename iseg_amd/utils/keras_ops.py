@@ -37,6 +37,17 @@ def set_bn_epsilon(model, epsilon=1e-3):
             layer.epsilon = epsilon
 
 
+def load_h5_weight(model, path, skip_mismatch=False, use_v2_behavior=False, by_name=True):
+    """utils/keras_ops.py:107-127: Keras HDF5 weights (or their .npz conversion, saver/weights_file.py) into `model`, by layer name or
+    -- by_name=False, the `.topology.h5` files of backbones/feature_extractor.py:167-169 -- by layer order"""
+    from ..saver import load_weights_from_group_by_name, load_weights_from_group_topological, open_weights
+
+    f = open_weights(path)
+    if by_name:
+        return load_weights_from_group_by_name(f, model, skip_mismatch=skip_mismatch)
+    return load_weights_from_group_topological(f, model)
+
+
 def capture_func(obj, name):
     fn = getattr(obj, name, None)
     return fn if callable(fn) else None
