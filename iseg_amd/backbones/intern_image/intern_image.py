@@ -99,19 +99,19 @@ class InternImageLayer(Layer):
     def call(self, inputs, training=None):
         masks = self.drop_path_masks or (None, None)
         dp = lambda t, i: F.drop_path(t, self.drop_path_rate, bool(training), mask=masks[i])  # noqa: E731
-        residual = x = inputs
+        x, residual = F.fork(inputs, 2)      # residual forks: gradients summed by our own kernel
         if self.use_post_norm:
             x = dp(self._scale(self.norm1(self.dcn(x, training=training)), self.gamma1), 0)
-            residual = x = F.add(residual, x)
+            x, residual = F.fork(F.add(residual, x), 2)
             x = dp(self._scale(self.norm2(self.mlp(x, training=training)), self.gamma2), 1)
             return F.add(x, residual)
         if self.use_res_post_norm:
             x = dp(self.res_post_norm1(self.dcn(self.norm1(x), training=training)), 0)
-            residual = x = F.add(residual, x)
+            x, residual = F.fork(F.add(residual, x), 2)
             x = dp(self.res_post_norm2(self.mlp(self.norm2(x), training=training)), 1)
             return F.add(x, residual)
         x = dp(self._scale(self.dcn(self.norm1(x), training=training), self.gamma1), 0)
-        residual = x = F.add(residual, x)
+        x, residual = F.fork(F.add(residual, x), 2)
         x = dp(self._scale(self.mlp(self.norm2(x), training=training), self.gamma2), 1)
         return F.add(x, residual)
 

@@ -154,16 +154,17 @@ class SwinTransformerBlock(Layer):
         n, h, w, c = inputs.shape
         ws = self.window_size
         masks = self.drop_path_masks or (None, None)
-        shortcut = inputs.reshape(n, h * w, c)
+        inputs, shortcut = F.fork(inputs, 2)      # residual fork (gradients summed by our own kernel)
+        shortcut = shortcut.reshape(n, h * w, c)
         x = self.norm1(inputs)
         part, rev, hp, wp = window_index_tables(n, h, w, ws, self.shift_size)
         n_win = n * (hp // ws) * (wp // ws)
         x_windows = F.permute_rows(x, part, rev, (n_win, ws * ws, c))      # pad + roll + partition
         attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
         x = F.permute_rows(attn_windows, rev, part, (n, h * w, c))         # reverse + roll back + crop
-        x = F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0]))
+        x, skip = F.fork(F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0])), 2)
         y = self.mlp(self.norm2(x), training=training)
-        x = F.add(x, F.drop_path(y, self.drop_path_prob, training, mask=masks[1]))
+        x = F.add(skip, F.drop_path(y, self.drop_path_prob, training, mask=masks[1]))
         return x.reshape(n, h, w, c)
 
 

@@ -56,11 +56,12 @@ class TransformerBlock(Layer):
     def call(self, inputs, training=None):
         training = get_training_value(training)
         masks = self.drop_path_masks or (None, None)
-        x = self.attention_norm(inputs)
+        branch, skip = F.fork(inputs, 2)      # residual forks: their gradients are summed by our own kernel, not by autograd
+        x = self.attention_norm(branch)
         x = self.attention(x, x, training=training)
         if self.drop_path_rate != 0.0 and training:
             x = F.drop_path(x, self.drop_path_rate, training, mask=masks[0])
-        x = identity = F.add(x, inputs)
+        x, identity = F.fork(F.add(x, skip), 2)
         x = self.mlp_norm(x)
         x = self.mlp(x, training=training)
         if self.drop_path_rate != 0.0 and training:

@@ -490,6 +490,34 @@ def add(a, b):
     return _AddFn.apply(a, b)
 
 
+class _ForkFn(Function):
+    """One tensor, several consumers.  torch.autograd would add the consumers' gradients with its own elementwise kernels; here every
+    consumer gets an alias, and the backward node sums the arriving gradients with iseg_axpby -- no ATen arithmetic on the step."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [_c(g) for g in grads if g is not None]
+        if not live:
+            return None, None
+        total = live[0]
+        for i, g in enumerate(live[1:]):
+            if g.dtype != total.dtype:
+                g = K.cast(g, total.dtype)
+            total = K.axpby(total, g, 1.0, 1.0, out=(total if i > 0 else None))      # the first sum allocates, the rest accumulate in place
+        return total, None
+
+
+def fork(x, n=2):
+    """n aliases of x, one per consumer (see _ForkFn); a no-op outside autograd"""
+    if nn.dry_run() or n <= 1 or not (torch.is_tensor(x) and x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * n
+    return _ForkFn.apply(x, n)
+
+
 _RNG_COUNTER = [0]
 
 

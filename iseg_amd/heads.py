@@ -3,6 +3,7 @@ layers/simpledecoder.py) but composes them only in downstream user projects (Seg
 layers/core_model_ext.py:91).  These are the <= 15-line compositions the BASELINE configs name."""
 from .layers.aspp import AtrousSpatialPyramidPooling
 from .layers.core_model_ext import SegManaged
+from . import functional as F
 from .layers.model_builder import ConvNormAct
 from .nn import Layer
 
@@ -69,7 +70,8 @@ class SimpleDecoderHead(Layer):
 
     def call(self, inputs, training=None):
         e = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
-        return self.decoder((e, self.high_conv(e, training=training)), training=training)
+        low, high = F.fork(e, 2)      # the endpoint feeds both decoder inputs
+        return self.decoder((low, self.high_conv(high, training=training)), training=training)
 
 
 def _managed(backbone_name, head, num_class, output_stride, build_input_size, backbone_custom_fn=None):

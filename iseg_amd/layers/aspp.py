@@ -30,10 +30,12 @@ class AtrousSpatialPyramidPooling(Layer):
 
     def call(self, inputs, training=None):
         results = []
+        branches = int(self.use_image_level) + int(self.use_pixel_level) + len(self.asp_convs)
+        xs = list(F.fork(inputs, branches))      # one alias per branch: the branch gradients are summed by our own kernel
         if self.use_image_level:
-            results.append(self.image_level_block(inputs, training=training))
+            results.append(self.image_level_block(xs.pop(0), training=training))
         if self.use_pixel_level:
-            results.append(self.pixel_level_block(inputs, training=training))
+            results.append(self.pixel_level_block(xs.pop(0), training=training))
         for conv in self.asp_convs:
-            results.append(conv(inputs, training=training))
+            results.append(conv(xs.pop(0), training=training))
         return F.concat(results)

@@ -37,13 +37,14 @@ class DeformableConvolutionV3(Layer):
         self.built = True
 
     def call(self, inputs, training=False):
-        x = inputs
-        x_proj = self.input_proj(x)
-        x1 = self.dw_norm(self.dw_conv(x))
+        xa, xb = F.fork(inputs, 2)      # two consumers each for the input and for x1: gradients summed by our own kernel
+        x_proj = self.input_proj(xa)
+        x1 = self.dw_norm(self.dw_conv(xb))
         if self.activation == "gelu":
             x1 = F.gelu(x1)
-        offset = self.offset(x1)
-        mask = F.softmax_groups(self.mask(x1), self.kernel_size * self.kernel_size)
+        x1a, x1b = F.fork(x1, 2)
+        offset = self.offset(x1a)
+        mask = F.softmax_groups(self.mask(x1b), self.kernel_size * self.kernel_size)
         pad = self.kernel_size // 2 if self.padding.upper() == "SAME" else 0
         x = F.dcnv3_core(x_proj, offset, mask, self.groups, self.filters_per_group, (self.kernel_size, self.kernel_size),
                          self.strides, self.dilation_rate, pad, self.offset_scale)

@@ -29,6 +29,10 @@ class FeaturePyramidNetwork(Layer):
             skip_feature = self.skip_convs[i](skip_feature, training=training)
             x = resize_image(x, size=skip_feature.shape[1:3])
             x = F.add(x, skip_feature)
-            result_endpoints.append(x)
+            if i > 0:      # this level is returned AND feeds the next one: fork (gradients summed by our own kernel)
+                out, x = F.fork(x, 2)
+                result_endpoints.append(out)
+            else:
+                result_endpoints.append(x)
         result_endpoints.reverse()
         return result_endpoints

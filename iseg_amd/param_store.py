@@ -61,7 +61,10 @@ class ParamStore:
             self.flat_bf16.copy_(self.flat_w)   # host-side layout only (no GPU): never on the compute path
 
     def zero_grad(self):
-        self.flat_g.zero_()
+        if self.flat_g.is_cuda:
+            K.fill_f32(self.flat_g, 0.0)      # (torch's .zero_() is an ATen fill kernel)
+        else:
+            self.flat_g.zero_()
 
     def broadcast_from_rank0(self):
         from . import dist

@@ -421,6 +421,16 @@ def resnet_aspp_forward(w, x, training=False, output_stride=32, head="aspp_head"
     return {"endpoints": ends, "logits": O.resize_bilinear(small, (x.shape[1], x.shape[2]))}
 
 
+def vit_simple_decoder_forward(w, x, training=False, backbone="ViT-B_16", num_layer=12, pretrain_size=384, head="decoder_head", seg="seg"):
+    """BASELINE config 4's composition: ViT (backbones/vit.py:277-323, one endpoint) -> ConvNormAct(256, 1x1) as the high-level
+    branch -> SimpleDecoder(48, 256) with the endpoint itself as low-level input (layers/simpledecoder.py:21-36) -> logits 1x1 -> bilinear"""
+    e = vit_forward(w, x, backbone, num_layer, pretrain_size)
+    high = conv_norm_act(w, f"{head}/high_conv", e, training)
+    feat = simple_decoder(w, f"{head}/decoder", e, high, training)
+    small = O.conv2d(feat, w[f"{seg}/logits_conv/kernel"], w[f"{seg}/logits_conv/bias"], 1, 1, "same")
+    return {"endpoint": e, "logits": O.resize_bilinear(small, (x.shape[1], x.shape[2]))}
+
+
 def sliding_window_inference(fn, x, window):
     """core_inference.py:230-304: windows at get_sliding_start_indexs positions, logits zero-padded back and summed, divided by
     the per-pixel visit count"""

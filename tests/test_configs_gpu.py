@@ -97,6 +97,43 @@ def test_sliding_window_inference_matches_oracle(cuda):
     assert torch.equal(got.argmax(-1).cpu(), O.argmax_first(ref))
 
 
+def test_cfg4_vit_base_simple_decoder_through_the_sliding_window(cuda):
+    """BASELINE config 4 as specified: the full ViT-B/16 (12 layers, 768 wide, class token, bicubic 24x24 -> 8x8 position embedding)
+    + SimpleDecoder through inference_with_sliding_window on an image that is no multiple of the window: 160x208 with a 128x128
+    window -> 2x2 overlapping windows (rows start at 0 / 32, columns at 0 / 80), zero-padded back, summed and count-normalised"""
+    from iseg_amd import nn
+    from iseg_amd.core_inference import inference_with_sliding_window
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.heads import vit_base_simple_decoder
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(vit_base_simple_decoder(build_input_size=(128, 128)), seed=4)
+    x, _ = synthetic_batch(1, 160, 208, seed=9)
+    with torch.no_grad():
+        got = inference_with_sliding_window(x.cuda(), model, training=False, windows_size=(128, 128))
+    w = OM.export_weights(model)
+    visits = []
+
+    def fn(t):
+        visits.append(tuple(t.shape))
+        return OM.vit_simple_decoder_forward(w, t, training=False)["logits"]
+
+    ref = OM.sliding_window_inference(fn, x.double(), (128, 128))
+    assert visits == [(1, 128, 128, 3)] * 4 and O.sliding_start_indexs(160, 128) == [0, 32] and O.sliding_start_indexs(208, 128) == [0, 80]
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 160, 208, 21)
+    assert (got.cpu().double() - ref).abs().max().item() < 1e-3
+    assert torch.equal(got.argmax(-1).cpu(), O.argmax_first(ref))
+    # the count map of the tiling: corners 1, edges 2, the centre block 4
+    count = torch.zeros(160, 208)
+    for t in (0, 32):
+        for l in (0, 80):
+            count[t:t + 128, l:l + 128] += 1
+    assert count[0, 0] == 1 and count[80, 0] == 2 and count[0, 100] == 2 and count[80, 100] == 4
+    single = OM.vit_simple_decoder_forward(w, x.double()[:, :128, :128], training=False)["logits"]
+    assert (got[:, :32, :80].cpu().double() - single[:, :32, :80]).abs().max().item() < 1e-3      # count-1 corner = the first window alone
+
+
 def test_multi_scale_flip_inference_matches_oracle(cuda):
     from iseg_amd.data import synthetic_batch
 
