@@ -5,6 +5,8 @@
 // (x-mean)*rsqrt(var+eps)*gamma+beta.  BatchNorm follows the synchronized moments path of
 // layers/keras3/bn.py:10-73 / layers/syncbn.py:70-119: per-replica sum, sum of squares and count are reduced
 // (here: packed as one [2C+1] fp32 message for a single RCCL all-reduce), mean = S1/n, var = S2/n - mean^2.
+#include <stdlib.h>
+
 #include "common.h"
 #include "iseg_hip.h"
 
@@ -425,7 +427,12 @@ extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float
 static int ln_bwd_blocks(int64_t rows, int C) {
     const int lpr = ln_lanes_per_row(C);
     const int rpw = 64 / lpr;
-    int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4 * 8);  // >= 8 row-iterations per block
+    static const int iters = [] {
+        const char* e = getenv("ISEG_LN_BWD_ITERS");
+        const int v = e ? atoi(e) : 8;
+        return v > 0 ? v : 8;
+    }();
+    int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4 * iters);  // >= `iters` row-iterations per block
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     return (int)blocks;

@@ -715,6 +715,10 @@ class _ConvNeXtBlockFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        """Two queues.  The data-gradient chain (dbr -> dh -> dy2 -> LayerNorm -> depthwise data gradient) is what the next block waits
+        for; everything that only feeds the optimizer (column sums, the two weight-gradient GEMMs, layer-scale gradients, the depthwise
+        weight gradient) goes to a side HIP stream behind events, so the short kernels of the narrow stages overlap instead of queueing
+        (_side_stream; ISEG_SIDE_STREAM=0 keeps one queue).  Both queues meet before the gradients are announced to the reducer."""
         xc, y1, y2, mean, rstd, h, g, dp_mask = ctx.saved_tensors
         p, dil, pad = ctx.p, ctx.dil, ctx.pad
         N, H, W, C = xc.shape
@@ -723,39 +727,88 @@ class _ConvNeXtBlockFn(Function):
         do2 = _c(dout).reshape(M, C)
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
         cdt = xc.dtype
-        # --- pw2 + layer scale: everything from Z = g^T dbr and S = colsum(dbr), no pass over [M,C] for gamma
-        S = torch.empty(C, dtype=torch.float32, device=xc.device)
-        K.colsum(dbr, C, 0, 1, M, C, S)
+        side = _SideQueue(xc.device)
         dy2 = None
         if ctx.fused:
             # h is the tiled weight buffer here: g = gelu(pre), dh = (dbr @ (W2 gamma)^T) * gelu'(pre), dy2 = dh @ W1^T in one launch
             g, dh, dy2 = K.convnext_mlp_bwd(y2, dbr, h, p.b1.data)
-        if p.gamma is not None:
-            Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
-            K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr
-            K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
-            w2eff = None if ctx.fused else K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
         else:
-            K.dense_wgrad(g, dbr, _grad(p.w2))
-            K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
-            w2eff = nn.w(p.w2)
-        del g
-        if not ctx.fused:
+            w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt) if p.gamma is not None else nn.w(p.w2)
             dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_MUL_AUX, aux=h)          # [M,4C] = (dbr @ W2g^T) * gelu'(pre), h = gelu'(pre)
         del h
-        K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))      # db1 rides the wgrad GEMM (virtual ones-row) when C % 128 != 0
+
+        # --- side: pw2 + layer scale from Z = g^T dbr and S = colsum(dbr) (no pass over [M,C] for gamma), then dW1 (+ db1)
+        def param_grads():
+            S = torch.empty(C, dtype=torch.float32, device=xc.device)
+            K.colsum(dbr, C, 0, 1, M, C, S)
+            if p.gamma is not None:
+                Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
+                K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr
+                K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+            else:
+                K.dense_wgrad(g, dbr, _grad(p.w2))
+                K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
+            K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))      # db1 rides the wgrad GEMM (virtual ones-row) when C % 128 != 0
+
+        side.run(param_grads, dbr, g, dh, y2)
         if not ctx.fused:
             dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                # [M,C]
-        del dh
+        del g, dh
         dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
         dy1 = dy1.reshape(N, H, W, C)
-        K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad)
+        side.run(lambda: K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad), xc, dy1)
         dx = None
         if ctx.needs_input_grad[0]:
             padb = (Kk - 1) * dil - pad
             dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
+        side.join()
         dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma)
         return (dx,) + (None,) * 12
+
+
+# ---------------------------------------------------------------------------------------------------------
+# side queue for work that only feeds the optimizer
+# ---------------------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+def _side_enabled():
+    import os
+
+    return os.environ.get("ISEG_SIDE_STREAM", "1") != "0"
+
+
+class _SideQueue:
+    """run(fn, *tensors): enqueue fn on this device's side stream behind everything the current stream has enqueued so far; `tensors`
+    are the buffers fn reads that the caller may release before the side stream gets to them (the caching allocator is told).
+    join(): the current stream waits for the side stream.  With ISEG_SIDE_STREAM=0 (or on the CPU) run() just calls fn."""
+
+    def __init__(self, device):
+        self.stream = None
+        if device.type == "cuda" and _side_enabled():
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            st = _SIDE_STREAMS.get(key)
+            if st is None:
+                st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+            self.stream = st
+        self.used = False
+
+    def run(self, fn, *tensors):
+        if self.stream is None:
+            return fn()
+        main = torch.cuda.current_stream()
+        self.stream.wait_stream(main)
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.stream)
+        self.used = True
+
+    def join(self):
+        if self.stream is not None and self.used:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.used = False
 
 
 def convnext_block(x, params, dilation, eps, dp_mask):
