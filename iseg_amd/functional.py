@@ -718,7 +718,7 @@ class _ConvNeXtBlockFn(Function):
         """Two queues.  The data-gradient chain (dbr -> dh -> dy2 -> LayerNorm -> depthwise data gradient) is what the next block waits
         for; everything that only feeds the optimizer (column sums, the two weight-gradient GEMMs, layer-scale gradients, the depthwise
         weight gradient) goes to a side HIP stream behind events, so the short kernels of the narrow stages overlap instead of queueing
-        (_side_stream; ISEG_SIDE_STREAM=0 keeps one queue).  Both queues meet before the gradients are announced to the reducer."""
+        (_SideQueue; opt-in with ISEG_SIDE_STREAM=1 -- measured slower than one queue on one GPU, see _side_enabled).  Both queues meet before the gradients are announced to the reducer."""
         xc, y1, y2, mean, rstd, h, g, dp_mask = ctx.saved_tensors
         p, dil, pad = ctx.p, ctx.dil, ctx.pad
         N, H, W, C = xc.shape
@@ -775,13 +775,15 @@ _SIDE_STREAMS = {}
 def _side_enabled():
     import os
 
-    return os.environ.get("ISEG_SIDE_STREAM", "1") != "0"
+    # measured on the flagship step (MI355X, 30 steps, interleaved A/B): 12.12 ms with one queue, 12.26 ms with two -- the narrow-stage
+    # kernels already overlap their tails on one stream and the extra event traffic costs more than the concurrency returns; off by default
+    return os.environ.get("ISEG_SIDE_STREAM", "0") == "1"
 
 
 class _SideQueue:
     """run(fn, *tensors): enqueue fn on this device's side stream behind everything the current stream has enqueued so far; `tensors`
     are the buffers fn reads that the caller may release before the side stream gets to them (the caching allocator is told).
-    join(): the current stream waits for the side stream.  With ISEG_SIDE_STREAM=0 (or on the CPU) run() just calls fn."""
+    join(): the current stream waits for the side stream.  Without ISEG_SIDE_STREAM=1 (or on the CPU) run() just calls fn."""
 
     def __init__(self, device):
         self.stream = None
