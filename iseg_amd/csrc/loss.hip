@@ -216,20 +216,24 @@ __device__ __forceinline__ void lerp_src(int dst, float scale, int in_size, int&
     t = src - f;
 }
 
-template <class TI, int CMAX>
+// CMAX: register arrays; EXACT: C == CMAX known at compile time (the common 19 / 21 class heads: no per-class bound checks, no padding).
+// A band is cut into `nsplit` row ranges, one wavefront each, so that the grid is several resident rounds deep (even tail).
+template <class TI, int CMAX, bool EXACT>
 __global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__ z, const int32_t* __restrict__ labels,
-                                                          const float* __restrict__ class_w, int N, int Hi, int Wi, int Ho, int Wo, int C,
-                                                          int sy, int sx, int nwc, int ignore, float grad_scale, float* __restrict__ item_loss,
-                                                          float* __restrict__ partial, unsigned long long* __restrict__ cm) {
+                                                          const float* __restrict__ class_w, int N, int Hi, int Wi, int Ho, int Wo, int Crt,
+                                                          int sy, int sx, int nwc, int nsplit, int ignore, float grad_scale,
+                                                          float* __restrict__ item_loss, float* __restrict__ partial,
+                                                          unsigned long long* __restrict__ cm) {
+    const int C = EXACT ? CMAX : Crt;
     __shared__ unsigned int hist[CMAX * CMAX];
     if (cm)
         for (int i = threadIdx.x; i < C * C; i += 256) hist[i] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nitems = N * (Hi + 1) * nwc;
+    const int nitems = N * (Hi + 1) * nsplit * nwc;
     const int item = blockIdx.x * 4 + wid;
     if (item < nitems) {
-        const int wc = item % nwc, b = (item / nwc) % (Hi + 1), n = item / (nwc * (Hi + 1));
+        const int wc = item % nwc, part = (item / nwc) % nsplit, b = (item / (nwc * nsplit)) % (Hi + 1), n = item / (nwc * nsplit * (Hi + 1));
         const float fy = (float)Hi / (float)Ho, fx = (float)Wi / (float)Wo;
         const int x = 64 * wc - sx / 2 + lane;
         const bool xv = x >= 0 && x < Wo;
@@ -237,7 +241,9 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__
         float tx;
         lerp_src(xv ? x : 0, fx, Wi, clo, chi, tx);
         const int rlo = max(b - 1, 0), rhi = min(b, Hi - 1);
-        const int y0 = max(b * sy - sy / 2, 0), y1 = min(b * sy + sy / 2, Ho);
+        const int rows_per_part = (sy + nsplit - 1) / nsplit;
+        const int yb0 = b * sy - sy / 2 + part * rows_per_part;
+        const int y0 = max(yb0, 0), y1 = min(min(yb0 + rows_per_part, b * sy + sy / 2), Ho);
         float top[CMAX], dif[CMAX], a0[CMAX], a1[CMAX];
         {
             const TI* r0 = z + ((int64_t)(n * Hi + rlo) * Wi) * C;
@@ -257,46 +263,55 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__
         }
         float loss = 0.f;
         const int32_t* lab = labels + ((int64_t)n * Ho) * Wo + (xv ? x : 0);
-        for (int y = y0; y < y1; ++y) {
-            int ylo, yhi;
-            float t;
-            lerp_src(y, fy, Hi, ylo, yhi, t);
-            int yl = xv ? lab[(int64_t)y * Wo] : ignore;
-            const bool keep = xv && yl != ignore;
-            if (ignore == 0) yl -= 1;
-            const bool in_range = yl >= 0 && yl < C;
-            float w = keep ? 1.f : 0.f;
-            if (class_w) w *= in_range ? class_w[yl] : 0.f;
-            float v[CMAX];
-            float mx = -3.0e38f;
-            int best = 0;
+        constexpr int RB = 8;      // rows whose labels are requested together (one dependent L2 round trip per row otherwise)
+        for (int yb = y0; yb < y1; yb += RB) {
+            int labs[RB];
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) {
-                v[c] = top[c] + dif[c] * t;
-                if (c < C && v[c] > mx) {      // strict: first maximal index, as tf.argmax
-                    mx = v[c];
-                    best = c;
-                }
-            }
-            if (cm && keep && in_range) atomicAdd(&hist[yl * C + best], 1u);
-            float se = 0.f, zy = 0.f;
+            for (int q = 0; q < RB; ++q) labs[q] = (xv && yb + q < y1) ? lab[(int64_t)(yb + q) * Wo] : ignore;
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c) {
-                if (c == yl) zy = v[c];
-                v[c] = c < C ? __expf(v[c] - mx) : 0.f;
-                se += v[c];
-            }
-            const float lse = mx + __logf(se);
-            loss += in_range ? w * (lse - zy) : 0.f;
-            if (partial) {
-                const float g = w * grad_scale;
-                const float inv = in_range ? g / se : 0.f;
-                const float w1 = t, w0 = 1.f - t;
+            for (int q = 0; q < RB; ++q) {
+                const int y = yb + q;
+                if (y >= y1) break;
+                int ylo, yhi;
+                float t;
+                lerp_src(y, fy, Hi, ylo, yhi, t);
+                int yl = labs[q];
+                const bool keep = xv && yl != ignore;
+                if (ignore == 0) yl -= 1;
+                const bool in_range = yl >= 0 && yl < C;
+                float w = keep ? 1.f : 0.f;
+                if (class_w) w *= in_range ? class_w[yl] : 0.f;
+                float v[CMAX];
+                float mx = -3.0e38f;
+                int best = 0;
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c) {
-                    const float d = v[c] * inv - ((c == yl) ? g : 0.f);
-                    a0[c] = fmaf(w0, d, a0[c]);
-                    a1[c] = fmaf(w1, d, a1[c]);
+                    v[c] = top[c] + dif[c] * t;
+                    if (c < C && v[c] > mx) {      // strict: first maximal index, as tf.argmax
+                        mx = v[c];
+                        best = c;
+                    }
+                }
+                if (cm && keep && in_range) atomicAdd(&hist[yl * C + best], 1u);
+                float se = 0.f, zy = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    if (c == yl) zy = v[c];
+                    v[c] = c < C ? __expf(v[c] - mx) : 0.f;
+                    se += v[c];
+                }
+                const float lse = mx + __logf(se);
+                loss += in_range ? w * (lse - zy) : 0.f;
+                if (partial) {
+                    const float g = w * grad_scale;
+                    const float inv = in_range ? g / se : 0.f;
+                    const float w1 = t, w0 = 1.f - t;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) {
+                        const float d = v[c] * inv - ((c == yl) ? g : 0.f);
+                        a0[c] = fmaf(w0, d, a0[c]);
+                        a1[c] = fmaf(w1, d, a1[c]);
+                    }
                 }
             }
         }
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__
         if (partial) {
             // [row lo / hi][column lo / hi][c], summed over the sx lanes of this lane's segment (xor butterfly: every lane ends with the sum)
             const int cseg = (64 * wc + lane) / sx;
-            float* dst = partial + (((int64_t)(n * (Hi + 1) + b) * (Wi + 1) + cseg) * 4) * C;
+            float* dst = partial + ((((int64_t)(n * (Hi + 1) + b) * nsplit + part) * (Wi + 1) + cseg) * 4) * C;
             const float wx1 = xv ? tx : 0.f, wx0 = xv ? 1.f - tx : 0.f;
 #pragma unroll
             for (int c = 0; c < CMAX; ++c) {
@@ -333,7 +348,7 @@ __global__ __launch_bounds__(256) void upsample_ce_kernel(const TI* __restrict__
 
 // dz[n, i, j, c] = the partials of the (band, row-slot) x (segment, column-slot) pairs that address source cell (i, j), in a fixed order
 template <class TI>
-__global__ void upsample_ce_gather_kernel(const float* __restrict__ partial, TI* __restrict__ dz, int N, int Hi, int Wi, int C) {
+__global__ void upsample_ce_gather_kernel(const float* __restrict__ partial, TI* __restrict__ dz, int N, int Hi, int Wi, int C, int nsplit) {
     const int64_t total = (int64_t)N * Hi * Wi * C;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
@@ -351,10 +366,20 @@ __global__ void upsample_ce_gather_kernel(const float* __restrict__ partial, TI*
         if (j == Wi - 1) cc[nc] = Wi, xs[nc++] = 1;
         float s = 0.f;
         for (int u = 0; u < nb; ++u)
-            for (int v = 0; v < nc; ++v)
-                s += partial[((((int64_t)(n * (Hi + 1) + bb[u]) * (Wi + 1) + cc[v]) * 4) + ys[u] * 2 + xs[v]) * C + c];
+            for (int q = 0; q < nsplit; ++q)
+                for (int v = 0; v < nc; ++v)
+                    s += partial[(((((int64_t)(n * (Hi + 1) + bb[u]) * nsplit + q) * (Wi + 1) + cc[v]) * 4) + ys[u] * 2 + xs[v]) * C + c];
         dz[e] = from_f32<TI>(s);
     }
+}
+
+static inline int upsample_ce_nsplit(int N, int Hi, int nwc, int sy) {
+    // measured at 16 x 512 x 512 / 21 classes (2448 band x column items): 128 us unsplit, 139 us with 4 row ranges per band -- the
+    // per-wavefront setup (84 source-logit loads, the 84-value segment reduction) outweighs the evener tail.  The kernel is VALU-bound
+    // (SQ_ACTIVE_INST_VALU = 36 % of wave cycles at 4.2 cycles per instruction, ~480 instructions per pixel row): split only small grids
+    int ns = 1;
+    while (ns < 4 && (int64_t)N * (Hi + 1) * nwc * ns < 1024 && sy / (ns * 2) >= 8) ns *= 2;
+    return ns;
 }
 
 static inline bool upsample_ce_geometry(int Hi, int Wi, int Ho, int Wo, int C, int& sy, int& sx) {
@@ -447,8 +472,9 @@ extern "C" size_t iseg_upsample_ce_workspace_bytes(int N, int Hi, int Wi, int Ho
     int sy, sx;
     if (!upsample_ce_geometry(Hi, Wi, Ho, Wo, C, sy, sx)) return 0;
     const int nwc = ((Wi + 1) * sx + 63) / 64;
-    const size_t items = (size_t)N * (Hi + 1) * nwc;
-    return (items + 3) / 4 * 4 * sizeof(float) + (size_t)N * (Hi + 1) * (Wi + 1) * 4 * C * sizeof(float);
+    const int ns = upsample_ce_nsplit(N, Hi, nwc, sy);
+    const size_t items = (size_t)N * (Hi + 1) * ns * nwc;
+    return (items + 3) / 4 * 4 * sizeof(float) + (size_t)N * (Hi + 1) * ns * (Wi + 1) * 4 * C * sizeof(float);
 }
 
 extern "C" int iseg_upsample_ce(const void* z, int dtype, const int32_t* labels, const float* class_w, int N, int Hi, int Wi, int Ho, int Wo,
@@ -467,31 +493,34 @@ extern "C" int iseg_upsample_ce(const void* z, int dtype, const int32_t* labels,
         return ISEG_ERR_WORKSPACE;
     }
     const int nwc = ((Wi + 1) * sx + 63) / 64;
-    const int items = N * (Hi + 1) * nwc;
+    const int ns = upsample_ce_nsplit(N, Hi, nwc, sy);
+    const int items = N * (Hi + 1) * ns * nwc;
     float* item_loss = (float*)ws;
     float* partial = dz ? item_loss + (items + 3) / 4 * 4 : nullptr;
     const int blocks = (items + 3) / 4;
-#define UCE(TI, CMAX)                                                                                                                   \
-    hipLaunchKernelGGL((upsample_ce_kernel<TI, CMAX>), dim3(blocks), dim3(256), 0, stream, (const TI*)z, labels, class_w, N, Hi, Wi, Ho, Wo, C, \
-                       sy, sx, nwc, ignore_label, grad_scale, item_loss, partial, (unsigned long long*)cm)
-    if (dtype == ISEG_BF16) {
-        if (C <= 8) UCE(bf16_t, 8);
-        else if (C <= 24) UCE(bf16_t, 24);
-        else UCE(bf16_t, 32);
-    } else {
-        if (C <= 8) UCE(float, 8);
-        else if (C <= 24) UCE(float, 24);
-        else UCE(float, 32);
-    }
+#define UCE(TI, CMAX, EXACT)                                                                                                            \
+    hipLaunchKernelGGL((upsample_ce_kernel<TI, CMAX, EXACT>), dim3(blocks), dim3(256), 0, stream, (const TI*)z, labels, class_w, N, Hi, Wi, Ho, \
+                       Wo, C, sy, sx, nwc, ns, ignore_label, grad_scale, item_loss, partial, (unsigned long long*)cm)
+#define UCE_T(TI)                          \
+    do {                                   \
+        if (C == 21) UCE(TI, 21, true);    \
+        else if (C == 19) UCE(TI, 19, true); \
+        else if (C <= 8) UCE(TI, 8, false);  \
+        else if (C <= 24) UCE(TI, 24, false); \
+        else UCE(TI, 32, false);             \
+    } while (0)
+    if (dtype == ISEG_BF16) UCE_T(bf16_t);
+    else UCE_T(float);
+#undef UCE_T
 #undef UCE
     hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, stream, (const float*)item_loss, items, loss_sum, loss_sum_scale);
     if (dz) {
         const int64_t total = (int64_t)N * Hi * Wi * C;
         const int gb = (int)(ceil_div64(total, 256) < 1024 ? ceil_div64(total, 256) : 1024);
         if (dtype == ISEG_BF16)
-            hipLaunchKernelGGL((upsample_ce_gather_kernel<bf16_t>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (bf16_t*)dz, N, Hi, Wi, C);
+            hipLaunchKernelGGL((upsample_ce_gather_kernel<bf16_t>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (bf16_t*)dz, N, Hi, Wi, C, ns);
         else
-            hipLaunchKernelGGL((upsample_ce_gather_kernel<float>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (float*)dz, N, Hi, Wi, C);
+            hipLaunchKernelGGL((upsample_ce_gather_kernel<float>), dim3(gb), dim3(256), 0, stream, (const float*)partial, (float*)dz, N, Hi, Wi, C, ns);
     }
     return iseg_check_launch("iseg_upsample_ce");
 }

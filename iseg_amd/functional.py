@@ -208,10 +208,16 @@ class _Conv2dFn(Function):
         else:
             y = torch.empty((M, Cout), dtype=cdt, device=x.device)
             Kd, og = kh * kw * Cin_g, Cout // groups
+            keep_col = None
             for g in range(groups):
                 col = K.im2col(_group_slice(xc, g, Cin_g, groups), kh, kw, strides[0], strides[1], dilation[0], dilation[1], pt, pl, Ho, Wo, cdt)
                 K.gemm(col, nn.w(W).reshape(Kd, Cout)[:, g * og:], y[:, g * og:], M, og, Kd, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=1,
                        b_kcontig=0, bias=(b.data[g * og:(g + 1) * og] if b is not None else None))
+                keep_col = col
+            # a patchify stem on the image (Cin = 3, kernel == stride): the column buffer is smaller than the fp32 image it came from, and
+            # the weight gradient is its only other reader -- keep it instead of running im2col again in backward (63 us at 16 x 512 x 512)
+            ctx.col = keep_col if (groups == 1 and W.requires_grad and not ctx.needs_input_grad[0] and Kd * keep_col.element_size() <=
+                                   Cin * xc.element_size() * strides[0] * strides[1]) else None
         ctx.W, ctx.b = W, b
         ctx.geom, ctx.route = geom, (direct, igemm)
         ctx.x_dtype = x.dtype
@@ -245,8 +251,23 @@ class _Conv2dFn(Function):
             dy4 = dy2.reshape(N, Ho, Wo, Cout)
             if W.requires_grad:
                 K.conv2d_igemm_bwd_weight(xc, dy4, _grad(W), g_, accumulate=True)
-            if need_dx:
+            if need_dx and st == (1, 1):
                 dx = K.conv2d_igemm_bwd_data(dy4, nn.w(W), g_)
+            elif need_dx:
+                # strided: only 1 / (sh * sw) of the (tap, pixel) pairs of the gather form are non-zero, and the MFMA cannot skip them
+                # (ConvNeXt's 2x2 / s2 downsample at 128x128: 115 us gathered vs ~50 us here).  dcol = dy @ W^T, then the gather-form
+                # col2im (deterministic; for kernel == stride a pure permutation)
+                ldc = (Kd + 7) // 8 * 8
+                dx = torch.empty((N, H, Wd, Cin), dtype=cdt, device=dy.device) if groups > 1 else None
+                for g in range(groups):
+                    dcol = torch.empty((M, ldc), dtype=cdt, device=dy.device)
+                    K.gemm(dy2[:, g * og:], nn.w(W).reshape(Kd, Cout)[:, g * og:], dcol, M, Kd, og, lda=Cout, ldb=Cout, ldd=ldc, a_kcontig=1,
+                           b_kcontig=1)
+                    dxg = K.col2im(dcol, N, H, Wd, Cin_g, kh, kw, st[0], st[1], di[0], di[1], pt, pl, Ho, Wo)
+                    if groups == 1:
+                        dx = dxg
+                    else:
+                        K.copy2d(dxg.reshape(-1, Cin_g), Cin_g, dx.reshape(-1, Cin)[:, g * Cin_g:], Cin, N * H * Wd, Cin_g)
         else:
             if need_dx:
                 dx = torch.empty((N, H, Wd, Cin), dtype=cdt, device=dy.device)
@@ -254,7 +275,9 @@ class _Conv2dFn(Function):
             for g in range(groups):
                 dyg = dy2[:, g * og:]
                 if W.requires_grad:
-                    col = K.im2col(_group_slice(xc, g, Cin_g, groups), kh, kw, st[0], st[1], di[0], di[1], pt, pl, Ho, Wo, cdt)
+                    col = getattr(ctx, "col", None)
+                    if col is None:
+                        col = K.im2col(_group_slice(xc, g, Cin_g, groups), kh, kw, st[0], st[1], di[0], di[1], pt, pl, Ho, Wo, cdt)
                     K.gemm(col, dyg, _grad(W).reshape(Kd, Cout)[:, g * og:], Kd, og, M, lda=col.stride(0), ldb=Cout, ldd=Cout, a_kcontig=0,
                            b_kcontig=0, accumulate=True)
                     del col
