@@ -195,6 +195,8 @@ int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, i
 int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, int dtype, iseg_stream_t stream);
 /* utils/drops.py:14-20: s[n] = floor(keep + u_n)/keep */
 int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, iseg_stream_t stream);
+/* P masks of n samples each in one launch (s [P, n], keep_probs [P] on the device): the drop_path call sites of one training step */
+int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
 /* keras.activations.relu / gelu where no GEMM epilogue is available; bwd: dx = dy*act'(aux) */
 int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, iseg_stream_t stream);
@@ -210,7 +212,6 @@ size_t iseg_layerscale_grads_workspace_bytes(int K, int N);
 int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S, float* dW2,
                           float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
                           iseg_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------------------
  * tf.image.resize (half-pixel, no antialias): utils/common.py:107-134 resize_image
  * --------------------------------------------------------------------------------------------------------- */

@@ -44,9 +44,7 @@ class Block(Layer):
         if self.drop_path_prob != 0.0 and training:
             mask = self.drop_path_mask
             if mask is None:
-                from .. import kernels as K
-
-                mask = K.drop_path_mask(inputs.shape[0], 1.0 - self.drop_path_prob, F.next_seed(), inputs.device)
+                mask = F.drop_path_factors(inputs.shape[0], 1.0 - self.drop_path_prob, inputs.device)
         d = self.dwconv.dilation_rate
         return F.convnext_block(inputs, self._params(), d[0], self.norm.epsilon, mask)
 

@@ -296,6 +296,16 @@ __global__ void drop_path_mask_kernel(float* __restrict__ s, int n, float keep, 
     if (i < n) s[i] = floorf(keep + uniform01(seed, (uint64_t)i)) / keep;
 }
 
+// the masks of a whole training step in one launch: row p (one per drop_path call site, in call order) uses its own keep probability
+// and its own stream of the counter-based generator
+__global__ void drop_path_masks_kernel(float* __restrict__ s, const float* __restrict__ keep, int P, int n, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P * n) return;
+    const int p = i / n;
+    const float k = keep[p];
+    s[i] = floorf(k + uniform01(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(p + 1), (uint64_t)(i - p * n))) / k;
+}
+
 __global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -382,14 +392,24 @@ __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __r
     if (ty == 0 && n < Ndim) partials[(int64_t)blockIdx.y * Ndim + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 
-__global__ void layerscale_stage2_kernel(const float* __restrict__ partials, int P, const float* __restrict__ b2,
-                                         const float* __restrict__ gamma, const float* __restrict__ S, float* __restrict__ dgamma,
-                                         float* __restrict__ db2, int Ndim, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= Ndim) return;
+// stage 2: 16 columns x 16 partial-row lanes per workgroup (P / 16 dependent steps instead of P), fixed order
+__global__ __launch_bounds__(256) void layerscale_stage2_kernel(const float* __restrict__ partials, int P, const float* __restrict__ b2,
+                                                                const float* __restrict__ gamma, const float* __restrict__ S,
+                                                                float* __restrict__ dgamma, float* __restrict__ db2, int Ndim,
+                                                                int accumulate) {
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = blockIdx.x * 16 + tx;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partials[(int64_t)p * Ndim + n];
-    const float dg = s + b2[n] * S[n], dbv = gamma[n] * S[n];
+    if (n < Ndim)
+        for (int p = ty; p < P; p += 16) s += partials[(int64_t)p * Ndim + n];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || n >= Ndim) return;
+    float t = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][tx];
+    const float dg = t + b2[n] * S[n], dbv = gamma[n] * S[n];
     if (accumulate) {
         dgamma[n] += dg;
         db2[n] += dbv;
@@ -582,6 +602,12 @@ extern "C" int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t se
     return iseg_check_launch("iseg_drop_path_mask");
 }
 
+extern "C" int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, hipStream_t stream) {
+    ISEG_REQUIRE(s && keep_probs && P > 0 && n > 0, "iseg_drop_path_masks: bad arguments");
+    hipLaunchKernelGGL(drop_path_masks_kernel, dim3((P * n + 255) / 256), dim3(256), 0, stream, s, keep_probs, P, n, seed);
+    return iseg_check_launch("iseg_drop_path_masks");
+}
+
 extern "C" int iseg_fill_f32(float* p, float value, int64_t n, hipStream_t stream) {
     ISEG_REQUIRE(p && n >= 0, "iseg_fill_f32: bad arguments");
     if (n == 0) return ISEG_OK;
@@ -611,7 +637,7 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
     }
     hipLaunchKernelGGL(layerscale_stage1_kernel, dim3((N + 63) / 64, P), dim3(256), 0, stream, Z, W2, gamma, dW2, (float*)ws, K, N,
                        accumulate);
-    hipLaunchKernelGGL(layerscale_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const float*)ws, P, b2, gamma, S,
+    hipLaunchKernelGGL(layerscale_stage2_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)ws, P, b2, gamma, S,
                        dgamma, db2, N, accumulate);
     return iseg_check_launch("iseg_layerscale_grads");
 }

@@ -583,12 +583,63 @@ class _RowScaleFn(Function):
         return K.rowscale(_c(dy).reshape(-1, C), s, ctx.rpg).reshape(dy.shape), None
 
 
+class _DropPathPool:
+    """The drop-path call sites of a training step draw from ONE launch: the first step records the (samples, keep probability)
+    sequence, every later step replays it -- one [P, n] tensor of factors, rows handed out in call order.  A step that asks for
+    something else (another batch size, eval in between) simply falls back to one launch per call and re-records."""
+
+    def __init__(self):
+        self.active, self.plan, self.rec, self.masks, self.cursor, self.keeps = False, None, None, None, 0, None
+
+    def begin(self):
+        if self.rec and self.rec != self.plan:
+            self.plan, self.keeps = list(self.rec), None
+        self.active, self.rec, self.cursor, self.masks = True, [], 0, None
+
+    def end(self):
+        self.active = False
+
+    def take(self, n, keep, device):
+        keep = float(keep)
+        if not self.active:
+            return K.drop_path_mask(n, keep, next_seed(), device)
+        self.rec.append((n, keep))
+        k = self.cursor
+        if self.plan is not None and k < len(self.plan) and self.plan[k] == (n, keep) and all(q[0] == n for q in self.plan):
+            if self.masks is None:
+                if self.keeps is None or self.keeps.device != device:
+                    self.keeps = torch.tensor([q[1] for q in self.plan], dtype=torch.float32, device=device)
+                self.masks = K.drop_path_masks(self.keeps, n, next_seed())
+            self.cursor = k + 1
+            return self.masks[k]
+        self.plan = None      # the sequence changed: individual launches until the next step re-records it
+        return K.drop_path_mask(n, keep, next_seed(), device)
+
+
+_DROP_PATH_POOL = _DropPathPool()
+
+
+class drop_path_pool:
+    """with F.drop_path_pool(): one training step's forward (CoreTrain's step uses it)"""
+
+    def __enter__(self):
+        _DROP_PATH_POOL.begin()
+
+    def __exit__(self, *a):
+        _DROP_PATH_POOL.end()
+
+
+def drop_path_factors(n, keep_prob, device):
+    """per-sample factors floor(keep + u) / keep (utils/drops.py:14-20) for one call site"""
+    return _DROP_PATH_POOL.take(int(n), keep_prob, device)
+
+
 def drop_path(x, drop_prob, training, mask=None):
     """utils/drops.py:8-22.  `mask` (per-sample factors floor(keep+u)/keep) can be injected for parity tests."""
     if (not training) or drop_prob == 0.0:
         return x
     if mask is None:
-        mask = K.drop_path_mask(x.shape[0], 1.0 - drop_prob, next_seed(), x.device)
+        mask = drop_path_factors(x.shape[0], 1.0 - drop_prob, x.device)
     return _RowScaleFn.apply(x, mask)
 
 
@@ -749,6 +800,8 @@ class _ConvNeXtBlockFn(Function):
         Kk = p.dw_kernel.shape[0]
         do2 = _c(dout).reshape(M, C)
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
+        S = torch.empty(C, dtype=torch.float32, device=xc.device)      # column sums of dbr (layer-scale and bias gradients)
+        K.colsum(dbr, C, 0, 1, M, C, S)
         cdt = xc.dtype
         side = _SideQueue(xc.device)
         dy2 = None
@@ -762,8 +815,6 @@ class _ConvNeXtBlockFn(Function):
 
         # --- side: pw2 + layer scale from Z = g^T dbr and S = colsum(dbr) (no pass over [M,C] for gamma), then dW1 (+ db1)
         def param_grads():
-            S = torch.empty(C, dtype=torch.float32, device=xc.device)
-            K.colsum(dbr, C, 0, 1, M, C, S)
             if p.gamma is not None:
                 Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
                 K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr

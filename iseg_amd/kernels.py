@@ -440,6 +440,14 @@ def drop_path_mask(n, keep_prob, seed, device):
     return s
 
 
+def drop_path_masks(keep_probs_dev, n, seed):
+    """[P, n] per-sample drop-path factors, row p with keep probability keep_probs_dev[p]: one launch for a whole step"""
+    P = keep_probs_dev.numel()
+    s = torch.empty((P, n), dtype=torch.float32, device=keep_probs_dev.device)
+    _hip.call("iseg_drop_path_masks", ptr(s), ptr(keep_probs_dev), P, n, seed, stream())
+    return s
+
+
 def fill_f32(t, value):
     _hip.call("iseg_fill_f32", ptr(t), value, t.numel(), stream())
     return t

@@ -91,7 +91,7 @@ class TrainableModel:
         ys = y if isinstance(y, (tuple, list)) else None
         self.store.zero_grad()
         dist.set_active_reducer(self.reducer)
-        with F.defer_logits_upsample():
+        with F.defer_logits_upsample(), F.drop_path_pool():
             outputs = self.model(x, training=True)
         if isinstance(outputs, dict):
             outputs = list(outputs.values())

@@ -1,0 +1,36 @@
+"""One launch for all drop-path masks of a training step (reference utils/drops.py:8-22).  (Two other small fusions were measured and
+dropped: drop-path gradient + column sums in one pass, and layer-scale gradients straight from the split-K slabs -- DESIGN 5.2.)"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_drop_path_pool_serves_a_step_from_one_launch(cuda):
+    import iseg_amd.functional as F
+    from iseg_amd import kernels as K
+
+    keeps = [0.9, 0.8, 0.5, 1.0 - 1e-3]
+    launches = []
+    real_one, real_many = K.drop_path_mask, K.drop_path_masks
+    K.drop_path_mask = lambda *a, **k: (launches.append("one"), real_one(*a, **k))[1]
+    K.drop_path_masks = lambda *a, **k: (launches.append("many"), real_many(*a, **k))[1]
+    try:
+        per_step = []
+        for step in range(3):
+            with F.drop_path_pool():
+                per_step.append([F.drop_path_factors(64, k, torch.device("cuda:0")) for k in keeps])
+        assert launches == ["one"] * 4 + ["many"] + ["many"]      # the first step records, later steps draw from one launch each
+        for masks in per_step:
+            for m, k in zip(masks, keeps):
+                assert tuple(m.shape) == (64,)
+                vals = set(round(v, 5) for v in m.cpu().tolist())
+                assert vals <= {0.0, round(1.0 / k, 5)}, (k, vals)      # floor(keep + u) / keep
+        assert not torch.equal(per_step[1][2], per_step[2][2])          # a new draw each step
+        kept = torch.stack([F.drop_path_factors(4096, 0.5, torch.device("cuda:0")) for _ in range(1)])[0]
+        assert 0.4 < (kept > 0).float().mean().item() < 0.6
+        with F.drop_path_pool():                                          # another batch size: falls back, then re-records
+            a = F.drop_path_factors(32, 0.9, torch.device("cuda:0"))
+        assert tuple(a.shape) == (32,)
+    finally:
+        K.drop_path_mask, K.drop_path_masks = real_one, real_many
