@@ -419,6 +419,78 @@ class _BatchNormTrainFn(Function):
         return dx.reshape(dy.shape), None, None, None, None, None, None, None, None
 
 
+class _BatchNormGroupFn(Function):
+    """Several independent SyncBN layers whose inputs all exist before any of them is normalised (the five ASPP branches,
+    layers/aspp.py:57-71): their packed statistics travel in ONE all-reduce forward and ONE backward instead of one per layer --
+    the exposed latency of a small RCCL message is paid once (hard part 4).  Arithmetic per layer is _BatchNormTrainFn's."""
+
+    @staticmethod
+    def forward(ctx, n, relu, layers, *tensors):
+        xs, gammas, betas = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        x2s = [_c(x).reshape(-1, x.shape[-1]) for x in xs]
+        Cs = [x2.shape[1] for x2 in x2s]
+        offs = [0]
+        for C in Cs:
+            offs.append(offs[-1] + 2 * C + 1)
+        msg = torch.empty(offs[-1], dtype=torch.float32, device=x2s[0].device)
+        for i, x2 in enumerate(x2s):
+            K.bn_stats(x2, Cs[i], x2.shape[0], Cs[i], out=msg[offs[i]:offs[i + 1]])
+        dist.all_reduce_sum(msg)
+        ys, saved = [], []
+        for i, x2 in enumerate(x2s):
+            L = layers[i]
+            mean, rstd = K.bn_finalize(msg[offs[i]:offs[i + 1]], Cs[i], L["eps"], L["momentum"], L["moving_mean"], L["moving_var"])
+            y = torch.empty_like(x2)
+            K.bn_apply_fwd(x2, Cs[i], mean, rstd, gammas[i].data, betas[i].data, y, Cs[i], x2.shape[0], Cs[i], relu)
+            ys.append(y.reshape(xs[i].shape))
+            saved += [x2, y if relu else None, mean, rstd]
+        ctx.n, ctx.relu, ctx.gammas, ctx.betas = n, relu, gammas, betas
+        ctx.save_for_backward(*saved)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, relu = ctx.n, ctx.relu
+        sv = ctx.saved_tensors
+        Cs = [sv[4 * i].shape[1] for i in range(n)]
+        offs = [0]
+        for C in Cs:
+            offs.append(offs[-1] + 2 * C)
+        msg = torch.empty(offs[-1], dtype=torch.float32, device=sv[0].device)
+        dy2s = []
+        for i in range(n):
+            x2, y, mean, rstd = sv[4 * i:4 * i + 4]
+            rows, C = x2.shape
+            dy2 = _c(dys[i]).reshape(rows, C)
+            dy2s.append(dy2)
+            sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, rows, C, relu, out=msg[offs[i]:offs[i + 1]])
+            if ctx.betas[i].requires_grad:      # local parameter gradients (the gradient all-reduce sums them over ranks later)
+                K.axpby(sums[:C], _grad(ctx.betas[i]), 1.0, 1.0, out=_grad(ctx.betas[i]))
+            if ctx.gammas[i].requires_grad:
+                K.axpby(sums[C:], _grad(ctx.gammas[i]), 1.0, 1.0, out=_grad(ctx.gammas[i]))
+            dist.grads_ready(ctx.gammas[i], ctx.betas[i])
+        world = 1
+        if dist.active():
+            msg = msg.clone()
+            dist.all_reduce_sum(msg)
+            world = dist.world_size()
+        dxs = []
+        for i in range(n):
+            x2, y, mean, rstd = sv[4 * i:4 * i + 4]
+            rows, C = x2.shape
+            dx = torch.empty_like(x2)
+            K.bn_bwd_apply(dy2s[i], C, x2, C, y, C, mean, rstd, ctx.gammas[i].data, msg[offs[i]:offs[i + 1]], 1.0 / (rows * world), dx, C, rows,
+                           C, relu)
+            dxs.append(dx.reshape(dys[i].shape))
+        return (None, None, None) + tuple(dxs) + (None,) * (2 * n)
+
+
+def batch_norm_group(xs, bns, relu=True):
+    """training-mode SyncBN of several tensors with one statistics exchange; bns: the BatchNormalization layers (built)"""
+    layers = [dict(eps=float(b.epsilon), momentum=float(b.momentum), moving_mean=b.moving_mean, moving_var=b.moving_variance) for b in bns]
+    return _BatchNormGroupFn.apply(len(xs), bool(relu), layers, *xs, *[b.gamma for b in bns], *[b.beta for b in bns])
+
+
 class _BatchNormInferFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, moving_mean, moving_var, eps, relu):

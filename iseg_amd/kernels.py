@@ -252,8 +252,9 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dgamma, dbeta, dx_add=None, accu
     return dx
 
 
-def bn_stats(x2d, ldx, rows, Cc):
-    packed = torch.empty(2 * Cc + 1, dtype=torch.float32, device=x2d.device)
+def bn_stats(x2d, ldx, rows, Cc, out=None):
+    """packed [2C+1] = (sum, sum of squares, count); `out`: a slice of a larger message (several layers, one all-reduce)"""
+    packed = out if out is not None else torch.empty(2 * Cc + 1, dtype=torch.float32, device=x2d.device)
     need = _hip.lib().iseg_bn_workspace_bytes(rows, Cc)
     ws, wsb = workspace(need, x2d.device)
     _hip.call("iseg_bn_stats", ptr(x2d), ldx, ptr(packed), rows, Cc, dt(x2d), ptr(ws), wsb, stream())
@@ -273,8 +274,8 @@ def bn_apply_fwd(x2d, ldx, mean, rstd, gamma, beta, y2d, ldy, rows, Cc, relu):
     return y2d
 
 
-def bn_bwd_reduce(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, rows, Cc, relu):
-    sums = torch.empty(2 * Cc, dtype=torch.float32, device=x2d.device)
+def bn_bwd_reduce(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, rows, Cc, relu, out=None):
+    sums = out if out is not None else torch.empty(2 * Cc, dtype=torch.float32, device=x2d.device)
     need = _hip.lib().iseg_bn_workspace_bytes(rows, Cc)
     ws, wsb = workspace(need, x2d.device)
     _hip.call("iseg_bn_bwd_reduce", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(sums), rows, Cc,

@@ -29,6 +29,8 @@ class AtrousSpatialPyramidPooling(Layer):
         self.built = True
 
     def call(self, inputs, training=None):
+        if self._can_group(training):
+            return self._call_grouped(inputs)
         results = []
         branches = int(self.use_image_level) + int(self.use_pixel_level) + len(self.asp_convs)
         xs = list(F.fork(inputs, branches))      # one alias per branch: the branch gradients are summed by our own kernel
@@ -39,3 +41,40 @@ class AtrousSpatialPyramidPooling(Layer):
         for conv in self.asp_convs:
             results.append(conv(xs.pop(0), training=training))
         return F.concat(results)
+
+    # ---- data-parallel training: the branches' SyncBN statistics share one all-reduce (and one in backward) -----------------------
+    def _branch_blocks(self):
+        blocks = []
+        if self.use_image_level:
+            blocks.append(self.image_level_block.convbnrelu)
+        if self.use_pixel_level:
+            blocks.append(self.pixel_level_block)
+        return blocks + list(self.asp_convs)
+
+    def _can_group(self, training):
+        from .. import dist, nn
+        from .base_layers import BatchNormalization
+
+        if not (training and dist.active()) or nn.dry_run():
+            return False
+        for b in self._branch_blocks():
+            if not (isinstance(b.bn, BatchNormalization) and b.bn.synchronized and b.bn.trainable and b.activation is F.relu and
+                    b.dropout is None and b.bn.built):
+                return False
+        return True
+
+    def _call_grouped(self, inputs):
+        """conv of every branch first, then ONE statistics exchange for the five BatchNormalizations (F.batch_norm_group)"""
+        blocks = self._branch_blocks()
+        xs = list(F.fork(inputs, len(blocks)))
+        h, w = inputs.shape[1], inputs.shape[2]
+        pre = []
+        for i, b in enumerate(blocks):
+            x = xs[i]
+            if self.use_image_level and i == 0:
+                x = F.global_avg_pool(x)
+            pre.append(b.conv(x))
+        outs = list(F.batch_norm_group(pre, [b.bn for b in blocks], relu=True))
+        if self.use_image_level:
+            outs[0] = F.broadcast_hw(outs[0], h, w)
+        return F.concat(outs)

@@ -53,8 +53,17 @@ def _step(rank, world, port, q, size, batch, rccl_single=False):
     x, y = synthetic_batch(batch, size[0], size[1], seed=3)
     per = batch // world
     xs, ys = x[rank * per:(rank + 1) * per].cuda(), y[rank * per:(rank + 1) * per].cuda()
+    sizes = []
+    real_allreduce = dist.all_reduce_sum
+    dist.all_reduce_sum = lambda t, async_op=False: (sizes.append(int(t.numel())), real_allreduce(t, async_op=async_op))[1]
     losses = [float(tm.train_step(xs, ys)[0]) for _ in range(2)]
+    dist.all_reduce_sum = real_allreduce
     torch.cuda.synchronize()
+    if world > 1 or rccl_single:
+        # the five ASPP branches (256 channels each) exchange their SyncBN statistics in ONE message per direction and step
+        # (layers/aspp.py _call_grouped): 5 x (2 x 256 + 1) forward, 5 x (2 x 256) backward; the end conv keeps its own pair
+        assert sizes.count(5 * 513) == 2 and sizes.count(5 * 512) == 2, sizes
+        assert sizes.count(513) == 2 and sizes.count(512) == 2, sizes
     # numpy arrays are pickled by value (torch tensors would travel through /dev/shm handles that die with this process)
     out = {p.iseg_name: p.detach().cpu().numpy().copy() for p in model.parameters()}
     out.update({b.iseg_name: b.detach().cpu().numpy().copy() for b in model.buffers() if hasattr(b, "iseg_name")})
