@@ -397,6 +397,21 @@ int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const
                        int heads, int head_dim, float scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * On-device input pipeline: data_process/pipeline.py:85-170 (StandardAugmentationsPipeline, training branch) + data_process/input_norm.py:7-80
+ * as one gather per output pixel -- random scale (bilinear image / nearest label, utils.py:303-370), bottom / right pad with the mean
+ * pixel / ignore label (augments/pad_augment.py), random crop, random flip, random erasing with noise (augments/random_erasing_augment.py)
+ * and out = v * norm_scale[c] + norm_shift[c].  images [B, Hs, Ws, 3] float32 (dtype 0) or uint8 (dtype 2), zero-padded to a common size;
+ * labels [B, Hs, Ws] int32 or NULL; params [B, iseg_augment_params_ints()] int32 on the device, per sample:
+ * H, W (valid source size), newH, newW (after the scale), off_y, off_x (crop offset in the scaled + padded image), flip, n_erase (<= 5),
+ * then n_erase x (y, x, h, w) in output coordinates.  The host draws them; the device only draws the erase noise (seed).
+ * --------------------------------------------------------------------------------------------------------- */
+int iseg_augment_params_ints(void);
+int iseg_augment_crop_batch(const void* images, int image_dtype, const int32_t* labels, const int32_t* params, const float* mean_pixel,
+                            const float* norm_scale, const float* norm_shift, int ignore_label, float* out_images, int32_t* out_labels, int B,
+                            int Hs, int Ws, int crop_h, int crop_w, uint64_t seed, iseg_stream_t stream);
+int iseg_normalize_image(const float* x, float* y, int64_t pixels, const float* norm_scale, const float* norm_shift, iseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Fused logits tail of the training step: tf.image.resize(bilinear) of the low-resolution logits z [N,Hi,Wi,C] to the label size
  * (layers/core_model_ext.py:199-256) + the ignore-label cross-entropy mean and its gradient w.r.t. z
  * (losses/catecrossentropy_ignore_label.py:44-88) + the argmax confusion matrix (metrics/seg_metric_wrapper.py:89-102), in one pass that

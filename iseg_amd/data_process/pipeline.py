@@ -1,0 +1,106 @@
+"""data_process/pipeline.py of the reference (:85-170): StandardAugmentationsPipeline with the same constructor keywords.  Training:
+random scale (one of the discrete factors min..max step, aspect kept) -> pad bottom / right with the mean pixel / ignore label up to the
+crop size -> random crop -> random flip -> random erasing; evaluation: pad only.  The reference maps these over a tf.data stream on the
+host; here the host only draws the decisions (numpy Generator, seeded) and ONE kernel (csrc/augment.hip) gathers every output pixel of the
+batch straight from the source images -- at > 1 000 images/s per GPU a host-side image pipeline would be the bottleneck."""
+import numpy as np
+import torch
+
+from .. import kernels as K
+from .. import nn
+from .input_norm import norm_affine
+from .input_norm_types import InputNormTypes
+
+
+class StandardAugmentationsPipeline:
+    def __init__(self, training=False, mean_pixel=[127.5, 127.5, 127.5], ignore_label=255, max_resize_height=None, max_resize_width=None,
+                 crop_height=513, crop_width=513, eval_crop_height=None, eval_crop_width=None, prob_of_flip=0.5, prob_of_erase=0.5,
+                 min_scale_factor=0.5, max_scale_factor=2.0, scale_factor_step_size=0.1, random_brightness=False,
+                 photo_metric_distortions=False, random_erase=True, random_jepg_quality=False, random_noisy_eval_level=0, name=None,
+                 input_norm_type=InputNormTypes.NONE, seed=0):
+        if eval_crop_height is None:
+            eval_crop_height = crop_height
+        if eval_crop_width is None:
+            eval_crop_width = crop_width
+        if not training:
+            crop_height, crop_width = eval_crop_height, eval_crop_width
+        for flag, what in ((max_resize_height or max_resize_width, "ResizeAugment"), (random_brightness, "RandomBrightnessAugment"),
+                           (photo_metric_distortions, "RandomPhotoMetricDistortions"), (random_jepg_quality, "RandomJEPGQualityAugment"),
+                           (random_noisy_eval_level > 1e-3, "RandomNoisyEvalAugment")):
+            if flag:
+                raise NotImplementedError(f"{what} is not part of the on-device pipeline (the standard recipe leaves it off)")
+        if min_scale_factor < 0 or min_scale_factor > max_scale_factor:
+            raise ValueError("Unexpected value of min_scale_factor.")
+        self.training, self.name = training, name
+        self.mean_pixel, self.ignore_label = [float(v) for v in mean_pixel], int(ignore_label)
+        self.target_height, self.target_width = int(crop_height), int(crop_width)
+        self.prob_of_flip, self.prob_of_erase, self.random_erase = prob_of_flip, prob_of_erase, random_erase
+        self.min_scale_factor, self.max_scale_factor, self.scale_factor_step_size = min_scale_factor, max_scale_factor, scale_factor_step_size
+        self.input_norm_type = input_norm_type
+        self.rng = np.random.default_rng(seed)
+        self._launches = 0
+
+    # ---- the random decisions (host) -------------------------------------------------------------------------------------------------
+    def get_random_scale(self):
+        """utils.py:303-328: a uniform draw from linspace(min, max, num_steps); step 0 = continuous uniform"""
+        lo, hi, step = self.min_scale_factor, self.max_scale_factor, self.scale_factor_step_size
+        if lo == hi:
+            return float(lo)
+        if step == 0:
+            return float(self.rng.uniform(lo, hi))
+        num_steps = int((hi - lo) / step + 1)
+        return float(np.linspace(np.float32(lo), np.float32(hi), num_steps, dtype=np.float32)[self.rng.integers(0, num_steps)])
+
+    def draw(self, sizes):
+        """per-sample parameter table [B, iseg_augment_params_ints()] for source sizes [(H, W), ...]"""
+        n_int = K.augment_params_ints()
+        tab = np.zeros((len(sizes), n_int), dtype=np.int32)
+        ch, cw = self.target_height, self.target_width
+        for b, (H, W) in enumerate(sizes):
+            nH, nW, oy, ox, flip, rects = H, W, 0, 0, 0, []
+            if self.training:
+                s = self.get_random_scale()
+                if s != 1.0:      # tf.cast(tf.cast(h, float32) * scale, int32)
+                    nH, nW = int(np.float32(H) * np.float32(s)), int(np.float32(W) * np.float32(s))
+                ph, pw = max(nH, ch), max(nW, cw)      # size after PadAugment
+                oy = int(self.rng.integers(0, ph - ch + 1))
+                ox = int(self.rng.integers(0, pw - cw + 1))
+                flip = int(self.rng.random() <= self.prob_of_flip)
+                if self.random_erase and self.rng.random() <= self.prob_of_erase:
+                    # random_erasing_augment.py:64-106 with min_area_size 0, max_area_size 0.25, 1..5 areas (the pipeline's settings)
+                    max_h, max_w = int(np.float32(ch) * np.float32(0.25)), int(np.float32(cw) * np.float32(0.25))
+                    for _ in range(int(self.rng.integers(1, 5))):
+                        ah = min(max(int(self.rng.integers(0, max(max_h, 1))), 1), ch)
+                        aw = min(max(int(self.rng.integers(0, max(max_w, 1))), 1), cw)
+                        rects.append((int(self.rng.integers(0, max(ch - ah, 1))), int(self.rng.integers(0, max(cw - aw, 1))), ah, aw))
+            tab[b, :8] = [H, W, nH, nW, oy, ox, flip, len(rects)]
+            for e, r in enumerate(rects):
+                tab[b, 8 + 4 * e:12 + 4 * e] = r
+        return tab
+
+    # ---- the batch on the device -----------------------------------------------------------------------------------------------------
+    def apply_batch(self, images, labels, sizes=None, params=None):
+        """images [B, Hs, Ws, 3] uint8 / float32 (samples smaller than Hs x Ws sit in the top-left corner, `sizes` = their (H, W)),
+        labels [B, Hs, Ws] int32 or None  ->  (float32 [B, crop_h, crop_w, 3] normalised, int32 [B, crop_h, crop_w] or None)"""
+        B, Hs, Ws, _ = images.shape
+        if sizes is None:
+            sizes = [(Hs, Ws)] * B
+        if params is None:
+            params = self.draw(sizes)
+        dev = images.device
+        scale, shift = norm_affine(self.input_norm_type)
+        self._launches += 1
+        seed = (nn.seed() * 0x9E3779B97F4A7C15 + self._launches * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return K.augment_crop_batch(images, labels, torch.from_numpy(params).to(dev), self.mean_pixel, scale, shift, self.ignore_label,
+                                    self.target_height, self.target_width, seed)
+
+    def __call__(self, ds):
+        """dataset -> dataset of augmented samples (batch of one through the same kernel), for code written against the tf.data form"""
+        if ds is None:
+            return ds
+
+        def one(image, label):
+            img, lab = self.apply_batch(image.unsqueeze(0).to(nn.device()), label.unsqueeze(0).to(nn.device()).to(torch.int32))
+            return img[0], lab[0]
+
+        return ds.map(one)

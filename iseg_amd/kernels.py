@@ -490,6 +490,44 @@ def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# input pipeline (csrc/augment.hip)
+# ---------------------------------------------------------------------------------------------------------
+def augment_params_ints():
+    return int(_hip.lib().iseg_augment_params_ints())
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def augment_crop_batch(images, labels, params, mean_pixel, norm_scale, norm_shift, ignore_label, crop_h, crop_w, seed):
+    """scale -> pad -> crop -> flip -> erase -> normalise as one gather (data_process/pipeline.py:85-170); params: int32 [B, n] on the device"""
+    _require_cuda(images, params)
+    if images.dtype not in (torch.float32, torch.uint8):
+        raise TypeError("augment_crop_batch takes float32 or uint8 images")
+    B, Hs, Ws, _ = images.shape
+    images = images.contiguous()
+    out = torch.empty((B, crop_h, crop_w, 3), dtype=torch.float32, device=images.device)
+    lab = out_lab = None
+    if labels is not None:
+        lab = labels.contiguous()
+        if lab.dtype != torch.int32:
+            lab = lab.to(torch.int32)
+        out_lab = torch.empty((B, crop_h, crop_w), dtype=torch.int32, device=images.device)
+    _hip.call("iseg_augment_crop_batch", ptr(images), 0 if images.dtype == torch.float32 else 2, ptr(lab), ptr(params.contiguous()),
+              _f3(mean_pixel), _f3(norm_scale), _f3(norm_shift), int(ignore_label), ptr(out), ptr(out_lab), B, Hs, Ws, int(crop_h), int(crop_w),
+              int(seed), stream())
+    return out, out_lab
+
+
+def normalize_image(x, norm_scale, norm_shift):
+    _require_cuda(x)
+    y = torch.empty_like(x)
+    _hip.call("iseg_normalize_image", ptr(x), ptr(y), x.numel() // 3, _f3(norm_scale), _f3(norm_shift), stream())
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------------
 # resize / loss / metric / optimizer
 # ---------------------------------------------------------------------------------------------------------
 def resize_bilinear(x, Ho, Wo, out_dtype=None):

@@ -1,0 +1,109 @@
+"""On-device input pipeline (csrc/augment.hip; reference data_process/pipeline.py:85-170, data_process/utils.py:303-370,
+augments/{pad,random_crop,random_flip,random_erasing}_augment.py, data_process/input_norm.py:7-80) against the step-by-step restatement:
+resize (oracle tf.image.resize bilinear / nearest) -> pad -> crop -> flip -> erase -> normalise, on the same drawn decisions."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(img, lab, p, mean, ignore, ch, cw, scale, shift):
+    """one sample through the reference's sequence of augmentations; returns (image [ch, cw, 3] float64, label [ch, cw], erased mask)"""
+    H, W, nH, nW, oy, ox, flip, ne = [int(v) for v in p[:8]]
+    x = torch.from_numpy(img[:H, :W].astype(np.float64))[None]
+    y = torch.from_numpy(lab[:H, :W].astype(np.int64))[None, :, :, None]
+    if (nH, nW) != (H, W):
+        x = O.resize_bilinear(x, (nH, nW))
+        y = O.resize_nearest(y, (nH, nW))
+    ph, pw = max(nH, ch), max(nW, cw)
+    xp = torch.empty(1, ph, pw, 3, dtype=torch.float64)
+    xp[:] = torch.tensor(mean, dtype=torch.float64)
+    xp[:, :nH, :nW] = x
+    yp = torch.full((1, ph, pw, 1), ignore, dtype=torch.int64)
+    yp[:, :nH, :nW] = y
+    xc, yc = xp[0, oy:oy + ch, ox:ox + cw], yp[0, oy:oy + ch, ox:ox + cw, 0]
+    if flip:
+        xc, yc = xc.flip(1), yc.flip(1)
+    erased = torch.zeros(ch, cw, dtype=torch.bool)
+    for e in range(ne):
+        ey, ex, eh, ew = [int(v) for v in p[8 + 4 * e:12 + 4 * e]]
+        erased[ey:ey + eh, ex:ex + ew] = True
+    yc = torch.where(erased, torch.tensor(ignore), yc)
+    xc = xc * torch.tensor(scale, dtype=torch.float64) + torch.tensor(shift, dtype=torch.float64)
+    return xc, yc, erased
+
+
+@pytest.mark.parametrize("img_dtype", [np.uint8, np.float32])
+@pytest.mark.parametrize("norm", ["ZERO_MEAN", "KERAS", "KERAS_SCALE", "NONE"])
+def test_training_pipeline_matches_the_sequence_of_augmentations(cuda, img_dtype, norm):
+    from iseg_amd.data_process import InputNormTypes, StandardAugmentationsPipeline, get_mean_pixel, norm_affine
+
+    nt = InputNormTypes[norm]
+    ch, cw = 48, 40
+    pipe = StandardAugmentationsPipeline(training=True, mean_pixel=get_mean_pixel(nt), ignore_label=255, crop_height=ch, crop_width=cw,
+                                         input_norm_type=nt, seed=5)
+    rng = np.random.default_rng(1)
+    sizes = [(37, 50), (64, 33), (20, 20), (64, 64), (51, 47), (30, 61)]
+    Hs, Ws = 64, 64
+    imgs = rng.integers(0, 256, (len(sizes), Hs, Ws, 3)).astype(img_dtype)
+    labs = rng.integers(0, 21, (len(sizes), Hs, Ws)).astype(np.int32)
+    saw = {"flip": 0, "erase": 0, "pad": 0, "up": 0, "down": 0}
+    for trial in range(6):
+        params = pipe.draw(sizes)
+        out, lab = pipe.apply_batch(torch.from_numpy(imgs).cuda(), torch.from_numpy(labs).cuda(), sizes, params=params)
+        assert tuple(out.shape) == (len(sizes), ch, cw, 3) and out.dtype == torch.float32 and tuple(lab.shape) == (len(sizes), ch, cw)
+        scale, shift = norm_affine(nt)
+        for b, (H, W) in enumerate(sizes):
+            p = params[b]
+            saw["flip"] += int(p[6])
+            saw["erase"] += int(p[7] > 0)
+            saw["pad"] += int(p[2] < ch or p[3] < cw)
+            saw["up"] += int(p[2] > H)
+            saw["down"] += int(p[2] < H)
+            assert 0 <= p[4] <= max(p[2], ch) - ch and 0 <= p[5] <= max(p[3], cw) - cw
+            xr, yr, erased = _reference(imgs[b], labs[b], p, pipe.mean_pixel, 255, ch, cw, scale, shift)
+            got, gl = out[b].cpu().double(), lab[b].cpu().long()
+            keep = ~erased
+            assert torch.equal(gl, yr)                                                        # labels: exact, erased -> ignore
+            err = (got[keep] - xr[keep]).abs().max().item() if keep.any() else 0.0
+            assert err <= 2e-4 * max(1.0, xr.abs().max().item()), (trial, b, err)
+            if erased.any():      # noise in [0, 255) through the normalisation
+                lo = torch.tensor([min(s * 0 + t, s * 255 + t) for s, t in zip(scale, shift)])
+                hi = torch.tensor([max(s * 0 + t, s * 255 + t) for s, t in zip(scale, shift)])
+                e = got[erased]
+                assert (e >= lo - 1e-4).all() and (e <= hi + 1e-4).all() and e.std() > 0.05 * (hi - lo).mean()
+    assert all(v > 0 for v in saw.values()), saw                                              # every branch was exercised
+
+
+def test_scale_factors_are_the_discrete_grid_and_eval_only_pads(cuda):
+    from iseg_amd.data_process import StandardAugmentationsPipeline
+
+    pipe = StandardAugmentationsPipeline(training=True, crop_height=32, crop_width=32, seed=2)
+    draws = {round(pipe.get_random_scale(), 4) for _ in range(400)}
+    assert draws == {round(float(v), 4) for v in np.linspace(np.float32(0.5), np.float32(2.0), 16, dtype=np.float32)}
+    ev = StandardAugmentationsPipeline(training=False, crop_height=40, crop_width=48, eval_crop_height=24, eval_crop_width=28)
+    assert (ev.target_height, ev.target_width) == (24, 28)
+    img = torch.arange(2 * 20 * 20 * 3, dtype=torch.float32).reshape(2, 20, 20, 3).cuda()
+    lab = torch.ones(2, 20, 20, dtype=torch.int32).cuda()
+    out, ol = ev.apply_batch(img, lab)
+    assert torch.equal(out[:, :20, :20], img) and bool((out[:, 20:] == 127.5).all()) and bool((out[:, :, 20:] == 127.5).all())
+    assert bool((ol[:, :20, :20] == 1).all()) and bool((ol[:, 20:] == 255).all())
+    with pytest.raises(NotImplementedError):
+        StandardAugmentationsPipeline(training=True, random_brightness=True)
+
+
+def test_normalize_input_value_range(cuda):
+    from iseg_amd.data_process import InputNormTypes, normalize_input_value_range
+
+    x = (torch.rand(2, 5, 7, 3) * 255).cuda()
+    z = normalize_input_value_range(x, InputNormTypes.ZERO_MEAN)
+    assert (z.cpu() - ((2.0 / 255.0) * x.cpu() - 1.0)).abs().max().item() < 1e-6
+    k = normalize_input_value_range(x, InputNormTypes.KERAS)
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    assert (k.cpu() - (x.cpu() - mean) / std).abs().max().item() < 1e-5
+    ks = normalize_input_value_range(x, InputNormTypes.KERAS_SCALE)
+    assert (ks.cpu() - (x.cpu() / 255.0 - mean / 255.0) / (std / 255.0)).abs().max().item() < 1e-5
+    assert normalize_input_value_range(x, InputNormTypes.NONE) is x
