@@ -167,10 +167,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
     if (slabs) slabs += grp * slab_group_stride;
     if (epi.bias) epi.bias += grp * N;
 
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    int t, ksplit;
+    tile_and_split(ntiles, t, ksplit);
     const int tile_n = t % tiles_n, tile_m = t / tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
 
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
             __syncthreads();
         }
     }
-    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, false, vecD);
+    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, false, vecD, ksplit);
 }
 
 struct Problem {

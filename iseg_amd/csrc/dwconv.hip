@@ -582,6 +582,225 @@ static int fwd_cv() { static int v = env_int("ISEG_DW_FWD_CV", 8); return v == 4
 static int fwd_rolled() { static int v = env_int("ISEG_DW_FWD_ROLLED", 1); return v != 0; }
 static int bw_cv() { static int v = env_int("ISEG_DW_BW_CV", 4); return v == 8 ? 8 : 4; }
 
+// DMA-tiled bf16 weight gradient (K x K, dil == 1, C % 32 == 0): the variant the ConvNeXt stages take.
+//   * a workgroup owns a 32-channel slab and walks (image, row band, column band) tiles; the x tile (with halo) and the dy tile
+//     go HBM -> LDS by global_load_lds_dwordx4 (one instruction = 16 pixels x 64 B; halo and padding pixels read a zero page), so
+//     the fill costs one address per 16-B piece and no staging registers; two workgroups per CU overlap one's fill with the
+//     other's arithmetic;
+//   * lane (cg, r, ky): 8 channels, tile row r, kernel row ky -- slides a K-wide register window along the row: per output pixel
+//     two ds_read_b128, 16 unpack and 4 K packed FMAs (K x 8 MACs); ky is the slowest lane index so only the first wavefront
+//     carries the bias sums;
+//   * row strides of 39 / 33 pixels (== 192 / 64 mod 256 B) keep the four rows a 16-lane read group touches on distinct banks;
+//   * accumulators persist over the workgroup's tiles; lanes -> workgroup by a fixed-order sum over r in LDS, workgroups -> result
+//     by launch_reduce_rows (deterministic).
+// Measured (16 images, us per launch incl. the partial reduce, register-batched kernel -> this one): 128x128x96 133.5 -> 70.4, 64x64x192
+// 71.3 -> 42.8, 32x32x384 44.8 -> 25.2, 16x16x768 42.7 -> 17.5.  SQ counters at 128x128x96: 20.1 M VALU wave-instructions (1740 per tile
+// and wavefront: 32 steps x (28 packed FMA + 16 unpack) + ~285 for the fill), VALU busy 78 % of the wavefront lifetime -- the kernel is
+// bound by the unpack + FMA issue, not by LDS (bank conflicts 5 % of LDS cycles) or HBM (L2 hit rate 80 %, 14 MB of misses).
+typedef __attribute__((address_space(3))) void* dw_lds_ptr;
+typedef const __attribute__((address_space(1))) void* dw_glb_ptr;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+__device__ uint4 dw_zero_page[4];      // 64 zero bytes (device globals are zero-initialised)
+
+__device__ __forceinline__ void unpack_bf16x8(const char* p, f32x2* out) {
+    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p);
+    const uint4 v = __builtin_bit_cast(uint4, raw);
+    out[0] = f32x2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+    out[1] = f32x2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    out[2] = f32x2{__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u)};
+    out[3] = f32x2{__uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+}
+
+template <int K, int TWD>
+__global__ __launch_bounds__(256, 2) void dwconv_bwd_weight_dma_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                       float* __restrict__ partials, int N, int H, int W, int C,
+                                                                       int pad_t, int pad_l, int TH, int tiles_h, int tiles_w) {
+    constexpr int IW = TWD + K - 1, IWP = IW + 1, DWP = TWD + 1, NT = K * K + 1;
+    static_assert((IWP * 64) % 256 == 192 && (DWP * 64) % 256 == 64, "row strides must spread rows over the banks");
+    extern __shared__ __attribute__((aligned(1024))) char smem_wg[];
+    const int IH = TH + K - 1;
+    const int xpieces = (IH * IWP + 15) / 16, dpieces = (TH * DWP + 15) / 16;
+    char* xt = smem_wg;                      // [IH][IWP][32] bf16
+    char* dt = smem_wg + xpieces * 1024;     // [TH][DWP][32] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = tid & 3, r = (tid >> 2) % TH, ky = (tid >> 2) / TH;
+    const bool worker = ky < K;
+    const int c0 = blockIdx.y * 32;
+    // blockIdx.x round-robins over the 8 XCDs: give each XCD a contiguous run of the tile sequence (neighbouring tiles share halo in its L2)
+    int lb = blockIdx.x;
+    if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    f32x2 acc[K][4], accb[4];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j][q] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accb[q] = f32x2{0.f, 0.f};
+    const int ntiles = N * tiles_h * tiles_w;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(dw_zero_page) + (lane & 3) * 8;
+    // DMA piece i of this wavefront is x piece (dy piece) wid + 4 i of the tile image; its pixel's (row, column) within the tile does not
+    // depend on the tile, so it is worked out once.  Padding slots (the spare column, rows past the tile) get row 0x7fff: never inside
+    // the image.
+    constexpr int MAXPX = (((9 + K - 1) * IWP + 15) / 16 + 3) / 4, MAXPD = ((9 * DWP + 15) / 16 + 3) / 4;
+    int xrc[MAXPX], drc[MAXPD];
+#pragma unroll
+    for (int i = 0; i < MAXPX; ++i) {
+        const int pix = (wid + 4 * i) * 16 + (lane >> 2);
+        const int rr = pix / IWP, cc = pix - rr * IWP;
+        xrc[i] = ((cc >= IW || rr >= IH ? 0x7fff : rr) << 16) | cc;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXPD; ++i) {
+        const int pix = (wid + 4 * i) * 16 + (lane >> 2);
+        const int rr = pix / DWP, cc = pix - rr * DWP;
+        drc[i] = ((cc >= TWD || rr >= TH ? 0x7fff : rr) << 16) | cc;
+    }
+    for (int tile = lb; tile < ntiles; tile += gridDim.x) {
+        int b = tile;
+        const int tw_i = b % tiles_w;
+        b /= tiles_w;
+        const int th_i = b % tiles_h;
+        const int n = b / tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * TWD;
+        __syncthreads();      // previous tile consumed
+        const bf16_t* xb = x + (((n * H + h0 - pad_t) * W + w0 - pad_l) * C + c0 + (lane & 3) * 8);      // (may point before the image: only used under `ok`)
+        const bf16_t* db = dy + (((n * H + h0) * W + w0) * C + c0 + (lane & 3) * 8);
+#pragma unroll
+        for (int i = 0; i < MAXPX; ++i) {
+            const int p = wid + 4 * i;
+            if (p < xpieces) {      // wavefront-uniform
+                int rc = xrc[i];
+                asm volatile("" : "+v"(rc));      // keep one register per piece: without this hipcc hoists every derived offset out of the tile loop and spills
+                const int rr = rc >> 16, cc = rc & 0xffff;
+                const bool ok = (unsigned)(h0 - pad_t + rr) < (unsigned)H && (unsigned)(w0 - pad_l + cc) < (unsigned)W;
+                const bf16_t* src = ok ? xb + __mul24(__mul24(rr, W) + cc, C) : zero;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr)src, (dw_lds_ptr)(xt + p * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXPD; ++i) {
+            const int p = wid + 4 * i;
+            if (p < dpieces) {
+                int rc = drc[i];
+                asm volatile("" : "+v"(rc));
+                const int rr = rc >> 16, cc = rc & 0xffff;
+                const bool ok = (unsigned)(h0 + rr) < (unsigned)H && (unsigned)(w0 + cc) < (unsigned)W;
+                const bf16_t* src = ok ? db + __mul24(__mul24(rr, W) + cc, C) : zero;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr)src, (dw_lds_ptr)(dt + p * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (worker) {
+            const char* xr = xt + ((r + ky) * IWP) * 64 + cg * 16;
+            const char* dr = dt + (r * DWP) * 64 + cg * 16;
+            f32x2 win[K][4];
+#pragma unroll
+            for (int j = 0; j < K - 1; ++j) unpack_bf16x8(xr + j * 64, win[j]);
+            // one output pixel: window slot (t + K - 1) % K takes the new x pixel, tap j reads slot (t + j) % K.  t only enters through
+            // t % K, so the row runs as a rolled loop over groups of K pixels plus a static tail (a full unroll makes hipcc hoist
+            // every ds_read of the row and spill)
+            auto step = [&](const char* xp, const char* dp, int t) {
+                unpack_bf16x8(xp, win[(t + K - 1) % K]);
+                f32x2 d[4];
+                unpack_bf16x8(dp, d);
+                if (wid == 0) {      // kernel row 0 lives in the first wavefront only (ky is the slowest lane index)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) accb[q] += d[q];
+                }
+#pragma unroll
+                for (int j = 0; j < K; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[j][q] = __builtin_elementwise_fma(win[(t + j) % K][q], d[q], acc[j][q]);
+            };
+            constexpr int GROUPS = TWD / K, TAIL = TWD % K;
+            const char* xp = xr + (K - 1) * 64;
+            const char* dp = dr;
+#pragma unroll 1
+            for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    step(xp + t * 64, dp + t * 64, t);
+                    if (t == K / 2) asm volatile("" ::: "memory");      // keeps hipcc from hoisting all 2 K ds_reads of the group (register pressure)
+                }
+                xp += K * 64;
+                dp += K * 64;
+            }
+#pragma unroll
+            for (int t = 0; t < TAIL; ++t) step(xp + t * 64, dp + t * 64, t);
+        }
+    }
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem_wg);      // [TH][NT][32]
+    if (worker) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float* dst = red + ((r * NT + ky * K + j) * 32 + cg * 8);
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[j][0].x, acc[j][0].y, acc[j][1].x, acc[j][1].y);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[j][2].x, acc[j][2].y, acc[j][3].x, acc[j][3].y);
+        }
+        if (ky == 0) {
+            float* dst = red + ((r * NT + K * K) * 32 + cg * 8);
+            *reinterpret_cast<float4*>(dst) = make_float4(accb[0].x, accb[0].y, accb[1].x, accb[1].y);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(accb[2].x, accb[2].y, accb[3].x, accb[3].y);
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * NT * C;
+    for (int i = tid; i < NT * 32; i += 256) {
+        const int tap = i >> 5, c = i & 31;
+        float s = 0.f;
+        for (int rr = 0; rr < TH; ++rr) s += red[(rr * NT + tap) * 32 + c];
+        out[(int64_t)tap * C + c0 + c] = s;
+    }
+}
+
+struct BwDmaGeom {
+    int ok, th, twd, tiles_h, tiles_w, slabs, bx;
+    size_t lds_bytes;
+};
+
+static int use_bw_dma() { static int v = env_int("ISEG_DW_BW_DMA", 1); return v != 0; }
+
+static BwDmaGeom bw_dma_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
+    BwDmaGeom g;
+    g.ok = 0;
+    if (!use_bw_dma() || elem != 2 || K != 7 || dil != 1 || C % 32 != 0) return g;
+    g.twd = W <= 16 ? 16 : 32;
+    const int t8 = (H + 7) / 8, t9 = (H + 8) / 9;
+    g.th = t9 < t8 ? 9 : 8;
+    if (g.th > H) g.th = H;
+    g.tiles_h = (H + g.th - 1) / g.th;
+    g.tiles_w = (W + g.twd - 1) / g.twd;
+    g.slabs = C / 32;
+    const int64_t ntiles = (int64_t)N * g.tiles_h * g.tiles_w;
+    if (ntiles >= (1ll << 30)) return g;
+    // two resident workgroups per CU: ~512 in flight; every workgroup of a slab gets the same number of tiles (+-1)
+    int64_t cap = 512 / g.slabs;
+    if (cap < 8) cap = 8;
+    const int64_t rounds = ceil_div64(ntiles, cap);
+    int64_t bx = ceil_div64(ntiles, rounds);
+    if (bx % 8 && (bx + 7) / 8 * 8 <= ntiles) bx = (bx + 7) / 8 * 8;
+    g.bx = (int)bx;
+    const int ih = g.th + K - 1;
+    const size_t pieces = (size_t)(ih * (g.twd + K) + 15) / 16 + (size_t)(g.th * (g.twd + 1) + 15) / 16;
+    const size_t red = (size_t)g.th * (K * K + 1) * 32 * sizeof(float);
+    g.lds_bytes = pieces * 1024 > red ? pieces * 1024 : red;
+    g.ok = 1;
+    return g;
+}
+
+static void launch_bw_dma(const void* x, const void* dy, float* ws, int N, int H, int W, int C, int pad_t, int pad_l, const BwDmaGeom& g,
+                          hipStream_t s) {
+    if (g.twd == 16)
+        hipLaunchKernelGGL((dwconv_bwd_weight_dma_kernel<7, 16>), dim3(g.bx, g.slabs), dim3(256), g.lds_bytes, s, (const bf16_t*)x,
+                           (const bf16_t*)dy, ws, N, H, W, C, pad_t, pad_l, g.th, g.tiles_h, g.tiles_w);
+    else
+        hipLaunchKernelGGL((dwconv_bwd_weight_dma_kernel<7, 32>), dim3(g.bx, g.slabs), dim3(256), g.lds_bytes, s, (const bf16_t*)x,
+                           (const bf16_t*)dy, ws, N, H, W, C, pad_t, pad_l, g.th, g.tiles_h, g.tiles_w);
+}
+
 struct BwGeom {
     int cv, gs, rt, slabs, wseg, ipl, bx;
     int lds, tiles_h, tiles_w;   // LDS-tiled variant
@@ -596,7 +815,8 @@ static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
     g.lds = 0;
     // bf16 takes the register-batched kernel below at every plane size (measured at 64x64x192: 69 us vs 88 us for the LDS tiles, equal
     // at 128x128x96); the LDS-tiled variant serves fp32 storage
-    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w() && elem != 2) {
+    static const int lds_bf16 = env_int("ISEG_DW_BW_LDS_BF16", 0);
+    if (use_bw_lds() && dil == 1 && C % 8 == 0 && W >= bw_lds_min_w() && (elem != 2 || lds_bf16)) {
         // channel slab of <= 6 groups (48 channels): 6 x K x rt lanes.  Small planes (W <= 32: one tile spans the row) take
         // the widest slab whose lane rows still cover the whole image height, so one tile = one image plane.
         static const int max_groups = env_int("ISEG_DW_BW_LDS_GROUPS", 3);   // measured 1..6 at 128x128x96 / 64x64x192: 163/107, 155/101, 137/88, 141/99, 144/92 us
@@ -761,6 +981,8 @@ extern "C" size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int W, 
     const BwGeom g3 = bw_geom(N, H, W, C, K, 1, 2);
     int bx = g.bx > g2.bx ? g.bx : g2.bx;
     if (g3.bx > bx) bx = g3.bx;
+    const BwDmaGeom gd = bw_dma_geom(N, H, W, C, K, 1, 2);
+    if (gd.ok && gd.bx > bx) bx = gd.bx;
     return (size_t)bx * (K * K + 1) * C * sizeof(float);
 }
 
@@ -771,14 +993,18 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
     ISEG_REQUIRE(C % 8 == 0, "iseg_dwconv2d_bwd_weight: C=%d must be a multiple of 8", C);
     ISEG_REQUIRE(K == 3 || K == 5 || K == 7, "iseg_dwconv2d_bwd_weight: kernel size %d unsupported", K);
     ISEG_REQUIRE((int64_t)N * H * W * C < (1ll << 31), "iseg_dwconv2d_bwd_weight: more than 2^31 elements");
-    const BwGeom g = bw_geom(N, H, W, C, K, dil, dtype == ISEG_BF16 ? 2 : 4);
+    const BwDmaGeom gd = bw_dma_geom(N, H, W, C, K, dil, dtype == ISEG_BF16 ? 2 : 4);
+    BwGeom g = bw_geom(N, H, W, C, K, dil, dtype == ISEG_BF16 ? 2 : 4);
     ISEG_REQUIRE(g.gs * K * g.rt <= 256, "iseg_dwconv2d_bwd_weight: slab does not fit a block");
+    if (gd.ok) g.bx = gd.bx;
     const size_t need = (size_t)g.bx * (K * K + 1) * C * sizeof(float);
     if (!ws || ws_bytes < need) {
         iseg_set_error("iseg_dwconv2d_bwd_weight: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    if (g.lds) {
+    if (gd.ok) {
+        launch_bw_dma(x, dy, (float*)ws, N, H, W, C, pad_t, pad_l, gd, stream);
+    } else if (g.lds) {
 #define DW_BWL(T, KK)                                                                                                               \
     hipLaunchKernelGGL((dwconv_bwd_weight_lds_kernel<T, KK>), dim3(g.bx, g.slabs), dim3(256), g.lds_bytes, stream, (const T*)x,         \
                        (const T*)dy, (float*)ws, N, H, W, C, pad_t, pad_l, g.gs, g.rt, g.tiles_h, g.tiles_w)

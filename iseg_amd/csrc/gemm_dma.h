@@ -46,10 +46,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         B += epi.off_b(blockIdx.z);
         D += epi.off_d(blockIdx.z);
     }
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    int t, ksplit;
+    tile_and_split(ntiles, t, ksplit);
     const int tile_n = t % tiles_n, tile_m = t / tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     const int nk = (int)((kend - kbeg) / 64);
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     // ---- epilogue from registers: per 16-row block, two 8-column vectors per lane (N % 8 == 0 and aligned operands are
     // eligibility conditions, so there is no scalar path) ----
     const bool split = slabs != nullptr;
-    float* const slab = split ? slabs + (int64_t)blockIdx.y * M * N : nullptr;
+    float* const slab = split ? slabs + (int64_t)ksplit * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wm * 64 + i * 16 + c15;

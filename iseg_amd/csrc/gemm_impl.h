@@ -232,6 +232,21 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return base + (b >> 3);
 }
 
+// (output tile, K split) of a workgroup.  The remap runs over the FLATTENED grid (split-major): the workgroups that share an XCD get a
+// contiguous run of (split, tile) pairs, i.e. all tiles of the same K-slice -- which read the same rows of both operands -- sit on one
+// L2.  Remapping only inside a split (round 1) dealt the tiles of one K-slice over all eight XCDs: the stage-3 weight gradient
+// (36 tiles x 13 splits) moved 212 MB for 63 MB of operands (profiles/r02_pmc.json).
+__device__ __forceinline__ void tile_and_split(int ntiles, int& tile, int& split) {
+    if (gridDim.y > 1) {
+        const int v = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, ntiles * gridDim.y);
+        tile = v % ntiles;
+        split = v / ntiles;
+    } else {
+        tile = xcd_remap(blockIdx.x, ntiles);
+        split = 0;
+    }
+}
+
 constexpr int KPAD = 8;   // K-contiguous tiles: row stride BK + 8 elements (conflict-free ds_read_b128 for BK 32/64/96/128)
 constexpr int MNPAD = 8;  // MN-contiguous tiles: row stride B{M,N} + 8 elements
 
@@ -350,14 +365,14 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, i
 template <int WM, int WN, int FM, int FN, class TO>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[FM][FN], char* smem, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                               int64_t m0, int64_t n0, int wm, int wn, int wid, int lane, float* __restrict__ slabs,
-                                              const Epi& epi, bool ones_row, int vecD) {
+                                              const Epi& epi, bool ones_row, int vecD, int ksplit) {
     constexpr int TM = FM * 16, TN = FN * 16;
     constexpr int EPI_ROWS = 32;
     constexpr int EPI_STRIDE = TN + 4;
     float* const ew = reinterpret_cast<float*>(smem) + wid * EPI_ROWS * EPI_STRIDE;
     const bool split = slabs != nullptr;
     const int64_t slab_rows = M + (ones_row ? 1 : 0);
-    float* const slab = split ? slabs + (int64_t)blockIdx.y * slab_rows * N : nullptr;
+    float* const slab = split ? slabs + (int64_t)ksplit * slab_rows * N : nullptr;
     constexpr int PASSES = (TM + EPI_ROWS - 1) / EPI_ROWS;
     constexpr int FPP = EPI_ROWS / 16;  // fragments (in M) per pass
     constexpr int CPR = TN / 8;         // 8-column groups per row
@@ -452,10 +467,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         D += epi.off_d(blockIdx.z);
     }
 
-    const int t = xcd_remap(blockIdx.x, ntiles);
+    int t, ksplit;
+    tile_and_split(ntiles, t, ksplit);
     const int tile_n = t % tiles_n, tile_m = t / tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+    const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
 
@@ -507,7 +523,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_kernel(const bf16_t* __
         }
     }
 
-    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, ones_row, vecD);
+    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, ones_row, vecD, ksplit);
 }
 
 // experiment knob (read once)

@@ -192,7 +192,8 @@ def test_layernorm_fwd_bwd(cuda, dtype, rows, C):
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape,Kk,dil", [((2, 13, 17, 96), 7, 1), ((1, 40, 70, 32), 7, 1), ((1, 16, 16, 768), 7, 2), ((2, 9, 9, 192), 7, 1), ((1, 20, 11, 64), 3, 1),
-                                         ((1, 8, 8, 112), 3, 2), ((1, 33, 5, 384), 5, 1)])
+                                         ((1, 8, 8, 112), 3, 2), ((1, 33, 5, 384), 5, 1), ((3, 64, 64, 64), 7, 1), ((1, 73, 100, 32), 7, 1), ((2, 16, 16, 96), 7, 1),
+                                         ((1, 7, 5, 32), 7, 1), ((5, 32, 32, 160), 7, 1)])
 def test_dwconv_fwd_bwd(cuda, dtype, shape, Kk, dil):
     k = K()
     N, H, W, C = shape

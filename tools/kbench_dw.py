@@ -23,7 +23,6 @@ for (S, C) in [(128, 96), (64, 192), (32, 384), (16, 768)]:
     out.append(f"S{S}C{C} fwd {f:6.1f} bww {b:6.1f}")
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
-for minw in ("48", "0"):
-    for bwl in ("1", "0"):
-        env = dict(os.environ, ISEG_DW_BW_LDS_MINW=minw, ISEG_DW_BW_LDS=bwl, TAG=f"bw_lds_minw={minw} bw_lds={bwl}")
-        subprocess.run([sys.executable, "-c", code], env=env)
+for dma in ("1", "0"):
+    env = dict(os.environ, ISEG_DW_BW_DMA=dma, TAG=f"bw_dma={dma}")
+    subprocess.run([sys.executable, "-c", code], env=env)
