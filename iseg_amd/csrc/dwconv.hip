@@ -801,6 +801,168 @@ static void launch_bw_dma(const void* x, const void* dy, float* ws, int N, int H
                            (const bf16_t*)dy, ws, N, H, W, C, pad_t, pad_l, g.th, g.tiles_h, g.tiles_w);
 }
 
+// DMA-tiled bf16 forward / data-gradient (K x K, dil == 1, C % 32 == 0): the ConvNeXt stages' variant.
+//   * persistent workgroups walk (channel slab, image, row band, column band) units; the input tile with its halo goes HBM -> LDS by
+//     global_load_lds_dwordx4 exactly as in the weight-gradient kernel above (zero page for the padding), two workgroups per CU;
+//   * lane (cg, row, seg): 8 channels, output row `row` of a 16-row band, TWO consecutive output pixels (seg = the wavefront, so a 16-lane
+//     LDS read group spans four rows: the 39 / 23-pixel row stride puts them on distinct banks);
+//   * per kernel row: the K x 8 fp32 weights of the lane's channels (LDS, broadcast reads) and TWO + K - 1 input pixels, each unpacked once
+//     and fed to up to K taps: (TWO + K - 1) x 8 unpack + TWO x K x 4 packed FMAs;
+//   * bias, residual add (`add`) and the bf16 rounding happen on the accumulators; the weights are re-staged only when the slab changes.
+template <int K, int TWO>
+__global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, const bf16_t* __restrict__ add,
+                                                                bf16_t* __restrict__ y, int N, int H, int W, int C, int pad_t, int pad_l,
+                                                                int flip, int tiles_h, int tiles_w, int slabs) {
+    constexpr int TH = 16, TWD = 4 * TWO, IH = TH + K - 1, IW = TWD + K - 1, IWP = IW + 1;
+    static_assert((IWP * 64) % 256 == 192, "row stride must spread four consecutive rows over the banks");
+    constexpr int XPIECES = (IH * IWP + 15) / 16, MAXPX = (XPIECES + 3) / 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem_fd[];
+    char* xt = smem_fd;                                                   // [IH][IWP][32] bf16
+    float* wl = reinterpret_cast<float*>(smem_fd + XPIECES * 1024);       // [K*K][32] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = tid & 3, row = (tid >> 2) & 15, seg = wid;
+    int lb = blockIdx.x;
+    if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    const int ntiles = N * tiles_h * tiles_w;
+    const int units = ntiles * slabs;
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(dw_zero_page) + (lane & 3) * 8;
+    int xrc[MAXPX];
+#pragma unroll
+    for (int i = 0; i < MAXPX; ++i) {
+        const int pix = (wid + 4 * i) * 16 + (lane >> 2);
+        const int rr = pix / IWP, cc = pix - rr * IWP;
+        xrc[i] = ((cc >= IW || rr >= IH ? 0x7fff : rr) << 16) | cc;
+    }
+    int cur_slab = -1;
+    f32x2 bv[4];
+    for (int u = lb; u < units; u += gridDim.x) {
+        const int slab = u / ntiles;
+        int b = u - slab * ntiles;
+        const int tw_i = b % tiles_w;
+        b /= tiles_w;
+        const int th_i = b % tiles_h;
+        const int n = b / tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * TWD;
+        const int c0 = slab * 32;
+        __syncthreads();      // previous unit consumed
+        if (slab != cur_slab) {      // workgroup-uniform
+            cur_slab = slab;
+            for (int i = tid; i < K * K * 8; i += 256) {      // float4 granules: [tap][32]
+                int tap = i >> 3;
+                const int c4 = (i & 7) * 4;
+                if (flip) tap = K * K - 1 - tap;
+                reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(w + tap * C + c0 + c4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = bias ? f32x2{bias[c0 + cg * 8 + 2 * q], bias[c0 + cg * 8 + 2 * q + 1]} : f32x2{0.f, 0.f};
+        }
+        const bf16_t* xb = x + (((n * H + h0 - pad_t) * W + w0 - pad_l) * C + c0 + (lane & 3) * 8);
+#pragma unroll
+        for (int i = 0; i < MAXPX; ++i) {
+            const int p = wid + 4 * i;
+            if (p < XPIECES) {
+                int rc = xrc[i];
+                asm volatile("" : "+v"(rc));
+                const int rr = rc >> 16, cc = rc & 0xffff;
+                const bool ok = (unsigned)(h0 - pad_t + rr) < (unsigned)H && (unsigned)(w0 - pad_l + cc) < (unsigned)W;
+                const bf16_t* src = ok ? xb + __mul24(__mul24(rr, W) + cc, C) : zero;
+                __builtin_amdgcn_global_load_lds((dw_glb_ptr)src, (dw_lds_ptr)(xt + p * 1024), 16, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x2 acc[TWO][4];
+#pragma unroll
+        for (int t = 0; t < TWO; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[t][q] = bv[q];
+#pragma unroll 1
+        for (int ky = 0; ky < K; ++ky) {
+            f32x2 wr[K][4];
+            const float* wrow = wl + (ky * K) * 32 + cg * 8;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float4 a = *reinterpret_cast<const float4*>(wrow + kx * 32), c = *reinterpret_cast<const float4*>(wrow + kx * 32 + 4);
+                wr[kx][0] = f32x2{a.x, a.y};
+                wr[kx][1] = f32x2{a.z, a.w};
+                wr[kx][2] = f32x2{c.x, c.y};
+                wr[kx][3] = f32x2{c.z, c.w};
+            }
+            const char* xr = xt + ((row + ky) * IWP + seg * TWO) * 64 + cg * 16;
+#pragma unroll
+            for (int s = 0; s < TWO + K - 1; ++s) {
+                f32x2 xs[4];
+                unpack_bf16x8(xr + s * 64, xs);
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const int t = s - kx;
+                    if (t >= 0 && t < TWO) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][q] = __builtin_elementwise_fma(xs[q], wr[kx][q], acc[t][q]);
+                    }
+                }
+            }
+        }
+        const int oh = h0 + row;
+        if (oh < H) {
+            const int ow0 = w0 + seg * TWO;
+            const int off0 = ((n * H + oh) * W + ow0) * C + c0 + cg * 8;
+            if (add) {
+                f32x2 av[TWO][4];
+#pragma unroll
+                for (int t = 0; t < TWO; ++t)
+                    if (ow0 + t < W) unpack_bf16x8(reinterpret_cast<const char*>(add + off0 + t * C), av[t]);
+#pragma unroll
+                for (int t = 0; t < TWO; ++t)
+                    if (ow0 + t < W) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[t][q] += av[t][q];
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < TWO; ++t)
+                if (ow0 + t < W) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o[2 * q] = (bf16_t)acc[t][q].x;
+                        o[2 * q + 1] = (bf16_t)acc[t][q].y;
+                    }
+                    *reinterpret_cast<bf16x8*>(y + off0 + t * C) = o;
+                }
+        }
+    }
+}
+
+static int use_fwd_dma() { static int v = env_int("ISEG_DW_FWD_DMA", 1); return v != 0; }
+
+static bool launch_fwd_dma(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int K,
+                           int dil, int pad_t, int pad_l, int flip, hipStream_t s) {
+    if (!use_fwd_dma() || K != 7 || dil != 1 || C % 32 != 0) return false;
+    const int two = W <= 16 ? 4 : 8;
+    const int twd = 4 * two;
+    const int tiles_h = (H + 15) / 16, tiles_w = (W + twd - 1) / twd, slabs = C / 32;
+    const int64_t units = (int64_t)N * tiles_h * tiles_w * slabs;
+    if (units >= (1ll << 30)) return false;
+    // measured (16 images, us, LDS kernel -> this one): 128x128x96 70.4 -> 53.8, 64x64x192 37.2 -> 33.9, 16x16x768 14.5 -> 12.1, but 32x32x384
+    // 19.2 -> 21.5: with one unit per workgroup nothing overlaps the tile fill, and the wide variant only fits two workgroups per CU
+    if (two == 8 && units < 768) return false;
+    // two resident workgroups per CU (512 slots); every workgroup gets the same number of units (+-1)
+    const int64_t rounds = ceil_div64(units, 512);
+    int64_t nwg = ceil_div64(units, rounds);
+    if (nwg % 8 && (nwg + 7) / 8 * 8 <= units && (nwg + 7) / 8 * 8 <= 512) nwg = (nwg + 7) / 8 * 8;
+    const int ih = 16 + K - 1, iwp = twd + K;
+    const size_t lds = (size_t)((ih * iwp + 15) / 16) * 1024 + (size_t)K * K * 32 * sizeof(float);
+    if (two == 4)
+        hipLaunchKernelGGL((dwconv_fwd_dma_kernel<7, 4>), dim3((unsigned)nwg), dim3(256), lds, s, (const bf16_t*)x, w, bias, (const bf16_t*)add,
+                           (bf16_t*)y, N, H, W, C, pad_t, pad_l, flip, tiles_h, tiles_w, slabs);
+    else
+        hipLaunchKernelGGL((dwconv_fwd_dma_kernel<7, 8>), dim3((unsigned)nwg), dim3(256), lds, s, (const bf16_t*)x, w, bias, (const bf16_t*)add,
+                           (bf16_t*)y, N, H, W, C, pad_t, pad_l, flip, tiles_h, tiles_w, slabs);
+    return true;
+}
+
 struct BwGeom {
     int cv, gs, rt, slabs, wseg, ipl, bx;
     int lds, tiles_h, tiles_w;   // LDS-tiled variant
@@ -970,6 +1132,8 @@ extern "C" int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bia
     (K == 7   ? launch_fwd_cv<T, 7>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
      : K == 5 ? launch_fwd_cv<T, 5>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
               : launch_fwd_cv<T, 3>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream))
+    if (dtype == ISEG_BF16 && launch_fwd_dma(x, w, bias, add, y, N, H, W, C, K, dil, pad_t, pad_l, flip, stream))
+        return iseg_check_launch("iseg_dwconv2d");
     return dtype == ISEG_BF16 ? DW_FWD(bf16_t) : DW_FWD(float);
 #undef DW_FWD
 }

@@ -24,5 +24,5 @@ for (S, C) in [(128, 96), (64, 192), (32, 384), (16, 768)]:
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
 for dma in ("1", "0"):
-    env = dict(os.environ, ISEG_DW_BW_DMA=dma, TAG=f"bw_dma={dma}")
+    env = dict(os.environ, ISEG_DW_BW_DMA=dma, ISEG_DW_FWD_DMA=dma, TAG=f"dma={dma}")
     subprocess.run([sys.executable, "-c", code], env=env)
