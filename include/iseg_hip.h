@@ -344,13 +344,16 @@ int iseg_relpos_bias_scatter_grad_window(const float* dbias, int ld, float* dtab
  * layers/dcn_v3/op.py:16-109 dcnv3_op + utils.py:14-209 (reference points, dilation grids, bilinear sampler), restated
  * exactly (see csrc/dcnv3.hip for the formulae and the [y,x]-vs-[x,y] quirk).  x [N,H,W,G*Cg] (unpadded; `pad` zero ring is
  * implicit), offset [N,Ho,Wo,G*kh*kw*2], mask [N,Ho,Wo,G*kh*kw] (already soft-maxed), y [N,Ho,Wo,G*Cg].
- * Backward: dx_f32 [N,H,W,G*Cg] fp32, ZEROED by the caller, receives atomic adds; doffset / dmask in the storage dtype.
+ * Backward: dx_f32 [N,H,W,G*Cg] fp32 (written in full, no need to clear it); doffset / dmask in the storage dtype.  Group widths 8 and
+ * 16 (InternImage: 16) take the deterministic path -- int64 fixed-point LDS windows per (output tile, group), then an ordered gather --
+ * and need iseg_dcnv3_bwd_workspace_bytes(...) of scratch (0 = the fallback path, which scatters with fp32 atomics, is taken).
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mask, void* y, int N, int H, int W, int G, int Cg, int kh, int kw,
                    int stride, int dil, int pad, float offset_scale, int dtype, iseg_stream_t stream);
+size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale);
 int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset, void* dmask,
                    int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype,
-                   iseg_stream_t stream);
+                   void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* out[c] (+)= sum_r a[r][c]*b[r][c]: gradient of the per-channel layer scale x * gamma (backbones/intern_image/
  * intern_image_layer.py:128,136,160,168) */
 int iseg_scale_cols(const void* x, const float* colscale, void* y, int64_t rows, int C, int dtype, iseg_stream_t stream);

@@ -110,7 +110,8 @@ SIGNATURES = {
     "iseg_relpos_bias_gather": (_i, [_p, _p, _p, _i, _i, _p]),
     "iseg_relpos_bias_scatter_grad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p]),
     "iseg_dcnv3_fwd": (_i, [_p, _p, _p, _p] + [_i] * 10 + [_f, _i, _p]),
-    "iseg_dcnv3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _p]),
+    "iseg_dcnv3_bwd_workspace_bytes": (_z, [_i] * 10 + [_f]),
+    "iseg_dcnv3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _p, _z, _p]),
     "iseg_scale_cols": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "iseg_mul_colsum_workspace_bytes": (_z, [_l, _i]),
     "iseg_mul_colsum": (_i, [_p, _p, _l, _i, _p, _i, _i, _p, _z, _p]),

@@ -18,6 +18,8 @@
 // (reductions over the group's channels) need no cross-lane step; the gradient of x is scattered with fp32 atomics.
 #include "common.h"
 #include "iseg_hip.h"
+#include <stdlib.h>
+#include <math.h>
 
 namespace {
 
@@ -227,6 +229,177 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Deterministic backward pass (Cg in {8, 16}): no floating-point atomics anywhere.
+//   * a workgroup owns (image, 16 x 16 output tile, group) and an LDS window of WS x WS padded-input pixels around the tile's zero-offset
+//     sampling footprint (the footprint of output rows lies along the input's x axis and vice versa -- the reference's transposed base
+//     grid -- so the window's x origin follows the tile's row index);
+//   * lane = (output pixel, sampling point p): tap geometry once, the group's Cg channels in registers -- the offset / mask gradients
+//     need no cross-lane step;
+//   * the input gradient is accumulated in 2^-40 fixed point (int64): integer adds commute, so the LDS atomics (ds_add_u64) give the
+//     same bits whatever the order.  Samples that leave the window (|offset| beyond the window margin) go to a dense int64 side
+//     buffer with global integer atomics -- equally order-free, only slower;
+//   * the window is written out as fp32 and a second kernel sums, for every input pixel, the windows covering it in tile order and adds
+//     the side buffer when any workgroup used it.
+// Values are clamped to |v| < 2^23 by the fixed-point conversion (resolution 9.1e-13).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int DCN_TS = 16, DCN_WS = 24;
+constexpr float DCN_FIX = 256.f;                  // 2^8: high word = floor(v * 2^8), low word = fract * 2^32
+constexpr double DCN_UNFIX = 1.0 / 1099511627776.0;      // 2^-40
+
+struct DcnWin {
+    int tiles_y, tiles_x;      // output tiles
+    int c0x, c0y, rx, ry;      // window origin: x0(ty) = ty*TS*stride*(Win-2)/Hin + c0x - rx,  y0(tx) = tx*TS*stride*(Hin-2)/Win + c0y - ry
+};
+
+__device__ __forceinline__ int dcn_win_x0(const DcnGeom& g, const DcnWin& wn, int ty) {
+    return (ty * DCN_TS * g.stride * (g.Win - 2)) / g.Hin + wn.c0x - wn.rx;
+}
+__device__ __forceinline__ int dcn_win_y0(const DcnGeom& g, const DcnWin& wn, int tx) {
+    return (tx * DCN_TS * g.stride * (g.Hin - 2)) / g.Win + wn.c0y - wn.ry;
+}
+
+__device__ __forceinline__ unsigned long long dcn_to_fixed(float v256) {      // v256 = value * 2^8
+    const float fl = floorf(v256);
+    const int hi = (int)fl;                                     // saturating
+    const unsigned lo = (unsigned)((v256 - fl) * 4294967296.f);
+    return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+
+template <class T, int CG>
+__global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
+                                                            const T* __restrict__ dy, T* __restrict__ doffset, T* __restrict__ dmask,
+                                                            float* __restrict__ windows, unsigned long long* __restrict__ side,
+                                                            int* __restrict__ side_used, DcnGeom g, DcnWin wn) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long win_acc[];      // [WS*WS][CG], channel slot rotated by the pixel index
+    constexpr int WPIX = DCN_WS * DCN_WS;
+    for (int i = threadIdx.x; i < WPIX * CG; i += 256) win_acc[i] = 0ull;
+    int b = blockIdx.x;
+    const int gi = b % g.G;
+    b /= g.G;
+    const int tx = b % wn.tiles_x;
+    b /= wn.tiles_x;
+    const int ty = b % wn.tiles_y;
+    const int n = b / wn.tiles_y;
+    const int wx0 = dcn_win_x0(g, wn, ty), wy0 = dcn_win_y0(g, wn, tx);
+    const int h = ty * DCN_TS + (threadIdx.x >> 4), w = tx * DCN_TS + (threadIdx.x & 15);
+    const bool live = h < g.Ho && w < g.Wo;
+    const int P = g.kh * g.kw;
+    const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
+    float d[CG];
+    if (live) {
+#pragma unroll
+        for (int c0 = 0; c0 < CG; c0 += 8) ldv<T, 8>(dy + (pix * g.G + gi) * CG + c0, d + c0);
+    }
+    bool spilled = false;
+    __syncthreads();
+    for (int p = 0; p < P; ++p) {      // uniform: every lane of the workgroup is on the same sampling point
+        if (!live) continue;
+        const T* op = offset + ((pix * g.G + gi) * P + p) * 2;
+        const float m = to_f32(mask[(pix * g.G + gi) * P + p]);
+        const Tap tp = dcn_tap(g, h, w, p, to_f32(op[0]), to_f32(op[1]));
+        const float wgt[4] = {tp.dx1 * tp.dy1, tp.dx1 * tp.dy0, tp.dx0 * tp.dy1, tp.dx0 * tp.dy0};
+        const float wpx[4] = {-tp.dy1, -tp.dy0, tp.dy1, tp.dy0};
+        const float wpy[4] = {-tp.dx1, tp.dx1, -tp.dx0, tp.dx0};
+        const int ys[4] = {tp.y0, tp.y1, tp.y0, tp.y1};
+        const int xs[4] = {tp.x0, tp.x0, tp.x1, tp.x1};
+        float gm = 0.f, gpx = 0.f, gpy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t src = dcn_src(g, n, ys[k], xs[k]);
+            if (src < 0) continue;
+            float v[CG];
+#pragma unroll
+            for (int c0 = 0; c0 < CG; c0 += 8) ldv<T, 8>(x + src + gi * CG + c0, v + c0);
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) dot = fmaf(d[c], v[c], dot);
+            gm = fmaf(wgt[k], dot, gm);
+            gpx = fmaf(wpx[k], dot, gpx);
+            gpy = fmaf(wpy[k], dot, gpy);
+            const float coef = m * wgt[k] * DCN_FIX;
+            const int lx = xs[k] - wx0, ly = ys[k] - wy0;
+            if ((unsigned)lx < (unsigned)DCN_WS && (unsigned)ly < (unsigned)DCN_WS) {
+                const int wp = ly * DCN_WS + lx;
+                unsigned long long* dst = win_acc + wp * CG;
+#pragma unroll
+                for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + wp) & (CG - 1)), dcn_to_fixed(d[c] * coef));
+            } else {
+                spilled = true;
+                unsigned long long* dst = side + src + gi * CG;
+#pragma unroll
+                for (int c = 0; c < CG; ++c) atomicAdd(dst + c, dcn_to_fixed(d[c] * coef));
+            }
+        }
+        dmask[(pix * g.G + gi) * P + p] = from_f32<T>(gm);
+        doffset[((pix * g.G + gi) * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
+        doffset[((pix * g.G + gi) * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
+    }
+    if (spilled) atomicOr(side_used, 1);
+    __syncthreads();
+    float* out = windows + (int64_t)blockIdx.x * WPIX * CG;
+    for (int i = threadIdx.x; i < WPIX * CG; i += 256) {
+        const int wp = i / CG, c = i % CG;
+        out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + wp) & (CG - 1))] * DCN_UNFIX);
+    }
+}
+
+// dx[n, uy, ux, g, :] = sum of the windows that cover padded pixel (uy + pad, ux + pad), tile-row-major, + the side buffer
+template <int CG>
+__global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __restrict__ windows, const unsigned long long* __restrict__ side,
+                                                               const int* __restrict__ side_used, float* __restrict__ dx, DcnGeom g,
+                                                               DcnWin wn) {
+    constexpr int WPIX = DCN_WS * DCN_WS, Q = CG / 4;
+    const int64_t total = (int64_t)g.N * g.H * g.W * g.G * Q;
+    const bool use_side = *side_used != 0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int qc = (int)(i % Q);
+        int64_t t = i / Q;
+        const int gi = (int)(t % g.G);
+        t /= g.G;
+        const int ux = (int)(t % g.W);
+        t /= g.W;
+        const int uy = (int)(t % g.H);
+        const int n = (int)(t / g.H);
+        const int px = ux + g.pad, py = uy + g.pad;
+        // tiles whose window may hold (py, px): x0(ty) = floor(ty * kx / Hin) + c0x - rx grows with the tile ROW index; bracket the solutions
+        // of x0(ty) <= px < x0(ty) + WS with one tile of slack and test exactly below
+        const int64_t kx = (int64_t)DCN_TS * g.stride * (g.Win - 2), ky = (int64_t)DCN_TS * g.stride * (g.Hin - 2);
+        const int64_t ax = px - wn.c0x + wn.rx, ay = py - wn.c0y + wn.ry;
+        const int ty_hi = (int)min((int64_t)wn.tiles_y - 1, kx > 0 ? ((ax + 1) * g.Hin) / kx + 1 : (int64_t)wn.tiles_y - 1);
+        const int ty_lo = (int)max((int64_t)0, kx > 0 ? ((ax - DCN_WS) * g.Hin) / kx - 1 : (int64_t)0);
+        const int tx_hi = (int)min((int64_t)wn.tiles_x - 1, ky > 0 ? ((ay + 1) * g.Win) / ky + 1 : (int64_t)wn.tiles_x - 1);
+        const int tx_lo = (int)max((int64_t)0, ky > 0 ? ((ay - DCN_WS) * g.Win) / ky - 1 : (int64_t)0);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+            const int lx = px - dcn_win_x0(g, wn, ty);
+            if ((unsigned)lx >= (unsigned)DCN_WS) continue;
+            for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+                const int ly = py - dcn_win_y0(g, wn, tx);
+                if ((unsigned)ly >= (unsigned)DCN_WS) continue;
+                const int64_t blk = (((int64_t)n * wn.tiles_y + ty) * wn.tiles_x + tx) * g.G + gi;
+                const float4 v = *reinterpret_cast<const float4*>(windows + (blk * WPIX + ly * DCN_WS + lx) * CG + qc * 4);
+                acc.x += v.x;
+                acc.y += v.y;
+                acc.z += v.z;
+                acc.w += v.w;
+            }
+        }
+        const int64_t e = ((((int64_t)n * g.H + uy) * g.W + ux) * g.G + gi) * CG + qc * 4;
+        if (use_side) {
+            acc.x += (float)((double)(long long)side[e] * DCN_UNFIX);
+            acc.y += (float)((double)(long long)side[e + 1] * DCN_UNFIX);
+            acc.z += (float)((double)(long long)side[e + 2] * DCN_UNFIX);
+            acc.w += (float)((double)(long long)side[e + 3] * DCN_UNFIX);
+        }
+        *reinterpret_cast<float4*>(dx + e) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void dcn_zero_kernel(uint4* __restrict__ p, int64_t n16) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // dgamma partials of a per-channel scale y = x * gamma[c]:  out[c] = sum_r a[r][c] * b[r][c]
 template <class T>
 __global__ __launch_bounds__(256) void mul_colsum_partial_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t rows, int C,
@@ -337,6 +510,42 @@ static int make_geom(DcnGeom* g, int N, int H, int W, int G, int Cg, int kh, int
     return ISEG_OK;
 }
 
+
+// window geometry of the deterministic backward pass; ok = 0 when the zero-offset footprint of a tile does not fit the window
+static bool dcn_window(const DcnGeom& g, DcnWin* wn) {
+    if (g.Cg != 8 && g.Cg != 16) return false;
+    if (g.Win <= 2 || g.Hin <= 2) return false;
+    wn->tiles_y = (g.Ho + DCN_TS - 1) / DCN_TS;
+    wn->tiles_x = (g.Wo + DCN_TS - 1) / DCN_TS;
+    const double half = (double)((g.dil * (g.kh - 1)) / 2), halfw = (double)((g.dil * (g.kw - 1)) / 2);
+    // px(h, j) = ((half + 0.5 + h stride) / Hin + (-halfw + j dil) s / Win) (Win - 2),  j = p / kh in [0, P / kh)
+    // py(w, i) = ((halfw + 0.5 + w stride) / Win + (-half + i dil) s / Hin) (Hin - 2),  i = p % kh
+    const int nj = (g.kh * g.kw + g.kh - 1) / g.kh, ni = g.kh;
+    const double ax = (double)g.stride * (g.Win - 2) / g.Hin, ay = (double)g.stride * (g.Hin - 2) / g.Win;
+    const double gx_lo = -halfw * g.s * (g.Win - 2) / g.Win, gx_hi = (-halfw + (nj - 1) * g.dil) * g.s * (g.Win - 2) / g.Win;
+    const double gy_lo = -half * g.s * (g.Hin - 2) / g.Hin, gy_hi = (-half + (ni - 1) * g.dil) * g.s * (g.Hin - 2) / g.Hin;
+    const double bx = (half + 0.5) * (g.Win - 2) / g.Hin, by = (halfw + 0.5) * (g.Hin - 2) / g.Win;
+    const double lox = bx + (gx_lo < gx_hi ? gx_lo : gx_hi), hix = bx + (gx_lo < gx_hi ? gx_hi : gx_lo);
+    const double loy = by + (gy_lo < gy_hi ? gy_lo : gy_hi), hiy = by + (gy_lo < gy_hi ? gy_hi : gy_lo);
+    // corners x0 = floor(px), x1 = x0 + 1; the integer tile origin (ty TS stride (Win-2)) / Hin is within one pixel of ty TS ax
+    const int spanx = (int)ceil((DCN_TS - 1) * ax + (hix - lox)) + 3, spany = (int)ceil((DCN_TS - 1) * ay + (hiy - loy)) + 3;
+    if (spanx > DCN_WS || spany > DCN_WS) return false;
+    wn->rx = (DCN_WS - spanx) / 2;
+    wn->ry = (DCN_WS - spany) / 2;
+    wn->c0x = (int)floor(lox) - 1;
+    wn->c0y = (int)floor(loy) - 1;
+    return true;
+}
+
+static size_t dcn_win_bytes(const DcnGeom& g, const DcnWin& wn, size_t* side_off, size_t* flag_off) {
+    size_t win = (size_t)g.N * wn.tiles_y * wn.tiles_x * g.G * DCN_WS * DCN_WS * g.Cg * sizeof(float);
+    win = (win + 255) / 256 * 256;
+    size_t side = (size_t)g.N * g.H * g.W * g.G * g.Cg * sizeof(unsigned long long);
+    side = (side + 255) / 256 * 256;
+    *side_off = win;
+    *flag_off = win + side;
+    return win + side + 256;
+}
 }  // namespace
 
 extern "C" int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mask, void* y, int N, int H, int W, int G, int Cg, int kh,
@@ -361,13 +570,70 @@ extern "C" int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mas
     return iseg_check_launch("iseg_dcnv3_fwd");
 }
 
+extern "C" size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
+                                                 float offset_scale) {
+    DcnGeom g;
+    if (make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd_workspace_bytes") != ISEG_OK) return 0;
+    DcnWin wn;
+    if (!dcn_window(g, &wn)) return 0;
+    size_t so, fo;
+    return dcn_win_bytes(g, wn, &so, &fo);
+}
+
 extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset,
                               void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
-                              float offset_scale, int dtype, hipStream_t stream) {
+                              float offset_scale, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
     ISEG_REQUIRE(x && offset && mask && dy && dx_f32 && doffset && dmask, "iseg_dcnv3_bwd: null pointer");
     DcnGeom g;
     const int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd");
     if (rc != ISEG_OK) return rc;
+    DcnWin wn;
+    static const bool allow_win = [] { const char* e = getenv("ISEG_DCN_BWD_WIN"); return !e || atoi(e) != 0; }();
+    if (allow_win && dcn_window(g, &wn)) {
+        size_t side_off, flag_off;
+        const size_t need = dcn_win_bytes(g, wn, &side_off, &flag_off);
+        if (!ws || ws_bytes < need) {
+            iseg_set_error("iseg_dcnv3_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        float* windows = (float*)ws;
+        unsigned long long* side = (unsigned long long*)((char*)ws + side_off);
+        int* flag = (int*)((char*)ws + flag_off);
+        const int64_t n16 = (int64_t)(need - side_off) / 16;      // side buffer + flag
+        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)side, n16);
+        const unsigned blocks = (unsigned)((int64_t)N * wn.tiles_y * wn.tiles_x * G);
+        const size_t lds = (size_t)DCN_WS * DCN_WS * Cg * sizeof(unsigned long long);
+#define DCN_WIN(T, CG)                                                                                                                      \
+    do {                                                                                                                                    \
+        static const bool raised = [] {                                                                                                     \
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv3_bwd_win_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       DCN_WS * DCN_WS * CG * 8) == hipSuccess;                                                             \
+        }();                                                                                                                                \
+        (void)raised;                                                                                                                       \
+        hipLaunchKernelGGL((dcnv3_bwd_win_kernel<T, CG>), dim3(blocks), dim3(256), lds, stream, (const T*)x, (const T*)offset, (const T*)mask, \
+                           (const T*)dy, (T*)doffset, (T*)dmask, windows, side, flag, g, wn);                                               \
+    } while (0)
+        if (dtype == ISEG_BF16) {
+            if (Cg == 16) DCN_WIN(bf16_t, 16);
+            else DCN_WIN(bf16_t, 8);
+        } else {
+            if (Cg == 16) DCN_WIN(float, 16);
+            else DCN_WIN(float, 8);
+        }
+#undef DCN_WIN
+        const int64_t threads = (int64_t)N * H * W * G * (Cg / 4);
+        if (Cg == 16)
+            hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<16>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, dx_f32, g, wn);
+        else
+            hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<8>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, dx_f32, g, wn);
+        return iseg_check_launch("iseg_dcnv3_bwd");
+    }
+    // fallback (other group widths, footprints wider than the window): fp32 atomics into a zeroed dx
+    {
+        const int64_t n16 = (int64_t)N * H * W * G * Cg * 4 / 16, rem = ((int64_t)N * H * W * G * Cg * 4) % 16;
+        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16 + 1)), dim3(256), 0, stream, (uint4*)dx_f32, n16);
+        if (rem) (void)hipMemsetAsync((char*)dx_f32 + n16 * 16, 0, rem, stream);
+    }
     const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
     const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
 #define DCN_BWD(T, CV)                                                                                                              \

@@ -794,11 +794,12 @@ def dcnv3_bwd(x, offset, mask, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale
     if tuple(dy.shape) != (N, Ho, Wo, Cc) or Cc != G * Cg:
         raise ValueError("dcnv3_bwd: dy shape does not match the forward geometry")
     dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
-    fill_f32(dx, 0.0)
     doff = torch.empty_like(offset)
     dmask = torch.empty_like(mask)
-    _hip.check(_hip.lib().iseg_dcnv3_bwd(ptr(x), ptr(offset), ptr(mask), ptr(dy), ptr(dx), ptr(doff), ptr(dmask), N, H, W, G, Cg, kh, kw,
-                                        stride, dil, pad, float(offset_scale), dt(x), stream()), "iseg_dcnv3_bwd")
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_dcnv3_bwd_workspace_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
+    _hip.check(L.iseg_dcnv3_bwd(ptr(x), ptr(offset), ptr(mask), ptr(dy), ptr(dx), ptr(doff), ptr(dmask), N, H, W, G, Cg, kh, kw,
+                                stride, dil, pad, float(offset_scale), dt(x), ptr(ws), wsb, stream()), "iseg_dcnv3_bwd")
     return dx, doff, dmask
 
 

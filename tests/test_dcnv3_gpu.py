@@ -121,3 +121,28 @@ def test_intern_image_small_member(cuda, dtype, post_norm):
         assert not bad, bad
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,G,spread", [((1, 40, 37, 32), 2, 1.5), ((2, 33, 30, 16), 2, 9.0), ((1, 44, 50, 48), 3, 4.0)])
+def test_dcnv3_backward_windows_and_side_buffer(cuda, dtype, shape, G, spread):
+    """several 16 x 16 output tiles (windows overlap, the gather sums them in tile order) and offsets far beyond the window margin (the
+    int64 side buffer): same gradients as the oracle, and bit-identical from run to run"""
+    from iseg_amd import _hip
+    from iseg_amd import kernels as K
+
+    N, H, W, C = shape
+    Cg = C // G
+    assert _hip.lib().iseg_dcnv3_bwd_workspace_bytes(N, H, W, G, Cg, 3, 3, 1, 1, 1, 1.0) > 0      # the deterministic path serves these shapes
+    x, xr = q(rnd(shape, 11), dtype)
+    off, offr = q(rnd((N, H, W, G * 9 * 2), 12) * spread, dtype)
+    m, mr = q(torch.softmax(rnd((N, H, W, G, 9), 13), -1).reshape(N, H, W, G * 9), dtype)
+    dy, dyr = q(rnd(shape, 14), dtype)
+    for t in (xr, offr, mr):
+        t.requires_grad_(True)
+    O.dcnv3_op(xr, offr, mr, (3, 3), (1, 1), "SAME", (1, 1), G, Cg, 1.0).backward(dyr)
+    dx, doff, dm = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    close(dx, xr.grad, torch.float32, "dcnv3 dx", f32_tol=2e-5 if dtype == torch.float32 else 2e-2)
+    close(dm, mr.grad, dtype, "dcnv3 dmask", f32_tol=2e-5, bf16_tol=2e-2)
+    dx2, doff2, dm2 = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(dx, dx2) and torch.equal(doff, doff2) and torch.equal(dm, dm2)
