@@ -198,6 +198,24 @@ def roofline_from_timer(report, steps, survey=None):
     return common
 
 
+def step_fractions(args, ips_per_gpu, sec_per_step):
+    """the WHOLE step against both peaks, beside the single-kernel `roofline`: matrix-core fraction from the model's algorithmic flops
+    (TRAIN_GFLOP_PER_IMAGE) at the measured rate, HBM fraction from the step's PMC traffic (profiles/r02_pmc.json: rocprofv3 FETCH_SIZE /
+    WRITE_SIZE passes over this same command at the default batch and size; null for another workload or without the file)"""
+    out = {"mfma_frac": round(ips_per_gpu * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4), "hbm_frac": None, "traffic_bytes": None}
+    if args.batch == 16 and args.size == 512 and not args.fp32:
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+                st = json.load(f)["step"]
+            out["traffic_bytes"] = int(st["traffic_bytes"])
+            out["hbm_frac"] = round(st["traffic_bytes"] / sec_per_step / (HBM_PEAK_GBS * 1e9), 4)
+            out["mfma_busy_frac"] = st.get("mfma_occupancy")
+            out["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES, separate passes)"
+        except (OSError, KeyError, ValueError):
+            pass
+    return out
+
+
 def cpu_baseline(args):
     """The CPU oracle (oracle/, a port: the TensorFlow reference cannot run here) doing the same train step -- forward, mean
     ignore-label CE, backward -- in fp32 on the host cores, on a bounded sample: batch 1 at the benchmark resolution."""
@@ -304,6 +322,7 @@ def main():
         "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
         "final_loss": round(loss_val, 5),
     }
+    res["step"] = step_fractions(args, ips / world, elapsed / args.steps)
     if timer is not None:
         res["roofline"] = roofline_from_timer(timer.report(), args.steps, survey_report)
     if world == 1 and not args.no_cpu_baseline:
