@@ -34,6 +34,7 @@
 // C = 192; two wavefronts per SIMD let one's gelu overlap the other's MFMAs.
 #include "common.h"
 #include "iseg_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,13 +42,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 
-constexpr int MLP_NS = 3;                 // ring stages
 constexpr int OUT_SLAB = 32 * 36 * 4;     // per-wavefront epilogue slab: 32 rows x (32 + 4 pad) floats
 
 // NIMG images of C * 64 bytes per 32-hidden-unit slab, SUB slabs per ring stage, WAVES wavefronts of 32 rows.  Pieces of a stage are
 // dealt round-robin over the wavefronts; when PIECES % WAVES != 0 the first NHI wavefronts issue one piece more, and each wavefront
 // counts its own DMAs in the vmcnt wait.
-template <int C, int SUB, int WAVES, int NIMG> struct MlpGeom {
+template <int C, int SUB, int WAVES, int NIMG, int NSTAGES> struct MlpGeom {
+    static constexpr int NS = NSTAGES;      // ring stages
     static constexpr int HID = 4 * C, KK = C / 16, CB = C / 32;
     static constexpr int IMG = C * 64;
     static constexpr int SLAB = NIMG * IMG;
@@ -55,9 +56,9 @@ template <int C, int SUB, int WAVES, int NIMG> struct MlpGeom {
     static constexpr int PIECES = STAGE / 1024;
     static constexpr int PLO = PIECES / WAVES, NHI = PIECES % WAVES, PHI = PLO + (NHI ? 1 : 0);
     static constexpr int NST = HID / (32 * SUB);
-    static constexpr int RING = MLP_NS * STAGE > WAVES * OUT_SLAB ? MLP_NS * STAGE : WAVES * OUT_SLAB;
+    static constexpr int RING = NS * STAGE > WAVES * OUT_SLAB ? NS * STAGE : WAVES * OUT_SLAB;
     static constexpr int LDS = RING + HID * 4;         // + b1 as floats
-    static_assert(C % 32 == 0 && STAGE % 1024 == 0 && HID % (32 * SUB) == 0 && PLO >= 1 && NST >= MLP_NS - 1, "geometry");
+    static_assert(C % 32 == 0 && STAGE % 1024 == 0 && HID % (32 * SUB) == 0 && PLO >= 1 && NST >= NS - 1 && NS >= 2 && LDS <= 160 * 1024, "geometry");
 };
 
 __device__ __forceinline__ bf16x8 lds_frag(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
@@ -81,20 +82,20 @@ template <class G, int WAVES> struct RingFeeder {
 
 #define MLP_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int C, int SUB>
-__global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const void* __restrict__ FW,
+template <int C, int SUB, int WAVES, int NSTAGES>
+__global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const void* __restrict__ FW,
                                                                const float* __restrict__ b1, const float* __restrict__ b2,
                                                                const float* __restrict__ gamma, const float* __restrict__ rowscale,
                                                                int64_t rows_per_group, const bf16_t* __restrict__ R, bf16_t* __restrict__ O,
                                                                int64_t M) {
-    using G = MlpGeom<C, SUB, 8, 2>;
-    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = MLP_NS;
+    using G = MlpGeom<C, SUB, WAVES, 2, NSTAGES>;
+    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const b1s = reinterpret_cast<float*>(smem + G::RING);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * 256 + wid * 32;
+    const int64_t m0 = (int64_t)blockIdx.x * (32 * WAVES) + wid * 32;
 
     // ---- B operand of the first product: this wavefront's 32 rows of y2, all C channels, straight from global memory ----
     bf16x8 yf[KK];
@@ -105,12 +106,12 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
     }
-    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < HID; i += 64 * WAVES) b1s[i] = b1[i];
     // the loads above must have landed before the ring starts (keeps the compiler's own vmcnt bookkeeping out of the loop)
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) asm volatile("" ::"v"(yf[kk]));
 
-    RingFeeder<G, 8> feed(FW, wid, lane);
+    RingFeeder<G, WAVES> feed(FW, wid, lane);
 
     f32x16 acc[CB];
 #pragma unroll
@@ -120,11 +121,24 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
 
     const int fo = r * 32 + h * 16;      // this lane's fragment inside a [32 rows][16 k] piece
 
+    // A ring stage is one contiguous run of NF = SUB * (KK + 2 CB) fragment pieces (A1 then A2 of each slab) consumed in address order:
+    // the fragments go through a rolling window of FD registers sets, FD pieces ahead of the MFMA that uses them.  Left to itself hipcc
+    // sinks every ds_read_b128 next to its MFMA and waits for it (lgkmcnt(0) per MFMA: ~3x the MFMA time with one wavefront per SIMD);
+    // the sched_barrier after each MFMA pins the order written here.
+    constexpr int NF = SUB * (KK + 2 * CB), FD = 4;
     auto compute = [&](int stage, int kt) {
+        const char* fb = smem + stage * STAGE + fo;
+        bf16x8 win[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) win[d] = lds_frag(fb + d * 1024);
+        auto take = [&](int f) {
+            const bf16x8 a = win[f % FD];
+            if (f + FD < NF) win[f % FD] = lds_frag(fb + (f + FD) * 1024);
+            return a;
+        };
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
-            const char* img1 = smem + stage * STAGE + sub * SLAB + fo;
-            const char* img2 = img1 + IMG;
+            const int f0 = sub * (KK + 2 * CB);
             f32x16 hacc;
             {
                 const float* bb = b1s + 32 * (kt * SUB + sub) + 4 * h;      // register 4 i + u is hidden row 8 i + 4 h + u
@@ -138,15 +152,21 @@ __global__ __launch_bounds__(512) void convnext_mlp_fwd_kernel(const bf16_t* __r
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img1 + kk * 1024), yf[kk], hacc, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) {
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + kk), yf[kk], hacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             bf16x8 gf[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) gf[j >> 3][j & 7] = (bf16_t)gelu_sig(hacc[j]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img2 + (2 * cb + s) * 1024), gf[s], acc[cb], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + KK + 2 * cb + s), gf[s], acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
         }
     };
 
@@ -249,13 +269,13 @@ __device__ __forceinline__ void acc_to_row_pieces(const float* v, uint4& p0, uin
     p1 = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
-template <int C, int SUB, int WAVES>
+template <int C, int SUB, int WAVES, int NSTAGES>
 __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ D,
                                                                       const void* __restrict__ BW, const float* __restrict__ b1,
                                                                       bf16_t* __restrict__ Gout, bf16_t* __restrict__ DHout,
                                                                       bf16_t* __restrict__ DY, int64_t M) {
-    using G = MlpGeom<C, SUB, WAVES, 3>;
-    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = MLP_NS;
+    using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
+    constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
     constexpr int STORES = 4 * SUB;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const b1s = reinterpret_cast<float*>(smem + G::RING);
@@ -294,12 +314,21 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
     const bool row_ok = m0 + r < M;
     const int64_t row_o = (row_ok ? m0 + r : 0) * HID + 8 * h;
 
+    // fragment pieces of a stage in address order: A1 (KK), A3 (KK), A4 (2 CB) of each slab -- rolling window as in the forward kernel
+    constexpr int NF = SUB * (2 * KK + 2 * CB), FD = C >= 384 ? 2 : 4;      // (C = 384 runs at 490 of 512 registers)
     auto compute = [&](int stage, int kt) {
+        const char* fb = smem + stage * STAGE + fo;
+        bf16x8 win[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) win[d] = lds_frag(fb + d * 1024);
+        auto take = [&](int f) {
+            const bf16x8 a = win[f % FD];
+            if (f + FD < NF) win[f % FD] = lds_frag(fb + (f + FD) * 1024);
+            return a;
+        };
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
-            const char* img1 = smem + stage * STAGE + sub * SLAB + fo;
-            const char* img3 = img1 + IMG;
-            const char* img4 = img1 + 2 * IMG;
+            const int f0 = sub * (2 * KK + 2 * CB);
             f32x16 hacc, dacc;
             {
                 const float* bb = b1s + 32 * (kt * SUB + sub) + 4 * h;
@@ -315,9 +344,15 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
 #pragma unroll
             for (int j = 0; j < 16; ++j) dacc[j] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img1 + kk * 1024), yf[kk], hacc, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) {
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + kk), yf[kk], hacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img3 + kk * 1024), df[kk], dacc, 0, 0, 0);
+            for (int kk = 0; kk < KK; ++kk) {
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + KK + kk), df[kk], dacc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float gv[16], dv[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
@@ -328,11 +363,14 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
             bf16x8 hf[2];
 #pragma unroll
             for (int j = 0; j < 16; ++j) hf[j >> 3][j & 7] = (bf16_t)dv[j];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_frag(img4 + (2 * cb + s) * 1024), hf[s], acc[cb], 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + 2 * KK + 2 * cb + s), hf[s], acc[cb], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             uint4 g0, g1, d0, d1;
             acc_to_row_pieces(gv, g0, g1);
             acc_to_row_pieces(dv, d0, d1);
@@ -426,38 +464,44 @@ __global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const flo
     }
 }
 
-template <int C, int SUB>
+template <int C, int SUB, int WAVES, int NSTAGES>
 int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float* b2, const float* gamma, const float* rowscale,
                    int64_t rows_per_group, const void* residual, void* out, int64_t M, hipStream_t s) {
-    using G = MlpGeom<C, SUB, 8, 2>;
+    using G = MlpGeom<C, SUB, WAVES, 2, NSTAGES>;
     static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_fwd_kernel<C, SUB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   G::LDS) == hipSuccess;
-    }();
-    (void)raised;
-    const int grid = (int)ceil_div64(M, 256);
-    hipLaunchKernelGGL((convnext_mlp_fwd_kernel<C, SUB>), dim3(grid), dim3(512), G::LDS, s, (const bf16_t*)y2, FW, b1, b2, gamma, rowscale,
-                       rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M);
-    return iseg_check_launch("iseg_convnext_mlp_fwd");
-}
-
-template <int C, int SUB, int WAVES>
-int launch_mlp_bwd(const void* y2, const void* dbr, const void* BW, const float* b1, void* g, void* dh, void* dy2, int64_t M, hipStream_t s) {
-    using G = MlpGeom<C, SUB, WAVES, 3>;
-    static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_fwd_kernel<C, SUB, WAVES, NSTAGES>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
     }();
     (void)raised;
     const int grid = (int)ceil_div64(M, 32 * WAVES);
-    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, (const bf16_t*)dbr, BW, b1,
+    hipLaunchKernelGGL((convnext_mlp_fwd_kernel<C, SUB, WAVES, NSTAGES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, FW, b1, b2, gamma, rowscale,
+                       rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M);
+    return iseg_check_launch("iseg_convnext_mlp_fwd");
+}
+
+template <int C, int SUB, int WAVES, int NSTAGES>
+int launch_mlp_bwd(const void* y2, const void* dbr, const void* BW, const float* b1, void* g, void* dh, void* dy2, int64_t M, hipStream_t s) {
+    using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
+    static const bool raised = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
+    }();
+    (void)raised;
+    const int grid = (int)ceil_div64(M, 32 * WAVES);
+    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, (const bf16_t*)dbr, BW, b1,
                        (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M);
     return iseg_check_launch("iseg_convnext_mlp_bwd");
 }
 
 }  // namespace
 
-extern "C" int iseg_convnext_mlp_supported(int C, int dtype) { return dtype == ISEG_BF16 && (C == 96 || C == 192) ? 1 : 0; }
+extern "C" int iseg_convnext_mlp_supported(int C, int dtype) {
+    // C = 384 is instantiated (one wavefront per SIMD, 128-row workgroups, a two-stage ring in the backward kernel) but measured SLOWER than the
+    // GEMM pair at the flagship's 16384 rows: 115 vs 103 us forward, 199 vs 69 + 36 us backward -- only 128 workgroups, and with one wavefront
+    // per SIMD nothing overlaps the gelu VALU section with MFMAs.  Opt-in for experiments: ISEG_MLP_FUSED_384=1.
+    static const bool wide = [] { const char* e = getenv("ISEG_MLP_FUSED_384"); return e && atoi(e) != 0; }();
+    return dtype == ISEG_BF16 && (C == 96 || C == 192 || (C == 384 && wide)) ? 1 : 0;
+}
 
 extern "C" size_t iseg_convnext_mlp_tiled_bytes(int C, int backward) { return (size_t)(backward ? 3 : 2) * 4 * C * C * 2; }
 
@@ -473,21 +517,24 @@ extern "C" int iseg_convnext_mlp_prep(const float* W1, const float* W2, const fl
 extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1, const float* b2, const float* gamma,
                                      const float* rowscale, int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype,
                                      hipStream_t stream) {
-    ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_fwd: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_fwd: bf16 storage with C = 96, 192 or 384 only (C = %d, dtype = %d)", C, dtype);
     ISEG_REQUIRE(y2 && fw_tiled && b1 && b2 && residual && out && M > 0, "iseg_convnext_mlp_fwd: null operand or empty problem");
     ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_fwd: rowscale needs rows_per_group > 0");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1) & 15) == 0,
                  "iseg_convnext_mlp_fwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_fwd<96, 2>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
-    return launch_mlp_fwd<192, 1>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    if (C == 96) return launch_mlp_fwd<96, 2, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    if (C == 192) return launch_mlp_fwd<192, 1, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    // C = 384: 96 fragment + 192 accumulator registers per lane -> one wavefront per SIMD, 128-row workgroups
+    return launch_mlp_fwd<384, 1, 4, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
 }
 
 extern "C" int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled, const float* b1, void* g, void* dh, void* dy2,
                                      int64_t M, int C, int dtype, hipStream_t stream) {
-    ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_bwd: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_bwd: bf16 storage with C = 96, 192 or 384 only (C = %d, dtype = %d)", C, dtype);
     ISEG_REQUIRE(y2 && dbr && bw_tiled && b1 && g && dh && dy2 && M > 0, "iseg_convnext_mlp_bwd: null operand or empty problem");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dbr | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)g | (uintptr_t)dh | (uintptr_t)dy2) & 15) == 0,
                  "iseg_convnext_mlp_bwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_bwd<96, 2, 8>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
-    return launch_mlp_bwd<192, 1, 4>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
+    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
+    if (C == 192) return launch_mlp_bwd<192, 1, 4, 3>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
+    return launch_mlp_bwd<384, 1, 4, 2>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);      // 72-KiB slabs: a two-stage ring is what fits
 }

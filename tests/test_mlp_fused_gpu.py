@@ -58,9 +58,10 @@ def test_convnext_mlp_fwd_matches_oracle(cuda, C, M, groups, use_gamma, use_rs):
 def test_convnext_mlp_rejects_other_shapes(cuda):
     from iseg_amd import _hip, kernels as K
 
-    assert not K.convnext_mlp_supported(384, torch.bfloat16)
+    assert not K.convnext_mlp_supported(768, torch.bfloat16)      # 96-KiB weight slabs: no LDS ring fits
+    assert not K.convnext_mlp_supported(384, torch.bfloat16)      # instantiated, but slower than the GEMM pair: opt-in (ISEG_MLP_FUSED_384=1)
     assert not K.convnext_mlp_supported(96, torch.float32)
-    t = torch.zeros(64, 384, dtype=torch.bfloat16, device="cuda")
+    t = torch.zeros(64, 768, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(_hip.HipCallError):
         K.convnext_mlp_fwd(t, t, t, t, None, None, 0, t)
     with pytest.raises(_hip.HipCallError):
