@@ -171,6 +171,11 @@ int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t
  * Layout / elementwise
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, iseg_stream_t stream);
+/* K-contiguous copies of the bf16 compute kernels for the forward GEMMs (keras Dense / 1x1 Conv2D kernels are [K][N]; with both operands
+ * K-contiguous the LDS-DMA GEMM serves the forward pass too).  `count` bf16 matrices inside `src`, transposed into `dst`;
+ * table (device, int64 [count][4]) = {src element offset, dst element offset, rows, cols}; max_tiles = max over matrices of
+ * ceil(rows/64) * ceil(cols/64).  One launch per optimizer step (iseg_amd/nn.py wt()). */
+int iseg_transpose_batched(const void* src, void* dst, const int64_t* table, int count, int max_tiles, iseg_stream_t stream);
 /* dst[k][n] = src[k][n]*colscale[n]: layer-scale folded Dense kernel for the dgrad of backbones/convnext.py:54-57 */
 int iseg_scale_cols_cast(const float* src, const float* colscale, void* dst, int64_t rows, int cols, int dst_dtype,
                          iseg_stream_t stream);

@@ -426,7 +426,60 @@ static int layerscale_ksplits(int K) {
     return p;
 }
 
+
+// Batched 2-D transpose of bf16 matrices that live in one buffer: the K-contiguous copies of the Keras [K][N] kernels that the forward GEMMs
+// read (both operands K-contiguous = the LDS-DMA pipeline of gemm_dma.h).  table[t] = {src element offset, dst element offset, rows, cols};
+// block.y = matrix, block.x = 64 x 64 tile (blocks past a matrix's tile count exit).
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                                const int64_t* __restrict__ table) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
+    const int64_t* e = table + 4 * blockIdx.y;
+    const int64_t R = e[2], Cc = e[3];
+    const int tiles_c = (int)((Cc + 63) / 64), tiles_r = (int)((R + 63) / 64);
+    if ((int)blockIdx.x >= tiles_r * tiles_c) return;
+    const bf16_t* s = src + e[0];
+    bf16_t* d = dst + e[1];
+    const int64_t r0 = (int64_t)(blockIdx.x / tiles_c) * 64, c0 = (int64_t)(blockIdx.x % tiles_c) * 64;
+    const int t = threadIdx.x, tr = t >> 3, tc = (t & 7) * 8;
+    const bool vec = Cc % 8 == 0 && R % 8 == 0 && ((e[0] | e[1]) % 8) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t r = r0 + tr + 32 * i, c = c0 + tc;
+        bf16x8 v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (bf16_t)0.f;
+        if (r < R) {
+            if (vec && c + 8 <= Cc) v = *reinterpret_cast<const bf16x8*>(s + r * Cc + c);
+            else
+                for (int u = 0; u < 8; ++u)
+                    if (c + u < Cc) v[u] = s[r * Cc + c + u];
+        }
+        *reinterpret_cast<bf16x8*>(&tile[tr + 32 * i][tc]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oc = tr + 32 * i;                  // column of the source tile = row of the output
+        const int64_t orow = c0 + oc, ocol = r0 + tc;
+        if (orow >= Cc) continue;
+        bf16x8 v;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tile[tc + u][oc];
+        if (vec && ocol + 8 <= R) *reinterpret_cast<bf16x8*>(d + orow * R + ocol) = v;
+        else
+            for (int u = 0; u < 8; ++u)
+                if (ocol + u < R) d[orow * R + ocol + u] = v[u];
+    }
+}
+
 }  // namespace
+
+extern "C" int iseg_transpose_batched(const void* src, void* dst, const int64_t* table, int count, int max_tiles, hipStream_t stream) {
+    ISEG_REQUIRE(src && dst && table && count >= 0 && max_tiles >= 0, "iseg_transpose_batched: bad arguments");
+    if (count == 0 || max_tiles == 0) return ISEG_OK;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(max_tiles, count), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, table);
+    return iseg_check_launch("iseg_transpose_batched");
+}
 
 extern "C" int iseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t stream) {
     ISEG_REQUIRE(src && dst && n >= 0, "iseg_cast: bad arguments");

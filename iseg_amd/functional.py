@@ -853,8 +853,14 @@ class _ConvNeXtBlockFn(Function):
             h, g = bw, None
         else:
             h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
-            g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
-            out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+            w1t, w2t = (nn.wt(p.w1), nn.wt(p.w2)) if xc.dtype == torch.bfloat16 else (None, None)
+            if w1t is not None and w2t is not None:
+                # K-contiguous kernel copies: the forward products run on the LDS-DMA GEMM like the data gradients (256 x 128 tiles)
+                g = K.dense_fwd_t(y2, w1t, p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
+                out = K.dense_fwd_t(g, w2t, p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+            else:
+                g = K.dense_fwd(y2, nn.w(p.w1), p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
+                out = K.dense_fwd(g, nn.w(p.w2), p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
         ctx.p, ctx.dil, ctx.pad = p, dil, pad
         ctx.save_for_backward(xc, y1, y2, mean, rstd, h, g if grad else None, dp_mask)
         return out.reshape(N, H, W, C)

@@ -163,6 +163,18 @@ def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=
                 ldr=(residual.stride(0) if residual is not None else 0), a_act=a_act, pre_deriv=pre_deriv)
 
 
+def dense_fwd_t(x2d, Wt, bias=None, *, act=ACT_NONE, out=None, pre_out=None, colscale=None, rowscale=None, rows_per_group=0, residual=None,
+                pre_deriv=False):
+    """dense_fwd with the kernel given K-contiguous: Wt [N,K] (nn.wt): both operands K-contiguous, so the LDS-DMA GEMM serves it"""
+    M, K = x2d.shape
+    N = Wt.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
+    return gemm(x2d, Wt, out, M, N, K, lda=x2d.stride(0), ldb=Wt.stride(0), ldd=out.stride(0), a_kcontig=1, b_kcontig=1, bias=bias, act=act,
+                pre_out=pre_out, ldp=(pre_out.stride(0) if pre_out is not None else 0), colscale=colscale, rowscale=rowscale,
+                rows_per_group=rows_per_group, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), pre_deriv=pre_deriv)
+
+
 def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, rows_per_group=0, residual=None, accumulate=False):
     """dX [M,K] = dY [M,N] @ W[K,N]^T : W is consumed as stored (its rows are the N-contiguous reduction)."""
     M, N = dy2d.shape

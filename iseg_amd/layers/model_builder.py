@@ -3,6 +3,7 @@ get_training_value (:20-31) -- same constructor keywords, attribute names and ca
 import torch
 
 from .. import functional as F
+from .. import nn
 from ..nn import Layer
 from ..utils.common import resize_image
 from .base_layers import Conv2D, Dropout, get_activation
@@ -77,6 +78,7 @@ def _reset_weight(weight, initializer):
         shadow = getattr(weight, "iseg_compute", None)
         if shadow is not None:
             shadow.copy_(fresh.to(shadow.dtype))
+            nn.weights_changed()
 
 
 class ImageLevelBlock(Layer):

@@ -192,6 +192,57 @@ def w(param):
     return param.data
 
 
+# ---------------------------------------------------------------------------------------------------------
+# K-contiguous copies of the 2-D compute kernels (forward GEMMs through the LDS-DMA pipeline)
+# ---------------------------------------------------------------------------------------------------------
+_WEIGHTS_VERSION = [0]
+_WT = {"version": -1, "params": [], "index": {}, "buf": None, "views": [], "table": None, "base": 0, "max_tiles": 0, "ptrs": []}
+
+
+def weights_changed():
+    """the bf16 compute copies were rewritten (optimizer step, ParamStore.sync_shadow): transposed copies are stale"""
+    _WEIGHTS_VERSION[0] += 1
+
+
+def _wt_rebuild():
+    shadows = [p.iseg_compute for p in _WT["params"]]
+    dev = shadows[0].device
+    base = min(sh.data_ptr() for sh in shadows)
+    total, rows = 0, []
+    for sh in shadows:
+        k, n = sh.shape
+        rows.append([(sh.data_ptr() - base) // 2, total, k, n])
+        total += (k * n + 7) // 8 * 8
+    buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
+    _WT.update(buf=buf, base=base, views=[buf[do:do + k * n].view(n, k) for (_, do, k, n) in rows],
+               table=torch.tensor(rows, dtype=torch.int64).to(dev), ptrs=[sh.data_ptr() for sh in shadows],
+               max_tiles=max(((k + 63) // 64) * ((n + 63) // 64) for (_, _, k, n) in rows), version=-1)
+
+
+def wt(param):
+    """[N][K] bf16 copy of the 2-D kernel `param` ([K][N]) under mixed precision, or None (fp32 compute, no shadow, not 2-D).  All registered
+    kernels are re-transposed by ONE launch (iseg_transpose_batched) the first time any of them is asked for after a weight update."""
+    if compute_dtype() != torch.bfloat16:
+        return None
+    sh = getattr(param, "iseg_compute", None)
+    if sh is None or sh.dim() != 2 or not sh.is_cuda:
+        return None
+    i = _WT["index"].get(id(param))
+    if i is None or _WT["params"][i] is not param:
+        _WT["index"][id(param)] = i = len(_WT["params"])
+        _WT["params"].append(param)
+        _wt_rebuild()
+    if _WT["version"] != _WEIGHTS_VERSION[0]:
+        if any(p.iseg_compute.data_ptr() != q for p, q in zip(_WT["params"], _WT["ptrs"])):      # a new ParamStore re-homed the shadows
+            _wt_rebuild()
+        from . import _hip
+        from . import kernels as K
+
+        _hip.call("iseg_transpose_batched", _WT["base"], K.ptr(_WT["buf"]), K.ptr(_WT["table"]), len(_WT["params"]), _WT["max_tiles"], K.stream())
+        _WT["version"] = _WEIGHTS_VERSION[0]
+    return _WT["views"][i]
+
+
 _DRY = [False]
 
 

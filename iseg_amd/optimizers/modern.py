@@ -9,6 +9,7 @@ import torch
 
 from .. import _hip
 from .. import kernels as K
+from .. import nn
 from ..param_store import ParamStore
 
 
@@ -129,6 +130,7 @@ class AdamW(_FlatOptimizer):
                   K.ptr(self.seg_wd), K.ptr(self.hp), self.beta_1, self.beta_2, self.epsilon, K.ptr(seg_sq), cn, K.ptr(tot), gn, st.nblocks,
                   K.stream())
         self.iterations += 1
+        nn.weights_changed()      # the step kernel rewrote the bf16 compute copies
 
 
 class SGD(_FlatOptimizer):
@@ -154,3 +156,4 @@ class SGD(_FlatOptimizer):
                   K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_l2), K.ptr(self.hp), self.momentum, int(self.nesterov),
                   K.ptr(seg_sq), cn, K.ptr(tot), gn, st.nblocks, K.stream())
         self.iterations += 1
+        nn.weights_changed()      # the step kernel rewrote the bf16 compute copies

@@ -59,6 +59,7 @@ class ParamStore:
             K.cast(self.flat_w, torch.bfloat16, out=self.flat_bf16)
         else:
             self.flat_bf16.copy_(self.flat_w)   # host-side layout only (no GPU): never on the compute path
+        nn.weights_changed()
 
     def zero_grad(self):
         if self.flat_g.is_cuda:

@@ -8,6 +8,7 @@ import warnings
 import numpy as np
 import torch
 
+from .. import nn
 from ..nn import Layer
 from ..utils.slash_utils import replace_slash
 from .weights_file import layer_names_of, open_weights, weight_names_of, write_npz
@@ -73,6 +74,7 @@ def _assign(pairs):
             shadow = getattr(target, "iseg_compute", None)
             if shadow is not None:
                 shadow.copy_(t.to(shadow.dtype))
+                nn.weights_changed()
 
 
 def load_weights_from_group_by_name(f, model, skip_mismatch=False):

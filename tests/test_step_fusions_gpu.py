@@ -34,3 +34,37 @@ def test_drop_path_pool_serves_a_step_from_one_launch(cuda):
         assert tuple(a.shape) == (32,)
     finally:
         K.drop_path_mask, K.drop_path_masks = real_one, real_many
+
+
+def test_transposed_kernel_copies_follow_the_weights(cuda):
+    """nn.wt(): K-contiguous bf16 copies of 2-D kernels, all refreshed by one iseg_transpose_batched launch after a weight update"""
+    from iseg_amd import kernels as K
+    from iseg_amd import nn
+    from iseg_amd.optimizers.modern import SGD
+    from iseg_amd.param_store import ParamStore
+
+    nn.set_compute_dtype(torch.bfloat16)
+    try:
+        shapes = [(96, 384), (384, 96), (70, 24), (8, 200)]
+        ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+        store = ParamStore(ps)
+        for p in ps:
+            t = nn.wt(p)
+            assert t.shape == (p.shape[1], p.shape[0]) and t.is_contiguous()
+        for p in ps:
+            assert torch.equal(nn.wt(p), p.iseg_compute.t().contiguous())
+        opt = SGD(learning_rate=0.5)
+        opt.build(store)
+        store.flat_g.fill_(1.0)
+        before = nn.wt(ps[0]).clone()
+        opt.apply_gradients()
+        for p in ps:      # the first request after the step refreshes every registered copy
+            assert torch.equal(nn.wt(p), p.iseg_compute.t().contiguous())
+        assert not torch.equal(before, nn.wt(ps[0]))
+        # the forward GEMM through the K-contiguous copy agrees with the [K][N] path
+        x = torch.randn(300, 96, device="cuda").to(torch.bfloat16)
+        a = K.dense_fwd(x, nn.w(ps[0]), None)
+        b = K.dense_fwd_t(x, nn.wt(ps[0]), None)
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * a.float().abs().max().item()
+    finally:
+        nn.set_compute_dtype(torch.float32)
