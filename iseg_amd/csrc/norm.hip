@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // Each lane always owns the same channel chunks, so the parameter-gradient partials live in registers for
 // the whole row strip and are combined once per block through LDS.
 // ------------------------------------------------------------------------------------------------
-template <class T, int CPL>
+template <class T, int CPL, int U>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
@@ -106,56 +106,79 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * C; i += 256) lds_part[i] = 0.f;
     __syncthreads();
 
-    float dg[CPL][8], db[CPL][8];
+    float dg[CPL][8], db[CPL][8], gam[CPL][8];
 #pragma unroll
-    for (int i = 0; i < CPL; ++i)
+    for (int i = 0; i < CPL; ++i) {
+        const int c = li + i * lpr;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dg[i][u] = db[i][u] = 0.f;
+        for (int u = 0; u < 8; ++u) dg[i][u] = db[i][u] = gam[i][u] = 0.f;
+        if (c < nchunks) load8<float>(gamma + c * 8, gam[i]);
+    }
 
+    // U rows per lane group are in flight together: with wide rows (one row per wavefront and iteration) the loop is otherwise one dependent
+    // L2 / HBM round trip per row (measured 16384 x 384: 29 us for 38 MB)
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wid;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
-    for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
-        const int64_t row = rbase + sub;
-        const bool valid = row < rows;
-        const float mu = valid ? mean[row] : 0.f, rs = valid ? rstd[row] : 0.f;
-        float gv[CPL][8], xh[CPL][8];
-        float s1 = 0.f, s2 = 0.f;
+    for (int64_t rbase = wave_global * rpw * U; rbase < rows; rbase += nwaves * rpw * U) {
+        float d[U][CPL][8], xv[U][CPL][8], mu[U], rs[U];
+        bool valid[U];
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = li + i * lpr;
-            if (valid && c < nchunks) {
-                float d[8], xv[8], g[8];
-                load8<T>(dy + row * C + c * 8, d);
-                load8<T>(x + row * C + c * 8, xv);
-                load8<float>(gamma + c * 8, g);
+        for (int q = 0; q < U; ++q) {
+            const int64_t row = rbase + q * rpw + sub;
+            valid[q] = row < rows;
+            // every load is issued unconditionally from a clamped address and zeroed by a select afterwards: a branch per load makes hipcc
+            // wait for each one at the join, which serialises the rows again
+            const int64_t rc = valid[q] ? row : rows - 1;
+            mu[q] = mean[rc];
+            rs[q] = valid[q] ? rstd[rc] : 0.f;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int c = li + i * lpr;
+                const bool ok = valid[q] && c < nchunks;
+                const int cc = c < nchunks ? c : nchunks - 1;
+                load8<T>(dy + rc * C + cc * 8, d[q][i]);
+                load8<T>(x + rc * C + cc * 8, xv[q][i]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const float h = (xv[u] - mu) * rs;
-                    xh[i][u] = h;
-                    gv[i][u] = d[u] * g[u];
-                    s1 += gv[i][u];
-                    s2 += gv[i][u] * h;
-                    dg[i][u] += d[u] * h;
-                    db[i][u] += d[u];
+                    d[q][i][u] = ok ? d[q][i][u] : 0.f;
+                    xv[q][i][u] = ok ? xv[q][i][u] : mu[q];
                 }
             }
         }
-        s1 = group_sum(s1, lpr) / (float)C;
-        s2 = group_sum(s2, lpr) / (float)C;
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = li + i * lpr;
-            if (valid && c < nchunks) {
-                float o[8];
+        for (int q = 0; q < U; ++q) {
+            const int64_t row = rbase + q * rpw + sub;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o[u] = rs * (gv[i][u] - s1 - xh[i][u] * s2);
-                if (dx_add) {
-                    float a[8];
-                    load8<T>(dx_add + row * C + c * 8, a);
+            for (int i = 0; i < CPL; ++i)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) o[u] += a[u];
+                for (int u = 0; u < 8; ++u) {
+                    const float h = (xv[q][i][u] - mu[q]) * rs[q];      // (padding chunks: d = 0, so they add nothing)
+                    const float gv = d[q][i][u] * gam[i][u];
+                    xv[q][i][u] = h;
+                    s1 += gv;
+                    s2 += gv * h;
+                    dg[i][u] += d[q][i][u] * h;
+                    db[i][u] += d[q][i][u];
+                    d[q][i][u] = gv;
                 }
-                store8<T>(dx + row * C + c * 8, o);
+            s1 = group_sum(s1, lpr) / (float)C;
+            s2 = group_sum(s2, lpr) / (float)C;
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int c = li + i * lpr;
+                if (valid[q] && c < nchunks) {
+                    float o[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] = rs[q] * (d[q][i][u] - s1 - xv[q][i][u] * s2);
+                    if (dx_add) {
+                        float a[8];
+                        load8<T>(dx_add + row * C + c * 8, a);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) o[u] += a[u];
+                    }
+                    store8<T>(dx + row * C + c * 8, o);
+                }
             }
         }
     }
@@ -458,15 +481,19 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
     float* partials = (float*)ws;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const int cpl = (C / 8 + lpr - 1) / lpr;
-#define LN_BWD(T, CPL)                                                                                                   \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
+#define LN_BWD(T, CPL, U)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
                        mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr)
-#define LN_BWD_T(T)                  \
-    do {                             \
-        if (cpl <= 1) LN_BWD(T, 1);      \
-        else if (cpl <= 2) LN_BWD(T, 2); \
-        else if (cpl <= 4) LN_BWD(T, 4); \
-        else LN_BWD(T, 8);               \
+    // rows in flight per lane group: 4 when a wavefront holds one or two rows per iteration, 2 for four, else 1 (64 / lpr rows already)
+#define LN_BWD_T(T)                                     \
+    do {                                                \
+        if (cpl <= 1) {                                 \
+            if (lpr >= 32) LN_BWD(T, 1, 4);             \
+            else if (lpr >= 16) LN_BWD(T, 1, 2);        \
+            else LN_BWD(T, 1, 1);                       \
+        } else if (cpl <= 2) LN_BWD(T, 2, 4);           \
+        else if (cpl <= 4) LN_BWD(T, 4, 2);             \
+        else LN_BWD(T, 8, 1);                           \
     } while (0)
     if (dtype == ISEG_BF16) LN_BWD_T(bf16_t);
     else LN_BWD_T(float);
