@@ -25,6 +25,21 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _rows2d(t):
+    """[..., C] as ([rows, C] view, row stride in elements) WITHOUT a copy when the rows are equally spaced and 16-byte aligned -- the
+    gradient of a channel slice of a wider NHWC tensor (ASPP's concatenation) -- else through a contiguous copy"""
+    C = t.shape[-1]
+    if t.is_contiguous():
+        return t.reshape(-1, C), C
+    per16 = 16 // t.element_size()
+    if t.dim() >= 2 and t.stride(-1) == 1 and all(t.stride(i) == t.stride(i + 1) * t.shape[i + 1] for i in range(t.dim() - 2)):
+        ld = t.stride(-2)
+        if ld % per16 == 0 and t.storage_offset() % per16 == 0 and C % per16 == 0:
+            return t.as_strided((t.numel() // C, C), (ld, 1)), ld
+    t = t.contiguous()
+    return t.reshape(-1, C), C
+
+
 def _dry(shape, like, dtype=None):
     return torch.empty(tuple(int(v) for v in shape), dtype=dtype or like.dtype, device=like.device)
 
@@ -401,8 +416,8 @@ class _BatchNormTrainFn(Function):
     def backward(ctx, dy):
         x2, y, mean, rstd, packed = ctx.saved_tensors
         rows, C = x2.shape
-        dy2 = _c(dy).reshape(rows, C)
-        sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, rows, C, ctx.relu)
+        dy2, lddy = _rows2d(dy)
+        sums = K.bn_bwd_reduce(dy2, lddy, x2, C, y, C, mean, rstd, rows, C, ctx.relu)
         # local parameter gradients (the gradient all-reduce sums them over ranks later)
         if ctx.beta.requires_grad:
             K.axpby(sums[:C], _grad(ctx.beta), 1.0, 1.0, out=_grad(ctx.beta))
@@ -415,7 +430,7 @@ class _BatchNormTrainFn(Function):
             dist.all_reduce_sum(sums)
             n_total = rows * dist.world_size()
         dx = torch.empty_like(x2)
-        K.bn_bwd_apply(dy2, C, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / n_total, dx, C, rows, C, ctx.relu)
+        K.bn_bwd_apply(dy2, lddy, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / n_total, dx, C, rows, C, ctx.relu)
         return dx.reshape(dy.shape), None, None, None, None, None, None, None, None
 
 
@@ -461,9 +476,9 @@ class _BatchNormGroupFn(Function):
         for i in range(n):
             x2, y, mean, rstd = sv[4 * i:4 * i + 4]
             rows, C = x2.shape
-            dy2 = _c(dys[i]).reshape(rows, C)
-            dy2s.append(dy2)
-            sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, rows, C, relu, out=msg[offs[i]:offs[i + 1]])
+            dy2, lddy = _rows2d(dys[i])
+            dy2s.append((dy2, lddy))
+            sums = K.bn_bwd_reduce(dy2, lddy, x2, C, y, C, mean, rstd, rows, C, relu, out=msg[offs[i]:offs[i + 1]])
             if ctx.betas[i].requires_grad:      # local parameter gradients (the gradient all-reduce sums them over ranks later)
                 K.axpby(sums[:C], _grad(ctx.betas[i]), 1.0, 1.0, out=_grad(ctx.betas[i]))
             if ctx.gammas[i].requires_grad:
@@ -479,8 +494,8 @@ class _BatchNormGroupFn(Function):
             x2, y, mean, rstd = sv[4 * i:4 * i + 4]
             rows, C = x2.shape
             dx = torch.empty_like(x2)
-            K.bn_bwd_apply(dy2s[i], C, x2, C, y, C, mean, rstd, ctx.gammas[i].data, msg[offs[i]:offs[i + 1]], 1.0 / (rows * world), dx, C, rows,
-                           C, relu)
+            K.bn_bwd_apply(dy2s[i][0], dy2s[i][1], x2, C, y, C, mean, rstd, ctx.gammas[i].data, msg[offs[i]:offs[i + 1]], 1.0 / (rows * world),
+                           dx, C, rows, C, relu)
             dxs.append(dx.reshape(dys[i].shape))
         return (None, None, None) + tuple(dxs) + (None,) * (2 * n)
 
@@ -777,7 +792,8 @@ class _BroadcastHWFn(Function):
     def backward(ctx, dy):
         N, H, W, C = dy.shape
         out = torch.empty((N, C), dtype=torch.float32, device=dy.device)
-        K.colsum(_c(dy), C, H * W * C, N, H * W, C, out)
+        dy2, lddy = _rows2d(dy)
+        K.colsum(dy2, lddy, H * W * lddy, N, H * W, C, out)
         return K.cast(out, dy.dtype).reshape(N, 1, 1, C), None, None
 
 
