@@ -17,6 +17,7 @@
 // 44.6 -> 32.1 us, M=4096 N=4096 K=1024 59.9 -> 43.0 us; end to end the flagship gains 0.5 % (its dgrads are epilogue-bound).
 #pragma once
 #include "gemm_impl.h"
+#include <stdlib.h>
 
 namespace iseg_mm {
 
@@ -225,6 +226,10 @@ int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default
 // most CUs -- it reads each B panel half as often; otherwise 128 x 128, two per CU when there are enough tiles, the deeper ring when
 // the grid is thin.
 inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
+    static const int forced = [] { const char* e = getenv("ISEG_GEMM_DMA_VARIANT"); return e ? atoi(e) : 0; }();      // experiment knob
+    static const int forced_epi = [] { const char* e = getenv("ISEG_GEMM_DMA_VARIANT_EPI"); return e ? atoi(e) : 0; }();
+    if (forced >= 1 && forced <= 4 && g->N > 64) return forced;
+    if (forced_epi >= 1 && forced_epi <= 4 && g->N > 64 && (g->act != 0 || g->aux || g->residual)) return forced_epi;
     const int64_t tiles256 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), tiles128 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128);
     if (g->N <= 64) return 1;
     if (tiles256 * nsplit >= 192) return 2;

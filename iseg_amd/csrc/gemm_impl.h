@@ -79,7 +79,7 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
             float d[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (FAST) gelu_fast_both(v[i], v[i], d[i]);
+                if (FAST) gelu_sig_both(v[i], v[i], d[i]);
                 else {
                     d[i] = gelu_erf_grad(v[i]);
                     v[i] = gelu_erf(v[i]);
@@ -88,7 +88,7 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
             store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_sig(v[i]) : gelu_erf(v[i]);
         }
     } else if (e.act == ISEG_ACT_MUL_AUX) {
         float a[8];
@@ -181,7 +181,7 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
             float d[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (FAST) gelu_fast_both(v[i], v[i], d[i]);
+                if (FAST) gelu_sig_both(v[i], v[i], d[i]);
                 else {
                     d[i] = gelu_erf_grad(v[i]);
                     v[i] = gelu_erf(v[i]);
@@ -190,7 +190,7 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
             store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_fast(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_sig(v[i]) : gelu_erf(v[i]);
         }
     } else if (e.act == ISEG_ACT_MUL_AUX) {
 #pragma unroll
