@@ -226,7 +226,10 @@ int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default
 // most CUs -- it reads each B panel half as often; otherwise 128 x 128, two per CU when there are enough tiles, the deeper ring when
 // the grid is thin.
 inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
-    static const int forced = [] { const char* e = getenv("ISEG_GEMM_DMA_VARIANT"); return e ? atoi(e) : 0; }();      // experiment knob
+    // experiment knobs.  Measured on the flagship step: 128 x 128 tiles, two workgroups per CU (3) for the GEMMs with fused gelu / aux / residual
+    // epilogues 10.66 vs 10.69 ms (equal), the deep-ring 128 x 128 (4) 11.28 ms; requesting the fused operands of four row blocks together
+    // in the epilogue: equal, +44 registers.  The 13-17 us these epilogues add are VALU (gelu) and un-overlapped operand reads either way.
+    static const int forced = [] { const char* e = getenv("ISEG_GEMM_DMA_VARIANT"); return e ? atoi(e) : 0; }();
     static const int forced_epi = [] { const char* e = getenv("ISEG_GEMM_DMA_VARIANT_EPI"); return e ? atoi(e) : 0; }();
     if (forced >= 1 && forced <= 4 && g->N > 64) return forced;
     if (forced_epi >= 1 && forced_epi <= 4 && g->N > 64 && (g->act != 0 || g->aux || g->residual)) return forced_epi;
