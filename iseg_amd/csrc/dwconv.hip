@@ -809,19 +809,19 @@ static void launch_bw_dma(const void* x, const void* dy, float* ws, int N, int H
 //   * per kernel row: the K x 8 fp32 weights of the lane's channels (LDS, broadcast reads) and TWO + K - 1 input pixels, each unpacked once
 //     and fed to up to K taps: (TWO + K - 1) x 8 unpack + TWO x K x 4 packed FMAs;
 //   * bias, residual add (`add`) and the bf16 rounding happen on the accumulators; the weights are re-staged only when the slab changes.
-template <int K, int TWO>
+template <int K, int TWO, int TH>
 __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                                 const float* __restrict__ bias, const bf16_t* __restrict__ add,
                                                                 bf16_t* __restrict__ y, int N, int H, int W, int C, int pad_t, int pad_l,
                                                                 int flip, int tiles_h, int tiles_w, int slabs) {
-    constexpr int TH = 16, TWD = 4 * TWO, IH = TH + K - 1, IW = TWD + K - 1, IWP = IW + 1;
+    constexpr int SEGS = 64 / TH, TWD = SEGS * TWO, IH = TH + K - 1, IW = TWD + K - 1, IWP = IW + 1;      // 4 channel groups x TH rows x SEGS segments
     static_assert((IWP * 64) % 256 == 192, "row stride must spread four consecutive rows over the banks");
     constexpr int XPIECES = (IH * IWP + 15) / 16, MAXPX = (XPIECES + 3) / 4;
     extern __shared__ __attribute__((aligned(1024))) char smem_fd[];
     char* xt = smem_fd;                                                   // [IH][IWP][32] bf16
     float* wl = reinterpret_cast<float*>(smem_fd + XPIECES * 1024);       // [K*K][32] fp32
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = tid & 3, row = (tid >> 2) & 15, seg = wid;
+    const int cg = tid & 3, row = (tid >> 2) % TH, seg = tid / (4 * TH);
     int lb = blockIdx.x;
     if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
     const int ntiles = N * tiles_h * tiles_w;
@@ -940,26 +940,39 @@ static int use_fwd_dma() { static int v = env_int("ISEG_DW_FWD_DMA", 1); return 
 static bool launch_fwd_dma(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int K,
                            int dil, int pad_t, int pad_l, int flip, hipStream_t s) {
     if (!use_fwd_dma() || K != 7 || dil != 1 || C % 32 != 0) return false;
-    const int two = W <= 16 ? 4 : 8;
-    const int twd = 4 * two;
-    const int tiles_h = (H + 15) / 16, tiles_w = (W + twd - 1) / twd, slabs = C / 32;
+    // tile shapes (rows x columns, output pixels per lane): 16 x 32 (8) for the wide planes, 8 x 32 (4) when that leaves fewer than two tiles per
+    // resident workgroup (32 x 32 planes: three smaller workgroups per CU overlap each other's fills), 16 x 16 (4) for 16-pixel planes.
+    // Measured (16 images, us, LDS kernel -> this one): 128x128x96 70.4 -> 53.8, 64x64x192 37.2 -> 33.9, 16x16x768 14.5 -> 12.1; 32x32x384 with
+    // the 16 x 32 tile 19.2 -> 21.5 (one tile per workgroup, nothing overlaps the fill), with the 8 x 32 tile -> 17.5
+    const int slabs = C / 32;
+    int two = W <= 16 ? 4 : 8, th = 16;
+    if (two == 8 && (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) * slabs < 1536) {      // (64x64x192: 33.6 -> 32.3 us; 128x128x96 would lose: 53.0 -> 58.5)
+        two = 4;
+        th = 8;
+    }
+    static const int force_small = env_int("ISEG_DW_FWD_SMALL", 0);      // experiment: the 8 x 32 (4) tile everywhere
+    if (force_small && W > 16) {
+        two = 4;
+        th = 8;
+    }
+    const int twd = (64 / th) * two;
+    const int tiles_h = (H + th - 1) / th, tiles_w = (W + twd - 1) / twd;
     const int64_t units = (int64_t)N * tiles_h * tiles_w * slabs;
     if (units >= (1ll << 30)) return false;
-    // measured (16 images, us, LDS kernel -> this one): 128x128x96 70.4 -> 53.8, 64x64x192 37.2 -> 33.9, 16x16x768 14.5 -> 12.1, but 32x32x384
-    // 19.2 -> 21.5: with one unit per workgroup nothing overlaps the tile fill, and the wide variant only fits two workgroups per CU
-    if (two == 8 && units < 768) return false;
-    // two resident workgroups per CU (512 slots); every workgroup gets the same number of units (+-1)
-    const int64_t rounds = ceil_div64(units, 512);
+    // resident workgroups: two per CU for the wide variant, three for the others; every workgroup gets the same number of units (+-1)
+    const int64_t slots = two == 8 ? 512 : 768;
+    const int64_t rounds = ceil_div64(units, slots);
     int64_t nwg = ceil_div64(units, rounds);
-    if (nwg % 8 && (nwg + 7) / 8 * 8 <= units && (nwg + 7) / 8 * 8 <= 512) nwg = (nwg + 7) / 8 * 8;
-    const int ih = 16 + K - 1, iwp = twd + K;
+    if (nwg % 8 && (nwg + 7) / 8 * 8 <= units && (nwg + 7) / 8 * 8 <= slots) nwg = (nwg + 7) / 8 * 8;
+    const int ih = th + K - 1, iwp = twd + K;
     const size_t lds = (size_t)((ih * iwp + 15) / 16) * 1024 + (size_t)K * K * 32 * sizeof(float);
-    if (two == 4)
-        hipLaunchKernelGGL((dwconv_fwd_dma_kernel<7, 4>), dim3((unsigned)nwg), dim3(256), lds, s, (const bf16_t*)x, w, bias, (const bf16_t*)add,
-                           (bf16_t*)y, N, H, W, C, pad_t, pad_l, flip, tiles_h, tiles_w, slabs);
-    else
-        hipLaunchKernelGGL((dwconv_fwd_dma_kernel<7, 8>), dim3((unsigned)nwg), dim3(256), lds, s, (const bf16_t*)x, w, bias, (const bf16_t*)add,
-                           (bf16_t*)y, N, H, W, C, pad_t, pad_l, flip, tiles_h, tiles_w, slabs);
+#define DW_FWD_DMA(TWO_, TH_)                                                                                                                  \
+    hipLaunchKernelGGL((dwconv_fwd_dma_kernel<7, TWO_, TH_>), dim3((unsigned)nwg), dim3(256), lds, s, (const bf16_t*)x, w, bias, (const bf16_t*)add, \
+                       (bf16_t*)y, N, H, W, C, pad_t, pad_l, flip, tiles_h, tiles_w, slabs)
+    if (two == 8) DW_FWD_DMA(8, 16);
+    else if (th == 8) DW_FWD_DMA(4, 8);
+    else DW_FWD_DMA(4, 16);
+#undef DW_FWD_DMA
     return true;
 }
 
