@@ -127,7 +127,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
 // choose the split so that a skinny-output contraction (wgrad: M,N small, K = pixels) still fills 256 CUs
 int choose_split(const iseg_gemm_args* g, int tile) {
     if (g->split_k > 0) return g->split_k;
-    const int64_t tiles = ceil_div64(g->M, tile) * ceil_div64(g->N, tile);
+    const int64_t tiles = ceil_div64(g->M + (g->colsum_out ? 1 : 0), tile) * ceil_div64(g->N, tile);
     if (tiles >= 256 || g->K < 2048 || g->batch > 1) return 1;
     // the LDS-DMA pipeline keeps several K-tiles in flight per workgroup: half-filled grids are better left unsplit
     if (g->in_dtype == ISEG_BF16 && tiles >= 96 && iseg_mm::dma_mode() && iseg_mm::dma_eligible(g, 128)) return 1;
@@ -188,7 +188,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     }
     if (g->colsum_out) {
         ISEG_REQUIRE(g->in_dtype == ISEG_BF16 && !g->a_kcontig && !g->b_kcontig, "iseg_gemm: colsum_out needs the bf16 wgrad orientation");
-        ISEG_REQUIRE(g->M % 128 != 0 && g->M % 8 == 0, "iseg_gemm: colsum_out needs a spare row in the last 128-row tile (M %% 128 != 0)");
+        ISEG_REQUIRE(g->M % 8 == 0, "iseg_gemm: colsum_out needs M %% 8 == 0");      // (M %% 128 == 0: the ones-row opens one more tile row)
     }
     const int64_t slab_rows = g->M + (g->colsum_out ? 1 : 0);
     const int nsplit = iseg_gemm_splits(g);

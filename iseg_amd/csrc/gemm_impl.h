@@ -533,7 +533,8 @@ int tile_waves();   // ISEG_GEMM_WAVES in {4,8,16}: workgroup size of the 128x12
 template <int WM, int WN, int FM, int FN, bool AKC, bool BKC, int BK, class TO>
 void launch_bf16(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
     constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
-    const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
+    // (the virtual ones-row of the weight-gradient orientation is output row M: one more tile row when M is a multiple of the tile)
+    const int tiles_m = (int)ceil_div64(g->M + ((!AKC && epi.colsum_out) ? 1 : 0), BM), tiles_n = (int)ceil_div64(g->N, BN);
     const int ntiles = tiles_m * tiles_n;
     const bf16_t* A = (const bf16_t*)g->A;
     const bf16_t* B = (const bf16_t*)g->B;

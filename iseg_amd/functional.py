@@ -895,7 +895,9 @@ class _ConvNeXtBlockFn(Function):
         do2 = _c(dout).reshape(M, C)
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
         S = torch.empty(C, dtype=torch.float32, device=xc.device)      # column sums of dbr (layer-scale and bias gradients)
-        K.colsum(dbr, C, 0, 1, M, C, S)
+        s_on_gemm = p.gamma is not None and (ctx.fused or g is not None) and xc.dtype == torch.bfloat16 and 4 * C >= 768      # rides Z = g^T dbr below
+        if not s_on_gemm:
+            K.colsum(dbr, C, 0, 1, M, C, S)
         cdt = xc.dtype
         side = _SideQueue(xc.device)
         dy2 = None
@@ -911,7 +913,7 @@ class _ConvNeXtBlockFn(Function):
         def param_grads():
             if p.gamma is not None:
                 Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
-                K.dense_wgrad(g, dbr, Z, accumulate=False)                          # Z = gelu(h)^T dbr
+                K.dense_wgrad(g, dbr, Z, accumulate=False, bias_grad=S if s_on_gemm else None)      # Z = gelu(h)^T dbr (+ S from its ones-row)
                 K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
             else:
                 K.dense_wgrad(g, dbr, _grad(p.w2))

@@ -68,3 +68,25 @@ def test_transposed_kernel_copies_follow_the_weights(cuda):
         assert (a.float() - b.float()).abs().max().item() <= 2e-2 * a.float().abs().max().item()
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("M,Kd,N", [(1000, 768, 96), (20000, 1536, 384), (4096, 96, 384), (3000, 200, 64)])
+def test_bias_gradient_on_the_weight_gradient_gemm(cuda, M, Kd, N):
+    """column sums of dY from the virtual ones-row of the weight-gradient GEMM, also when K is a multiple of the 128-row tile (one more
+    tile row) and under split-K"""
+    from iseg_amd import kernels as K
+
+    x = (torch.randn(M, Kd, device="cuda") * 0.5).to(torch.bfloat16)
+    dy = (torch.randn(M, N, device="cuda") * 0.5).to(torch.bfloat16)
+    dw = torch.full((Kd, N), 0.25, device="cuda")
+    db = torch.full((N,), -1.0, device="cuda")
+    K.dense_wgrad(x, dy, dw, accumulate=True, bias_grad=db)
+    ref_w = 0.25 + x.double().t() @ dy.double()
+    ref_b = -1.0 + dy.double().sum(0)
+    assert (dw.double() - ref_w).abs().max().item() <= 2e-3 * ref_w.abs().max().item()
+    assert (db.double() - ref_b).abs().max().item() <= 2e-3 * ref_b.abs().max().item()
+    dw2 = torch.empty_like(dw)
+    db2 = torch.empty_like(db)
+    K.dense_wgrad(x, dy, dw2, accumulate=False, bias_grad=db2)
+    assert (dw2.double() - (ref_w - 0.25)).abs().max().item() <= 2e-3 * ref_w.abs().max().item()
+    assert (db2.double() - (ref_b + 1.0)).abs().max().item() <= 2e-3 * ref_b.abs().max().item()
