@@ -88,8 +88,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 // sum over aligned groups of `width` lanes (width power of two <= 64)
+// Sum over aligned groups of `width` lanes (a power of two <= 64), result in every lane of the group.  Cross-lane steps are DPP / permlane
+// VALU operations (quad_perm, row_half_mirror, row_mirror inside a 16-lane row; v_permlane16_swap / v_permlane32_swap between rows), not
+// ds_bpermute round trips through the LDS crossbar (__shfl_xor): a 64-lane sum is 6 short VALU steps instead of 6 dependent LDS operations.
+#define ISEG_DPP_STEP(V, CTRL) ((V) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (V)), (CTRL), 0xf, 0xf, true)))
 __device__ __forceinline__ float group_sum(float v, int width) {
-    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (width >= 2) v = ISEG_DPP_STEP(v, 0xB1);       // quad_perm [1,0,3,2]
+    if (width >= 4) v = ISEG_DPP_STEP(v, 0x4E);       // quad_perm [2,3,0,1]
+    if (width >= 8) v = ISEG_DPP_STEP(v, 0x141);      // row_half_mirror: the other quad of each 8
+    if (width >= 16) v = ISEG_DPP_STEP(v, 0x140);     // row_mirror: the other half of each 16
+    if (width >= 32) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // [r0 r0 r2 r2], [r1 r1 r3 r3]
+        v = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+    }
+    if (width >= 64) {
+        const unsigned u = __builtin_bit_cast(unsigned, v);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // [lo lo], [hi hi]
+        v = __builtin_bit_cast(float, (unsigned)sw[0]) + __builtin_bit_cast(float, (unsigned)sw[1]);
+    }
     return v;
 }
 

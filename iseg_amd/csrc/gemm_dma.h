@@ -235,7 +235,8 @@ inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
     if (forced_epi >= 1 && forced_epi <= 4 && g->N > 64 && (g->act != 0 || g->aux || g->residual)) return forced_epi;
     const int64_t tiles256 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), tiles128 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128);
     if (g->N <= 64) return 1;
-    if (tiles256 * nsplit >= 192) return 2;
+    static const int t256 = [] { const char* e = getenv("ISEG_GEMM_DMA_T256"); return e ? atoi(e) : 192; }();
+    if (tiles256 * nsplit >= t256) return 2;
     if (tiles128 * nsplit >= 384) return 3;
     return 4;
 }
