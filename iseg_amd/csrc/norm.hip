@@ -450,12 +450,23 @@ extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float
 static int ln_bwd_blocks(int64_t rows, int C) {
     const int lpr = ln_lanes_per_row(C);
     const int rpw = 64 / lpr;
-    static const int iters = [] {
+    // every workgroup pays a fixed price (LDS combine, 2C partial sums written and read again by the reduce), so a workgroup takes ~24 K elements
+    // (48 KB of bf16 per operand), between 256 and 1024 workgroups.  Measured best (us incl. the reduce): 262144 x 96 -> 1024 workgroups (37),
+    // 65536 x 192 -> 512 (25), 16384 x 384 -> 256 (20.7; 2048 workgroups: 31), 4096 x 768 -> 256..512 (19).  ISEG_LN_BWD_ITERS pins the row
+    // groups per wavefront instead.
+    static const int iters_env = [] {
         const char* e = getenv("ISEG_LN_BWD_ITERS");
-        const int v = e ? atoi(e) : 8;
-        return v > 0 ? v : 8;
+        return e ? atoi(e) : 0;
     }();
-    int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4 * iters);  // >= `iters` row-iterations per block
+    int64_t blocks;
+    if (iters_env > 0) {
+        blocks = ceil_div64(rows, (int64_t)rpw * 4 * iters_env);
+    } else {
+        int64_t rows_per_block = 24576 / C;
+        if (rows_per_block < rpw * 4) rows_per_block = rpw * 4;
+        blocks = ceil_div64(rows, rows_per_block);
+        if (blocks < 256) blocks = ceil_div64(rows, (int64_t)rpw * 4) < 256 ? ceil_div64(rows, (int64_t)rpw * 4) : 256;
+    }
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
