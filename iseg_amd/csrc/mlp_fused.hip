@@ -215,13 +215,19 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
         }
         if (m < M) {
             const int c0 = 32 * cb + 16 * eh;
-            float res[16];
+            float res[16], bb[16], gg[16];
             load8<bf16_t>(R + m * C + c0, res);
             load8<bf16_t>(R + m * C + c0 + 8, res + 8);
+            load8<float>(b2 + c0, bb);      // (16-byte vector loads: one dword load per element was 96 extra loads per lane at C = 96)
+            load8<float>(b2 + c0 + 8, bb + 8);
+            if (gamma) {
+                load8<float>(gamma + c0, gg);
+                load8<float>(gamma + c0 + 8, gg + 8);
+            }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                float t = v[u] + b2[c0 + u];
-                if (gamma) t *= gamma[c0 + u];
+                float t = v[u] + bb[u];
+                if (gamma) t *= gg[u];
                 v[u] = fmaf(t, rs, res[u]);
             }
             store8<bf16_t>(O + m * C + c0, v);
@@ -520,7 +526,7 @@ extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const
     ISEG_REQUIRE(iseg_convnext_mlp_supported(C, dtype), "iseg_convnext_mlp_fwd: bf16 storage with C = 96, 192 or 384 only (C = %d, dtype = %d)", C, dtype);
     ISEG_REQUIRE(y2 && fw_tiled && b1 && b2 && residual && out && M > 0, "iseg_convnext_mlp_fwd: null operand or empty problem");
     ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_fwd: rowscale needs rows_per_group > 0");
-    ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1) & 15) == 0,
+    ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)gamma) & 15) == 0,
                  "iseg_convnext_mlp_fwd: operands must be 16-byte aligned");
     if (C == 96) return launch_mlp_fwd<96, 2, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
     if (C == 192) return launch_mlp_fwd<192, 1, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
