@@ -220,3 +220,34 @@ def test_bicubic_matrices_match_oracle_taps():
     r = torch.arange(16, dtype=torch.float64).reshape(1, 16, 1, 1).expand(1, 16, 2, 1)
     up = O.resize_bicubic(r, (32, 2))[0, 4:28, 0, 0]
     assert torch.allclose(up, (torch.arange(4, 28, dtype=torch.float64) + 0.5) / 2 - 0.5, atol=1e-3)
+
+
+def test_rows2d_views_channel_slices_without_copy():
+    """functional._rows2d: the gradient of a channel slice of a wider NHWC tensor reaches the kernels as a strided [rows, C] view"""
+    from iseg_amd import functional as F
+
+    big = torch.arange(2 * 3 * 4 * 40, dtype=torch.float32).reshape(2, 3, 4, 40)
+    sl = big[..., 8:24]                                    # 16 channels at offset 8: rows 160 B apart, 32-byte aligned start
+    v, ld = F._rows2d(sl)
+    assert ld == 40 and v.shape == (24, 16) and v.data_ptr() == sl.data_ptr()
+    assert torch.equal(v, sl.reshape(24, 16))
+    odd = big[..., 3:19]                                   # misaligned start: falls back to a contiguous copy
+    v2, ld2 = F._rows2d(odd)
+    assert ld2 == 16 and v2.is_contiguous() and torch.equal(v2, odd.reshape(24, 16))
+    c, ldc = F._rows2d(big)
+    assert ldc == 40 and c.data_ptr() == big.data_ptr()
+
+
+def test_transposed_kernel_copies_are_a_gpu_bf16_feature():
+    """nn.wt() hands out K-contiguous copies only for bf16 GPU shadows; everything else takes the [K][N] path"""
+    from iseg_amd import nn
+
+    p = torch.nn.Parameter(torch.randn(8, 16))
+    assert nn.wt(p) is None                                # fp32 compute dtype
+    nn.set_compute_dtype(torch.bfloat16)
+    try:
+        assert nn.wt(p) is None                            # no shadow installed
+        p.iseg_compute = p.data.to(torch.bfloat16)
+        assert nn.wt(p) is None                            # CPU shadow
+    finally:
+        nn.set_compute_dtype(torch.float32)
