@@ -472,6 +472,55 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t* __
     }
 }
 
+
+__device__ __forceinline__ void ld4(const float* p, float* v) { Vec16<float>::load(p, v); }
+__device__ __forceinline__ void ld4(const bf16_t* p, float* v) {
+    const bf16x4 r = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (float)r[u];
+}
+__device__ __forceinline__ void st4(float* p, const float* v) { Vec16<float>::store(p, v); }
+__device__ __forceinline__ void st4(bf16_t* p, const float* v) {
+    bf16x4 r;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = (bf16_t)v[u];
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// im2col for few input channels (stems: C = 3): with dw == 1 the KW * C elements of one (output pixel, kernel row) are ONE contiguous run in
+// the NHWC image and in the patch row, so a lane moves 4 consecutive elements of a run (16-byte fp32 / 8-byte bf16 load, 8-byte bf16 / 16-byte fp32
+// store) instead of one element.  Runs that touch the padding fall back to per-element bounds checks.  Requires (KW * C) % 4 == 0, ldc % 4 == 0,
+// (W * C) % 4 == 0, (sw * C) % 4 == 0, (pl * C) % 4 == 0 and a 16-byte aligned image (host-checked).
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void im2col_runs_kernel(const TI* __restrict__ x, TO* __restrict__ col, int N, int H, int W, int C, int KH,
+                                                          int KW, int sh, int sw, int dh, int pt, int pl, int Ho, int Wo, int64_t ldc) {
+    const int run = KW * C, q_per_run = run / 4;
+    const int64_t total = (int64_t)N * Ho * Wo * KH * q_per_run;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % q_per_run);
+        int64_t t = i / q_per_run;
+        const int kh = (int)(t % KH);
+        const int64_t m = t / KH;
+        const int ow = (int)(m % Wo);
+        const int oh = (int)((m / Wo) % Ho);
+        const int n = (int)(m / ((int64_t)Wo * Ho));
+        const int ih = oh * sh - pt + kh * dh;
+        const int e0 = (ow * sw - pl) * C + 4 * q;      // element offset inside image row ih (may be negative / past the row: padding)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ih < (unsigned)H) {
+            const TI* row = x + ((int64_t)n * H + ih) * W * C;
+            if (e0 >= 0 && e0 + 4 <= W * C) {
+                ld4(row + e0, v);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e0 + u >= 0 && e0 + u < W * C) v[u] = to_f32(row[e0 + u]);
+            }
+        }
+        st4(col + m * ldc + kh * run + 4 * q, v);
+    }
+}
+
 }  // namespace
 
 extern "C" int iseg_transpose_batched(const void* src, void* dst, const int64_t* table, int count, int max_tiles, hipStream_t stream) {
@@ -521,10 +570,15 @@ extern "C" int iseg_im2col(const void* x, int in_dtype, void* col, int out_dtype
     ISEG_REQUIRE(!(in_dtype == ISEG_BF16 && out_dtype == ISEG_F32), "iseg_im2col: bf16 -> f32 unsupported");
     const int64_t M = (int64_t)N * Ho * Wo;
     const bool vec = (C % 8 == 0) && (ldc % 8 == 0);
-    const unsigned blocks = cap_blocks(M * KH * KW * (vec ? C / 8 : C));
+    const bool runs = !vec && dw == 1 && (KW * C) % 4 == 0 && ldc % 4 == 0 && ((int64_t)W * C) % 4 == 0 && (sw * C) % 4 == 0 && (pl * C) % 4 == 0 &&
+                      ((uintptr_t)x % 16 == 0) && ((uintptr_t)col % 16 == 0);
+    const unsigned blocks = cap_blocks(runs ? M * KH * (KW * C / 4) : M * KH * KW * (vec ? C / 8 : C));
 #define IM2COL(TI, TO)                                                                                                        \
     do {                                                                                                                      \
-        if (vec)                                                                                                              \
+        if (runs)                                                                                                             \
+            hipLaunchKernelGGL((im2col_runs_kernel<TI, TO>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, (TO*)col, N, H, W, C, \
+                               KH, KW, sh, sw, dh, pt, pl, Ho, Wo, ldc);                                                      \
+        else if (vec)                                                                                                              \
             hipLaunchKernelGGL((im2col_kernel<TI, TO, 8>), dim3(blocks), dim3(256), 0, stream, (const TI*)x, (TO*)col, N, H, W, C, \
                                KH, KW, sh, sw, dh, dw, pt, pl, Ho, Wo, ldc);                                                  \
         else                                                                                                                  \

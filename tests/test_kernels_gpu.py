@@ -261,7 +261,8 @@ def test_batchnorm_train(cuda, dtype, rows, C, relu):
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape,kh,s,d,Cout", [((2, 16, 16, 64), 3, 1, 3, 32), ((1, 32, 32, 3), 4, 4, 1, 96), ((2, 16, 16, 96), 2, 2, 1, 192),
-                                              ((1, 15, 17, 16), 3, 2, 1, 24), ((1, 12, 12, 40), 3, 1, 9, 16), ((1, 16, 16, 32), 2, 1, 2, 64)])
+                                              ((1, 15, 17, 16), 3, 2, 1, 24), ((1, 12, 12, 40), 3, 1, 9, 16), ((1, 16, 16, 32), 2, 1, 2, 64),
+                                              ((1, 16, 16, 4), 3, 1, 1, 16), ((2, 18, 20, 12), 3, 2, 1, 8), ((1, 20, 24, 4), 5, 1, 1, 8)])
 def test_conv_via_im2col_gemm(cuda, dtype, shape, kh, s, d, Cout):
     k = K()
     N, H, W, C = shape
