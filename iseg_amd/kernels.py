@@ -188,9 +188,10 @@ def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, row
 
 def wgrad_can_fuse_bias(x2d):
     """the bias gradient can ride the weight-gradient GEMM (virtual ones-row = output row K): free when the last 128-row output tile has a spare
-    row, one more tile row otherwise -- worth it from 6 tile rows on (<= +17 % of the GEMM vs a column-sum pass + its reduce over dY)"""
+    row, one more tile row otherwise -- measured worth it from 3 tile rows on (flagship step 10.05 -> 9.94 ms when the stage-2 b1 gradients
+    joined: the column-sum pass over the [M, 4C] tensor and its reduce cost more than a quarter more weight-gradient tiles)"""
     k = x2d.shape[1]
-    return x2d.dtype == torch.bfloat16 and k % 8 == 0 and (k % 128 != 0 or k >= 768)
+    return x2d.dtype == torch.bfloat16 and k % 8 == 0 and (k % 128 != 0 or k >= 384)
 
 
 def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE, bias_grad=None):
