@@ -909,10 +909,9 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
             const int ow0 = w0 + seg * TWO;
             const int off0 = ((n * H + oh) * W + ow0) * C + c0 + cg * 8;
             if (add) {
-                f32x2 av[TWO][4];
+                f32x2 av[TWO][4];      // every load is issued (clamped to the row's first pixel past the edge): a branch per load makes hipcc wait for each
 #pragma unroll
-                for (int t = 0; t < TWO; ++t)
-                    if (ow0 + t < W) unpack_bf16x8(reinterpret_cast<const char*>(add + off0 + t * C), av[t]);
+                for (int t = 0; t < TWO; ++t) unpack_bf16x8(reinterpret_cast<const char*>(add + off0 + (ow0 + t < W ? t : 0) * C), av[t]);
 #pragma unroll
                 for (int t = 0; t < TWO; ++t)
                     if (ow0 + t < W) {
@@ -943,7 +942,10 @@ static bool launch_fwd_dma(const void* x, const float* w, const float* bias, con
     // tile shapes (rows x columns, output pixels per lane): 16 x 32 (8) for the wide planes, 8 x 32 (4) when that leaves fewer than two tiles per
     // resident workgroup (32 x 32 planes: three smaller workgroups per CU overlap each other's fills), 16 x 16 (4) for 16-pixel planes.
     // Measured (16 images, us, LDS kernel -> this one): 128x128x96 70.4 -> 53.8, 64x64x192 37.2 -> 33.9, 16x16x768 14.5 -> 12.1; 32x32x384 with
-    // the 16 x 32 tile 19.2 -> 21.5 (one tile per workgroup, nothing overlaps the fill), with the 8 x 32 tile -> 17.5
+    // the 16 x 32 tile 19.2 -> 21.5 (one tile per workgroup, nothing overlaps the fill), with the 8 x 32 tile -> 17.5.
+    // A double-buffered form (ONE workgroup per CU, the next tile's DMA issued from inline assembly so that hipcc puts no vmcnt(0) in front of
+    // the LDS reads) measured 65 us at 128x128x96 against 53 us for two single-buffered workgroups per CU: with one wavefront per SIMD nothing
+    // hides the LDS-read and FMA latencies
     const int slabs = C / 32;
     int two = W <= 16 ? 4 : 8, th = 16;
     if (two == 8 && (int64_t)N * ((H + 15) / 16) * ((W + 31) / 32) * slabs < 1536) {      // (64x64x192: 33.6 -> 32.3 us; 128x128x96 would lose: 53.0 -> 58.5)
