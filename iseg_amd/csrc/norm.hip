@@ -36,18 +36,32 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const int nchunks = C / 8;
     const int64_t wave_global = (int64_t)blockIdx.x * 4 + wid;
     const int64_t nwaves = (int64_t)gridDim.x * 4;
+    // a lane always owns the same channel chunks: gamma / beta live in registers for the whole strip (loading them per row was a second
+    // dependent round trip per row), and the row loads are issued unconditionally from clamped addresses (a branch per load makes hipcc
+    // wait for each one)
+    float g[CPL][8], bt[CPL][8];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = li + i * lpr;
+        const int cc = c < nchunks ? c : nchunks - 1;
+        load8<float>(gamma + cc * 8, g[i]);
+        load8<float>(beta + cc * 8, bt[i]);
+    }
     for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
         const int64_t row = rbase + sub;
         const bool valid = row < rows;
+        const int64_t rc = valid ? row : rows - 1;
         float v[CPL][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = li + i * lpr;
-            if (valid && c < nchunks) {
-                load8<T>(x + row * C + c * 8, v[i]);
+            const bool ok = valid && c < nchunks;
+            load8<T>(x + rc * C + (c < nchunks ? c : nchunks - 1) * 8, v[i]);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s += v[i][u];
+            for (int u = 0; u < 8; ++u) {
+                v[i][u] = ok ? v[i][u] : 0.f;
+                s += v[i][u];
             }
         }
         s = group_sum(s, lpr);
@@ -70,11 +84,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         for (int i = 0; i < CPL; ++i) {
             const int c = li + i * lpr;
             if (valid && c < nchunks) {
-                float g[8], b[8], o[8];
-                load8<float>(gamma + c * 8, g);
-                load8<float>(beta + c * 8, b);
+                float o[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o[u] = (v[i][u] - mean) * rstd * g[u] + b[u];
+                for (int u = 0; u < 8; ++u) o[u] = (v[i][u] - mean) * rstd * g[i][u] + bt[i][u];
                 store8<T>(y + row * C + c * 8, o);
             }
         }
