@@ -170,6 +170,14 @@ int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t
 /* ---------------------------------------------------------------------------------------------------------
  * Layout / elementwise
  * --------------------------------------------------------------------------------------------------------- */
+/* Deferred parameter-gradient reductions.  Keras accumulates nothing across ops -- this is a scheduling service of the library: between
+ * begin and end, every two-stage reduction of an entry point (iseg_layernorm_bwd, iseg_dwconv2d_bwd_weight, iseg_colsum) whose output lies
+ * inside [grad_base, grad_base + grad_bytes) and accumulates into it keeps its partial sums in `arena` (>= 1 MiB, caller-owned) instead of the
+ * call's workspace and is queued; iseg_deferred_flush runs one launch over the queue (same fixed summation order as the immediate reduce).
+ * The caller flushes before anything reads the gradient buffer (optimizer, clipping, all-reduce).  Single stream, not re-entrant. */
+int iseg_deferred_begin(void* grad_base, size_t grad_bytes, void* arena, size_t arena_bytes, iseg_stream_t stream);
+int iseg_deferred_flush(iseg_stream_t stream);
+int iseg_deferred_end(iseg_stream_t stream);
 int iseg_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, iseg_stream_t stream);
 /* K-contiguous copies of the bf16 compute kernels for the forward GEMMs (keras Dense / 1x1 Conv2D kernels are [K][N]; with both operands
  * K-contiguous the LDS-DMA GEMM serves the forward pass too).  `count` bf16 matrices inside `src`, transposed into `dst`;

@@ -71,6 +71,9 @@ SIGNATURES = {
     "iseg_bn_bwd_apply": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _f, _p, _l, _l, _i, _i, _i, _p]),
     "iseg_rsqrt_eps": (_i, [_p, _f, _p, _i, _p]),
     "iseg_cast": (_i, [_p, _i, _p, _i, _l, _p]),
+    "iseg_deferred_begin": (_i, [_p, _z, _p, _z, _p]),
+    "iseg_deferred_flush": (_i, [_p]),
+    "iseg_deferred_end": (_i, [_p]),
     "iseg_transpose_batched": (_i, [_p, _p, _p, _i, _i, _p]),
     "iseg_scale_cols_cast": (_i, [_p, _p, _p, _l, _i, _i, _p]),
     "iseg_im2col": (_i, [_p, _i, _p, _i] + [_i] * 14 + [_l, _p]),

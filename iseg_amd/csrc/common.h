@@ -110,6 +110,15 @@ __device__ __forceinline__ float group_sum(float v, int width) {
     return v;
 }
 
+// Deferred parameter-gradient reductions (api.hip).  Between iseg_deferred_begin() and iseg_deferred_end() a two-stage reduction whose
+// output lies inside the registered gradient buffer (and accumulates into it) is not launched: its partial sums go to the caller's arena and
+// a descriptor is queued; iseg_deferred_flush() runs ONE launch over all queued descriptors.  The ~70 five-microsecond reduce launches of a
+// training step (LayerNorm / depthwise / bias gradients) cost more at their kernel boundaries than in their work.
+//   iseg_deferred_partials(): arena slice for `bytes` of partials if this reduction may be deferred, else nullptr (launch it right away)
+float* iseg_deferred_partials(size_t bytes, const float* out0, const float* out1, int accumulate, hipStream_t stream);
+void iseg_deferred_push(const float* partials, int P, int64_t pstride, int64_t n, float* out0, float* out1, int64_t n0, float scale,
+                        hipStream_t stream);
+
 // Second stage of every two-stage reduction (LayerNorm / BatchNorm / colsum / depthwise-wgrad parameter gradients):
 //   out[b][j] (+)= scale * sum_{p<P} partials[b*bstride_in + p*pstride + j],  j < n,
 // written to out0 for j < n0 and to out1[j-n0] beyond (out1 may be null).  A block owns 16 columns; 16 row-lanes stride

@@ -1181,6 +1181,8 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
         iseg_set_error("iseg_dwconv2d_bwd_weight: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
+    float* const arena = iseg_deferred_partials(need, dw, db, accumulate, stream);      // (see common.h: deferred reductions)
+    if (arena) ws = arena;
     if (gd.ok) {
         launch_bw_dma(x, dy, (float*)ws, N, H, W, C, pad_t, pad_l, gd, stream);
     } else if (g.lds) {
@@ -1207,6 +1209,7 @@ extern "C" int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw
         else launch_bw_cv<float, 3>(x, dy, (float*)ws, N, H, W, C, dil, pad_t, pad_l, g, stream);
     }
     const int n = (K * K + 1) * C;
-    launch_reduce_rows((const float*)ws, g.bx, n, 0, 1, n, dw, db, K * K * C, 0, 1.f, accumulate, stream);
+    if (arena) iseg_deferred_push((const float*)ws, g.bx, n, n, dw, db, K * K * C, 1.f, stream);
+    else launch_reduce_rows((const float*)ws, g.bx, n, 0, 1, n, dw, db, K * K * C, 0, 1.f, accumulate, stream);
     return iseg_check_launch("iseg_dwconv2d_bwd_weight");
 }

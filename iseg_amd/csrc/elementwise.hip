@@ -631,6 +631,8 @@ extern "C" int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int
         iseg_set_error("iseg_colsum: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
+    float* const arena = batch == 1 ? iseg_deferred_partials(need, out, nullptr, accumulate, stream) : nullptr;      // (see common.h: deferred reductions)
+    if (arena) ws = arena;
     const size_t lds = (size_t)C * sizeof(float);
 #define COLSUM(T, VV)                                                                                                  \
     hipLaunchKernelGGL((colsum_partial_kernel<T, VV>), dim3(P, batch), dim3(256), lds, stream, (const T*)x, ldx, batch_stride, \
@@ -643,7 +645,8 @@ extern "C" int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int
         else COLSUM(float, 1);
     }
 #undef COLSUM
-    launch_reduce_rows((const float*)ws, P, C, (int64_t)P * C, batch, C, out, nullptr, C, C, scale, accumulate, stream);
+    if (arena) iseg_deferred_push((const float*)ws, P, C, C, out, nullptr, C, scale, stream);
+    else launch_reduce_rows((const float*)ws, P, C, (int64_t)P * C, batch, C, out, nullptr, C, C, scale, accumulate, stream);
     return iseg_check_launch("iseg_colsum");
 }
 

@@ -502,6 +502,8 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
         return ISEG_ERR_WORKSPACE;
     }
     float* partials = (float*)ws;
+    float* const arena = iseg_deferred_partials(need, dgamma, dbeta, accumulate_param_grads, stream);      // (see common.h: deferred reductions)
+    if (arena) partials = arena;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const int cpl = (C / 8 + lpr - 1) / lpr;
 #define LN_BWD(T, CPL, U)                                                                                                   \
@@ -522,7 +524,8 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
     else LN_BWD_T(float);
 #undef LN_BWD_T
 #undef LN_BWD
-    launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, dgamma, dbeta, C, 0, 1.f, accumulate_param_grads, stream);
+    if (arena) iseg_deferred_push(partials, blocks, 2 * C, 2 * C, dgamma, dbeta, C, 1.f, stream);
+    else launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, dgamma, dbeta, C, 0, 1.f, accumulate_param_grads, stream);
     return iseg_check_launch("iseg_layernorm_bwd");
 }
 

@@ -167,4 +167,8 @@ def set_active_reducer(r):
 def grads_ready(*params):
     r = _ACTIVE_REDUCER[0]
     if r is not None:
+        if active():      # the bucket's all-reduce reads the gradient buffer: queued reductions into it must have run
+            from . import kernels as K
+
+            K.deferred_flush()
         r.ready(*params)

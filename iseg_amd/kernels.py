@@ -3,6 +3,7 @@
 torch is used here only for device memory (torch.empty), dtype tags and the current HIP stream; every FLOP
 and every byte moved on the hot path happens inside libiseg_hip.so.  Nothing here falls back to torch ops.
 """
+import contextlib
 import ctypes as C
 
 import torch
@@ -918,3 +919,36 @@ def window_attention_bwd(qkv, table, dout, heads, scale):
     _hip.check(L.iseg_window_attention_bwd(ptr(qkv), ptr(table), ptr(dout), ptr(dqkv), ptr(dbias), B, T, heads, table.shape[0], float(scale),
                                            dt(qkv), ptr(ws), wsb, stream()), "iseg_window_attention_bwd")
     return dqkv, dbias
+
+
+# ---------------------------------------------------------------------------------------------------------
+# deferred parameter-gradient reductions (csrc/api.hip): one batched launch instead of ~70 five-microsecond ones per step
+# ---------------------------------------------------------------------------------------------------------
+_DEFER = {"arena": None, "active": False}
+
+
+@contextlib.contextmanager
+def deferred_reductions(flat_grad, arena_bytes=96 << 20):
+    """Between enter and exit, the second stage of LayerNorm / depthwise / bias gradient reductions whose output lies in `flat_grad` (and
+    accumulates into it) is queued inside the library and run by ONE launch per flush.  Exit flushes; call deferred_flush() before
+    anything else reads the gradient buffer (all-reduce, clipping).  ISEG_DEFER_REDUCE=0 turns the service off."""
+    import os
+
+    if not flat_grad.is_cuda or os.environ.get("ISEG_DEFER_REDUCE", "1") == "0" or _DEFER["active"]:
+        yield
+        return
+    arena = _DEFER["arena"]
+    if arena is None or arena.device != flat_grad.device or arena.numel() < arena_bytes:
+        arena = _DEFER["arena"] = torch.empty(arena_bytes, dtype=torch.uint8, device=flat_grad.device)
+    _hip.call("iseg_deferred_begin", ptr(flat_grad), flat_grad.numel() * flat_grad.element_size(), ptr(arena), arena.numel(), stream())
+    _DEFER["active"] = True
+    try:
+        yield
+    finally:
+        _DEFER["active"] = False
+        _hip.call("iseg_deferred_end", stream())
+
+
+def deferred_flush():
+    if _DEFER["active"]:
+        _hip.call("iseg_deferred_flush", stream())

@@ -11,6 +11,7 @@ import torch
 
 from . import dist
 from . import functional as F
+from . import kernels as K
 from . import nn
 from .param_store import ParamStore
 
@@ -124,7 +125,7 @@ class TrainableModel:
             else:
                 lv = fn(yt, out)
                 losses.append(lv.float().mean() * w)
-        with F.unit_loss_grad():
+        with F.unit_loss_grad(), K.deferred_reductions(self.store.flat_g):      # (flushed on exit, and by dist.grads_ready under data parallelism)
             torch.autograd.backward(losses)
         self.reducer.finish()
         dist.set_active_reducer(None)

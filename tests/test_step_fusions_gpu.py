@@ -90,3 +90,48 @@ def test_bias_gradient_on_the_weight_gradient_gemm(cuda, M, Kd, N):
     K.dense_wgrad(x, dy, dw2, accumulate=False, bias_grad=db2)
     assert (dw2.double() - (ref_w - 0.25)).abs().max().item() <= 2e-3 * ref_w.abs().max().item()
     assert (db2.double() - (ref_b + 1.0)).abs().max().item() <= 2e-3 * ref_b.abs().max().item()
+
+
+def test_deferred_gradient_reductions_match_immediate_ones(cuda):
+    """K.deferred_reductions: LayerNorm / depthwise / bias gradient reductions queued and run by one launch give the same gradients (same
+    summation order across workgroups; the producers' in-block LDS float atomics differ in the last bit from run to run either way), also
+    when two reductions hit the same gradient (conflict -> early flush) and when the arena is small"""
+    from iseg_amd import kernels as K
+
+    torch.manual_seed(0)
+    flat = torch.zeros(200000, device="cuda")
+    views = {"lng": flat[0:384], "lnb": flat[512:896], "dw": flat[1024:1024 + 49 * 96], "db": flat[8192:8192 + 96], "cb": flat[9000:9000 + 192],
+             "lng2": flat[10240:10240 + 96], "lnb2": flat[10496:10496 + 96]}
+    x = torch.randn(3000, 384, device="cuda").to(torch.bfloat16)
+    dy = torch.randn(3000, 384, device="cuda").to(torch.bfloat16)
+    g = torch.rand(384, device="cuda") + 0.5
+    b = torch.zeros(384, device="cuda")
+    _, mean, rstd = K.layernorm_fwd(x, g, b, 1e-6)
+    xs = torch.randn(4096, 96, device="cuda").to(torch.bfloat16)
+    dys = torch.randn(4096, 96, device="cuda").to(torch.bfloat16)
+    gs = torch.rand(96, device="cuda") + 0.5
+    _, means, rstds = K.layernorm_fwd(xs, gs, torch.zeros(96, device="cuda"), 1e-6)
+    xi = torch.randn(2, 32, 32, 96, device="cuda").to(torch.bfloat16)
+    di = torch.randn(2, 32, 32, 96, device="cuda").to(torch.bfloat16)
+    cs = torch.randn(5000, 192, device="cuda").to(torch.bfloat16)
+    outside = torch.zeros(192, device="cuda")
+
+    def run():
+        flat.zero_()
+        outside.zero_()
+        K.layernorm_bwd(dy, x, g, mean, rstd, views["lng"], views["lnb"])
+        K.dwconv2d_bwd_weight(xi, di, views["dw"].view(49, 96), views["db"], 7, 1, 3, 3)
+        K.colsum(cs, 192, 0, 1, 5000, 192, views["cb"], accumulate=True)
+        K.colsum(cs, 192, 0, 1, 5000, 192, outside, accumulate=True)          # not a gradient: always immediate
+        K.layernorm_bwd(dys, xs, gs, means, rstds, views["lng2"], views["lnb2"])
+        K.layernorm_bwd(dys, xs, gs, means, rstds, views["lng2"], views["lnb2"])    # same outputs again: conflict with the queued one
+        K.colsum(cs, 192, 0, 1, 5000, 192, views["cb"], accumulate=True)
+        return flat.clone(), outside.clone()
+
+    ref, ref_out = run()
+    for arena in (96 << 20, 1 << 20):
+        with K.deferred_reductions(flat, arena_bytes=arena):
+            got, got_out = run()         # (flat.clone() inside reads the buffer before the flush: compare after the exit instead)
+        assert torch.allclose(flat, ref, rtol=2e-5, atol=1e-3), (flat - ref).abs().max().item()
+        assert torch.allclose(outside, ref_out, rtol=2e-5, atol=1e-3)
+    assert not K._DEFER["active"]
