@@ -368,10 +368,13 @@ __global__ void copy2d_kernel(const T* __restrict__ src, int64_t lds_, T* __rest
 
 // layer-scale bookkeeping for one ConvNeXt block (backbones/convnext.py:56-57), from Z = g^T @ dout (unscaled):
 //   dW2[k][n] = Z[k][n]*gamma[n] ; dgamma[n] = sum_k W2[k][n]*Z[k][n] + b2[n]*S[n] ; db2[n] = gamma[n]*S[n], S = colsum(dout)
-// stage 1: elementwise dW2 and per-block partial column dots (block = 64 columns x 4 k-lanes, strip of k rows)
+// stage 1: elementwise dW2, db2, and per-block partial column dots (block = 64 columns x 4 k-lanes, strip of k rows); stage 2 = the common
+// row reduction of the partials into dgamma (reduce_rows, or the deferred queue when dgamma lies in the gradient buffer)
 __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __restrict__ Z, const float* __restrict__ W2,
-                                                                const float* __restrict__ gamma, float* __restrict__ dW2,
-                                                                float* __restrict__ partials, int Kdim, int Ndim, int accumulate) {
+                                                                const float* __restrict__ gamma, const float* __restrict__ b2,
+                                                                const float* __restrict__ S, float* __restrict__ dW2,
+                                                                float* __restrict__ db2, float* __restrict__ partials, int Kdim, int Ndim,
+                                                                int accumulate) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + tx;
@@ -389,33 +392,15 @@ __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __r
     }
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && n < Ndim) partials[(int64_t)blockIdx.y * Ndim + n] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
-}
-
-// stage 2: 16 columns x 16 partial-row lanes per workgroup (P / 16 dependent steps instead of P), fixed order
-__global__ __launch_bounds__(256) void layerscale_stage2_kernel(const float* __restrict__ partials, int P, const float* __restrict__ b2,
-                                                                const float* __restrict__ gamma, const float* __restrict__ S,
-                                                                float* __restrict__ dgamma, float* __restrict__ db2, int Ndim,
-                                                                int accumulate) {
-    __shared__ float red[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int n = blockIdx.x * 16 + tx;
-    float s = 0.f;
-    if (n < Ndim)
-        for (int p = ty; p < P; p += 16) s += partials[(int64_t)p * Ndim + n];
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty != 0 || n >= Ndim) return;
-    float t = red[0][tx];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) t += red[k][tx];
-    const float dg = t + b2[n] * S[n], dbv = gamma[n] * S[n];
-    if (accumulate) {
-        dgamma[n] += dg;
-        db2[n] += dbv;
-    } else {
-        dgamma[n] = dg;
-        db2[n] = dbv;
+    if (ty == 0 && n < Ndim) {
+        float part = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+        if (blockIdx.y == 0) {      // the S terms ride the first partial row, so the second stage is a plain row reduction (deferrable)
+            part += b2[n] * S[n];
+            const float dbv = gamma[n] * S[n];
+            if (accumulate) db2[n] += dbv;
+            else db2[n] = dbv;
+        }
+        partials[(int64_t)blockIdx.y * Ndim + n] = part;
     }
 }
 
@@ -745,10 +730,12 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
         iseg_set_error("iseg_layerscale_grads: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(layerscale_stage1_kernel, dim3((N + 63) / 64, P), dim3(256), 0, stream, Z, W2, gamma, dW2, (float*)ws, K, N,
+    float* const arena = iseg_deferred_partials(need, dgamma, nullptr, accumulate, stream);      // (see common.h: deferred reductions)
+    if (arena) ws = arena;
+    hipLaunchKernelGGL(layerscale_stage1_kernel, dim3((N + 63) / 64, P), dim3(256), 0, stream, Z, W2, gamma, b2, S, dW2, db2, (float*)ws, K, N,
                        accumulate);
-    hipLaunchKernelGGL(layerscale_stage2_kernel, dim3((N + 15) / 16), dim3(256), 0, stream, (const float*)ws, P, b2, gamma, S,
-                       dgamma, db2, N, accumulate);
+    if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
+    else launch_reduce_rows((const float*)ws, P, N, 0, 1, N, dgamma, nullptr, N, 0, 1.f, accumulate, stream);
     return iseg_check_launch("iseg_layerscale_grads");
 }
 
