@@ -394,17 +394,26 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
     for (int p = 0; p < NS - 1; ++p) feed.issue(smem, p);
     int stage = 0, fill = NS - 1;
     for (int kt = 0; kt < NST; ++kt) {
-        // in flight behind this wait: the next stage's DMAs and (active wavefronts) the previous stage's G / dH stores
-        if (NST - 1 - kt >= NS - 2) {
-            if (active) {
-                if (G::NHI && wid < G::NHI) MLP_WAIT((NS - 2) * G::PHI + STORES);
-                else MLP_WAIT((NS - 2) * G::PLO + STORES);
-            } else {
-                if (G::NHI && wid < G::NHI) MLP_WAIT((NS - 2) * G::PHI);
-                else MLP_WAIT((NS - 2) * G::PLO);
-            }
-        } else {
-            MLP_WAIT(0);
+        // Stage kt must have landed.  vmcnt retires in issue order, so the wait allows exactly the operations issued AFTER stage kt's DMAs:
+        // the G / dH stores of iteration kt-2 (issued behind DMA(kt)), the DMAs of the NS-2 following stages, the stores of iteration kt-1.
+        // (Allowing fewer -- the first version insisted on the kt-2 stores -- stalls every stage on the write acknowledgements of a kernel
+        // that streams 200 MB out; allowing more would let pieces of stage kt itself be pending.)
+        {
+            const bool more = NST - 1 - kt >= NS - 2;      // the following stages' DMAs are in flight
+            const bool hi = G::NHI && wid < G::NHI;
+#define MLP_WAIT_BWD(S_)                                                     \
+    do {                                                                     \
+        if (more) {                                                          \
+            if (hi) MLP_WAIT((NS - 2) * G::PHI + (S_));                      \
+            else MLP_WAIT((NS - 2) * G::PLO + (S_));                         \
+        } else {                                                             \
+            MLP_WAIT(S_);                                                    \
+        }                                                                    \
+    } while (0)
+            if (!active || kt == 0) MLP_WAIT_BWD(0);
+            else if (kt == 1) MLP_WAIT_BWD(STORES);
+            else MLP_WAIT_BWD(2 * STORES);
+#undef MLP_WAIT_BWD
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
