@@ -72,13 +72,20 @@ KERNEL_TIMER = [None]
 class KernelTimer:
     """records a (start, stop) event pair around every instrumented launch, grouped by a shape key; no host sync until report()"""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         self.records = {}
+        self.seen = {}          # key -> launches seen (timed or not)
         self._cur = None
         self.only = only        # None: every instrumented launch; else the one shape key to time
+        self.every = max(1, int(every))      # time every k-th matching launch: an event pair costs the stream a few microseconds of idle time
 
     def begin(self, key):
         if self.only is not None and key != self.only:
+            self._cur = None
+            return
+        n = self.seen.get(key, 0)
+        self.seen[key] = n + 1
+        if n % self.every:
             self._cur = None
             return
         e0 = torch.cuda.Event(enable_timing=True)
@@ -98,7 +105,7 @@ class KernelTimer:
         out = {}
         for key, pairs in self.records.items():
             ms = [a.elapsed_time(b) for a, b in pairs]
-            out[key] = (sum(ms) / len(ms) * 1e-3, len(ms))     # seconds per launch, launches
+            out[key] = (sum(ms) / len(ms) * 1e-3, self.seen.get(key, len(ms)))     # seconds per launch (over the timed ones), launches seen
         return out
 
 
