@@ -136,10 +136,14 @@ def _kernel_label(key):
     _, akc, bkc, M, N, K = key[:6]
     split = key[12]
     variant = key[13] if len(key) > 13 else 0
-    orient = {(1, 0): "forward x[M,K] @ kernel[K,N]", (1, 1): "dgrad dy[M,K] @ kernel[N,K]^T", (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
+    act, has_pre, has_res, has_aux = key[6:10]
+    orient = {(1, 0): "forward x[M,K] @ kernel[K,N]", (1, 1): "a[M,K] @ b[N,K]^T, both K-contiguous (data gradient, or forward on the K-contiguous kernel copy)",
+              (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
+    epi = {0: "", 1: "relu", 2: "gelu", 3: "gelu'(aux)", 4: "relu'(aux)", 5: "x aux"}.get(int(act), f"act{act}")
+    epi = " + ".join(t for t in (epi, "second output" if has_pre else "", "residual" if has_res else "") if t)
     name = "iseg_mm::gemm_bf16_kernel" if not variant else \
         "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages"}[variant]
-    return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''})"
+    return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''}{'; epilogue ' + epi if epi else ''})"
 
 
 def pick_dominant(report):
