@@ -79,7 +79,10 @@ def barrier():
 class GradReducer:
     """Bucketed, backward-overlapped all-reduce(sum) over the flat gradient buffer of a ParamStore."""
 
-    def __init__(self, store, bucket_bytes=48 << 20):
+    def __init__(self, store, bucket_bytes=48 << 20, head_bytes=(4 << 20, 16 << 20)):
+        """Buckets are contiguous runs of the flat buffer in model order.  The FIRST buckets hold the first layers, whose gradients are
+        ready last: nothing is left to overlap their all-reduce with, so they are small (head_bytes: 4 MB, then 16 MB) and only the
+        later ones -- ready early in the backward pass -- take the full bucket_bytes."""
         self.store = store
         self.buckets = []      # (lo, hi, n_params)
         self.bucket_of = {}    # id(param) -> bucket index
@@ -90,7 +93,8 @@ class GradReducer:
             self.bucket_of[id(p)] = len(self.buckets)
             cnt += 1
             acc += store.padded(n) * 4
-            if acc >= bucket_bytes:
+            cap = head_bytes[len(self.buckets)] if len(self.buckets) < len(head_bytes) else bucket_bytes
+            if acc >= min(cap, bucket_bytes):
                 self.buckets.append((lo, off + store.padded(n), cnt))
                 lo, cnt, acc = None, 0, 0
         if cnt:
