@@ -1230,6 +1230,35 @@ def rms_norm(x, scale, eps):
     return _RMSNormFn.apply(x, scale, float(eps))
 
 
+class _GRNFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        N, C = x.shape[0], x.shape[-1]
+        x3 = _c(x).reshape(N, -1, C)
+        y, nx, gx = K.grn_fwd(x3, gamma.data, beta.data, eps)
+        ctx.params = (gamma, beta)
+        ctx.eps = eps
+        ctx.save_for_backward(x3, nx, gx)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x3, nx, gx = ctx.saved_tensors
+        gamma, beta = ctx.params
+        dx = K.grn_bwd(_c(dy).reshape(x3.shape), x3, gamma.data, nx, gx, _grad(gamma), _grad(beta), ctx.eps)
+        dist.grads_ready(gamma, beta)
+        return dx.reshape(dy.shape), None, None, None
+
+
+def grn(x, gamma, beta, eps=1e-6):
+    """Global Response Normalization (backbones/convnext_v2.py:45-60): gamma * (x * nx) + beta + x with nx the per-sample channel response
+    (L2 norm over H, W) divided by its mean over channels; gamma, beta are fp32 parameters of shape [1, 1, 1, C]"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _GRNFn.apply(x, gamma, beta, float(eps))
+
+
 class _Pool2dFn(Function):
     @staticmethod
     def forward(ctx, x, geom, mode):

@@ -103,3 +103,9 @@ def intern_image_base_aspp(num_class=21, build_input_size=(512, 512), dropout_ra
     from .backbones import intern_image  # noqa: F401  (registers intern_image_base)
 
     return _managed("intern_image_base", ASPPHead(256, output_stride=32, dropout_rate=dropout_rate), num_class, 32, build_input_size)
+
+
+def convnext_v2_tiny_aspp(num_class=21, output_stride=32, build_input_size=(512, 512), dropout_rate=0.1):
+    """the BASELINE config-2 composition with the ConvNeXt V2 backbone (backbones/convnext_v2.py: GRN instead of layer scale)"""
+    return _managed("convnext_v2_tiny", ASPPHead(256, output_stride=output_stride, dropout_rate=dropout_rate), num_class, output_stride,
+                    build_input_size)

@@ -695,6 +695,31 @@ def rmsnorm_bwd(dy2d, x2d, scale, rstd, dscale, accumulate=True):
     return dx
 
 
+def grn_fwd(x3d, gamma, beta, eps):
+    """Global Response Normalization (backbones/convnext_v2.py:45-60) on [N, HW, C]: returns y and the per-(sample, channel) nx, gx"""
+    _require_cuda(x3d, gamma, beta)
+    N, HW, Cc = x3d.shape
+    y = torch.empty_like(x3d)
+    nx = torch.empty(N, Cc, dtype=torch.float32, device=x3d.device)
+    gx = torch.empty_like(nx)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_grn_workspace_bytes(N, HW, Cc), x3d.device)
+    _hip.check(L.iseg_grn_fwd(ptr(x3d), ptr(gamma), ptr(beta), ptr(y), ptr(nx), ptr(gx), N, HW, Cc, float(eps), dt(x3d), ptr(ws), wsb,
+                              stream()), "iseg_grn_fwd")
+    return y, nx, gx
+
+
+def grn_bwd(dy3d, x3d, gamma, nx, gx, dgamma, dbeta, eps, accumulate=True):
+    _require_cuda(dy3d, x3d, dgamma, dbeta)
+    N, HW, Cc = x3d.shape
+    dx = torch.empty_like(x3d)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_grn_workspace_bytes(N, HW, Cc), x3d.device)
+    _hip.check(L.iseg_grn_bwd(ptr(dy3d), ptr(x3d), ptr(gamma), ptr(nx), ptr(gx), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), N, HW, Cc,
+                              float(eps), dt(x3d), ptr(ws), wsb, stream()), "iseg_grn_bwd")
+    return dx
+
+
 POOL_MAX, POOL_AVG = 0, 1
 
 

@@ -44,7 +44,7 @@ def convnext_block(w, prefix, x, dilation=1, dp_factor=None):
     return y + x
 
 
-def convnext_backbone(w, x, depths=(3, 3, 9, 3), output_stride=32, dp_factors=None):
+def convnext_backbone(w, x, depths=(3, 3, 9, 3), output_stride=32, dp_factors=None, block=None):
     """returns [None, s0, s1, s2, s3]; dilation surgery as build_dilated_convnext (backbones/convnext.py:245-266)"""
     endpoints = [None]
     current_os, current_dil = 1, 1
@@ -65,10 +65,27 @@ def convnext_backbone(w, x, depths=(3, 3, 9, 3), output_stride=32, dp_factors=No
             x = O.layer_norm(x, w[f"{pn}/gamma"], w[f"{pn}/beta"], 1e-6)
             x = O.conv2d(x, w[f"{pc}/kernel"], w[f"{pc}/bias"], s, dil_conv, "same")
         for j in range(depth):
-            x = convnext_block(w, f"stages/{i}/{j}", x, dil_dw, None if dp_factors is None else dp_factors[blk])
+            x = (block or convnext_block)(w, f"stages/{i}/{j}", x, dil_dw, None if dp_factors is None else dp_factors[blk])
             blk += 1
         endpoints.append(x)
     return endpoints
+
+
+def convnext_v2_block(w, prefix, x, dilation=1, dp_factor=None):
+    """backbones/convnext_v2.py:83-98 Block.call: no layer scale, GRN between the GELU and the second pointwise product"""
+    y = O.depthwise_conv2d(x, w[f"{prefix}/dwconv/depthwise_kernel"], w[f"{prefix}/dwconv/bias"], 1, dilation)
+    y = O.layer_norm(y, w[f"{prefix}/norm/gamma"], w[f"{prefix}/norm/beta"], 1e-6)
+    y = O.gelu(O.dense(y, w[f"{prefix}/pwconv1/kernel"], w[f"{prefix}/pwconv1/bias"]))
+    y = O.grn(y, w[f"{prefix}/grn/gamma"], w[f"{prefix}/grn/beta"], 1e-6)
+    y = O.dense(y, w[f"{prefix}/pwconv2/kernel"], w[f"{prefix}/pwconv2/bias"])
+    if dp_factor is not None:
+        y = O.drop_path(y, dp_factor)
+    return y + x
+
+
+def convnext_v2_backbone(w, x, depths=(2, 2, 8, 2), output_stride=32, dp_factors=None):
+    """backbones/convnext_v2.py:205-218 with the dilation surgery of :284-306 (same walk as convnext_backbone)"""
+    return convnext_backbone(w, x, depths, output_stride, dp_factors, block=convnext_v2_block)
 
 
 def aspp(w, prefix, x, training, rates=(3, 6, 9), new_stats=None):

@@ -337,6 +337,14 @@ def rms_norm(x, scale, eps=1e-6):
     return x * (1.0 / torch.sqrt(var + eps)) * (1.0 + scale)
 
 
+def grn(x, gamma, beta, eps=1e-6):
+    """GlobalResponseNormlizationLayer.call (backbones/convnext_v2.py:45-60), x [N,H,W,C]; gamma, beta broadcast as [1,1,1,C]:
+    gx = (sum_{h,w} x^2 + eps)^0.5,  nx = gx / (mean_c gx + eps),  out = gamma * (x * nx) + beta + x"""
+    gx = torch.pow((x * x).sum(dim=(1, 2), keepdim=True) + eps, 0.5)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + eps)
+    return gamma.reshape(1, 1, 1, -1) * (x * nx) + beta.reshape(1, 1, 1, -1) + x
+
+
 # ------------------------------------------------------------------------------------------------------
 # pooling with padding="SAME": keras MaxPooling2D (backbones/resnet_common.py:215-217), tf.nn.avg_pool2d
 # (backbones/resnet_blocks.py:182-186; padded cells are excluded from the divisor)

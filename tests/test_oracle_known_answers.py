@@ -220,3 +220,24 @@ def test_tf_nn_gelu_docstring_values():
     x = torch.tensor([-3.0, -1.0, 0.0, 1.0, 3.0], dtype=torch.float64)
     # the documented values are float32 results (TF's fp32 erf): they sit within 5e-7 of the exact form
     assert O.gelu(x).tolist() == pytest.approx([-0.00404951, -0.15865529, 0.0, 0.8413447, 2.9959507], abs=5e-7)
+
+
+def test_global_response_normalization_by_hand():
+    """backbones/convnext_v2.py:45-60 on a 1x1x2 plane with two channels, eps = 0 so the numbers are exact: channel norms gx = [3, 4],
+    mean 3.5, nx = [6/7, 8/7]; out = gamma*(x*nx) + beta + x.  With the layer's initial gamma = beta = 0 it is the identity."""
+    x = torch.tensor([[[[3.0, 4.0], [0.0, 0.0]]]], dtype=torch.float64)
+    gamma = torch.tensor([2.0, -1.0], dtype=torch.float64)
+    beta = torch.tensor([0.5, 0.25], dtype=torch.float64)
+    y = O.grn(x, gamma.reshape(1, 1, 1, 2), beta.reshape(1, 1, 1, 2), eps=0.0)
+    want = [[36.0 / 7 + 3.5, -32.0 / 7 + 4.25], [0.5, 0.25]]
+    assert torch.allclose(y.reshape(2, 2), torch.tensor(want, dtype=torch.float64), atol=1e-12)
+    z = torch.zeros(8, dtype=torch.float64)
+    xr = torch.randn(2, 3, 5, 8, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(O.grn(xr, z, z), xr)
+    # samples are normalised independently: scaling one sample leaves its own nx unchanged (gx and its channel mean scale together, eps aside)
+    g = torch.rand(8, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    a = O.grn(xr, g, z, eps=0.0)
+    xs = xr.clone()
+    xs[1] *= 4.0
+    b = O.grn(xs, g, z, eps=0.0)
+    assert torch.allclose(b[0], a[0], atol=1e-12) and torch.allclose(b[1], 4.0 * a[1], atol=1e-10)

@@ -2,7 +2,7 @@
 """Throughput of the other BASELINE configurations on one GPU (bf16, synthetic data, full train step through TrainableModel, or the
 sliding-window inference driver for cfg4).  One JSON line per configuration.  Not the contract benchmark (that is bench.py / cfg2).
 
-  python tools/bench_configs.py [cfg1 cfg3 cfg4 cfg4_infer cfg5] [--steps K] [--warmup W] [--batch B]
+  python tools/bench_configs.py [cfg1 cfg3 cfg4 cfg4_infer cfg5 v2] [--steps K] [--warmup W] [--batch B]
 """
 import argparse
 import json
@@ -20,12 +20,13 @@ CONFIGS = {
     "cfg4": ("vit_base_simple_decoder", 512, 8, True, "ViT-B/16 + SimpleDecoder 512x512 (train step)"),
     "cfg4_infer": ("vit_base_simple_decoder", 640, 1, False, "ViT-B/16 + SimpleDecoder 640x640, sliding window 512"),
     "cfg5": ("intern_image_base_aspp", 512, 8, True, "InternImage-B + ASPP 512x512"),
+    "v2": ("convnext_v2_tiny_aspp", 512, 16, True, "ConvNeXt-V2-T + ASPP 512x512 (not a BASELINE configuration: the next backbone family)"),
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("names", nargs="*", default=list(CONFIGS))
+    ap.add_argument("names", nargs="*", default=[n for n in CONFIGS if n.startswith("cfg")])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0)
