@@ -310,13 +310,15 @@ int iseg_rmsnorm_bwd(const void* dy, const void* x, const float* scale, const fl
  * Global Response Normalization of ConvNeXt V2: backbones/convnext_v2.py:17-60 GlobalResponseNormlizationLayer.call,
  *   gx[n,c] = sqrt(sum_hw x^2 + eps);  nx = gx / (mean_c gx + eps);  y = gamma*(x*nx) + beta + x      (fp32 arithmetic, output in x's dtype)
  * x, y [N,HW,C] bf16 or fp32 (C % 8 == 0); gamma, beta [C] fp32; nx, gx [N,C] fp32 are written by the forward and read by the backward.
- * The backward returns dx and (+)= dgamma, dbeta; one workspace size serves both directions.  All reductions run in a fixed order.
+ * The backward returns dx and (+)= dgamma, dbeta; `mul` (NULL, or a tensor shaped like x) multiplies dx elementwise -- the saved derivative of
+ * the GELU in front of the layer (Block.call :91-92), so that chain-rule step needs no pass of its own.  One workspace size serves both
+ * directions.  All reductions run in a fixed order.
  * --------------------------------------------------------------------------------------------------------- */
 size_t iseg_grn_workspace_bytes(int64_t N, int64_t HW, int C);
 int iseg_grn_fwd(const void* x, const float* gamma, const float* beta, void* y, float* nx, float* gx, int64_t N, int64_t HW, int C,
                  float eps, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
-int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, void* dx, float* dgamma,
-                 float* dbeta, int accumulate_param_grads, int64_t N, int64_t HW, int C, float eps, int dtype, void* ws, size_t ws_bytes,
+int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, const void* mul, void* dx,
+                 float* dgamma, float* dbeta, int accumulate_param_grads, int64_t N, int64_t HW, int C, float eps, int dtype, void* ws, size_t ws_bytes,
                  iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------

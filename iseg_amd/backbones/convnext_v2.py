@@ -3,6 +3,9 @@ Stage :129-158, ConvNeXtV2 :161-233, convnext_v2_* :236-281 -- same classes, att
 [1, 1, 1, 4*filters], zero-initialised).  A V2 block has no layer scale; the response normalisation sits between the GELU and the second
 pointwise product and is one operator here (functional.grn -> csrc/grn.hip), its per-(sample, channel) statistics kept in fp32.
 build_dilated_convnext (backbones/convnext.py:245-266) applies unchanged: the attributes it edits are the same."""
+import os
+import types
+
 import numpy as np
 import torch
 
@@ -51,15 +54,32 @@ class Block(Layer):
         self.pwconv2.build((None, None, None, 4 * c))
         self.built = True
 
+    def _params(self):
+        return types.SimpleNamespace(dw_kernel=self.dwconv.depthwise_kernel, dw_bias=self.dwconv.bias, ln_gamma=self.norm.gamma,
+                                     ln_beta=self.norm.beta, w1=self.pwconv1.kernel, b1=self.pwconv1.bias, grn_gamma=self.grn.gamma,
+                                     grn_beta=self.grn.beta, w2=self.pwconv2.kernel, b2=self.pwconv2.bias)
+
     def call(self, inputs, training=None):
+        mask = None
+        if self.drop_path_prob != 0.0 and training:
+            mask = self.drop_path_mask
+            if mask is None:
+                mask = F.drop_path_factors(inputs.shape[0], 1.0 - self.drop_path_prob, inputs.device)
+        if os.environ.get("ISEG_V2_BLOCK_FUSED", "1") == "0":
+            return self.call_layers(inputs, mask)
+        d = self.dwconv.dilation_rate
+        return F.convnext_v2_block(inputs, self._params(), d[0], self.norm.epsilon, self.grn.epsilon, mask)      # one tape node per block
+
+    def call_layers(self, inputs, mask):
+        """the same block layer by layer through the generic operators (ISEG_V2_BLOCK_FUSED=0; the tests hold the two against each other)"""
         x, skip = F.fork(inputs, 2)      # residual fork: the two gradients are summed by our own kernel
         x = self.dwconv(x)
         x = self.norm(x)
         x = self.pwconv1(x)
         x = self.grn(x)
         x = self.pwconv2(x)
-        if self.drop_path_prob != 0.0 and training:
-            x = F.drop_path(x, self.drop_path_prob, training, mask=self.drop_path_mask)
+        if mask is not None:
+            x = F.drop_path(x, self.drop_path_prob, True, mask=mask)
         return F.add(x, skip)
 
 

@@ -136,11 +136,14 @@ __global__ __launch_bounds__(256) void grn_bwd_stats_kernel(float* __restrict__ 
     }
 }
 
-// forward: y = x * (gamma*nx + 1) + beta;   backward (BWD): dx = dy * (gamma*nx + 1) + x * t
+// forward: y = x * (gamma*nx + 1) + beta;   backward (BWD): dx = (dy * (gamma*nx + 1) + x * t) [* mul]
+// `mul` (optional, same shape as x) is the saved derivative of the activation that produced x: the chain rule through the GELU in front of the
+// normalisation costs one more read here instead of a pass of its own
 template <class T, bool BWD>
 __global__ __launch_bounds__(256) void grn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, const float* __restrict__ nx,
-                                                        const float* __restrict__ t, T* __restrict__ y, int64_t HW, int C, int64_t chunks) {
+                                                        const float* __restrict__ t, const T* __restrict__ mul, T* __restrict__ y, int64_t HW,
+                                                        int C, int64_t chunks) {
     const int nch = C / 8;
     const int64_t per = HW * nch;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
@@ -156,6 +159,12 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const T* __restrict__ x,
             load8<float>(t + (int64_t)n * C + c, b);
 #pragma unroll
             for (int u = 0; u < 8; ++u) o[u] = fmaf(d[u], fmaf(g[u], a[u], 1.f), v[u] * b[u]);
+            if (mul) {      // (uniform)
+                float m[8];
+                load8<T>(mul + i * 8, m);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] *= m[u];
+            }
         } else {
             load8<float>(beta + c, b);
 #pragma unroll
@@ -208,15 +217,15 @@ extern "C" int iseg_grn_fwd(const void* x, const float* gamma, const float* beta
     const unsigned blocks = (unsigned)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((grn_apply_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)nullptr,
-                           gamma, beta, (const float*)nx, (const float*)nullptr, (bf16_t*)y, HW, C, chunks);
+                           gamma, beta, (const float*)nx, (const float*)nullptr, (const bf16_t*)nullptr, (bf16_t*)y, HW, C, chunks);
     else
         hipLaunchKernelGGL((grn_apply_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (const float*)nullptr, gamma,
-                           beta, (const float*)nx, (const float*)nullptr, (float*)y, HW, C, chunks);
+                           beta, (const float*)nx, (const float*)nullptr, (const float*)nullptr, (float*)y, HW, C, chunks);
     return iseg_check_launch("iseg_grn_fwd");
 }
 
-extern "C" int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, void* dx, float* dgamma,
-                            float* dbeta, int accumulate, int64_t N, int64_t HW, int C, float eps, int dtype, void* ws, size_t ws_bytes,
+extern "C" int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, const void* mul, void* dx,
+                            float* dgamma, float* dbeta, int accumulate, int64_t N, int64_t HW, int C, float eps, int dtype, void* ws, size_t ws_bytes,
                             hipStream_t stream) {
     ISEG_REQUIRE(dy && x && gamma && nx && gx && dx && dgamma && dbeta && N > 0 && HW > 0 && C > 0, "iseg_grn_bwd: bad arguments");
     ISEG_REQUIRE((dtype == ISEG_BF16 || dtype == ISEG_F32) && C % 8 == 0, "iseg_grn_bwd: C %% 8 == 0 required (got dtype %d, C %d)", dtype, C);
@@ -245,9 +254,9 @@ extern "C" int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, c
     const unsigned blocks = (unsigned)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((grn_apply_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma,
-                           (const float*)nullptr, nx, (const float*)t, (bf16_t*)dx, HW, C, chunks);
+                           (const float*)nullptr, nx, (const float*)t, (const bf16_t*)mul, (bf16_t*)dx, HW, C, chunks);
     else
         hipLaunchKernelGGL((grn_apply_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (const float*)dy, gamma,
-                           (const float*)nullptr, nx, (const float*)t, (float*)dx, HW, C, chunks);
+                           (const float*)nullptr, nx, (const float*)t, (const float*)mul, (float*)dx, HW, C, chunks);
     return iseg_check_launch("iseg_grn_bwd");
 }

@@ -936,6 +936,83 @@ class _ConvNeXtBlockFn(Function):
         return (dx,) + (None,) * 12
 
 
+class _ConvNeXtV2BlockFn(Function):
+    """One tape node for a ConvNeXt V2 block (backbones/convnext_v2.py:83-98): depthwise 7x7 -> LayerNorm -> Dense 4C -> GELU -> GRN ->
+    Dense C -> drop path -> + inputs.  The first product's epilogue writes gelu(h) and gelu'(h); the second product's epilogue applies the
+    drop-path row factor and adds the block input; in the backward pass the GELU derivative rides the GRN data-gradient kernel, the bias
+    gradients ride the weight-gradient GEMMs and the residual gradient rides the depthwise data-gradient kernel -- no elementwise pass of
+    its own for any of them."""
+
+    @staticmethod
+    def forward(ctx, x, dw_kernel, dw_bias, ln_gamma, ln_beta, w1, b1, grn_gamma, grn_beta, w2, b2, dil, eps, grn_eps, dp_mask):
+        import types
+
+        p = types.SimpleNamespace(dw_kernel=dw_kernel, dw_bias=dw_bias, ln_gamma=ln_gamma, ln_beta=ln_beta, w1=w1, b1=b1, w2=w2, b2=b2,
+                                  grn_gamma=grn_gamma, grn_beta=grn_beta)
+        N, H, W, C = x.shape
+        xc = _c(x)
+        M = N * H * W
+        Kk = dw_kernel.shape[0]
+        pad = (Kk - 1) * dil // 2
+        y1 = K.dwconv2d(xc, dw_kernel.data.reshape(Kk * Kk, C), dw_bias.data, Kk, dil, pad, pad)
+        y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), ln_gamma.data, ln_beta.data, eps)
+        grad = any(ctx.needs_input_grad)
+        d = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None      # gelu'(pre-activation)
+        w1t, w2t = (nn.wt(w1), nn.wt(w2)) if xc.dtype == torch.bfloat16 else (None, None)
+        if w1t is not None and w2t is not None:
+            g = K.dense_fwd_t(y2, w1t, b1.data, act=K.ACT_GELU, pre_out=d, pre_deriv=grad)
+        else:
+            g = K.dense_fwd(y2, nn.w(w1), b1.data, act=K.ACT_GELU, pre_out=d, pre_deriv=grad)
+        z, nx, gx = K.grn_fwd(g.reshape(N, H * W, 4 * C), grn_gamma.data, grn_beta.data, grn_eps)
+        z = z.reshape(M, 4 * C)
+        if w1t is not None and w2t is not None:
+            out = K.dense_fwd_t(z, w2t, b2.data, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+        else:
+            out = K.dense_fwd(z, nn.w(w2), b2.data, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+        ctx.p, ctx.dil, ctx.pad, ctx.grn_eps = p, dil, pad, grn_eps
+        if grad:
+            ctx.save_for_backward(xc, y1, y2, mean, rstd, d, g, z, nx, gx, dp_mask)
+        return out.reshape(N, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, y1, y2, mean, rstd, d, g, z, nx, gx, dp_mask = ctx.saved_tensors
+        p, dil, pad = ctx.p, ctx.dil, ctx.pad
+        N, H, W, C = xc.shape
+        M = N * H * W
+        Kk = p.dw_kernel.shape[0]
+        do2 = _c(dout).reshape(M, C)
+        dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
+        K.dense_wgrad(z, dbr, _grad(p.w2), bias_grad=_grad(p.b2))
+        dz = K.dense_dgrad(dbr, nn.w(p.w2))                                           # [M, 4C]
+        del z
+        # GRN data gradient times gelu'(h) in one kernel; dgamma | dbeta from the same pass over dz
+        dh = K.grn_bwd(dz.reshape(N, H * W, 4 * C), g.reshape(N, H * W, 4 * C), p.grn_gamma.data, nx, gx, _grad(p.grn_gamma).reshape(-1),
+                       _grad(p.grn_beta).reshape(-1), ctx.grn_eps, mul=d).reshape(M, 4 * C)
+        del dz, g, d
+        K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))
+        dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                            # [M, C]
+        del dh
+        dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
+        dy1 = dy1.reshape(N, H, W, C)
+        K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            padb = (Kk - 1) * dil - pad
+            dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
+        dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.grn_gamma, p.grn_beta, p.w2, p.b2)
+        return (dx,) + (None,) * 14
+
+
+def convnext_v2_block(x, params, dilation, eps, grn_eps, dp_mask):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    p = params
+    return _ConvNeXtV2BlockFn.apply(x, p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.grn_gamma, p.grn_beta, p.w2, p.b2,
+                                    int(dilation), float(eps), float(grn_eps), dp_mask)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # side queue for work that only feeds the optimizer
 # ---------------------------------------------------------------------------------------------------------

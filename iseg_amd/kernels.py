@@ -709,13 +709,16 @@ def grn_fwd(x3d, gamma, beta, eps):
     return y, nx, gx
 
 
-def grn_bwd(dy3d, x3d, gamma, nx, gx, dgamma, dbeta, eps, accumulate=True):
+def grn_bwd(dy3d, x3d, gamma, nx, gx, dgamma, dbeta, eps, accumulate=True, mul=None):
+    """dx [* mul] and (+)= dgamma, dbeta; `mul`: saved activation derivative folded into the data gradient (see include/iseg_hip.h)"""
     _require_cuda(dy3d, x3d, dgamma, dbeta)
+    if mul is not None and (mul.dtype != x3d.dtype or mul.numel() != x3d.numel() or not mul.is_contiguous()):
+        raise ValueError("grn_bwd: mul must be a contiguous tensor shaped and typed like x")
     N, HW, Cc = x3d.shape
     dx = torch.empty_like(x3d)
     L = _hip.lib()
     ws, wsb = workspace(L.iseg_grn_workspace_bytes(N, HW, Cc), x3d.device)
-    _hip.check(L.iseg_grn_bwd(ptr(dy3d), ptr(x3d), ptr(gamma), ptr(nx), ptr(gx), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), N, HW, Cc,
+    _hip.check(L.iseg_grn_bwd(ptr(dy3d), ptr(x3d), ptr(gamma), ptr(nx), ptr(gx), ptr(mul), ptr(dx), ptr(dgamma), ptr(dbeta), int(accumulate), N, HW, Cc,
                               float(eps), dt(x3d), ptr(ws), wsb, stream()), "iseg_grn_bwd")
     return dx
 

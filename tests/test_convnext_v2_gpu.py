@@ -77,6 +77,29 @@ def test_grn_is_reproducible_and_zero_gamma_is_identity(cuda):
     assert dg.abs().max().item() > 0      # ... while gamma itself still learns
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_grn_backward_folds_the_activation_derivative(cuda, dtype):
+    """mul: dx of iseg_grn_bwd times a saved derivative tensor == the two steps done separately (rounded once instead of twice)"""
+    from iseg_amd import kernels as K
+
+    torch.manual_seed(9)
+    x = torch.randn(3, 50, 384, device="cuda").to(dtype)
+    dy = torch.randn_like(x)
+    mul = torch.rand_like(x) + 0.25
+    gamma = torch.randn(384, device="cuda")
+    _, nx, gx = K.grn_fwd(x, gamma, gamma, 1e-6)
+    dg0, db0 = torch.zeros(384, device="cuda"), torch.zeros(384, device="cuda")
+    dg1, db1 = torch.zeros(384, device="cuda"), torch.zeros(384, device="cuda")
+    plain = K.grn_bwd(dy, x, gamma, nx, gx, dg0, db0, 1e-6)
+    folded = K.grn_bwd(dy, x, gamma, nx, gx, dg1, db1, 1e-6, mul=mul)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)      # parameter gradients do not see the multiplier
+    want = plain.double() * mul.double()
+    tol = 1e-6 if dtype == torch.float32 else 1.2e-2
+    assert ((folded.double() - want).abs() <= tol * want.abs() + tol).all()
+    with pytest.raises(ValueError):
+        K.grn_bwd(dy, x, gamma, nx, gx, dg1, db1, 1e-6, mul=mul[:, :, :8])
+
+
 def test_grn_rejects_bad_arguments(cuda):
     from iseg_amd import _hip, kernels as K
 
@@ -113,13 +136,16 @@ def test_grn_parameter_gradients_through_the_deferred_queue(cuda):
     assert torch.equal(flat, ref)      # same rows, same fixed order
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,dil,dp", [((2, 8, 8, 80), 1, 0.0), ((3, 9, 7, 160), 2, 0.2), ((2, 4, 4, 320), 1, 0.5), ((2, 2, 2, 640), 1, 0.1)])
-def test_convnext_v2_block_forward_backward(cuda, dtype, shape, dil, dp):
+def test_convnext_v2_block_forward_backward(cuda, monkeypatch, dtype, shape, dil, dp, fused):
+    """the block as one tape node (default) and layer by layer through the generic operators (ISEG_V2_BLOCK_FUSED=0)"""
     from iseg_amd import nn
     from iseg_amd.backbones.convnext_v2 import Block
     from iseg_amd.param_store import ParamStore
 
+    monkeypatch.setenv("ISEG_V2_BLOCK_FUSED", fused)
     nn.set_compute_dtype(dtype)
     nn.set_device("cuda:0")
     try:
