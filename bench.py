@@ -101,7 +101,12 @@ def build_trainer(args):
     from iseg_amd.heads import convnext_tiny_aspp
     from iseg_amd.modelhelper import model_common_setup
 
-    strategy = common_env_setup(use_one_device_strategy=(args.gpus == 1), mixed_precision=not args.fp32, random_seed=0)
+    from iseg_amd import dist
+
+    # ISEG_DIST_SINGLE_RANK_COLLECTIVES=1 on one GPU: the mirrored strategy with a world of one rank, i.e. every SyncBN message and gradient
+    # bucket goes through RCCL -- the cost of the data-parallel plumbing itself, measurable without a second GPU
+    one_device = args.gpus == 1 and not dist._forced()
+    strategy = common_env_setup(use_one_device_strategy=one_device, mixed_precision=not args.fp32, random_seed=0)
     model = convnext_tiny_aspp(num_class=21, output_stride=32, build_input_size=(args.size, args.size))
     helper = model_common_setup(model, restore_checkpoint=False)
     helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-4, end_lr=0.0, epoch_steps=1000, train_epoch=30, optimizer="adamw",

@@ -83,6 +83,10 @@ class GradReducer:
         """Buckets are contiguous runs of the flat buffer in model order.  The FIRST buckets hold the first layers, whose gradients are
         ready last: nothing is left to overlap their all-reduce with, so they are small (head_bytes: 4 MB, then 16 MB) and only the
         later ones -- ready early in the backward pass -- take the full bucket_bytes."""
+        env = os.environ.get("ISEG_DP_BUCKETS_MB")      # experiments: "head0,head1,...,bucket" in MiB, e.g. "8,1024"
+        if env:
+            mb = [int(float(v) * (1 << 20)) for v in env.split(",")]
+            head_bytes, bucket_bytes = tuple(mb[:-1]), mb[-1]
         self.store = store
         self.buckets = []      # (lo, hi, n_params)
         self.bucket_of = {}    # id(param) -> bucket index
@@ -99,7 +103,14 @@ class GradReducer:
                 lo, cnt, acc = None, 0, 0
         if cnt:
             last = store.segments[-1]
-            self.buckets.append((lo, last[1] + store.padded(last[2]), cnt))
+            end = last[1] + store.padded(last[2])
+            if self.buckets and acc < bucket_bytes // 4:      # a small remainder rides the previous bucket instead of costing a collective
+                plo, _, pcnt = self.buckets[-1]
+                self.buckets[-1] = (plo, end, pcnt + cnt)
+                for p, off, n in store.segments[-cnt:]:
+                    self.bucket_of[id(p)] = len(self.buckets) - 1
+            else:
+                self.buckets.append((lo, end, cnt))
         self.uses = None       # id(param) -> ready() calls per step, learnt from the first step
         self.reset()
 
@@ -118,6 +129,9 @@ class GradReducer:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.launched[b] = True
+        from . import kernels as K
+
+        K.deferred_flush()      # the all-reduce reads the gradient buffer: reductions still queued into it must be enqueued first
         self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
 
     def ready(self, *params):
@@ -171,8 +185,4 @@ def set_active_reducer(r):
 def grads_ready(*params):
     r = _ACTIVE_REDUCER[0]
     if r is not None:
-        if active():      # the bucket's all-reduce reads the gradient buffer: queued reductions into it must have run
-            from . import kernels as K
-
-            K.deferred_flush()
-        r.ready(*params)
+        r.ready(*params)      # (queued parameter-gradient reductions are flushed when a bucket actually goes out: GradReducer._launch)

@@ -125,7 +125,7 @@ class TrainableModel:
             else:
                 lv = fn(yt, out)
                 losses.append(lv.float().mean() * w)
-        with F.unit_loss_grad(), K.deferred_reductions(self.store.flat_g):      # (flushed on exit, and by dist.grads_ready under data parallelism)
+        with F.unit_loss_grad(), K.deferred_reductions(self.store.flat_g):      # (flushed on exit, and before a gradient bucket goes out under data parallelism)
             torch.autograd.backward(losses)
         self.reducer.finish()
         dist.set_active_reducer(None)

@@ -280,3 +280,34 @@ def test_convnext_v2_registry_names_shapes_and_surgery():
     assert bb.stages[3].blocks[0].dwconv.dilation_rate == (4, 4) and bb.stages[1].blocks[0].dwconv.dilation_rate == (1, 1)
     huge = v2.convnext_v2_huge()
     assert [len(s.blocks) for s in huge.stages] == [3, 3, 27, 3] and huge.stages[3].blocks[0].filters == 2816
+
+
+def test_grad_reducer_bucket_layout():
+    """the buckets tile the flat gradient buffer exactly once, in model order; the first ones are the small head sizes; a small remainder rides
+    the previous bucket (distribution/distribution_utils.py:158-169 is one all-reduce per variable in the reference)"""
+    import torch
+
+    from iseg_amd import dist, nn
+    from iseg_amd.backbones import convnext as cx
+    from iseg_amd.param_store import ParamStore
+
+    nn.set_device("cpu")
+    with nn.dry_run_scope():
+        net = cx.ConvNeXt(depths=[1, 1, 1, 1], filters_list=[8, 16, 32, 64])
+        net(torch.empty(1, 32, 32, 3))
+    st = ParamStore(list(net.parameters()))
+    total = st.segments[-1][1] + st.padded(st.segments[-1][2])
+    for kw in ({"bucket_bytes": 64 << 10, "head_bytes": (4 << 10, 16 << 10)}, {"bucket_bytes": 8 << 10, "head_bytes": ()}, {"bucket_bytes": 1 << 30}):
+        red = dist.GradReducer(st, **kw)
+        assert red.buckets[0][0] == 0 and red.buckets[-1][1] == total
+        for (lo0, hi0, _), (lo1, _, _) in zip(red.buckets, red.buckets[1:]):
+            assert hi0 == lo1
+        assert sum(c for _, _, c in red.buckets) == len(st.segments)
+        for p, off, n in st.segments:
+            lo, hi, _ = red.buckets[red.bucket_of[id(p)]]
+            assert lo <= off and off + n <= hi
+        if len(red.buckets) > 1:      # no tiny trailing collective
+            assert (red.buckets[-1][1] - red.buckets[-1][0]) * 4 >= kw["bucket_bytes"] // 4
+    red = dist.GradReducer(st, bucket_bytes=64 << 10, head_bytes=(4 << 10, 16 << 10))
+    sizes = [(hi - lo) * 4 for lo, hi, _ in red.buckets]
+    assert sizes[0] < sizes[-1] and sizes[0] >= 4 << 10
