@@ -27,7 +27,7 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 // swizzle key of a B-tile row (see the fragment read below: a 16-lane read group holds rows {x, 8+x, 16+x, 24+x} + const, x = 0..3)
 __device__ __forceinline__ int b_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int WM, int WN, int NS, class TO>
+template <int WM, int WN, int NS, class TO, bool PERSIST = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
@@ -47,10 +47,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         B += epi.off_b(blockIdx.z);
         D += epi.off_d(blockIdx.z);
     }
+    // PERSIST (one K split, no batch, NS >= 3): gridDim.x <= the number of CUs and a workgroup walks the virtual workgroup ids
+    // blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x % 8 == 0, so every id of a workgroup maps to the same XCD and xcd_remap hands
+    // it tiles of that XCD's contiguous run).  The first NS-1 stages of tile i+1 are requested BEFORE tile i's epilogue: the ring is
+    // idle there (the epilogue runs from registers), so the HBM -> LDS latency of the next tile and the epilogue's own operand reads,
+    // GELU evaluations and stores overlap instead of queueing.
     int t, ksplit;
-    tile_and_split(ntiles, t, ksplit);
-    const int tile_n = t % tiles_n, tile_m = t / tiles_n;
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    if (PERSIST) {
+        t = xcd_remap(blockIdx.x, ntiles);
+        ksplit = 0;
+    } else {
+        tile_and_split(ntiles, t, ksplit);
+    }
+    int64_t m0 = (int64_t)(t / tiles_n) * BM, n0 = (int64_t)(t % tiles_n) * BN;
     const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     const int nk = (int)((kend - kbeg) / 64);
@@ -58,23 +67,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     // per-lane DMA sources: piece p of this wavefront covers stage rows 8*(wid + p*NW) .. +7 (A rows first, then B rows);
     // lane l fills LDS slot (row l>>3, chunk l&7) with source chunk (l&7) ^ (l>>3)
     const bf16_t* src[PPW];
-    {
+    auto point = [&](int64_t pm0, int64_t pn0) {
         const int rsub = lane >> 3;
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
             const int r = (wid + p * NW) * 8 + rsub;
             if (r < BM) {
-                int64_t row = m0 + r;
+                int64_t row = pm0 + r;
                 row = row < M ? row : M - 1;
                 src[p] = A + row * lda + kbeg + ((lane & 7) ^ (r & 7)) * 8;
             } else {
                 const int rb = r - BM;
-                int64_t row = n0 + rb;
+                int64_t row = pn0 + rb;
                 row = row < N ? row : N - 1;
                 src[p] = B + row * ldb + kbeg + ((lane & 7) ^ b_key(rb)) * 8;
             }
         }
-    }
+    };
+    point(m0, n0);
     auto issue = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
@@ -84,10 +94,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     };
 
     f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // Fragment addresses.  A: row (lane & 15) of 16-row block i, chunk (4*ks + (lane >> 4)) ^ (row & 7).
     // B: fragment j of the wave tile takes the rows 32*(j >> 1) + 8*(c >> 2) + 4*(j & 1) + (c & 3), c = lane & 15, and is the FIRST
@@ -117,6 +123,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
+    if (PERSIST) {      // (NS >= 3) prologue of the first tile; every later tile's prologue is issued in front of the previous epilogue
+#pragma unroll
+        for (int p = 0; p < NS - 1; ++p)
+            if (p < nk) issue(p);
+    }
+    for (int vt = blockIdx.x;;) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (NS == 2) {
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -137,9 +153,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     } else {
         // ring of NS stages, NS-1 tiles in flight, ONE barrier per K-step: the barrier of step kt proves both that tile kt has
         // landed for everyone and that everyone is past the fragment reads of tile kt-1, whose stage tile kt+NS-1 then takes
+        if (!PERSIST) {
 #pragma unroll
-        for (int p = 0; p < NS - 1; ++p)
-            if (p < nk) issue(p);
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nk) issue(p);
+        }
         int stage = 0, fill = (NS - 1) % NS;
         for (int kt = 0; kt < nk; ++kt) {
             const int ahead = nk - 1 - kt;      // tiles issued after tile kt that may stay in flight (capped at NS-2)
@@ -158,16 +176,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         __builtin_amdgcn_s_barrier();      // the epilogue slab overwrites the ring
         asm volatile("" ::: "memory");
     }
+    // (the barrier above: every wavefront is past its last fragment read, the whole ring is free)
+    const int64_t em0 = m0, en0 = n0;
+    if (PERSIST) {
+        vt += gridDim.x;
+        if (vt < ntiles) {
+            t = xcd_remap(vt, ntiles);
+            m0 = (int64_t)(t / tiles_n) * BM;
+            n0 = (int64_t)(t % tiles_n) * BN;
+            point(m0, n0);
+#pragma unroll
+            for (int p = 0; p < NS - 1; ++p)
+                if (p < nk) issue(p);
+        }
+    }
     // ---- epilogue from registers: per 16-row block, two 8-column vectors per lane (N % 8 == 0 and aligned operands are
     // eligibility conditions, so there is no scalar path) ----
     const bool split = slabs != nullptr;
     float* const slab = split ? slabs + (int64_t)ksplit * M * N : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int64_t m = m0 + wm * 64 + i * 16 + c15;
+        const int64_t m = em0 + wm * 64 + i * 16 + c15;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int64_t n = n0 + wn * 64 + 32 * h + 8 * g;
+            const int64_t n = en0 + wn * 64 + 32 * h + 8 * g;
             if (m < M && n < N) {
                 float v[8];
 #pragma unroll
@@ -184,6 +216,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
             }
         }
     }
+    if (!PERSIST || vt >= ntiles) break;
+    }      // tiles of this workgroup
 }
 
 // eligibility of a problem for the DMA pipeline (checked on the host)
@@ -219,6 +253,23 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
                        g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
 }
 
+// persistent form of the 256 x 128 kernel: one workgroup per CU (its 144-KiB ring allows no more), each walking ntiles / gridDim.x tiles
+template <class TO>
+void launch_dma_persistent(const iseg_gemm_args* g, const Epi& epi, int64_t k_per_split, int cus, hipStream_t s) {
+    constexpr int WM = 4, WN = 2, NS = 3, BM = WM * 64, BN = WN * 64;
+    const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
+    const int ntiles = tiles_m * tiles_n;
+    constexpr int lds = NS * (BM + BN) * 128;
+    static const bool raised = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    }();
+    (void)raised;
+    const int grid = (ntiles < cus ? ntiles : cus) & ~7;      // a multiple of 8: every virtual id of a workgroup sits on its XCD
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, true>), dim3(grid), dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+                       (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, (float*)nullptr, epi, 1);
+}
+
 int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default)
 
 // 1: 128 x 64 (4-deep ring)   2: 256 x 128 (8 wavefronts, 3-deep ring)   3: 128 x 128, two workgroups per CU (2 stages)
@@ -241,9 +292,29 @@ inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
     return 4;
 }
 
+// number of CUs of the current device (persistent grids)
+inline int dma_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 8) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 template <class TO>
 void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
-    switch (dma_variant(g, nsplit)) {
+    const int variant = dma_variant(g, nsplit);
+    // several 256 x 128 tiles per CU, one K split, no batch: the persistent form overlaps a tile's epilogue with the next tile's first DMAs
+    static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 1; }();
+    if (variant == 2 && persist && nsplit == 1 && g->batch <= 1 && !slabs) {
+        const int cus = dma_cus();
+        if (ceil_div64(g->M, 256) * ceil_div64(g->N, 128) > cus) {
+            launch_dma_persistent<TO>(g, epi, kps, cus, s);
+            return;
+        }
+    }
+    switch (variant) {
         case 1: launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 2: launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
