@@ -147,7 +147,8 @@ def _kernel_label(key):
     epi = {0: "", 1: "relu", 2: "gelu", 3: "gelu'(aux)", 4: "relu'(aux)", 5: "x aux"}.get(int(act), f"act{act}")
     epi = " + ".join(t for t in (epi, "second output" if has_pre else "", "residual" if has_res else "") if t)
     name = "iseg_mm::gemm_bf16_kernel" if not variant else \
-        "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages"}[variant]
+        "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages",
+                                              5: "256x128,3 stages,persistent", 6: "256x192,2 stages"}[variant]
     return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''}{'; epilogue ' + epi if epi else ''})"
 
 

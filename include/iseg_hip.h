@@ -106,11 +106,17 @@ typedef struct iseg_gemm_args {
     int pre_deriv; /* 1 (needs act = ISEG_ACT_GELU and pre_out): pre_out receives gelu'(pre-activation) instead of the pre-activation --
                       the forward epilogue has Phi(v) and exp(-v^2/2) in hand anyway, and the backward GEMM's epilogue becomes one
                       multiply (ISEG_ACT_MUL_AUX) instead of re-evaluating erf per element (50 us of VALU per 100 M elements) */
+    /* B per row group (b_group_rows > 0): rows [i*b_group_rows, (i+1)*b_group_rows) of A / D are multiplied by B + i*b_group_stride
+       (elements) -- one kernel per sample, e.g. the Dense after ConvNeXt V2's response normalisation with the per-sample channel factors
+       folded into its kernel (backbones/convnext_v2.py:92-93).  Every epilogue option stays available (rows keep their global index).
+       bf16, both operands K-contiguous, b_group_rows % 256 == 0, no split-K, no batch; anything else returns ISEG_ERR_UNSUPPORTED. */
+    int64_t b_group_rows, b_group_stride;
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
 /* which main loop iseg_gemm runs for this problem (profiling labels): 0 = register-staged gemm_bf16_kernel / fp32 kernel,
-   1..4 = LDS-DMA pipeline gemm_bf16_dma_kernel with tile 128x64 / 256x128 / 128x128 (2 stages) / 128x128 (3 stages) */
+   1..4 = LDS-DMA pipeline gemm_bf16_dma_kernel with tile 128x64 / 256x128 / 128x128 (2 stages) / 128x128 (3 stages),
+   5 = 256x128 persistent (one workgroup per CU walks several tiles), 6 = 256x192 (2 stages) */
 int iseg_gemm_variant(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
 int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);

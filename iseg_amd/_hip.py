@@ -39,6 +39,8 @@ class GemmArgs(C.Structure):
         ("sa_outer", C.c_int64), ("sa_inner", C.c_int64), ("sb_outer", C.c_int64), ("sb_inner", C.c_int64),
         ("sd_outer", C.c_int64), ("sd_inner", C.c_int64),
         ("pre_deriv", C.c_int),
+        ("b_group_rows", C.c_int64),
+        ("b_group_stride", C.c_int64),
     ]
 
 

@@ -128,7 +128,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
 int choose_split(const iseg_gemm_args* g, int tile) {
     if (g->split_k > 0) return g->split_k;
     const int64_t tiles = ceil_div64(g->M + (g->colsum_out ? 1 : 0), tile) * ceil_div64(g->N, tile);
-    if (tiles >= 256 || g->K < 2048 || g->batch > 1) return 1;
+    if (tiles >= 256 || g->K < 2048 || g->batch > 1 || g->b_group_rows > 0) return 1;
     // the LDS-DMA pipeline keeps several K-tiles in flight per workgroup: half-filled grids are better left unsplit
     if (g->in_dtype == ISEG_BF16 && tiles >= 96 && iseg_mm::dma_mode() && iseg_mm::dma_eligible(g, 128)) return 1;
     // two 128x128 workgroups fit a CU: the grid must stay within ONE resident round of 512 (measured: 42 splits of a 12-tile
@@ -154,7 +154,7 @@ extern "C" int iseg_gemm_variant(const iseg_gemm_args* g) {
     const int nsplit = iseg_gemm_splits(g);
     const int64_t kps = nsplit > 1 ? ceil_div64(ceil_div64(g->K, nsplit), 128) * 128 : g->K;
     if (!iseg_mm::dma_mode() || !iseg_mm::dma_eligible(g, kps)) return 0;
-    return iseg_mm::dma_variant(g, (int)ceil_div64(g->K, kps));
+    return iseg_mm::dma_form(g, (int)ceil_div64(g->K, kps));
 }
 
 extern "C" size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* g) {
@@ -178,13 +178,21 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
             g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
-            g->pre_deriv};
+            g->pre_deriv, g->b_group_rows, g->b_group_stride};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);
         ISEG_REQUIRE(!g->bias && !g->colscale && !g->rowscale && !g->residual && !g->aux && !g->pre_out && !g->colsum_out &&
                          g->act == ISEG_ACT_NONE && g->a_act == ISEG_ACT_NONE,
                      "iseg_gemm: a batched problem takes only the alpha / accumulate epilogue");
+    }
+    if (g->b_group_rows > 0) {
+        if (!(g->in_dtype == ISEG_BF16 && g->a_kcontig && g->b_kcontig && batch == 1 && g->split_k <= 1 && g->b_group_rows % 256 == 0 &&
+              g->b_group_stride % 8 == 0 && iseg_mm::dma_mode() && iseg_mm::dma_eligible(g, g->K))) {
+            iseg_set_error("iseg_gemm: B per row group needs the LDS-DMA path (bf16, K-contiguous operands, K %% 64 == 0, aligned) with "
+                           "b_group_rows %% 256 == 0, no split and no batch");
+            return ISEG_ERR_UNSUPPORTED;
+        }
     }
     if (g->colsum_out) {
         ISEG_REQUIRE(g->in_dtype == ISEG_BF16 && !g->a_kcontig && !g->b_kcontig, "iseg_gemm: colsum_out needs the bf16 wgrad orientation");
@@ -263,7 +271,7 @@ extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_byt
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
             g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
-            g->pre_deriv};
+            g->pre_deriv, g->b_group_rows, g->b_group_stride};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);

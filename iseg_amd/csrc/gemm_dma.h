@@ -27,13 +27,14 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 // swizzle key of a B-tile row (see the fragment read below: a 16-lane read group holds rows {x, 8+x, 16+x, 24+x} + const, x = 0..3)
 __device__ __forceinline__ int b_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int WM, int WN, int NS, class TO, bool PERSIST = false>
+template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
                                                                      float* __restrict__ slabs, Epi epi, int vecD) {
     constexpr int NW = WM * WN;
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 64, BN = WN * FN * 16;      // a wavefront owns 64 rows x FN*16 columns (FN = 4, or 6 for the 256 x 192 tile)
+    static_assert(FN % 2 == 0, "column fragments come in pairs (eight consecutive columns per lane)");
     constexpr int PIECES = (BM + BN) / 8;      // 1-KiB DMA pieces (8 rows x 128 B) per stage
     constexpr int PPW = PIECES / NW;           // pieces each wavefront issues per stage
     static_assert(PIECES % NW == 0, "stage pieces must divide over the wavefronts");
@@ -80,7 +81,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
                 const int rb = r - BM;
                 int64_t row = pn0 + rb;
                 row = row < N ? row : N - 1;
-                src[p] = B + row * ldb + kbeg + ((lane & 7) ^ b_key(rb)) * 8;
+                // (B per row group: a tile never straddles two groups, b_group_rows % 256 == 0 is checked on the host)
+                const bf16_t* Bg = epi.b_group_rows > 0 ? B + (pm0 / epi.b_group_rows) * epi.b_group_stride : B;
+                src[p] = Bg + row * ldb + kbeg + ((lane & 7) ^ b_key(rb)) * 8;
             }
         }
     };
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][FN];
 
     // Fragment addresses.  A: row (lane & 15) of 16-row block i, chunk (4*ks + (lane >> 4)) ^ (row & 7).
     // B: fragment j of the wave tile takes the rows 32*(j >> 1) + 8*(c >> 2) + 4*(j & 1) + (c & 3), c = lane & 15, and is the FIRST
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     const int g = lane >> 4, c15 = lane & 15;
     const int a_sw = (g ^ (lane & 7)) * 16;      // ks = 0; ks = 1 flips bit 6 of the byte offset (chunk ^ 4)
     const int a_off = (wm * 64 + c15) * 128;
-    const int b_row0 = wn * 64 + 8 * (c15 >> 2) + (c15 & 3);
+    const int b_row0 = wn * (FN * 16) + 8 * (c15 >> 2) + (c15 & 3);
     const int b_sw = (g ^ b_key(b_row0)) * 16;   // + 32*(j >> 1) + 4*(j & 1) leaves the key (bits 0,1,3 of the row) unchanged
     const int b_off = BM * 128 + b_row0 * 128;
 
@@ -112,15 +115,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         const char* sb = smem + stage * STAGE + b_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[FN];
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 2048 + (a_sw ^ (ks * 64)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * 128 + (b_sw ^ (ks * 64)));
+            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * 128 + (b_sw ^ (ks * 64)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
     };
     if (PERSIST) {      // (NS >= 3) prologue of the first tile; every later tile's prologue is issued in front of the previous epilogue
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (NS == 2) {
         issue(0);
         for (int kt = 0; kt < nk; ++kt) {
@@ -198,8 +201,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     for (int i = 0; i < 4; ++i) {
         const int64_t m = em0 + wm * 64 + i * 16 + c15;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t n = en0 + wn * 64 + 32 * h + 8 * g;
+        for (int h = 0; h < FN / 2; ++h) {
+            const int64_t n = en0 + wn * (FN * 16) + 32 * h + 8 * g;
             if (m < M && n < N) {
                 float v[8];
 #pragma unroll
@@ -235,9 +238,9 @@ inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
     return true;
 }
 
-template <int WM, int WN, int NS, class TO>
+template <int WM, int WN, int NS, class TO, int FN = 4>
 void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 64, BN = WN * FN * 16;
     const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
     const int ntiles = tiles_m * tiles_n;
     const int vecD = 1;
@@ -245,12 +248,12 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
     dim3 grid(ntiles, nsplit, batch);
     constexpr int lds = NS * (BM + BN) * 128;
     static const bool raised = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   lds) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     }();
     (void)raised;
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda, (const bf16_t*)g->B,
-                       g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+                       (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
 }
 
 // persistent form of the 256 x 128 kernel: one workgroup per CU (its 144-KiB ring allows no more), each walking ntiles / gridDim.x tiles
@@ -273,7 +276,7 @@ void launch_dma_persistent(const iseg_gemm_args* g, const Epi& epi, int64_t k_pe
 int dma_mode();      // ISEG_GEMM_DMA: 0 = never, 1 = whenever eligible (default)
 
 // 1: 128 x 64 (4-deep ring)   2: 256 x 128 (8 wavefronts, 3-deep ring)   3: 128 x 128, two workgroups per CU (2 stages)
-// 4: 128 x 128, one workgroup per CU with the 3-deep ring.  Measured on MI355X (tools/kbench_gemm_ref.py): 256 x 128 once it fills
+// 4: 128 x 128, one workgroup per CU with the 3-deep ring.  (dispatch_dma adds two forms of 2: persistent, and 256 x 192.)  Measured on MI355X (tools/kbench_gemm_ref.py): 256 x 128 once it fills
 // most CUs -- it reads each B panel half as often; otherwise 128 x 128, two per CU when there are enough tiles, the deeper ring when
 // the grid is thin.
 inline int dma_variant(const iseg_gemm_args* g, int nsplit) {
@@ -302,22 +305,36 @@ inline int dma_cus() {
     return n;
 }
 
+// dma_variant plus the two further forms of the 256-row tile:
+//   6: 256 x 192 tiles (a wavefront owns 64 x 96, two ring stages = 112 KiB): a third fewer re-reads of the A panel than 256 x 128 when N is a
+//      multiple of 192 (the 4C = 768 / 1536 / 3072 outputs of the ConvNeXt stages) and the tiles fill whole rounds of the CUs at least as well.
+//      Measured (tools/kbench_gemm_dma_ab.py): M=4096 N=3072 K=768 34.5 -> 27.5 us (384 tiles = 1.5 rounds -> 256 = one round),
+//      M=16384 N=1536 K=384 34.4 -> 33.1 us, with the x aux epilogue 42.2 -> 41.4 us, M=65536 N=768 K=192 45.7 -> 43.0 us.
+//   5: several 256 x 128 tiles per CU, one K split, no batch: the persistent form overlaps a tile's epilogue with the next tile's first DMAs.
+inline int dma_form(const iseg_gemm_args* g, int nsplit) {
+    const int variant = dma_variant(g, nsplit);
+    if (variant != 2 || nsplit != 1 || g->batch > 1) return variant;
+    static const int wide = [] { const char* e = getenv("ISEG_GEMM_DMA_WIDE"); return e ? atoi(e) : 1; }();
+    static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 1; }();
+    const int cus = dma_cus();
+    const int64_t t128 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128);
+    if (wide && g->N % 192 == 0) {
+        const int64_t t192 = ceil_div64(g->M, 256) * (g->N / 192);
+        const double e128 = (double)t128 / (double)(ceil_div64(t128, cus) * cus), e192 = (double)t192 / (double)(ceil_div64(t192, cus) * cus);
+        if (t192 >= cus && e192 + 0.02 >= e128) return 6;
+    }
+    if (persist && t128 > cus) return 5;
+    return variant;
+}
+
 template <class TO>
 void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
-    const int variant = dma_variant(g, nsplit);
-    // several 256 x 128 tiles per CU, one K split, no batch: the persistent form overlaps a tile's epilogue with the next tile's first DMAs
-    static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 1; }();
-    if (variant == 2 && persist && nsplit == 1 && g->batch <= 1 && !slabs) {
-        const int cus = dma_cus();
-        if (ceil_div64(g->M, 256) * ceil_div64(g->N, 128) > cus) {
-            launch_dma_persistent<TO>(g, epi, kps, cus, s);
-            return;
-        }
-    }
-    switch (variant) {
+    switch (dma_form(g, nsplit)) {
         case 1: launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 2: launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
+        case 5: launch_dma_persistent<TO>(g, epi, kps, dma_cus(), s); break;
+        case 6: launch_dma<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;
         default: launch_dma<2, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
     }
 }

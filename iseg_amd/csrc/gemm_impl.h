@@ -36,6 +36,7 @@ struct Epi {
     int batch_inner;
     int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
     int pre_deriv;          // pre_out receives gelu'(pre) instead of pre (act == GELU)
+    int64_t b_group_rows, b_group_stride;      // B per row group (LDS-DMA kernel only): rows [i*b_group_rows, ...) use B + i*b_group_stride
     __device__ __forceinline__ int64_t off_a(int z) const { return (z / batch_inner) * sa_outer + (z % batch_inner) * sa_inner; }
     __device__ __forceinline__ int64_t off_b(int z) const { return (z / batch_inner) * sb_outer + (z % batch_inner) * sb_inner; }
     __device__ __forceinline__ int64_t off_d(int z) const { return (z / batch_inner) * sd_outer + (z % batch_inner) * sd_inner; }

@@ -115,8 +115,9 @@ class KernelTimer:
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
          accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False, batch=1, batch_inner=1,
-         sa=(0, 0), sb=(0, 0), sd=(0, 0), pre_deriv=False):
-    """batch > 1: problem z uses X + (z // batch_inner) * sX[0] + (z % batch_inner) * sX[1] (element strides)"""
+         sa=(0, 0), sb=(0, 0), sd=(0, 0), pre_deriv=False, b_group=None):
+    """batch > 1: problem z uses X + (z // batch_inner) * sX[0] + (z % batch_inner) * sX[1] (element strides);
+    b_group=(rows, stride): rows [i*rows, (i+1)*rows) of A / D use B + i*stride (one kernel per sample; LDS-DMA path only)"""
     _require_cuda(A, B, D)
     if A.dtype != B.dtype:
         raise TypeError(f"gemm operands differ in dtype: {A.dtype} vs {B.dtype}")
@@ -134,6 +135,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.colsum_out, g.colsum_accumulate = ptr(colsum_out), int(colsum_accumulate)
     g.batch, g.batch_inner = int(batch), int(batch_inner)
     g.pre_deriv = int(bool(pre_deriv))
+    g.b_group_rows, g.b_group_stride = (int(b_group[0]), int(b_group[1])) if b_group is not None else (0, 0)
     (g.sa_outer, g.sa_inner), (g.sb_outer, g.sb_inner), (g.sd_outer, g.sd_inner) = sa, sb, sd
     for t in (residual, aux, pre_out):
         if t is not None and t.dtype != D.dtype:

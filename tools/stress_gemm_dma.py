@@ -10,7 +10,7 @@ from iseg_amd import kernels as K  # noqa: E402
 
 torch.manual_seed(0)
 shapes = [(300, 64, 256), (1000, 136, 128), (7000, 384, 192), (16384, 512, 128), (25000, 264, 320), (640, 128, 2048), (16384, 1536, 384),
-          (4096, 768, 3072), (40000, 640, 128), (33000, 1032, 448)]      # the last ones: several 256 x 128 tiles per CU (persistent form), ragged
+          (4096, 768, 3072), (40000, 640, 128), (33000, 1032, 448), (70000, 768, 192), (4096, 3072, 768), (66000, 576, 128)]      # several 256 x 128 tiles per CU (persistent form), ragged; N % 192 == 0 with >= 256 tiles (256 x 192 tiles)
 worst = 0.0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     for M, N, Kd in shapes:
