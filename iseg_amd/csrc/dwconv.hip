@@ -907,11 +907,14 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
         const int oh = h0 + row;
         if (oh < H) {
             const int ow0 = w0 + seg * TWO;
-            const int off0 = ((n * H + oh) * W + ow0) * C + c0 + cg * 8;
+            const int offr = (n * H + oh) * W * C + c0 + cg * 8;
+            const int off0 = offr + ow0 * C;
             if (add) {
-                f32x2 av[TWO][4];      // every load is issued (clamped to the row's first pixel past the edge): a branch per load makes hipcc wait for each
+                // every load is issued, clamped to the row's last pixel (a segment may start past the edge of a narrow plane): a branch per
+                // load makes hipcc wait for each
+                f32x2 av[TWO][4];
 #pragma unroll
-                for (int t = 0; t < TWO; ++t) unpack_bf16x8(reinterpret_cast<const char*>(add + off0 + (ow0 + t < W ? t : 0) * C), av[t]);
+                for (int t = 0; t < TWO; ++t) unpack_bf16x8(reinterpret_cast<const char*>(add + offr + (ow0 + t < W ? ow0 + t : W - 1) * C), av[t]);
 #pragma unroll
                 for (int t = 0; t < TWO; ++t)
                     if (ow0 + t < W) {
