@@ -326,6 +326,22 @@ int iseg_grn_fwd(const void* x, const float* gamma, const float* beta, void* y, 
 int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, const void* mul, void* dx,
                  float* dgamma, float* dbeta, int accumulate_param_grads, int64_t N, int64_t HW, int C, float eps, int dtype, void* ws, size_t ws_bytes,
                  iseg_stream_t stream);
+/* The normalisation folded into the Dense that follows it (Block.call :92-93, x = grn(x); x = pwconv2(x)): with a_n = gamma*nx_n + 1 per sample,
+ *   grn(g) W + b = g (diag(a_n) W) + (b + beta W),   dW = sum_n diag(a_n) (g_n^T dbr_n) + beta (x) colsum(dbr),
+ * and the statistics of the GRN backward follow from the per-sample products g_n^T dbr_n as well -- the passes that would write grn(g) and
+ * read it back disappear.  iseg_grn_fwd with y == NULL only computes nx, gx.
+ *   iseg_grn_fold_weights: out[n][o][k] = wt[o][k] * a_n[k]    (wt: the K-contiguous bf16 kernel copy [Cout][C4]; out feeds iseg_gemm's B per row group)
+ *   iseg_grn_fold_bias:    out[c] = b[c] + sum_k beta[k] W[k][c]                      (W: the fp32 kernel [C4][Cout])
+ *   iseg_grn_fold_wgrad:   slabs [N*slabs_per_sample][C4][Cout] fp32 = g^T dbr of consecutive equal row chunks (a batched iseg_gemm), S = colsum(dbr):
+ *                          dW (+)= sum_n a_n (.) G_n + beta (x) S;  dstats [N][2*C4] = (sum_hw dz*g | sum dz in row 0, zeros below)
+ *   iseg_grn_bwd_folded:   iseg_grn_bwd with those statistics given (dstats is overwritten): no pass over dy for them */
+int iseg_grn_fold_weights(const void* wt, const float* gamma, const float* nx, void* out, int64_t N, int Cout, int C4, iseg_stream_t stream);
+int iseg_grn_fold_bias(const float* W, const float* beta, const float* b, float* out, int C4, int Cout, iseg_stream_t stream);
+int iseg_grn_fold_wgrad(const float* slabs, int slabs_per_sample, const float* W, const float* gamma, const float* beta, const float* nx,
+                        const float* S, float* dW, float* dstats, int accumulate, int64_t N, int C4, int Cout, iseg_stream_t stream);
+int iseg_grn_bwd_folded(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, const void* mul, float* dstats,
+                        void* dx, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t N, int64_t HW, int C, float eps, int dtype,
+                        void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * keras MaxPooling2D(3, strides=2, "same") backbones/resnet_common.py:215-217 and tf.nn.avg_pool2d(..., "SAME")

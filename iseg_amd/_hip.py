@@ -108,6 +108,10 @@ SIGNATURES = {
     "iseg_grn_workspace_bytes": (_z, [_l, _l, _i]),
     "iseg_grn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _l, _i, _f, _i, _p, _z, _p]),
     "iseg_grn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _l, _i, _f, _i, _p, _z, _p]),
+    "iseg_grn_fold_weights": (_i, [_p, _p, _p, _p, _l, _i, _i, _p]),
+    "iseg_grn_fold_bias": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "iseg_grn_fold_wgrad": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p]),
+    "iseg_grn_bwd_folded": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _l, _i, _f, _i, _p, _z, _p]),
     "iseg_softmax_rows_fwd": (_i, [_p, _p, _l, _i, _i, _i, _p, _i, _p, _i, _f, _f, _i, _p]),
     "iseg_softmax_rows_bwd": (_i, [_p, _p, _p, _l, _i, _i, _f, _f, _i, _p]),
     "iseg_clip_fwd": (_i, [_p, _p, _l, _f, _f, _i, _p]),

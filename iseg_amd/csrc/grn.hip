@@ -174,6 +174,113 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const T* __restrict__ x,
     }
 }
 
+// ---- the normalisation folded into the Dense that follows it (backbones/convnext_v2.py:92-93: x = grn(x); x = pwconv2(x)) ----------------------
+//   z = g*a_n + beta with a_n = gamma*nx_n + 1 per sample, so  z W + b = g (diag(a_n) W) + (b + beta W): N scaled copies of the small kernel and
+//   one bias vector replace the pass that would write z;  dW = sum_n diag(a_n) G_n + beta (x) S  with G_n = g_n^T dbr_n (per-sample weight-gradient
+//   slabs) and S = colsum(dbr);  the statistics of the GRN backward come from the same slabs: sum_hw dz*g = rowsum(G_n . W), sum dz = W S.
+
+// out[n][o][k] = wt[o][k] * (gamma[k]*nx[n][k] + 1): K-contiguous per-sample kernels for the LDS-DMA GEMM (B per row group)
+__global__ __launch_bounds__(256) void grn_fold_weights_kernel(const bf16_t* __restrict__ wt, const float* __restrict__ gamma,
+                                                               const float* __restrict__ nx, bf16_t* __restrict__ out, int Cout, int C4,
+                                                               int64_t chunks) {
+    const int nch = C4 / 8;
+    const int64_t per = (int64_t)Cout * nch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / per);
+        const int64_t r = i - (int64_t)n * per;
+        const int k = (int)(r % nch) * 8;
+        float w[8], g[8], a[8];
+        load8<bf16_t>(wt + r * 8, w);
+        load8<float>(gamma + k, g);
+        load8<float>(nx + (int64_t)n * C4 + k, a);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] *= fmaf(g[u], a[u], 1.f);
+        store8<bf16_t>(out + i * 8, w);
+    }
+}
+
+// out[c] = b[c] + sum_k beta[k] * W[k][c]      (W [C4][Cout] fp32 master; 64 columns x 16 row lanes per workgroup, four independent loads per
+// lane and trip, fixed order: with 4 row lanes and one load per trip the 2-3 workgroups of a stage-0 kernel needed 58 us of pure latency)
+__global__ __launch_bounds__(1024) void grn_fold_bias_kernel(const float* __restrict__ W, const float* __restrict__ beta, const float* __restrict__ b,
+                                                             float* __restrict__ out, int C4, int Cout) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < Cout) {
+        int k = ty;
+        for (; k + 48 < C4; k += 64) {
+            s0 = fmaf(beta[k], W[(int64_t)k * Cout + c], s0);
+            s1 = fmaf(beta[k + 16], W[(int64_t)(k + 16) * Cout + c], s1);
+            s2 = fmaf(beta[k + 32], W[(int64_t)(k + 32) * Cout + c], s2);
+            s3 = fmaf(beta[k + 48], W[(int64_t)(k + 48) * Cout + c], s3);
+        }
+        for (; k < C4; k += 16) s0 = fmaf(beta[k], W[(int64_t)k * Cout + c], s0);
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < Cout) {
+        float t = red[0][tx];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t += red[q][tx];
+        out[c] = (b ? b[c] : 0.f) + t;
+    }
+}
+
+// one workgroup per kernel row k.  slabs [nslab][C4][Cout] hold G = g^T dbr of consecutive row chunks, `sps` chunks per sample.
+//   dW[k][c] (+)= sum_n a_n[k] * G_n[k][c] + beta[k]*S[c];   dstats[n][k] = sum_c G_n[k][c]*W[k][c];   dstats[0][C4+k] = sum_c W[k][c]*S[c]
+template <int CPT>
+__global__ __launch_bounds__(256) void grn_fold_wgrad_kernel(const float* __restrict__ slabs, int sps, const float* __restrict__ W,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ nx, const float* __restrict__ S, float* __restrict__ dW,
+                                                             float* __restrict__ dstats, int N, int C4, int Cout, int accumulate) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    const int64_t row = (int64_t)k * Cout;
+    const int64_t slab = (int64_t)C4 * Cout;
+    float w[CPT], acc[CPT], sv[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + j * 256;
+        w[j] = c < Cout ? W[row + c] : 0.f;
+        sv[j] = c < Cout ? S[c] : 0.f;
+        acc[j] = 0.f;
+    }
+    const float gk = gamma[k];
+    for (int n = 0; n < N; ++n) {
+        const float a = fmaf(gk, nx[(int64_t)n * C4 + k], 1.f);
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = threadIdx.x + j * 256;
+            if (c < Cout) {
+                float gs = 0.f;
+                for (int q = 0; q < sps; ++q) gs += slabs[((int64_t)n * sps + q) * slab + row + c];
+                acc[j] = fmaf(a, gs, acc[j]);
+                d = fmaf(gs, w[j], d);
+            }
+        }
+        d = block_sum_256(d, red);
+        if (threadIdx.x == 0) dstats[(int64_t)n * 2 * C4 + k] = d;
+    }
+    float ws = 0.f;
+    const float bk = beta[k];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < Cout) {
+            const float v = fmaf(bk, sv[j], acc[j]);
+            dW[row + c] = accumulate ? dW[row + c] + v : v;
+            ws = fmaf(w[j], sv[j], ws);
+        }
+    }
+    ws = block_sum_256(ws, red);
+    if (threadIdx.x == 0) {
+        dstats[C4 + k] = ws;
+        for (int n = 1; n < N; ++n) dstats[(int64_t)n * 2 * C4 + C4 + k] = 0.f;
+    }
+}
+
 int grn_parts(int64_t N, int64_t HW, int C) {
     const int nch = C / 8;
     const int tpc = nch < 256 ? nch : 256;
@@ -198,7 +305,7 @@ extern "C" size_t iseg_grn_workspace_bytes(int64_t N, int64_t HW, int C) {
 
 extern "C" int iseg_grn_fwd(const void* x, const float* gamma, const float* beta, void* y, float* nx, float* gx, int64_t N, int64_t HW,
                             int C, float eps, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
-    ISEG_REQUIRE(x && gamma && beta && y && nx && gx && N > 0 && HW > 0 && C > 0, "iseg_grn_fwd: bad arguments");
+    ISEG_REQUIRE(x && nx && gx && N > 0 && HW > 0 && C > 0 && (!y || (gamma && beta)), "iseg_grn_fwd: bad arguments");
     ISEG_REQUIRE((dtype == ISEG_BF16 || dtype == ISEG_F32) && C % 8 == 0, "iseg_grn_fwd: C %% 8 == 0 required (got dtype %d, C %d)", dtype, C);
     ISEG_REQUIRE(N <= 65535, "iseg_grn_fwd: at most 65535 samples");
     ISEG_REQUIRE(ws && ws_bytes >= iseg_grn_workspace_bytes(N, HW, C), "iseg_grn_fwd: workspace too small");
@@ -213,6 +320,7 @@ extern "C" int iseg_grn_fwd(const void* x, const float* gamma, const float* beta
                            parts, HW, C);
     launch_reduce_rows(parts, P, C, (int64_t)P * C, (int)N, C, sumsq, nullptr, C, C, 1.f, 0, stream);
     hipLaunchKernelGGL(grn_stats_kernel, dim3((unsigned)N), dim3(256), 0, stream, (const float*)sumsq, nx, gx, C, eps);
+    if (!y) return iseg_check_launch("iseg_grn_fwd");      // statistics only: the caller folds gamma*nx + 1 into the next layer's kernel
     const int64_t chunks = N * HW * (C / 8);
     const unsigned blocks = (unsigned)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
     if (dtype == ISEG_BF16)
@@ -259,4 +367,57 @@ extern "C" int iseg_grn_bwd(const void* dy, const void* x, const float* gamma, c
         hipLaunchKernelGGL((grn_apply_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (const float*)dy, gamma,
                            (const float*)nullptr, nx, (const float*)t, (const float*)mul, (float*)dx, HW, C, chunks);
     return iseg_check_launch("iseg_grn_bwd");
+}
+
+extern "C" int iseg_grn_fold_weights(const void* wt, const float* gamma, const float* nx, void* out, int64_t N, int Cout, int C4,
+                                     hipStream_t stream) {
+    ISEG_REQUIRE(wt && gamma && nx && out && N > 0 && Cout > 0 && C4 > 0 && C4 % 8 == 0, "iseg_grn_fold_weights: bad arguments");
+    const int64_t chunks = N * Cout * (C4 / 8);
+    const unsigned blocks = (unsigned)(ceil_div64(chunks, 256) < 4096 ? ceil_div64(chunks, 256) : 4096);
+    hipLaunchKernelGGL(grn_fold_weights_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)wt, gamma, nx, (bf16_t*)out, Cout, C4, chunks);
+    return iseg_check_launch("iseg_grn_fold_weights");
+}
+
+extern "C" int iseg_grn_fold_bias(const float* W, const float* beta, const float* b, float* out, int C4, int Cout, hipStream_t stream) {
+    ISEG_REQUIRE(W && beta && out && C4 > 0 && Cout > 0, "iseg_grn_fold_bias: bad arguments");
+    hipLaunchKernelGGL(grn_fold_bias_kernel, dim3((unsigned)((Cout + 63) / 64)), dim3(1024), 0, stream, W, beta, b, out, C4, Cout);
+    return iseg_check_launch("iseg_grn_fold_bias");
+}
+
+extern "C" int iseg_grn_fold_wgrad(const float* slabs, int slabs_per_sample, const float* W, const float* gamma, const float* beta, const float* nx,
+                                   const float* S, float* dW, float* dstats, int accumulate, int64_t N, int C4, int Cout, hipStream_t stream) {
+    ISEG_REQUIRE(slabs && W && gamma && beta && nx && S && dW && dstats && slabs_per_sample > 0 && N > 0 && C4 > 0 && Cout > 0,
+                 "iseg_grn_fold_wgrad: bad arguments");
+    ISEG_REQUIRE(Cout <= 4096 && N <= 65535, "iseg_grn_fold_wgrad: at most 4096 output channels");
+#define FOLD_WG(CPT_)                                                                                                                        \
+    hipLaunchKernelGGL((grn_fold_wgrad_kernel<CPT_>), dim3((unsigned)C4), dim3(256), 0, stream, slabs, slabs_per_sample, W, gamma, beta, nx, S, dW, \
+                       dstats, (int)N, C4, Cout, accumulate)
+    if (Cout <= 256) FOLD_WG(1);
+    else if (Cout <= 512) FOLD_WG(2);
+    else if (Cout <= 1024) FOLD_WG(4);
+    else if (Cout <= 2048) FOLD_WG(8);
+    else FOLD_WG(16);
+#undef FOLD_WG
+    return iseg_check_launch("iseg_grn_fold_wgrad");
+}
+
+extern "C" int iseg_grn_bwd_folded(const void* dy, const void* x, const float* gamma, const float* nx, const float* gx, const void* mul,
+                                   float* dstats, void* dx, float* dgamma, float* dbeta, int accumulate, int64_t N, int64_t HW, int C, float eps,
+                                   int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && gamma && nx && gx && dstats && dx && dgamma && dbeta && N > 0 && HW > 0 && C > 0, "iseg_grn_bwd_folded: bad arguments");
+    ISEG_REQUIRE((dtype == ISEG_BF16 || dtype == ISEG_F32) && C % 8 == 0, "iseg_grn_bwd_folded: C %% 8 == 0 required (got dtype %d, C %d)", dtype, C);
+    ISEG_REQUIRE(N <= 65535, "iseg_grn_bwd_folded: at most 65535 samples");
+    ISEG_REQUIRE(ws && ws_bytes >= iseg_grn_workspace_bytes(N, HW, C), "iseg_grn_bwd_folded: workspace too small");
+    float* t = (float*)ws;
+    hipLaunchKernelGGL(grn_bwd_stats_kernel, dim3((unsigned)N), dim3(256), 0, stream, dstats, 2 * (int64_t)C, gamma, nx, gx, t, C, eps);
+    launch_reduce_rows(dstats, (int)N, 2 * (int64_t)C, 0, 1, 2 * (int64_t)C, dgamma, dbeta, C, 0, 1.f, accumulate, stream);
+    const int64_t chunks = N * HW * (C / 8);
+    const unsigned blocks = (unsigned)(ceil_div64(chunks, 256) < 8192 ? ceil_div64(chunks, 256) : 8192);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((grn_apply_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)dy, gamma,
+                           (const float*)nullptr, nx, (const float*)t, (const bf16_t*)mul, (bf16_t*)dx, HW, C, chunks);
+    else
+        hipLaunchKernelGGL((grn_apply_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (const float*)dy, gamma,
+                           (const float*)nullptr, nx, (const float*)t, (const float*)mul, (float*)dx, HW, C, chunks);
+    return iseg_check_launch("iseg_grn_bwd_folded");
 }

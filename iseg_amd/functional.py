@@ -936,6 +936,9 @@ class _ConvNeXtBlockFn(Function):
         return (dx,) + (None,) * 12
 
 
+_GRN_FOLD_RATIO = int(os.environ.get("ISEG_V2_GRN_FOLD_RATIO", "1"))      # experiments: fold from HW * ratio >= 2 * (4C) on
+
+
 class _ConvNeXtV2BlockFn(Function):
     """One tape node for a ConvNeXt V2 block (backbones/convnext_v2.py:83-98): depthwise 7x7 -> LayerNorm -> Dense 4C -> GELU -> GRN ->
     Dense C -> drop path -> + inputs.  The first product's epilogue writes gelu(h) and gelu'(h); the second product's epilogue applies the
@@ -963,12 +966,26 @@ class _ConvNeXtV2BlockFn(Function):
             g = K.dense_fwd_t(y2, w1t, b1.data, act=K.ACT_GELU, pre_out=d, pre_deriv=grad)
         else:
             g = K.dense_fwd(y2, nn.w(w1), b1.data, act=K.ACT_GELU, pre_out=d, pre_deriv=grad)
-        z, nx, gx = K.grn_fwd(g.reshape(N, H * W, 4 * C), grn_gamma.data, grn_beta.data, grn_eps)
-        z = z.reshape(M, 4 * C)
-        if w1t is not None and w2t is not None:
-            out = K.dense_fwd_t(z, w2t, b2.data, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+        # Wide planes (at least two activation rows per kernel row and sample): the normalisation is folded into the second product --
+        # per-sample kernels diag(gamma*nx_n + 1) W2 and the bias b2 + beta W2 -- so grn(g) is never written (csrc/grn.hip, "folded")
+        HW = H * W
+        ctx.fold = (w2t is not None and HW % 256 == 0 and HW * _GRN_FOLD_RATIO >= 8 * C and C >= 64 and C % 16 == 0      # (the LDS-DMA GEMM's own conditions)
+                    and os.environ.get("ISEG_V2_GRN_FOLD", "1") == "1")
+        if ctx.fold:
+            nx, gx = K.grn_stats(g.reshape(N, HW, 4 * C), grn_eps)
+            w2n = K.grn_fold_weights(w2t, grn_gamma.data.reshape(-1), nx)
+            bias2 = K.grn_fold_bias(w2.data.reshape(4 * C, C), grn_beta.data.reshape(-1), b2.data)
+            out = torch.empty((M, C), dtype=xc.dtype, device=xc.device)
+            K.gemm(g, w2n, out, M, C, 4 * C, lda=4 * C, ldb=4 * C, ldd=C, a_kcontig=1, b_kcontig=1, bias=bias2, rowscale=dp_mask,
+                   rows_per_group=HW, residual=xc.reshape(M, C), ldr=C, b_group=(HW, 4 * C * C))
+            z = None
         else:
-            out = K.dense_fwd(z, nn.w(w2), b2.data, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
+            z, nx, gx = K.grn_fwd(g.reshape(N, HW, 4 * C), grn_gamma.data, grn_beta.data, grn_eps)
+            z = z.reshape(M, 4 * C)
+            if w1t is not None and w2t is not None:
+                out = K.dense_fwd_t(z, w2t, b2.data, rowscale=dp_mask, rows_per_group=HW, residual=xc.reshape(M, C))
+            else:
+                out = K.dense_fwd(z, nn.w(w2), b2.data, rowscale=dp_mask, rows_per_group=HW, residual=xc.reshape(M, C))
         ctx.p, ctx.dil, ctx.pad, ctx.grn_eps = p, dil, pad, grn_eps
         if grad:
             ctx.save_for_backward(xc, y1, y2, mean, rstd, d, g, z, nx, gx, dp_mask)
@@ -983,12 +1000,33 @@ class _ConvNeXtV2BlockFn(Function):
         Kk = p.dw_kernel.shape[0]
         do2 = _c(dout).reshape(M, C)
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
-        K.dense_wgrad(z, dbr, _grad(p.w2), bias_grad=_grad(p.b2))
-        dz = K.dense_dgrad(dbr, nn.w(p.w2))                                           # [M, 4C]
-        del z
-        # GRN data gradient times gelu'(h) in one kernel; dgamma | dbeta from the same pass over dz
-        dh = K.grn_bwd(dz.reshape(N, H * W, 4 * C), g.reshape(N, H * W, 4 * C), p.grn_gamma.data, nx, gx, _grad(p.grn_gamma).reshape(-1),
-                       _grad(p.grn_beta).reshape(-1), ctx.grn_eps, mul=d).reshape(M, 4 * C)
+        HW = H * W
+        if ctx.fold:
+            # G = g^T dbr per sample (per row chunk where a sample alone would not fill the CUs): dW2, the GRN statistics and dbeta all come
+            # from these small products -- no pass over dz for them, and no grn(g) to read
+            S = K.colsum(dbr, C, 0, 1, M, C, torch.empty(C, dtype=torch.float32, device=xc.device))
+            K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))
+            tiles = -(-4 * C // 128) * -(-C // 128)
+            sps = 1
+            while N * sps * tiles < 384 and HW % (2 * sps) == 0 and HW // (2 * sps) >= 512:
+                sps *= 2
+            rows = HW // sps
+            slabs = torch.empty((N * sps, 4 * C, C), dtype=torch.float32, device=xc.device)
+            K.gemm(g, dbr, slabs, 4 * C, C, rows, lda=4 * C, ldb=C, ldd=C, a_kcontig=0, b_kcontig=0, batch=N * sps, batch_inner=1,
+                   sa=(rows * 4 * C, 0), sb=(rows * C, 0), sd=(4 * C * C, 0))
+            dstats = K.grn_fold_wgrad(slabs, sps, p.w2.data.reshape(4 * C, C), p.grn_gamma.data.reshape(-1), p.grn_beta.data.reshape(-1), nx, S,
+                                      _grad(p.w2).reshape(4 * C, C))
+            del slabs
+            dz = K.dense_dgrad(dbr, nn.w(p.w2))                                       # [M, 4C]
+            dh = K.grn_bwd_folded(dz.reshape(N, HW, 4 * C), g.reshape(N, HW, 4 * C), p.grn_gamma.data.reshape(-1), nx, gx, dstats,
+                                  _grad(p.grn_gamma).reshape(-1), _grad(p.grn_beta).reshape(-1), ctx.grn_eps, mul=d).reshape(M, 4 * C)
+        else:
+            K.dense_wgrad(z, dbr, _grad(p.w2), bias_grad=_grad(p.b2))
+            dz = K.dense_dgrad(dbr, nn.w(p.w2))                                       # [M, 4C]
+            del z
+            # GRN data gradient times gelu'(h) in one kernel; dgamma | dbeta from the same pass over dz
+            dh = K.grn_bwd(dz.reshape(N, HW, 4 * C), g.reshape(N, HW, 4 * C), p.grn_gamma.data, nx, gx, _grad(p.grn_gamma).reshape(-1),
+                           _grad(p.grn_beta).reshape(-1), ctx.grn_eps, mul=d).reshape(M, 4 * C)
         del dz, g, d
         K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))
         dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                            # [M, C]

@@ -725,6 +725,62 @@ def grn_bwd(dy3d, x3d, gamma, nx, gx, dgamma, dbeta, eps, accumulate=True, mul=N
     return dx
 
 
+def grn_stats(x3d, eps):
+    """nx, gx of grn_fwd without writing the normalised tensor (the caller folds gamma*nx + 1 into the next kernel)"""
+    _require_cuda(x3d)
+    N, HW, Cc = x3d.shape
+    nx = torch.empty(N, Cc, dtype=torch.float32, device=x3d.device)
+    gx = torch.empty_like(nx)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_grn_workspace_bytes(N, HW, Cc), x3d.device)
+    _hip.check(L.iseg_grn_fwd(ptr(x3d), None, None, None, ptr(nx), ptr(gx), N, HW, Cc, float(eps), dt(x3d), ptr(ws), wsb, stream()), "iseg_grn_fwd")
+    return nx, gx
+
+
+def grn_fold_weights(wt, gamma, nx):
+    """[N, Cout, C4] bf16: the K-contiguous kernel copy wt [Cout, C4] times (gamma*nx_n + 1) per sample"""
+    _require_cuda(wt, gamma, nx)
+    Cout, C4 = wt.shape
+    N = nx.shape[0]
+    out = torch.empty((N, Cout, C4), dtype=wt.dtype, device=wt.device)
+    _hip.call("iseg_grn_fold_weights", ptr(wt), ptr(gamma), ptr(nx), ptr(out), N, Cout, C4, stream())
+    return out
+
+
+def grn_fold_bias(W, beta, b):
+    """b + beta @ W for the fp32 kernel W [C4, Cout]"""
+    _require_cuda(W, beta)
+    C4, Cout = W.shape
+    out = torch.empty(Cout, dtype=torch.float32, device=W.device)
+    _hip.call("iseg_grn_fold_bias", ptr(W), ptr(beta), ptr(b), ptr(out), C4, Cout, stream())
+    return out
+
+
+def grn_fold_wgrad(slabs, slabs_per_sample, W, gamma, beta, nx, S, dW, accumulate=True):
+    """dW (+)= sum_n (gamma*nx_n + 1) (.) G_n + beta (x) S from the per-chunk products slabs [N*sps, C4, Cout]; returns dstats [N, 2*C4]"""
+    _require_cuda(slabs, W, dW)
+    C4, Cout = W.shape
+    N = nx.shape[0]
+    dstats = torch.empty((N, 2 * C4), dtype=torch.float32, device=W.device)
+    _hip.call("iseg_grn_fold_wgrad", ptr(slabs), int(slabs_per_sample), ptr(W), ptr(gamma), ptr(beta), ptr(nx), ptr(S), ptr(dW), ptr(dstats),
+              int(accumulate), N, C4, Cout, stream())
+    return dstats
+
+
+def grn_bwd_folded(dy3d, x3d, gamma, nx, gx, dstats, dgamma, dbeta, eps, accumulate=True, mul=None):
+    """grn_bwd with the per-sample statistics given (dstats from grn_fold_wgrad; overwritten)"""
+    _require_cuda(dy3d, x3d, dstats, dgamma, dbeta)
+    N, HW, Cc = x3d.shape
+    if mul is not None and (mul.dtype != x3d.dtype or mul.numel() != x3d.numel() or not mul.is_contiguous()):
+        raise ValueError("grn_bwd_folded: mul must be a contiguous tensor shaped and typed like x")
+    dx = torch.empty_like(x3d)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_grn_workspace_bytes(N, HW, Cc), x3d.device)
+    _hip.check(L.iseg_grn_bwd_folded(ptr(dy3d), ptr(x3d), ptr(gamma), ptr(nx), ptr(gx), ptr(mul), ptr(dstats), ptr(dx), ptr(dgamma), ptr(dbeta),
+                                     int(accumulate), N, HW, Cc, float(eps), dt(x3d), ptr(ws), wsb, stream()), "iseg_grn_bwd_folded")
+    return dx
+
+
 POOL_MAX, POOL_AVG = 0, 1
 
 

@@ -185,6 +185,120 @@ def test_convnext_v2_block_forward_backward(cuda, monkeypatch, dtype, shape, dil
         nn.set_compute_dtype(torch.float32)
 
 
+def test_grn_fold_kernels_match_the_unfolded_operator(cuda):
+    """the normalisation folded into the next Dense: scaled kernel copies + bias reproduce grn(g) @ W + b through iseg_gemm's per-row-group B,
+    and the folded backward (per-sample g^T dbr products) reproduces dW, dgamma, dbeta and the data gradient of the plain operators"""
+    from iseg_amd import kernels as K
+
+    torch.manual_seed(3)
+    N, HW, C4, Co = 3, 512, 256, 64
+    bf = torch.bfloat16
+    g = torch.randn(N, HW, C4, device="cuda").to(bf)
+    W = torch.randn(C4, Co, device="cuda") * C4 ** -0.5
+    b = torch.randn(Co, device="cuda") * 0.1
+    gamma = torch.randn(C4, device="cuda") * 0.5
+    beta = torch.randn(C4, device="cuda") * 0.1
+    wt = W.to(bf).t().contiguous()
+    nx, gx = K.grn_stats(g, 1e-6)
+    z, nx2, gx2 = K.grn_fwd(g, gamma, beta, 1e-6)
+    assert torch.equal(nx, nx2) and torch.equal(gx, gx2)
+    # forward
+    w2n = K.grn_fold_weights(wt, gamma, nx)
+    a = gamma * nx + 1.0
+    assert torch.equal(w2n, (wt.float()[None] * a[:, None, :]).to(bf))
+    bias2 = K.grn_fold_bias(W, beta, b)
+    assert torch.allclose(bias2, b + beta @ W, rtol=1e-5, atol=1e-5)
+    M = N * HW
+    res = torch.randn(M, Co, device="cuda").to(bf)
+    out = torch.empty(M, Co, dtype=bf, device="cuda")
+    K.gemm(g.reshape(M, C4), w2n, out, M, Co, C4, lda=C4, ldb=C4, ldd=Co, a_kcontig=1, b_kcontig=1, bias=bias2, residual=res, ldr=Co,
+           b_group=(HW, Co * C4))
+    want = (g.double() * a.double()[:, None, :] + beta.double()).reshape(M, C4) @ W.double() + b.double() + res.double()
+    assert _rel(out, want.cpu()) < 1e-2
+    # the unsupported layouts are refused, not mis-computed
+    from iseg_amd import _hip
+    with pytest.raises(_hip.HipCallError):
+        K.gemm(g.reshape(M, C4), w2n, out, M, Co, C4, lda=C4, ldb=C4, ldd=Co, a_kcontig=1, b_kcontig=1, b_group=(HW - 8, Co * C4))
+    # backward
+    dbr = torch.randn(M, Co, device="cuda").to(bf)
+    d = (torch.rand(M, C4, device="cuda") + 0.25).to(bf)
+    dW_ref = torch.zeros(C4, Co, device="cuda")
+    db_ref = torch.zeros(Co, device="cuda")
+    K.dense_wgrad(z.reshape(M, C4), dbr, dW_ref, bias_grad=db_ref)
+    dz = K.dense_dgrad(dbr, W.to(bf))
+    dg_ref, dbt_ref = torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda")
+    dh_ref = K.grn_bwd(dz.reshape(N, HW, C4), g, gamma, nx, gx, dg_ref, dbt_ref, 1e-6, mul=d)
+    for sps in (1, 2):
+        rows = HW // sps
+        slabs = torch.empty(N * sps, C4, Co, device="cuda")
+        K.gemm(g.reshape(M, C4), dbr, slabs, C4, Co, rows, lda=C4, ldb=Co, ldd=Co, a_kcontig=0, b_kcontig=0, batch=N * sps, batch_inner=1,
+               sa=(rows * C4, 0), sb=(rows * Co, 0), sd=(C4 * Co, 0))
+        S = K.colsum(dbr, Co, 0, 1, M, Co, torch.empty(Co, device="cuda"))
+        dW = torch.zeros(C4, Co, device="cuda")
+        dstats = K.grn_fold_wgrad(slabs, sps, W, gamma, beta, nx, S, dW)
+        # (the reference product used the bf16-rounded grn(g); the folded one scales exact per-sample products)
+        assert _rel(dW, dW_ref.cpu().double()) < 6e-3
+        assert torch.allclose(S, db_ref, rtol=1e-4, atol=1e-3)
+        dg, dbt = torch.zeros(C4, device="cuda"), torch.zeros(C4, device="cuda")
+        dh = K.grn_bwd_folded(dz.reshape(N, HW, C4), g, gamma, nx, gx, dstats, dg, dbt, 1e-6, mul=d)
+        assert _rel(dg, dg_ref.cpu().double()) < 6e-3 and _rel(dbt, dbt_ref.cpu().double()) < 6e-3
+        assert _rel(dh, dh_ref.cpu().double()) < 1.5e-2
+
+
+@pytest.mark.parametrize("shape,dp", [((2, 32, 32, 64), 0.0), ((2, 32, 32, 96), 0.3)])
+def test_convnext_v2_block_with_the_normalisation_folded(cuda, monkeypatch, shape, dp):
+    """wide planes take the folded route (functional._ConvNeXtV2BlockFn): it must agree with the oracle and with the unfolded route"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.convnext_v2 import Block
+    from iseg_amd.param_store import ParamStore
+
+    dtype = torch.bfloat16
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        N, H, W, C = shape
+        outs = {}
+        for fold in ("1", "0"):
+            monkeypatch.setenv("ISEG_V2_GRN_FOLD", fold)
+            blk = Block(C, drop_path_prob=dp, name="stages/0/0")
+            with nn.dry_run_scope():
+                blk(torch.empty(shape, dtype=dtype, device="cuda"))
+            blk._iseg_store = ParamStore(list(blk.parameters()))
+            randomize_parameters(blk, 3)
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(shape, generator=g).to(dtype)
+            dy = torch.randn(shape, generator=g).to(dtype)
+            f = None
+            if dp > 0:
+                keep = 1 - dp
+                f = torch.floor(keep + torch.rand(N, generator=g)) / keep
+                f[0] = 1 / keep
+                blk.drop_path_mask = f.float().cuda()
+            xg = x.cuda().requires_grad_(True)
+            y = blk(xg, training=True)
+            assert y.grad_fn.fold == (fold == "1")
+            y.backward(dy.cuda())
+            outs[fold] = (y.detach(), xg.grad, {p.iseg_name: p.grad.clone() for p in blk.parameters()})
+            if fold == "1":
+                w = {k: v.requires_grad_(True) for k, v in OM.export_weights(blk).items()}
+                xr = x.double().requires_grad_(True)
+                yr = OM.convnext_v2_block(w, "stages/0/0", xr, 1, None if f is None else f.double())
+                yr.backward(dy.double())
+                assert _rel(y, yr.detach()) < 2e-2
+                errs = {"dx": _rel(xg.grad, xr.grad)}
+                for p in blk.parameters():
+                    errs[p.iseg_name] = _rel(p.grad, w[p.iseg_name].grad)
+                bad = {k: v for k, v in errs.items() if v > 4e-2}
+                assert not bad, bad
+        ya, dxa, ga = outs["1"]
+        yb, dxb, gb = outs["0"]
+        assert _rel(ya, yb.cpu().double()) < 2e-2 and _rel(dxa, dxb.cpu().double()) < 3e-2
+        for k in ga:
+            assert _rel(ga[k], gb[k].cpu().double()) < 3e-2, k
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("output_stride", [32, 8])
 def test_convnext_v2_nano_endpoints_match_oracle(cuda, output_stride):
     """get_backbone("convnext_v2_nano") with the dilation surgery, fp32, all four endpoints and the input gradient"""
