@@ -846,17 +846,6 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
         const int h0 = th_i * TH, w0 = tw_i * TWD;
         const int c0 = slab * 32;
         __syncthreads();      // previous unit consumed
-        if (slab != cur_slab) {      // workgroup-uniform
-            cur_slab = slab;
-            for (int i = tid; i < K * K * 8; i += 256) {      // float4 granules: [tap][32]
-                int tap = i >> 3;
-                const int c4 = (i & 7) * 4;
-                if (flip) tap = K * K - 1 - tap;
-                reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(w + tap * C + c0 + c4);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = bias ? f32x2{bias[c0 + cg * 8 + 2 * q], bias[c0 + cg * 8 + 2 * q + 1]} : f32x2{0.f, 0.f};
-        }
         const bf16_t* xb = x + (((n * H + h0 - pad_t) * W + w0 - pad_l) * C + c0 + (lane & 3) * 8);
 #pragma unroll
         for (int i = 0; i < MAXPX; ++i) {
@@ -869,6 +858,18 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
                 const bf16_t* src = ok ? xb + __mul24(__mul24(rr, W) + cc, C) : zero;
                 __builtin_amdgcn_global_load_lds((dw_glb_ptr)src, (dw_lds_ptr)(xt + p * 1024), 16, 0, 0);
             }
+        }
+        // (behind the tile's DMA, so the two round trips overlap: staged in front of it, the weights cost a dependent trip of their own per slab)
+        if (slab != cur_slab) {      // workgroup-uniform
+            cur_slab = slab;
+            for (int i = tid; i < K * K * 8; i += 256) {      // float4 granules: [tap][32]
+                int tap = i >> 3;
+                const int c4 = (i & 7) * 4;
+                if (flip) tap = K * K - 1 - tap;
+                reinterpret_cast<float4*>(wl)[i] = *reinterpret_cast<const float4*>(w + tap * C + c0 + c4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = bias ? f32x2{bias[c0 + cg * 8 + 2 * q], bias[c0 + cg * 8 + 2 * q + 1]} : f32x2{0.f, 0.f};
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
