@@ -145,3 +145,43 @@ def test_multi_scale_flip_inference_matches_oracle(cuda):
     ref = OM.multi_scale_inference(lambda t: OM.convnext_aspp_forward(w, t, training=False)["logits"], x.double(), (0.5, 1.0, 1.5), True)
     assert tuple(got.shape) == tuple(ref.shape) == (1, 65, 96, 21)
     assert (got.cpu().double() - ref).abs().max().item() < 1e-3
+
+
+def test_graphed_inference_replays_bit_exact(cuda):
+    """iseg_amd.graphs.GraphedCall: the captured HIP graph of a sliding-window inference returns exactly the eager logits, also for a
+    new image of the same shape, and a different shape gets its own graph"""
+    from iseg_amd import heads, nn
+    from iseg_amd.core_inference import inference_with_sliding_window
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.graphs import graphed_inference
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    try:
+        model = heads.convnext_tiny_aspp(build_input_size=(64, 64))
+        from iseg_amd.param_store import ParamStore
+
+        model._iseg_store = ParamStore(list(model.parameters()))
+        randomize_parameters(model, 5)      # (refreshes the bf16 shadows itself)
+        g = graphed_inference(model, (64, 64))
+        x, _ = synthetic_batch(1, 96, 80, seed=3)
+        x = x.cuda()
+
+        def eager(v):
+            with torch.no_grad():
+                return inference_with_sliding_window(v, model, training=False, windows_size=(64, 64))
+
+        want = eager(x).clone()
+        for i in range(4):      # two eager warm-up calls, the capture, one replay
+            got = g(x)
+            assert torch.equal(got, want), i
+        x2 = torch.flip(x, dims=[2])
+        assert torch.equal(g(x2), eager(x2))
+        x3, _ = synthetic_batch(1, 64, 128, seed=4)
+        x3 = x3.cuda()
+        for _ in range(4):
+            got3 = g(x3)
+        assert torch.equal(got3, eager(x3))
+        assert len(g.entries) == 2 and all(e[1] is not None for e in g.entries.values())
+    finally:
+        nn.set_compute_dtype(torch.float32)
