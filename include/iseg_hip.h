@@ -206,6 +206,8 @@ int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int batch, int
 int iseg_broadcast_rows(const void* v, int v_dtype, void* y, int64_t ldy, int64_t batch_stride, int batch, int64_t rows, int C,
                         float scale, int accumulate, int dtype, iseg_stream_t stream);
 int iseg_axpby(const void* a, const void* b, void* y, float alpha, float beta, int64_t n, int dtype, iseg_stream_t stream);
+/* dst0[i] += src[i], dst1[i] += src[n+i] (NULL destinations are skipped): dbeta | dgamma of a normalisation layer's packed backward sums */
+int iseg_accumulate_pair(const float* src, int n, float* dst0, float* dst1, iseg_stream_t stream);
 /* y = x * s_dev[0] (chain rule with a device-resident scalar; no host read) */
 int iseg_scale_dev(const void* x, const float* s_dev, void* y, int64_t n, int dtype, iseg_stream_t stream);
 int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,

@@ -84,6 +84,7 @@ SIGNATURES = {
     "iseg_colsum": (_i, [_p, _l, _l, _i, _l, _i, _p, _f, _i, _i, _p, _z, _p]),
     "iseg_broadcast_rows": (_i, [_p, _i, _p, _l, _l, _i, _l, _i, _f, _i, _i, _p]),
     "iseg_axpby": (_i, [_p, _p, _p, _f, _f, _l, _i, _p]),
+    "iseg_accumulate_pair": (_i, [_p, _i, _p, _p, _p]),
     "iseg_scale_dev": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_rowscale": (_i, [_p, _p, _p, _l, _i, _l, _i, _p]),
     "iseg_dropout": (_i, [_p, _p, _l, _f, _u64, _i, _p]),

@@ -233,6 +233,15 @@ __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T
         y[i] = from_f32<T>(alpha * to_f32(a[i]) + (b ? beta * to_f32(b[i]) : 0.f));
 }
 
+// dst0[i] += src[i], dst1[i] += src[n + i]  (either destination may be null): the two parameter gradients a normalisation layer's packed
+// backward sums carry (dbeta | dgamma), in one launch
+__global__ __launch_bounds__(256) void accumulate_pair_kernel(const float* __restrict__ src, int n, float* __restrict__ dst0, float* __restrict__ dst1) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n; i += gridDim.x * 256) {
+        float* d = i < n ? dst0 : dst1;
+        if (d) d[i < n ? i : i - n] += src[i];
+    }
+}
+
 template <class T>
 __global__ void scale_dev_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ y, int64_t n) {
     const float f = s[0];
@@ -665,6 +674,13 @@ extern "C" int iseg_axpby(const void* a, const void* b, void* y, float alpha, fl
         hipLaunchKernelGGL((axpby_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)a, (const float*)b, (float*)y,
                            alpha, beta, n);
     return iseg_check_launch("iseg_axpby");
+}
+
+extern "C" int iseg_accumulate_pair(const float* src, int n, float* dst0, float* dst1, hipStream_t stream) {
+    ISEG_REQUIRE(src && n > 0, "iseg_accumulate_pair: bad arguments");
+    if (!dst0 && !dst1) return ISEG_OK;
+    hipLaunchKernelGGL(accumulate_pair_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, stream, src, n, dst0, dst1);
+    return iseg_check_launch("iseg_accumulate_pair");
 }
 
 extern "C" int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,

@@ -419,10 +419,7 @@ class _BatchNormTrainFn(Function):
         dy2, lddy = _rows2d(dy)
         sums = K.bn_bwd_reduce(dy2, lddy, x2, C, y, C, mean, rstd, rows, C, ctx.relu)
         # local parameter gradients (the gradient all-reduce sums them over ranks later)
-        if ctx.beta.requires_grad:
-            K.axpby(sums[:C], _grad(ctx.beta), 1.0, 1.0, out=_grad(ctx.beta))
-        if ctx.gamma.requires_grad:
-            K.axpby(sums[C:], _grad(ctx.gamma), 1.0, 1.0, out=_grad(ctx.gamma))
+        K.accumulate_pair(sums, C, _grad(ctx.beta) if ctx.beta.requires_grad else None, _grad(ctx.gamma) if ctx.gamma.requires_grad else None)
         dist.grads_ready(ctx.gamma, ctx.beta)
         n_total = rows
         if ctx.sync and dist.active():
@@ -479,10 +476,9 @@ class _BatchNormGroupFn(Function):
             dy2, lddy = _rows2d(dys[i])
             dy2s.append((dy2, lddy))
             sums = K.bn_bwd_reduce(dy2, lddy, x2, C, y, C, mean, rstd, rows, C, relu, out=msg[offs[i]:offs[i + 1]])
-            if ctx.betas[i].requires_grad:      # local parameter gradients (the gradient all-reduce sums them over ranks later)
-                K.axpby(sums[:C], _grad(ctx.betas[i]), 1.0, 1.0, out=_grad(ctx.betas[i]))
-            if ctx.gammas[i].requires_grad:
-                K.axpby(sums[C:], _grad(ctx.gammas[i]), 1.0, 1.0, out=_grad(ctx.gammas[i]))
+            # local parameter gradients (the gradient all-reduce sums them over ranks later)
+            K.accumulate_pair(sums, C, _grad(ctx.betas[i]) if ctx.betas[i].requires_grad else None,
+                              _grad(ctx.gammas[i]) if ctx.gammas[i].requires_grad else None)
             dist.grads_ready(ctx.gammas[i], ctx.betas[i])
         world = 1
         if dist.active():
@@ -528,10 +524,8 @@ class _BatchNormInferFn(Function):
         dy2 = _c(dy).reshape(-1, C)
         if x2 is not None:
             sums = K.bn_bwd_reduce(dy2, C, x2, C, y, C, mean, rstd, x2.shape[0], C, ctx.relu)
-            if ctx.beta.requires_grad:
-                K.axpby(sums[:C], _grad(ctx.beta), 1.0, 1.0, out=_grad(ctx.beta))
-            if ctx.gamma.requires_grad:
-                K.axpby(sums[C:], _grad(ctx.gamma), 1.0, 1.0, out=_grad(ctx.gamma))
+            K.accumulate_pair(sums, C, _grad(ctx.beta) if ctx.beta.requires_grad else None,
+                              _grad(ctx.gamma) if ctx.gamma.requires_grad else None)
             dist.grads_ready(ctx.gamma, ctx.beta)
         if ctx.relu:
             dy2 = K.act_bwd(dy2, y, K.ACT_RELU)

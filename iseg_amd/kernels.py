@@ -434,6 +434,13 @@ def colsum(x, ldx, batch_stride, batch, rows, Cc, out, scale=1.0, accumulate=Fal
     return out
 
 
+def accumulate_pair(src, n, dst0, dst1):
+    """dst0 += src[:n]; dst1 += src[n:2n]   (fp32; None destinations are skipped)"""
+    if dst0 is None and dst1 is None:
+        return
+    _hip.call("iseg_accumulate_pair", ptr(src), int(n), ptr(dst0), ptr(dst1), stream())
+
+
 def broadcast_rows(v, y, ldy, batch_stride, batch, rows, Cc, scale=1.0, accumulate=False):
     _hip.call("iseg_broadcast_rows", ptr(v), dt(v), ptr(y), ldy, batch_stride, batch, rows, Cc, scale, int(accumulate), dt(y),
               stream())
