@@ -165,6 +165,10 @@ int iseg_bn_finalize(const float* packed, int C, float eps, float momentum, floa
                      float* moving_var, iseg_stream_t stream);
 int iseg_bn_apply_fwd(const void* x, int64_t ldx, const float* mean, const float* rstd, const float* gamma, const float* beta,
                       void* y, int64_t ldy, int64_t rows, int C, int relu, int dtype, iseg_stream_t stream);
+/* iseg_bn_finalize + iseg_bn_apply_fwd in one launch (same arithmetic): mean, rstd [C] are outputs, moving_* updated in place (may be NULL) */
+int iseg_bn_apply_fwd_packed(const void* x, int64_t ldx, const float* packed, float eps, float momentum, const float* gamma, const float* beta,
+                             float* mean, float* rstd, float* moving_mean, float* moving_var, void* y, int64_t ldy, int64_t rows, int C,
+                             int relu, int dtype, iseg_stream_t stream);
 int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
                        const float* rstd, float* sums, int64_t rows, int C, int relu, int dtype, void* ws, size_t ws_bytes,
                        iseg_stream_t stream);

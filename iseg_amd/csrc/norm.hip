@@ -319,6 +319,60 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// bn_finalize + bn_apply in one launch: every lane derives mean / rstd of its eight channels from the packed sums with bn_finalize_kernel's
+// arithmetic (bit-identical), the lane that owns row 0 of a channel chunk also writes mean, rstd and the moving statistics
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_packed_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ packed, float eps,
+                                                              float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ moving_mean,
+                                                              float* __restrict__ moving_var, T* __restrict__ y, int64_t ldy, int64_t rows, int C,
+                                                              int relu) {
+    const int nchunks = C / 8;
+    const int64_t total = rows * nchunks;
+    const float n = packed[2 * C];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nchunks;
+        const int c = (int)(i % nchunks) * 8;
+        float v[8], m[8], s[8], g[8], b[8], var[8];
+        load8<T>(x + r * ldx + c, v);
+        load8<float>(packed + c, m);
+        load8<float>(packed + C + c, var);
+        load8<float>(gamma + c, g);
+        load8<float>(beta + c, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            m[u] = m[u] / n;
+            var[u] = fmaxf(var[u] / n - m[u] * m[u], 0.f);
+            s[u] = rsqrtf(var[u] + eps);
+        }
+        if (r == 0) {
+            store8<float>(mean + c, m);
+            store8<float>(rstd + c, s);
+            if (moving_mean) {
+                float mm[8];
+                load8<float>(moving_mean + c, mm);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mm[u] = mm[u] * momentum + m[u] * (1.f - momentum);
+                store8<float>(moving_mean + c, mm);
+            }
+            if (moving_var) {
+                float mv[8];
+                load8<float>(moving_var + c, mv);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = mv[u] * momentum + var[u] * (1.f - momentum);
+                store8<float>(moving_var + c, mv);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
+            if (relu) o = fmaxf(o, 0.f);
+            v[u] = o;
+        }
+        store8<T>(y + r * ldy + c, v);
+    }
+}
+
 // backward reductions: partial [2][C] = (sum dz, sum dz*xhat) with dz = dy * relu'(y)
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
@@ -586,6 +640,24 @@ extern "C" int iseg_bn_apply_fwd(const void* x, int64_t ldx, const float* mean, 
         hipLaunchKernelGGL((bn_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x, ldx, mean,
                            rstd, gamma, beta, (float*)y, ldy, rows, C, relu);
     return iseg_check_launch("iseg_bn_apply_fwd");
+}
+
+extern "C" int iseg_bn_apply_fwd_packed(const void* x, int64_t ldx, const float* packed, float eps, float momentum, const float* gamma,
+                                        const float* beta, float* mean, float* rstd, float* moving_mean, float* moving_var, void* y, int64_t ldy,
+                                        int64_t rows, int C, int relu, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && packed && gamma && beta && mean && rstd && y && rows > 0, "iseg_bn_apply_fwd_packed: bad arguments");
+    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "iseg_bn_apply_fwd_packed: C/ldx/ldy must be multiples of 8");
+    ISEG_REQUIRE((((uintptr_t)packed | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)moving_mean | (uintptr_t)moving_var) & 15) == 0,
+                 "iseg_bn_apply_fwd_packed: statistics must be 16-byte aligned");
+    int64_t blocks = ceil_div64(rows * (C / 8), 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_apply_packed_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, ldx, packed, eps,
+                           momentum, gamma, beta, mean, rstd, moving_mean, moving_var, (bf16_t*)y, ldy, rows, C, relu);
+    else
+        hipLaunchKernelGGL((bn_apply_packed_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x, ldx, packed, eps,
+                           momentum, gamma, beta, mean, rstd, moving_mean, moving_var, (float*)y, ldy, rows, C, relu);
+    return iseg_check_launch("iseg_bn_apply_fwd_packed");
 }
 
 extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,

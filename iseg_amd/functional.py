@@ -405,9 +405,8 @@ class _BatchNormTrainFn(Function):
         packed = K.bn_stats(x2, C, rows, C)
         if sync:
             dist.all_reduce_sum(packed)          # ONE [2C+1] message (sum, sumsq, count) instead of the reference's three
-        mean, rstd = K.bn_finalize(packed, C, eps, momentum, moving_mean, moving_var)
         y = torch.empty_like(x2)
-        K.bn_apply_fwd(x2, C, mean, rstd, gamma.data, beta.data, y, C, rows, C, relu)
+        mean, rstd = K.bn_finalize_apply(packed, x2, C, gamma.data, beta.data, y, C, rows, C, eps, momentum, moving_mean, moving_var, relu)
         ctx.gamma, ctx.beta, ctx.relu, ctx.sync = gamma, beta, relu, sync
         ctx.save_for_backward(x2, y if relu else None, mean, rstd, packed)
         return y.reshape(x.shape)
@@ -443,17 +442,17 @@ class _BatchNormGroupFn(Function):
         Cs = [x2.shape[1] for x2 in x2s]
         offs = [0]
         for C in Cs:
-            offs.append(offs[-1] + 2 * C + 1)
-        msg = torch.empty(offs[-1], dtype=torch.float32, device=x2s[0].device)
+            offs.append(offs[-1] + 2 * C + 4)      # [sum | sumsq | count] + 3 floats of padding: every layer's slot stays 16-byte aligned
+        msg = torch.zeros(offs[-1], dtype=torch.float32, device=x2s[0].device)
         for i, x2 in enumerate(x2s):
-            K.bn_stats(x2, Cs[i], x2.shape[0], Cs[i], out=msg[offs[i]:offs[i + 1]])
+            K.bn_stats(x2, Cs[i], x2.shape[0], Cs[i], out=msg[offs[i]:offs[i] + 2 * Cs[i] + 1])
         dist.all_reduce_sum(msg)
         ys, saved = [], []
         for i, x2 in enumerate(x2s):
             L = layers[i]
-            mean, rstd = K.bn_finalize(msg[offs[i]:offs[i + 1]], Cs[i], L["eps"], L["momentum"], L["moving_mean"], L["moving_var"])
             y = torch.empty_like(x2)
-            K.bn_apply_fwd(x2, Cs[i], mean, rstd, gammas[i].data, betas[i].data, y, Cs[i], x2.shape[0], Cs[i], relu)
+            mean, rstd = K.bn_finalize_apply(msg[offs[i]:offs[i] + 2 * Cs[i] + 1], x2, Cs[i], gammas[i].data, betas[i].data, y, Cs[i], x2.shape[0], Cs[i],
+                                             L["eps"], L["momentum"], L["moving_mean"], L["moving_var"], relu)
             ys.append(y.reshape(xs[i].shape))
             saved += [x2, y if relu else None, mean, rstd]
         ctx.n, ctx.relu, ctx.gammas, ctx.betas = n, relu, gammas, betas

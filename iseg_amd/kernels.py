@@ -293,6 +293,20 @@ def bn_finalize(packed, Cc, eps, momentum, moving_mean, moving_var):
     return mean, rstd
 
 
+def bn_finalize_apply(packed, x2d, ldx, gamma, beta, y2d, ldy, rows, Cc, eps, momentum, moving_mean, moving_var, relu):
+    """bn_finalize + bn_apply_fwd; one launch when the statistics vectors are 16-byte aligned (a slice of a grouped message may not be)"""
+    aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (packed, moving_mean, moving_var))
+    if not aligned:
+        mean, rstd = bn_finalize(packed, Cc, eps, momentum, moving_mean, moving_var)
+        bn_apply_fwd(x2d, ldx, mean, rstd, gamma, beta, y2d, ldy, rows, Cc, relu)
+        return mean, rstd
+    mean = torch.empty(Cc, dtype=torch.float32, device=packed.device)
+    rstd = torch.empty(Cc, dtype=torch.float32, device=packed.device)
+    _hip.call("iseg_bn_apply_fwd_packed", ptr(x2d), ldx, ptr(packed), eps, momentum, ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+              ptr(moving_mean), ptr(moving_var), ptr(y2d), ldy, rows, Cc, int(relu), dt(x2d), stream())
+    return mean, rstd
+
+
 def bn_apply_fwd(x2d, ldx, mean, rstd, gamma, beta, y2d, ldy, rows, Cc, relu):
     _hip.call("iseg_bn_apply_fwd", ptr(x2d), ldx, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y2d), ldy, rows, Cc, int(relu),
               dt(x2d), stream())

@@ -61,8 +61,9 @@ def _step(rank, world, port, q, size, batch, rccl_single=False):
     torch.cuda.synchronize()
     if world > 1 or rccl_single:
         # the five ASPP branches (256 channels each) exchange their SyncBN statistics in ONE message per direction and step
-        # (layers/aspp.py _call_grouped): 5 x (2 x 256 + 1) forward, 5 x (2 x 256) backward; the end conv keeps its own pair
-        assert sizes.count(5 * 513) == 2 and sizes.count(5 * 512) == 2, sizes
+        # (layers/aspp.py _call_grouped): 5 x (2 x 256 + 1, padded to 516 so every layer's slot stays 16-byte aligned) forward,
+        # 5 x (2 x 256) backward; the end conv keeps its own pair
+        assert sizes.count(5 * 516) == 2 and sizes.count(5 * 512) == 2, sizes
         assert sizes.count(513) == 2 and sizes.count(512) == 2, sizes
     # numpy arrays are pickled by value (torch tensors would travel through /dev/shm handles that die with this process)
     out = {p.iseg_name: p.detach().cpu().numpy().copy() for p in model.parameters()}
