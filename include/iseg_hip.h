@@ -175,6 +175,11 @@ int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx,
 int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
                       const float* rstd, const float* gamma, const float* sums, float inv_n, void* dx, int64_t lddx, int64_t rows,
                       int C, int relu, int dtype, iseg_stream_t stream);
+/* iseg_bn_bwd_apply that also books the layer's parameter gradients: dbeta += sums[0:C], dgamma += sums[C:2C] (either may be NULL).  Only
+ * when `sums` are this replica's own (no all-reduce in between): under data parallelism the gradients are summed over replicas later. */
+int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                          const float* rstd, const float* gamma, const float* sums, float inv_n, void* dx, int64_t lddx, float* dgamma,
+                          float* dbeta, int64_t rows, int C, int relu, int dtype, iseg_stream_t stream);
 int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t stream); /* inference: rstd of moving var */
 
 /* ---------------------------------------------------------------------------------------------------------

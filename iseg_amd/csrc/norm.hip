@@ -219,7 +219,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_part[i];
 }
 
-__global__ void set_scalar_kernel(float* __restrict__ p, float v) { *p = v; }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm
@@ -227,9 +226,10 @@ __global__ void set_scalar_kernel(float* __restrict__ p, float v) { *p = v; }
 // per-block partial sums of x and x^2 per channel: block handles a strip of rows; thread owns 8 channels.
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ partials,
-                                                       int64_t rows, int C) {
+                                                       int64_t rows, int C, float* __restrict__ count_out) {
     extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [2][C]
     const int nchunks = C / 8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = (float)rows;      // packed[2C]: this replica's element count per channel
     for (int i = threadIdx.x; i < 2 * C; i += 256) lds_s[i] = 0.f;
     __syncthreads();
     // thread t handles chunk (t % tpc) of rows (t / tpc) + k*rows_per_iter
@@ -448,13 +448,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float inv_n, T* __restrict__ dx, int64_t lddx, int64_t rows, int C,
-                                                           int relu) {
+                                                           int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int nchunks = C / 8;
     const int64_t total = rows * nchunks;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / nchunks;
         const int c = (int)(i % nchunks) * 8;
         float d[8], xv[8], m[8], rs[8], g[8], s1[8], s2[8];
+        if (r == 0 && (dgamma || dbeta)) {      // the lane that owns row 0 of a chunk also books the parameter gradients (dbeta | dgamma = sums)
+            float a[8], acc[8];
+            if (dbeta) {
+                load8<float>(sums + c, a);
+                load8<float>(dbeta + c, acc);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += a[u];
+                store8<float>(dbeta + c, acc);
+            }
+            if (dgamma) {
+                load8<float>(sums + C + c, a);
+                load8<float>(dgamma + c, acc);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += a[u];
+                store8<float>(dgamma + c, acc);
+            }
+        }
         load8<T>(dy + r * lddy + c, d);
         load8<T>(x + r * ldx + c, xv);
         if (relu) {
@@ -609,12 +626,11 @@ extern "C" int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t 
     const size_t lds = 2 * (size_t)C * sizeof(float);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)x, ldx, (float*)ws,
-                           rows, C);
+                           rows, C, packed + 2 * C);
     else
         hipLaunchKernelGGL((bn_stats_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)x, ldx, (float*)ws, rows,
-                           C);
+                           C, packed + 2 * C);
     launch_reduce_rows((const float*)ws, blocks, 2 * C, 0, 1, 2 * C, packed, nullptr, 2 * C, 0, 1.f, 0, stream);
-    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, stream, packed + 2 * C, (float)rows);
     return iseg_check_launch("iseg_bn_stats");
 }
 
@@ -682,20 +698,34 @@ extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
     return iseg_check_launch("iseg_bn_bwd_reduce");
 }
 
+extern "C" int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
+                                     const float* mean, const float* rstd, const float* gamma, const float* sums, float inv_n,
+                                     void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, int relu, int dtype,
+                                     hipStream_t stream);
+
 extern "C" int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
                                  const float* mean, const float* rstd, const float* gamma, const float* sums, float inv_n,
                                  void* dx, int64_t lddx, int64_t rows, int C, int relu, int dtype, hipStream_t stream) {
+    return iseg_bn_bwd_apply_acc(dy, lddy, x, ldx, y, ldy, mean, rstd, gamma, sums, inv_n, dx, lddx, nullptr, nullptr, rows, C, relu, dtype, stream);
+}
+
+extern "C" int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
+                                     const float* mean, const float* rstd, const float* gamma, const float* sums, float inv_n,
+                                     void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, int relu, int dtype,
+                                     hipStream_t stream) {
     ISEG_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && (!relu || y), "iseg_bn_bwd_apply: null pointer");
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "iseg_bn_bwd_apply: alignment");
+    ISEG_REQUIRE((((uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0 && (!(dgamma || dbeta) || ((uintptr_t)sums & 15) == 0),
+                 "iseg_bn_bwd_apply_acc: gradient vectors must be 16-byte aligned");
     int64_t blocks = ceil_div64(rows * (C / 8), 256);
     if (blocks > 4096) blocks = 4096;
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy,
                            (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, gamma, sums, inv_n, (bf16_t*)dx, lddx, rows,
-                           C, relu);
+                           C, relu, dgamma, dbeta);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dy, lddy,
                            (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, sums, inv_n, (float*)dx, lddx, rows, C,
-                           relu);
+                           relu, dgamma, dbeta);
     return iseg_check_launch("iseg_bn_bwd_apply");
 }

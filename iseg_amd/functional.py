@@ -417,16 +417,20 @@ class _BatchNormTrainFn(Function):
         rows, C = x2.shape
         dy2, lddy = _rows2d(dy)
         sums = K.bn_bwd_reduce(dy2, lddy, x2, C, y, C, mean, rstd, rows, C, ctx.relu)
-        # local parameter gradients (the gradient all-reduce sums them over ranks later)
-        K.accumulate_pair(sums, C, _grad(ctx.beta) if ctx.beta.requires_grad else None, _grad(ctx.gamma) if ctx.gamma.requires_grad else None)
-        dist.grads_ready(ctx.gamma, ctx.beta)
-        n_total = rows
+        dbeta = _grad(ctx.beta) if ctx.beta.requires_grad else None
+        dgamma = _grad(ctx.gamma) if ctx.gamma.requires_grad else None
+        dx = torch.empty_like(x2)
         if ctx.sync and dist.active():
+            # local parameter gradients first (the gradient all-reduce sums them over ranks later), then the statistics of all replicas
+            K.accumulate_pair(sums, C, dbeta, dgamma)
+            dist.grads_ready(ctx.gamma, ctx.beta)
             sums = sums.clone()
             dist.all_reduce_sum(sums)
-            n_total = rows * dist.world_size()
-        dx = torch.empty_like(x2)
-        K.bn_bwd_apply(dy2, lddy, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / n_total, dx, C, rows, C, ctx.relu)
+            K.bn_bwd_apply(dy2, lddy, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / (rows * dist.world_size()), dx, C, rows, C, ctx.relu)
+        else:      # the sums are this replica's own: the apply kernel books dbeta | dgamma itself
+            K.bn_bwd_apply(dy2, lddy, x2, C, y, C, mean, rstd, ctx.gamma.data, sums, 1.0 / rows, dx, C, rows, C, ctx.relu, dgamma=dgamma,
+                           dbeta=dbeta)
+            dist.grads_ready(ctx.gamma, ctx.beta)
         return dx.reshape(dy.shape), None, None, None, None, None, None, None, None
 
 

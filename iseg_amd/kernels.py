@@ -322,9 +322,14 @@ def bn_bwd_reduce(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, rows, Cc, relu, ou
     return sums
 
 
-def bn_bwd_apply(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, gamma, sums, inv_n, dx2d, lddx, rows, Cc, relu):
-    _hip.call("iseg_bn_bwd_apply", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), inv_n,
-              ptr(dx2d), lddx, rows, Cc, int(relu), dt(x2d), stream())
+def bn_bwd_apply(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, gamma, sums, inv_n, dx2d, lddx, rows, Cc, relu, dgamma=None, dbeta=None):
+    """dgamma / dbeta (+)= the packed sums, booked by the same launch -- only valid while `sums` are this replica's own"""
+    if dgamma is None and dbeta is None:
+        _hip.call("iseg_bn_bwd_apply", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), inv_n,
+                  ptr(dx2d), lddx, rows, Cc, int(relu), dt(x2d), stream())
+    else:
+        _hip.call("iseg_bn_bwd_apply_acc", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(y2d), ldy, ptr(mean), ptr(rstd), ptr(gamma), ptr(sums), inv_n,
+                  ptr(dx2d), lddx, ptr(dgamma), ptr(dbeta), rows, Cc, int(relu), dt(x2d), stream())
     return dx2d
 
 
