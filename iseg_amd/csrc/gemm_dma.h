@@ -311,12 +311,16 @@ inline int dma_cus() {
 //      (with equal rounds the flagship step measured the same and the in-situ launches of the x aux data gradient 51.7 vs 50.5 us).
 //      Measured (tools/kbench_gemm_dma_ab.py): M=4096 N=3072 K=768 34.5 -> 27.5 us (384 tiles = 1.5 rounds -> 256 = one round),
 //      M=16384 N=1536 K=384 34.4 -> 33.1 us, with the x aux epilogue 42.2 -> 41.4 us, M=65536 N=768 K=192 45.7 -> 43.0 us.
-//   5: several 256 x 128 tiles per CU, one K split, no batch: the persistent form overlaps a tile's epilogue with the next tile's first DMAs.
+//   5: several 256 x 128 tiles per CU, one K split, no batch: the persistent form overlaps a tile's epilogue with the next tile's first DMAs
+//      (ISEG_GEMM_DMA_PERSIST=1; see below why it is not the default).
 inline int dma_form(const iseg_gemm_args* g, int nsplit) {
     const int variant = dma_variant(g, nsplit);
     if (variant != 2 || nsplit != 1 || g->batch > 1) return variant;
     static const int wide = [] { const char* e = getenv("ISEG_GEMM_DMA_WIDE"); return e ? atoi(e) : 1; }();
-    static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 1; }();
+    // off by default: 1 us per launch faster back to back (tools/kbench_gemm_ref.py) but slower inside the training step -- 59.8 vs 53.9 us for the
+    // x aux data gradient under bench.py's event timer, 9.82 vs 9.70 ms per step: three tiles per workgroup is a static partition, and the
+    // hardware dispatcher's dynamic one (768 workgroups, a new one wherever a CU frees up) absorbs CUs that run behind on cold operands
+    static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 0; }();
     const int cus = dma_cus();
     const int64_t t128 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128);
     if (wide && g->N % 192 == 0) {
