@@ -250,6 +250,12 @@ int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, int out_dtype
 size_t iseg_resize_bilinear_bwd_workspace_bytes(int N, int Hi, int Wi, int Ho, int Wo, int C);
 int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, const void* dx_add, int N, int Hi, int Wi,
                              int Ho, int Wo, int C, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* tf.compat.v1.image.resize(x, size, method="bilinear", align_corners=True) (backbones/hrnet.py:303-304, 523-524): source coordinate
+ * dst*(in-1)/(out-1), same lerp order; the backward uses iseg_resize_bilinear_bwd_workspace_bytes */
+int iseg_resize_bilinear_ac_fwd(const void* x, int in_dtype, void* y, int out_dtype, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                iseg_stream_t stream);
+int iseg_resize_bilinear_ac_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, const void* dx_add, int N, int Hi, int Wi, int Ho, int Wo,
+                                int C, void* ws, size_t ws_bytes, iseg_stream_t stream);
 int iseg_resize_nearest_i32(const int32_t* x, int32_t* y, int N, int Hi, int Wi, int Ho, int Wo, int C, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -149,6 +149,8 @@ SIGNATURES = {
     "iseg_resize_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_resize_bilinear_bwd_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "iseg_resize_bilinear_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "iseg_resize_bilinear_ac_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "iseg_resize_bilinear_ac_bwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "iseg_resize_nearest_i32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_softmax_ce_workspace_bytes": (_z, [_l, _i]),
     "iseg_softmax_ce_ignore": (_i, [_p, _p, _p, _l, _i, _i, _p, _p, _f, _p, _f, _p, _p, _z, _p]),

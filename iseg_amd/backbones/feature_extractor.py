@@ -7,6 +7,7 @@ from .. import static_strings as ss
 from .backbone_registry import backbone_registry_dict
 from .convnext import build_dilated_convnext, convnext_large, convnext_tiny, convnext_xlarge, convnext_xxlarge
 from .convnext_v2 import convnext_v2_huge, convnext_v2_large, convnext_v2_nano, convnext_v2_tiny
+from .hrnet import HRNetW32, HRNetW48
 from .resnet_common import apply_multi_grid, build_atrous_resnet, resnet50, resnet101, resnet152
 
 
@@ -20,6 +21,8 @@ def _builtin_backbones():
         ss.CONVNEXT_V2_TINY: convnext_v2_tiny,
         ss.CONVNEXT_V2_LARGE: convnext_v2_large,
         ss.CONVNEXT_V2_HUGE: convnext_v2_huge,
+        ss.HRNET_W48: HRNetW48,
+        ss.HRNET_W32: HRNetW32,
         ss.RESNET50: resnet50,
         ss.RESNET52: resnet50,
         ss.RESNET101: resnet101,

@@ -17,8 +17,10 @@ struct Lerp {
     float t;
 };
 
+// AC: tf.compat.v1.image.resize(..., align_corners=True) -- src = dst * (in-1)/(out-1) (`scale` is that ratio); else TF2's half-pixel centres
+template <bool AC = false>
 __device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in_size) {
-    const float src = ((float)dst + 0.5f) * scale - 0.5f;
+    const float src = AC ? (float)dst * scale : ((float)dst + 0.5f) * scale - 0.5f;
     const float f = floorf(src);
     Lerp l;
     l.lo = max((int)f, 0);
@@ -39,14 +41,14 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 }
 
 // grid.x = N*Ho output rows (grid-stride), 256 threads walk the Wo*C elements of the row four at a time
-template <class TI, class TO>
+template <class TI, class TO, bool AC = false>
 __global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, int N, int Hi, int Wi,
                                                                   int Ho, int Wo, int C, float sy, float sx) {
     const int rowlen = Wo * C;
     const bool vec = (rowlen % 4 == 0);
     for (int row = blockIdx.x; row < N * Ho; row += gridDim.x) {
         const int n = row / Ho, oy = row - n * Ho;
-        const Lerp ly = lerp_of(oy, sy, Hi);
+        const Lerp ly = lerp_of<AC>(oy, sy, Hi);
         const TI* top = x + ((int64_t)n * Hi + ly.lo) * Wi * C;
         const TI* bot = x + ((int64_t)n * Hi + ly.hi) * Wi * C;
         TO* out = y + (int64_t)row * rowlen;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const TI* __re
                 v[u] = 0.f;
                 if (e < rowlen) {
                     const int ox = e / C, c = e - ox * C;
-                    const Lerp lx = lerp_of(ox, sx, Wi);
+                    const Lerp lx = lerp_of<AC>(ox, sx, Wi);
                     const float tl = to_f32(top[lx.lo * C + c]), tr = to_f32(top[lx.hi * C + c]);
                     const float bl = to_f32(bot[lx.lo * C + c]), br = to_f32(bot[lx.hi * C + c]);
                     const float tp = tl + (tr - tl) * lx.t;
@@ -142,18 +144,31 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_lds_kernel(const TI* 
 }
 
 // transposed interpolation weights of forward destination d onto source j
+template <bool AC = false>
 __device__ __forceinline__ float bwd_weight(int d, int j, float scale, int J) {
-    const Lerp l = lerp_of(d, scale, J);
+    const Lerp l = lerp_of<AC>(d, scale, J);
     float w = 0.f;
     if (l.lo == j) w += 1.f - l.t;
     if (l.hi == j) w += l.t;
     return w;
 }
 
+template <bool AC = false>
 __device__ __forceinline__ void bwd_range(int j, int J, int Dn, float inv, int& d0, int& d1) {
     // destinations whose lo or hi can equal j: src in (j-1, j+1)  ->  dst in ((j-0.5)*inv-0.5 , (j+1.5)*inv-0.5)
-    d0 = (int)floorf(((float)j - 0.5f) * inv - 0.5f) - 1;
-    d1 = (int)ceilf(((float)j + 1.5f) * inv - 0.5f) + 1;
+    // (aligned corners: src = dst*scale, dst in ((j-1)*inv, (j+1)*inv); a degenerate axis -- one output or one input -- scans everything)
+    if (AC) {
+        if (!(inv < 1e30f)) {
+            d0 = 0;
+            d1 = Dn - 1;
+            return;
+        }
+        d0 = (int)floorf(((float)j - 1.f) * inv) - 1;
+        d1 = (int)ceilf(((float)j + 1.f) * inv) + 1;
+    } else {
+        d0 = (int)floorf(((float)j - 0.5f) * inv - 0.5f) - 1;
+        d1 = (int)ceilf(((float)j + 1.5f) * inv - 0.5f) + 1;
+    }
     if (j == 0) d0 = 0;           // clamped sources: everything below maps to lo = hi = 0
     if (j == J - 1) d1 = Dn - 1;  // and everything above to J-1
     d0 = max(d0, 0);
@@ -245,21 +260,21 @@ __global__ __launch_bounds__(256) void resize_bwd_x_lds_kernel(const TI* __restr
 // one axis of the transposed interpolation, generic gather: out[o, j, q] = sum_{d in D(j)} w(d -> j) * in[o, d, q]
 //   outer o (size O), reduced axis d (size Dn, "destination" of the forward), kept axis j (size J, forward source),
 //   inner q (size Q, contiguous).   scale = J / Dn (forward in/out ratio along this axis)
-template <class TI, class TO>
+template <class TI, class TO, bool AC = false>
 __global__ void resize_bwd_axis_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t O, int Dn, int J, int64_t Q,
                                        float scale, const TO* __restrict__ add) {
     const int64_t total = O * J * Q;
-    const float inv = 1.0f / scale;
+    const float inv = scale > 0.f ? 1.0f / scale : 3.0e38f;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t q = i % Q;
         const int j = (int)((i / Q) % J);
         const int64_t o = i / (Q * J);
         int d0, d1;
-        bwd_range(j, J, Dn, inv, d0, d1);
+        bwd_range<AC>(j, J, Dn, inv, d0, d1);
         float acc = 0.f;
         const TI* p = in + o * Dn * Q + q;
         for (int d = d0; d <= d1; ++d) {
-            const float w = bwd_weight(d, j, scale, J);
+            const float w = bwd_weight<AC>(d, j, scale, J);
             if (w != 0.f) acc += w * to_f32(p[(int64_t)d * Q]);
         }
         if (add) acc += to_f32(add[i]);
@@ -474,6 +489,58 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
         hipLaunchKernelGGL((resize_bwd_axis_kernel<float, float>), dim3(cap_blocks(t2)), dim3(256), 0, stream, (const float*)tmp,
                            (float*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const float*)dx_add);
     return iseg_check_launch("iseg_resize_bilinear_bwd");
+}
+
+// tf.compat.v1.image.resize(x, size, method="bilinear", align_corners=True) (backbones/hrnet.py:303-304,523-524): generic gather kernels with
+// the aligned-corner coordinate map; same lerp order as the half-pixel entry points
+extern "C" int iseg_resize_bilinear_ac_fwd(const void* x, int in_dtype, void* y, int out_dtype, int N, int Hi, int Wi, int Ho, int Wo, int C,
+                                           hipStream_t stream) {
+    ISEG_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "iseg_resize_bilinear_ac_fwd: bad arguments");
+    ISEG_REQUIRE((int64_t)Wo * C < (1ll << 30) && (int64_t)Wi * C < (1ll << 30) && (int64_t)N * Ho < (1ll << 31),
+                 "iseg_resize_bilinear_ac_fwd: row too long");
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    int64_t blocks = (int64_t)N * Ho;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define RSA(TI, TO)                                                                                                                         \
+    hipLaunchKernelGGL((resize_bilinear_fwd_kernel<TI, TO, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (const TI*)x, (TO*)y, N, Hi, \
+                       Wi, Ho, Wo, C, sy, sx)
+    if (in_dtype == ISEG_F32 && out_dtype == ISEG_F32) RSA(float, float);
+    else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_F32) RSA(bf16_t, float);
+    else if (in_dtype == ISEG_BF16 && out_dtype == ISEG_BF16) RSA(bf16_t, bf16_t);
+    else if (in_dtype == ISEG_F32 && out_dtype == ISEG_BF16) RSA(float, bf16_t);
+    else {
+        iseg_set_error("iseg_resize_bilinear_ac_fwd: bad dtypes");
+        return ISEG_ERR_ARG;
+    }
+#undef RSA
+    return iseg_check_launch("iseg_resize_bilinear_ac_fwd");
+}
+
+extern "C" int iseg_resize_bilinear_ac_bwd(const void* dy, int dy_dtype, void* dx, int dx_dtype, const void* dx_add, int N, int Hi, int Wi,
+                                           int Ho, int Wo, int C, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dy && dx && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "iseg_resize_bilinear_ac_bwd: bad arguments");
+    const size_t need = iseg_resize_bilinear_bwd_workspace_bytes(N, Hi, Wi, Ho, Wo, C);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_resize_bilinear_ac_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    float* tmp = (float*)ws;
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const int64_t t1 = (int64_t)N * Ho * Wi * C, t2 = (int64_t)N * Hi * Wi * C;
+    // X pass: [N*Ho, Wo, C] -> [N*Ho, Wi, C] (fp32), then Y pass: [N, Ho, Wi*C] -> [N, Hi, Wi*C]
+    if (dy_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((resize_bwd_axis_kernel<bf16_t, float, true>), dim3(cap_blocks(t1)), dim3(256), 0, stream, (const bf16_t*)dy, tmp,
+                           (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
+    else
+        hipLaunchKernelGGL((resize_bwd_axis_kernel<float, float, true>), dim3(cap_blocks(t1)), dim3(256), 0, stream, (const float*)dy, tmp,
+                           (int64_t)N * Ho, Wo, Wi, (int64_t)C, sx, (const float*)nullptr);
+    if (dx_dtype == ISEG_BF16)
+        hipLaunchKernelGGL((resize_bwd_axis_kernel<float, bf16_t, true>), dim3(cap_blocks(t2)), dim3(256), 0, stream, (const float*)tmp,
+                           (bf16_t*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const bf16_t*)dx_add);
+    else
+        hipLaunchKernelGGL((resize_bwd_axis_kernel<float, float, true>), dim3(cap_blocks(t2)), dim3(256), 0, stream, (const float*)tmp,
+                           (float*)dx, (int64_t)N, Ho, Hi, (int64_t)Wi * C, sy, (const float*)dx_add);
+    return iseg_check_launch("iseg_resize_bilinear_ac_bwd");
 }
 
 extern "C" int iseg_resize_nearest_i32(const int32_t* x, int32_t* y, int N, int Hi, int Wi, int Ho, int Wo, int C,

@@ -732,23 +732,24 @@ def drop_path(x, drop_prob, training, mask=None):
 # ---------------------------------------------------------------------------------------------------------
 class _ResizeBilinearFn(Function):
     @staticmethod
-    def forward(ctx, x, Ho, Wo, out_dtype):
-        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
-        return K.resize_bilinear(_c(x), Ho, Wo, out_dtype=out_dtype)
+    def forward(ctx, x, Ho, Wo, out_dtype, align_corners=False):
+        ctx.in_shape, ctx.in_dtype, ctx.align = x.shape, x.dtype, bool(align_corners)
+        return K.resize_bilinear(_c(x), Ho, Wo, out_dtype=out_dtype, align_corners=ctx.align)
 
     @staticmethod
     def backward(ctx, dy):
         _, Hi, Wi, _ = ctx.in_shape
-        return K.resize_bilinear_bwd(_c(dy), Hi, Wi, ctx.in_dtype), None, None, None
+        return K.resize_bilinear_bwd(_c(dy), Hi, Wi, ctx.in_dtype, align_corners=ctx.align), None, None, None, None
 
 
-def resize_bilinear(x, size, out_dtype=None):
+def resize_bilinear(x, size, out_dtype=None, align_corners=False):
+    """tf.image.resize(method="bilinear") (half-pixel centres); align_corners=True: tf.compat.v1.image.resize(..., align_corners=True)"""
     Ho, Wo = int(size[0]), int(size[1])
     if nn.dry_run():
         return _dry((x.shape[0], Ho, Wo, x.shape[3]), x, out_dtype)
     if x.shape[1] == Ho and x.shape[2] == Wo and (out_dtype is None or out_dtype == x.dtype):
         return x
-    return _ResizeBilinearFn.apply(x, Ho, Wo, out_dtype or x.dtype)
+    return _ResizeBilinearFn.apply(x, Ho, Wo, out_dtype or x.dtype, bool(align_corners))
 
 
 class _GlobalAvgPoolFn(Function):

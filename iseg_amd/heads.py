@@ -109,3 +109,8 @@ def convnext_v2_tiny_aspp(num_class=21, output_stride=32, build_input_size=(512,
     """the BASELINE config-2 composition with the ConvNeXt V2 backbone (backbones/convnext_v2.py: GRN instead of layer scale)"""
     return _managed("convnext_v2_tiny", ASPPHead(256, output_stride=output_stride, dropout_rate=dropout_rate), num_class, output_stride,
                     build_input_size)
+
+
+def hrnet_w32_aspp(num_class=21, build_input_size=(512, 512), dropout_rate=0.1):
+    """HRNet-W32 (backbones/hrnet.py: the concatenated map at stride 4 is the last endpoint) + the ASPP head of the BASELINE composition"""
+    return _managed("hrnet_w32", ASPPHead(256, output_stride=32, dropout_rate=dropout_rate), num_class, 32, build_input_size)

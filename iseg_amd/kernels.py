@@ -581,20 +581,23 @@ def normalize_image(x, norm_scale, norm_shift):
 # ---------------------------------------------------------------------------------------------------------
 # resize / loss / metric / optimizer
 # ---------------------------------------------------------------------------------------------------------
-def resize_bilinear(x, Ho, Wo, out_dtype=None):
+def resize_bilinear(x, Ho, Wo, out_dtype=None, align_corners=False):
+    """align_corners: tf.compat.v1.image.resize(..., align_corners=True) coordinates instead of TF2's half-pixel centres"""
     _require_cuda(x)
     N, Hi, Wi, Cc = x.shape
     y = torch.empty((N, Ho, Wo, Cc), dtype=out_dtype or x.dtype, device=x.device)
-    _hip.call("iseg_resize_bilinear_fwd", ptr(x), dt(x), ptr(y), dt(y), N, Hi, Wi, Ho, Wo, Cc, stream())
+    _hip.call("iseg_resize_bilinear_ac_fwd" if align_corners else "iseg_resize_bilinear_fwd", ptr(x), dt(x), ptr(y), dt(y), N, Hi, Wi, Ho, Wo,
+              Cc, stream())
     return y
 
 
-def resize_bilinear_bwd(dy, Hi, Wi, dx_dtype, dx_add=None):
+def resize_bilinear_bwd(dy, Hi, Wi, dx_dtype, dx_add=None, align_corners=False):
     N, Ho, Wo, Cc = dy.shape
     dx = torch.empty((N, Hi, Wi, Cc), dtype=dx_dtype, device=dy.device)
     need = _hip.lib().iseg_resize_bilinear_bwd_workspace_bytes(N, Hi, Wi, Ho, Wo, Cc)
     ws, wsb = workspace(need, dy.device)
-    _hip.call("iseg_resize_bilinear_bwd", ptr(dy), dt(dy), ptr(dx), dt(dx), ptr(dx_add), N, Hi, Wi, Ho, Wo, Cc, ptr(ws), wsb, stream())
+    _hip.call("iseg_resize_bilinear_ac_bwd" if align_corners else "iseg_resize_bilinear_bwd", ptr(dy), dt(dy), ptr(dx), dt(dx), ptr(dx_add), N,
+              Hi, Wi, Ho, Wo, Cc, ptr(ws), wsb, stream())
     return dx
 
 

@@ -506,3 +506,95 @@ def convnext_aspp_adamw_curve(w, x, y, steps, trainable, lr_fn, wd_of, eps=1e-7,
             w[k], state[k] = nw.detach(), (nm, nv)
         w.update(new_stats)
     return curve
+
+
+# ------------------------------------------------------------------------------------------------------
+# HRNet (backbones/hrnet.py): Bottleneck stem layer, transition / branch / fuse modules per stage, aligned-corner resizes.
+# The fuse module writes each fused branch back into the list it reads from (:287-309), so branch i > 0 is built from the already
+# fused lower branches -- restated literally.
+# ------------------------------------------------------------------------------------------------------
+def _hr_conv_bn(w, conv, bn, x, training, stride=1, relu=True, new_stats=None):
+    y = O.conv2d(x, w[f"{conv}/kernel"], None, stride, 1, "same")
+    y = _bn(w, bn, y, training, 1e-3, new_stats=new_stats)
+    return torch.relu(y) if relu else y
+
+
+def _hr_block(w, name, x, bottleneck, downsample, training, new_stats):
+    residual = x
+    if downsample:      # DownSampleBlock :157-173 (1x1 conv, no activation)
+        residual = _hr_conv_bn(w, f"{name}/downsample/0", f"{name}/downsample/1", x, training, relu=False, new_stats=new_stats)
+    y = _hr_conv_bn(w, f"{name}/conv1", f"{name}/bn1", x, training, new_stats=new_stats)
+    if bottleneck:
+        y = _hr_conv_bn(w, f"{name}/conv2", f"{name}/bn2", y, training, new_stats=new_stats)
+        y = _hr_conv_bn(w, f"{name}/conv3", f"{name}/bn3", y, training, relu=False, new_stats=new_stats)
+    else:
+        y = _hr_conv_bn(w, f"{name}/conv2", f"{name}/bn2", y, training, relu=False, new_stats=new_stats)
+    return torch.relu(y + residual)
+
+
+def _hr_layer(w, name, x, bottleneck, filters, num_blocks, training, new_stats):
+    expansion = 4 if bottleneck else 1
+    for i in range(num_blocks):
+        x = _hr_block(w, f"{name}/{i}", x, bottleneck, i == 0 and x.shape[-1] != filters * expansion, training, new_stats)
+    return x
+
+
+def _hr_conv_block(w, name, x, training, stride=1, relu=True, new_stats=None):
+    return _hr_conv_bn(w, f"{name}/0", f"{name}/1", x, training, stride, relu, new_stats)
+
+
+def _hr_transition(w, name, x_list, filters_list, training, new_stats):
+    num_in = len(x_list)
+    out = []
+    for i, f in enumerate(filters_list):
+        if i < num_in:
+            out.append(_hr_conv_block(w, f"{name}/{i}", x_list[i], training, new_stats=new_stats) if f != x_list[i].shape[-1] else x_list[i])
+        else:
+            y = x_list[-1]
+            for j in range(i + 1 - num_in):
+                y = _hr_conv_block(w, f"{name}/{i}/{j}", y, training, stride=2, new_stats=new_stats)
+            out.append(y)
+    return out
+
+
+def _hr_fuse(w, name, x_list, training, new_stats):
+    x_list = list(x_list)
+    nb = len(x_list)
+    for i in range(nb):
+        if i == 0:
+            y = x_list[0]
+        else:
+            y = x_list[0]
+            for k in range(i):      # HighResolutionFuseStack(i, 0): i stride-2 blocks, ReLU on all but the last
+                y = _hr_conv_block(w, f"{name}/{i}/0/{k}", y, training, stride=2, relu=k != i - 1, new_stats=new_stats)
+        for j in range(1, nb):
+            x = x_list[j]
+            if j > i:
+                x = _hr_conv_block(w, f"{name}/{i}/{j}", x, training, relu=False, new_stats=new_stats)
+                x = O.resize_bilinear(x, x_list[i].shape[1:3], align_corners=True)
+            elif j < i:
+                for k in range(i - j):
+                    x = _hr_conv_block(w, f"{name}/{i}/{j}/{k}", x, training, stride=2, relu=k != i - j - 1, new_stats=new_stats)
+            y = y + x
+        x_list[i] = torch.relu(y)
+    return x_list
+
+
+def hrnet_forward(w, x, stages, training=False, new_stats=None):
+    """stages: [(num_modules, filters_list, num_blocks_list), ...] as HighResolutionNet.add_stage receives them (BasicBlock stages);
+    returns the branch list followed by the concatenation at the highest resolution (:506-538, return_endpoints=True)"""
+    x = _hr_conv_bn(w, "conv1", "bn1", x, training, stride=2, new_stats=new_stats)
+    x = _hr_conv_bn(w, "conv2", "bn2", x, training, stride=2, new_stats=new_stats)
+    x = _hr_layer(w, "layer1", x, True, 64, 4, training, new_stats)
+    x_list = [x]
+    for s, (num_modules, filters_list, num_blocks_list) in enumerate(stages):
+        name = f"stage{s + 2}"
+        x_list = _hr_transition(w, f"{name}/transition", x_list, filters_list, training, new_stats)
+        for m in range(num_modules):
+            x_list = [_hr_layer(w, f"{name}/{m}/branches/{i}", x_list[i], False, filters_list[i], num_blocks_list[i], training, new_stats)
+                      for i in range(len(x_list))]
+            if len(x_list) > 1:
+                x_list = _hr_fuse(w, f"{name}/{m}/fuse_layers", x_list, training, new_stats)
+    size = x_list[0].shape[1:3]
+    y = torch.cat([x_list[0]] + [O.resize_bilinear(t, size, align_corners=True) for t in x_list[1:]], dim=-1)
+    return x_list + [y]

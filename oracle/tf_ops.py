@@ -108,11 +108,15 @@ def moving_update(moving, batch, momentum):
 # ------------------------------------------------------------------------------------------------------
 # tf.image.resize (v2, half_pixel_centers=True, antialias=False)   -- utils/common.py:107-134
 # ------------------------------------------------------------------------------------------------------
-def _interp_weights(out_size, in_size, dtype):
+def _interp_weights(out_size, in_size, dtype, align_corners=False):
     # TF computes these in float32 (compute_interpolation_weights); keep float32 so ties resolve identically
-    scale = np.float32(in_size) / np.float32(out_size)
     dst = np.arange(out_size, dtype=np.float32)
-    src = (dst + np.float32(0.5)) * scale - np.float32(0.5)
+    if align_corners:      # tf.compat.v1.image.resize(..., align_corners=True): CalculateResizeScale = (in-1)/(out-1), LegacyScaler = dst*scale
+        scale = np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0.0)
+        src = dst * scale
+    else:
+        scale = np.float32(in_size) / np.float32(out_size)
+        src = (dst + np.float32(0.5)) * scale - np.float32(0.5)
     fl = np.floor(src)
     lo = np.maximum(fl, 0).astype(np.int64)
     hi = np.minimum(np.ceil(src), in_size - 1).astype(np.int64)
@@ -120,12 +124,13 @@ def _interp_weights(out_size, in_size, dtype):
     return torch.from_numpy(lo), torch.from_numpy(hi), torch.from_numpy(t).to(dtype)
 
 
-def resize_bilinear(x, size):
-    """value = top + (bottom-top)*ty, top = tl + (tr-tl)*tx; output float (TF returns float32)."""
+def resize_bilinear(x, size, align_corners=False):
+    """value = top + (bottom-top)*ty, top = tl + (tr-tl)*tx; output float (TF returns float32).  align_corners: the legacy
+    tf.compat.v1.image.resize coordinates backbones/hrnet.py:303-304,523-524 asks for."""
     Ho, Wo = size
     N, Hi, Wi, C = x.shape
-    ylo, yhi, ty = _interp_weights(Ho, Hi, x.dtype)
-    xlo, xhi, tx = _interp_weights(Wo, Wi, x.dtype)
+    ylo, yhi, ty = _interp_weights(Ho, Hi, x.dtype, align_corners)
+    xlo, xhi, tx = _interp_weights(Wo, Wi, x.dtype, align_corners)
     top_rows, bot_rows = x[:, ylo], x[:, yhi]
     tx = tx.view(1, 1, Wo, 1)
     ty = ty.view(1, Ho, 1, 1)

@@ -311,3 +311,24 @@ def test_grad_reducer_bucket_layout():
     red = dist.GradReducer(st, bucket_bytes=64 << 10, head_bytes=(4 << 10, 16 << 10))
     sizes = [(hi - lo) * 4 for lo, hi, _ in red.buckets]
     assert sizes[0] < sizes[-1] and sizes[0] >= 4 << 10
+
+
+def test_hrnet_registry_and_weight_names():
+    """backbones/feature_extractor.py:100-101 + backbones/hrnet.py:541-558: both names build; Keras-style weight names of the nested modules"""
+    import numpy as np
+
+    from iseg_amd.backbones.feature_extractor import get_backbone
+
+    bb = get_backbone("hrnet_w48", return_endpoints=True, image_shape=(1, 64, 64, 3))
+    shapes = {p.iseg_name: tuple(p.shape) for p in bb.parameters()}
+    assert shapes["conv1/kernel"] == (3, 3, 3, 64) and shapes["layer1/0/downsample/0/kernel"] == (1, 1, 64, 256)
+    assert shapes["layer1/3/conv3/kernel"] == (1, 1, 64, 256)
+    assert shapes["stage2/transition/0/0/kernel"] == (3, 3, 256, 48) and shapes["stage2/transition/1/0/0/kernel"] == (3, 3, 256, 96)
+    assert shapes["stage3/transition/2/0/0/kernel"] == (3, 3, 96, 192) and "stage3/transition/0/0/kernel" not in shapes      # same width: passthrough
+    assert shapes["stage4/2/fuse_layers/0/3/0/kernel"] == (1, 1, 384, 48)               # 1x1 from branch 3 into branch 0 (then resized up)
+    assert shapes["stage4/2/fuse_layers/3/0/0/0/kernel"] == (3, 3, 48, 48)              # three stride-2 steps from branch 0 into branch 3:
+    assert shapes["stage4/2/fuse_layers/3/0/2/0/kernel"] == (3, 3, 48, 384)             # ... the last one takes the destination width
+    assert shapes["stage4/0/branches/2/1/conv2/kernel"] == (3, 3, 192, 192)
+    total = sum(int(np.prod(s)) for s in shapes.values())
+    assert 6.4e7 < total < 6.7e7      # HRNet-W48 backbone: ~65 M parameters
+    assert len(bb.stages) == 3 and [len(s.modules_list) for s in bb.stages] == [1, 4, 3]

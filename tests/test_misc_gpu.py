@@ -248,3 +248,31 @@ def test_groupnorm_layer_through_factory(cuda, dtype):
             assert _param_err(p.grad, w[p.iseg_name].grad, gmax) < tol, p.iseg_name
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,size", [((2, 5, 7, 16), (13, 20)), ((1, 8, 8, 48), (32, 32)), ((2, 9, 4, 5), (3, 2)), ((1, 1, 6, 8), (4, 1)),
+                                        ((2, 16, 16, 24), (16, 31))])
+def test_resize_bilinear_align_corners_matches_oracle(cuda, dtype, shape, size):
+    """tf.compat.v1.image.resize(..., method="bilinear", align_corners=True) (backbones/hrnet.py:303-304,523-524): forward and the transposed map"""
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+
+    nn.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(sum(shape) + sum(size))
+        x = torch.randn(shape, generator=g).to(dtype)
+        dy = torch.randn((shape[0],) + tuple(size) + (shape[3],), generator=g).to(dtype)
+        xg = x.cuda().requires_grad_(True)
+        y = F.resize_bilinear(xg, size, align_corners=True)
+        y.backward(dy.cuda())
+        xr = x.double().requires_grad_(True)
+        yr = O.resize_bilinear(xr, size, align_corners=True)
+        yr.backward(dy.double())
+        tol = 1e-5 if dtype == torch.float32 else 1.2e-2
+        assert (y.detach().cpu().double() - yr.detach()).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+        assert (xg.grad.cpu().double() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+        if size[0] > 1 and size[1] > 1 and dtype == torch.float32:      # the corners map onto the corners exactly
+            assert torch.equal(y[:, 0, 0].cpu(), x[:, 0, 0]) and torch.equal(y[:, -1, -1].cpu(), x[:, -1, -1])
+    finally:
+        nn.set_compute_dtype(torch.float32)

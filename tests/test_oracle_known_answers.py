@@ -241,3 +241,14 @@ def test_global_response_normalization_by_hand():
     xs[1] *= 4.0
     b = O.grn(xs, g, z, eps=0.0)
     assert torch.allclose(b[0], a[0], atol=1e-12) and torch.allclose(b[1], 4.0 * a[1], atol=1e-10)
+
+
+def test_resize_bilinear_align_corners_by_hand():
+    """tf.compat.v1.image.resize(align_corners=True): corners map onto corners, so a linear ramp stays the same ramp sampled at
+    (in-1)/(out-1) steps: [0,1,2,3] -> 7 samples at step 0.5; rows 0,4,8 -> 5 rows at step 2"""
+    x = torch.arange(12, dtype=torch.float64).reshape(1, 3, 4, 1)
+    y = O.resize_bilinear(x, (5, 7), align_corners=True)[0, :, :, 0]
+    want = torch.tensor([[2.0 * r + 0.5 * c for c in range(7)] for r in range(5)], dtype=torch.float64)
+    assert torch.allclose(y, want, atol=1e-6)
+    one = O.resize_bilinear(x, (1, 1), align_corners=True)
+    assert one.shape == (1, 1, 1, 1) and float(one) == 0.0      # a single output samples the first corner

@@ -2,7 +2,7 @@
 """Throughput of the other BASELINE configurations on one GPU (bf16, synthetic data, full train step through TrainableModel, or the
 sliding-window inference driver for cfg4).  One JSON line per configuration.  Not the contract benchmark (that is bench.py / cfg2).
 
-  python tools/bench_configs.py [cfg1 cfg3 cfg4 cfg4_infer cfg5 v2] [--steps K] [--warmup W] [--batch B]
+  python tools/bench_configs.py [cfg1 cfg3 cfg4 cfg4_infer cfg5 v2 hrnet] [--steps K] [--warmup W] [--batch B]
 """
 import argparse
 import json
@@ -20,6 +20,7 @@ CONFIGS = {
     "cfg4": ("vit_base_simple_decoder", 512, 8, True, "ViT-B/16 + SimpleDecoder 512x512 (train step)"),
     "cfg4_infer": ("vit_base_simple_decoder", 640, 1, False, "ViT-B/16 + SimpleDecoder 640x640, sliding window 512"),
     "cfg5": ("intern_image_base_aspp", 512, 8, True, "InternImage-B + ASPP 512x512"),
+    "hrnet": ("hrnet_w32_aspp", 512, 8, True, "HRNet-W32 + ASPP 512x512 (not a BASELINE configuration)"),
     "v2": ("convnext_v2_tiny_aspp", 512, 16, True, "ConvNeXt-V2-T + ASPP 512x512 (not a BASELINE configuration: the next backbone family)"),
 }
 
