@@ -14,6 +14,10 @@ def _rel(a, b):
     return (a.detach().cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-8)
 
 
+def _rel_l2(a, b):
+    return ((a.detach().cpu().double() - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
 def test_hrnet_w32_endpoints_match_oracle(cuda):
     """get_backbone("hrnet_w32"), fp32, inference statistics: the four branches and the concatenated map"""
     from iseg_amd import nn
@@ -85,5 +89,48 @@ def test_small_hrnet_training_step_gradients(cuda, dtype):
                 errs[p.iseg_name] = _rel(p.grad, w[p.iseg_name].grad)
             bad = {k: round(v, 4) for k, v in errs.items() if v > 3e-3}
             assert not bad, bad
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_hrnet_fuse_module_forward_backward(cuda, dtype):
+    """one HighResolutionFuseModule with three branches in training mode (1x1 + aligned-corner up-sampling, chains of stride-2 3x3 blocks,
+    the write-back order): outputs, input gradients and parameter gradients -- shallow enough for an element-wise bf16 tolerance"""
+    from iseg_amd import nn
+    from iseg_amd.backbones import hrnet
+    from iseg_amd.param_store import ParamStore
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        name = "stage3/0/fuse_layers"
+        mod = hrnet.HighResolutionFuseModule(True, name=name)
+        shapes = [(2, 16, 24, 8), (2, 8, 12, 16), (2, 4, 6, 32)]
+        with nn.dry_run_scope():
+            mod([torch.empty(s, dtype=dtype, device="cuda") for s in shapes])
+        mod._iseg_store = ParamStore(list(mod.parameters()))
+        randomize_parameters(mod, 6)
+        g = torch.Generator().manual_seed(12)
+        xs = [torch.randn(s, generator=g).to(dtype) for s in shapes]
+        dys = [torch.randn(s, generator=g).to(dtype) for s in shapes]
+        xg = [x.cuda().requires_grad_(True) for x in xs]
+        outs = mod(list(xg), training=True)
+        torch.autograd.backward(outs, [d.cuda() for d in dys])
+        w = {k: v.requires_grad_(True) if v.is_floating_point() else v for k, v in OM.export_weights(mod).items()}
+        xr = [x.double().requires_grad_(True) for x in xs]
+        ref = OM._hr_fuse(w, name, xr, True, None)
+        torch.autograd.backward(ref, [d.double() for d in dys])
+        lo = dtype == torch.bfloat16
+        for got, want in zip(outs, ref):
+            assert _rel(got, want.detach()) < (3e-2 if lo else 1e-4)
+        # bf16: a ReLU gate whose pre-activation rounds across zero switches one element's gradient fully on or off (0.3-0.5 of the largest
+        # gradient for a handful of elements), so the storage path is held to the L2 error of each tensor; fp32 to the largest element error
+        err = _rel_l2 if lo else _rel
+        errs = {f"dx{i}": err(a.grad, b.grad) for i, (a, b) in enumerate(zip(xg, xr))}
+        for p in mod.parameters():
+            errs[p.iseg_name] = err(p.grad, w[p.iseg_name].grad)
+        bad = {k: round(v, 4) for k, v in errs.items() if v > (0.2 if lo else 2e-3)}      # (bf16 measured: <= 0.15, the gated stride-2 chain 2/0)
+        assert not bad, bad
     finally:
         nn.set_compute_dtype(torch.float32)
