@@ -26,6 +26,17 @@ class _FlatOptimizer:
         self._exclude = []
         self.store = None
         self.grad_scale = 1.0
+        self._owned = None      # None: every variable of the store; else the names this optimizer updates (MultiOptimizer)
+
+    def restrict_to(self, var_names):
+        """only the variables with these names are updated by this optimizer (optimizers/multi_optimizer.py routes (grad, var) pairs by
+        name, :42-55): the others keep learning-rate multiplier 0 and no decay in this optimizer's tables, i.e. the step leaves them as they are"""
+        self._owned = None if var_names is None else set(var_names)
+        if self.store is not None:
+            self._build_tables()
+
+    def _owns(self, p):
+        return self._owned is None or getattr(p, "iseg_name", None) in self._owned
 
     # Keras API
     def exclude_from_weight_decay(self, var_list=None, var_names=None):
@@ -114,8 +125,8 @@ class AdamW(_FlatOptimizer):
         self.v = getattr(self, "v", None) if getattr(self, "v", None) is not None else torch.zeros_like(st.flat_w)
         if self.amsgrad and getattr(self, "vhat", None) is None:
             self.vhat = torch.zeros_like(st.flat_w)
-        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if p.requires_grad else 0.0 for p in st.params]
-        wd = [float(self.weight_decay or 0.0) if (p.requires_grad and self._use_weight_decay(p)) else 0.0 for p in st.params]
+        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if (p.requires_grad and self._owns(p)) else 0.0 for p in st.params]
+        wd = [float(self.weight_decay or 0.0) if (p.requires_grad and self._owns(p) and self._use_weight_decay(p)) else 0.0 for p in st.params]
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
         self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=st.device)
 
@@ -143,8 +154,8 @@ class SGD(_FlatOptimizer):
     def _build_tables(self):
         st = self.store
         self.m = getattr(self, "m", None) if getattr(self, "m", None) is not None else torch.zeros_like(st.flat_w)
-        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if p.requires_grad else 0.0 for p in st.params]
-        l2 = [float(getattr(p, "l2_regularizer", 0.0)) if p.requires_grad else 0.0 for p in st.params]
+        lr_mult = [float(getattr(p, "lr_multiplier", 1.0)) if (p.requires_grad and self._owns(p)) else 0.0 for p in st.params]
+        l2 = [float(getattr(p, "l2_regularizer", 0.0)) if (p.requires_grad and self._owns(p)) else 0.0 for p in st.params]
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
         self.seg_l2 = torch.tensor(l2, dtype=torch.float32, device=st.device)
 

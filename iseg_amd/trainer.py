@@ -25,7 +25,17 @@ class TrainableModel:
         self.metrics = metrics or {}
         self.update_metrics = True
         if isinstance(optimizer, list):
-            raise NotImplementedError("multi-optimizer training (multi_optimizers_layers) is outside this round's hot path")
+            # several optimizers: the model names the layer groups (core_model.py:603, layers/core_model_ext.py:386-388 multi_optimizers_layers),
+            # one group per optimizer, and the pairs become a MultiOptimizer (optimizers/multi_optimizer.py)
+            from .optimizers.multi_optimizer import MultiOptimizer
+
+            fn = getattr(model, "multi_optimizers_layers", None)
+            groups = fn() if callable(fn) else None
+            if not groups or len(groups) != len(optimizer):
+                raise ValueError(f"a list of {len(optimizer)} optimizers needs model.multi_optimizers_layers() to return as many layer groups "
+                                 f"(got {None if not groups else len(groups)})")
+            optimizer = self.optimizer = MultiOptimizer(optimizers_and_layers=[(o, g if isinstance(g, list) else [g])
+                                                                                for o, g in zip(optimizer, groups)])
         if hasattr(model, "build_with_dummy"):
             model.build_with_dummy()
         params = list(model.parameters())

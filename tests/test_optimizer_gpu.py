@@ -152,3 +152,84 @@ def test_clipnorm_is_deterministic(cuda):
         outs.append(store.flat_w.clone())
     assert torch.equal(outs[0], outs[1])
     assert math.isfinite(outs[0].sum().item())
+
+
+class _Holder(torch.nn.Module):
+    """stands in for a Keras layer: MultiOptimizer.create_optimizer_spec only reads the variables' names"""
+
+    def __init__(self, params):
+        super().__init__()
+        for i, p in enumerate(params):
+            self.register_parameter(f"p{i}", p)
+
+
+def test_multi_optimizer_routes_variables_by_layer(cuda):
+    """optimizers/multi_optimizer.py:10-63: AdamW owns the variables of the first layer group, SGD-momentum those of the second; each
+    variable follows ITS optimizer's oracle update (schedule, multiplier, decay exclusions, clipvalue) and is left alone by the other; a
+    variable claimed twice is refused; a list of optimizers reaches the trainer through model.multi_optimizers_layers()"""
+    from iseg_amd.optimizers.modern import SGD, AdamW
+    from iseg_amd.optimizers.multi_optimizer import MultiOptimizer
+    from iseg_amd.param_store import ParamStore
+
+    ps = _params(4)
+    store = ParamStore(ps)
+    ga, gb = _Holder(ps[:3]), _Holder(ps[3:])
+    adam = AdamW(learning_rate=lambda it: 1e-2 / (1 + it), weight_decay=0.05, clipvalue=0.5)
+    sgd = SGD(learning_rate=0.05, momentum=0.9)
+    mo = MultiOptimizer(optimizers_and_layers=[(adam, [ga]), (sgd, gb)])
+    assert mo.optimizer_specs[0]["weights"] == NAMES[:3] and mo.optimizer_specs[1]["weights"] == NAMES[3:]
+    mo.exclude_from_weight_decay(var_names=["bias", "gamma", "beta"])
+    mo.build(store)
+    w = [p.data.detach().cpu().double() for p in ps]
+    m = [torch.zeros_like(x) for x in w]
+    v = [torch.zeros_like(x) for x in w]
+    for step in range(3):
+        gs = _grads(step, 11, nan=False)
+        for p, g in zip(ps, gs):
+            p.grad.copy_(g.cuda())
+        mo.apply_gradients()
+        for i, p in enumerate(ps):
+            mult = float(getattr(p, "lr_multiplier", 1.0))
+            if i < 3:
+                wd = 0.0 if any(k in NAMES[i] for k in ("bias", "gamma", "beta")) else 0.05
+                g = O.clip_gradients([gs[i].double()], clipvalue=0.5)[0]
+                w[i], m[i], v[i] = O.adamw_step(w[i], g, m[i], v[i], step + 1, 1e-2 / (1 + step), mult, wd)
+            else:
+                w[i], m[i] = O.sgd_step(w[i], gs[i].double(), m[i], 0.05, mult, 0.9, 0.0, False)
+            assert (p.data.cpu().double() - w[i]).abs().max().item() <= 3e-6 * max(1.0, w[i].abs().max().item()), (step, NAMES[i])
+            assert torch.equal(p.iseg_compute.cpu(), p.data.cpu().to(torch.bfloat16))
+    assert mo.iterations == 3 and adam.iterations == 3 and sgd.iterations == 3
+    with pytest.raises(ValueError):
+        MultiOptimizer(optimizers_and_layers=[(AdamW(), [ga]), (SGD(), [ga, gb])]).build(store)
+    with pytest.raises(NotImplementedError):
+        MultiOptimizer(optimizers_and_layers=[(AdamW(global_clipnorm=1.0), [ga]), (SGD(), [gb])]).build(store)
+
+
+def test_trainer_takes_a_list_of_optimizers_through_multi_optimizers_layers(cuda):
+    from iseg_amd import heads, nn
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.optimizers.modern import SGD, AdamW
+    from iseg_amd.optimizers.multi_optimizer import MultiOptimizer
+    from iseg_amd.trainer import TrainableModel
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    try:
+        model = heads.convnext_tiny_aspp(build_input_size=(64, 64))
+        opts = [AdamW(learning_rate=1e-3, weight_decay=0.05), SGD(learning_rate=1e-2, momentum=0.9)]
+        with pytest.raises(ValueError):      # the model has not named its layer groups
+            TrainableModel(model, optimizer=list(opts), loss=model.custom_losses(21, 255, 2), loss_weights=model.custom_losses_weights())
+        model.layers_for_multi_optimizers = [[model.backbone], [model.head, model.logits_conv]]
+        tm = TrainableModel(model, optimizer=list(opts), loss=model.custom_losses(21, 255, 2), loss_weights=model.custom_losses_weights(),
+                            metrics=model.custom_metrics(21, 255))
+        assert isinstance(tm.optimizer, MultiOptimizer)
+        owned = sum(len(s["weights"]) for s in tm.optimizer.optimizer_specs)
+        assert owned == len(list(model.parameters())) + len([b for b in model.buffers() if hasattr(b, "iseg_name")])
+        x, y = synthetic_batch(2, 64, 64, seed=5)
+        before = {p.iseg_name: p.data.clone() for p in model.parameters()}
+        losses = [float(tm.train_step(x.cuda(), y.cuda())[0].detach()) for _ in range(6)]
+        assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+        moved = [n for n, b in before.items() if not torch.equal(b, dict((p.iseg_name, p.data) for p in model.parameters())[n])]
+        assert len(moved) == len(before)      # every variable has an owner and was updated
+    finally:
+        nn.set_compute_dtype(torch.float32)
