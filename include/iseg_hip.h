@@ -183,6 +183,19 @@ int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t l
 int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t stream); /* inference: rstd of moving var */
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Exchange step of the data-parallel path: distribution/distribution_utils.py:158-169 all_reduce_values -> ReplicaContext.all_reduce(SUM)
+ * (SyncBN statistics layers/keras3/bn.py:60-117, gradient sums), over RCCL on xGMI.  One process per GPU: rank 0 creates the 128-byte id
+ * and hands it to the other ranks through the host program; every rank then calls iseg_comm_init.  iseg_allreduce_sum works in place and is
+ * stream-ordered.  RCCL is resolved at run time (no link dependency); ISEG_ERR_UNSUPPORTED when it cannot be found.
+ * (The Python host of this repository keeps using torch.distributed, which drives the same RCCL -- iseg_amd/dist.py.)
+ * --------------------------------------------------------------------------------------------------------- */
+typedef void* iseg_comm_t;
+int iseg_comm_unique_id(void* id128);
+int iseg_comm_init(iseg_comm_t* comm, int world_size, int rank, const void* id128);
+int iseg_allreduce_sum(iseg_comm_t comm, void* buf, size_t count, int dtype, iseg_stream_t stream);
+int iseg_comm_destroy(iseg_comm_t comm);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Layout / elementwise
  * --------------------------------------------------------------------------------------------------------- */
 /* Deferred parameter-gradient reductions.  Keras accumulates nothing across ops -- this is a scheduling service of the library: between

@@ -85,6 +85,10 @@ SIGNATURES = {
     "iseg_colsum_workspace_bytes": (_z, [_i, _l, _i]),
     "iseg_colsum": (_i, [_p, _l, _l, _i, _l, _i, _p, _f, _i, _i, _p, _z, _p]),
     "iseg_broadcast_rows": (_i, [_p, _i, _p, _l, _l, _i, _l, _i, _f, _i, _i, _p]),
+    "iseg_comm_unique_id": (_i, [_p]),
+    "iseg_comm_init": (_i, [C.POINTER(C.c_void_p), _i, _i, _p]),
+    "iseg_allreduce_sum": (_i, [_p, _p, _z, _i, _p]),
+    "iseg_comm_destroy": (_i, [_p]),
     "iseg_axpby": (_i, [_p, _p, _p, _f, _f, _l, _i, _p]),
     "iseg_accumulate_pair": (_i, [_p, _i, _p, _p, _p]),
     "iseg_scale_dev": (_i, [_p, _p, _p, _l, _i, _p]),

@@ -122,3 +122,35 @@ def test_rccl_backend_single_rank_collectives_are_identity(cuda):
     for k in plain[3]:
         d = float(abs(plain[3][k] - rccl[3][k]).max())
         assert d <= 1e-5 * max(float(abs(plain[3][k]).max()), 1e-3), (k, d)
+
+
+def test_c_abi_exchange_entry_points_single_rank(cuda):
+    """iseg_comm_unique_id / iseg_comm_init / iseg_allreduce_sum / iseg_comm_destroy (include/iseg_hip.h): RCCL through the C ABI on a world of
+    one rank -- the sum over one rank is the buffer itself, for the fp32 (SyncBN / gradient) and the bf16 message types, in stream order"""
+    import ctypes as C
+
+    from iseg_amd import _hip, kernels as K
+
+    L = _hip.lib()
+    uid = (C.c_char * 128)()
+    _hip.check(L.iseg_comm_unique_id(uid), "iseg_comm_unique_id")
+    assert any(bytes(uid))      # an id was written
+    comm = C.c_void_p()
+    _hip.check(L.iseg_comm_init(C.byref(comm), 1, 0, uid), "iseg_comm_init")
+    assert comm.value
+    try:
+        g = torch.Generator().manual_seed(0)
+        for dtype, code in ((torch.float32, K.F32), (torch.bfloat16, K.BF16)):
+            x = torch.randn(100003, generator=g).to(dtype).cuda()
+            want = x.clone()
+            y = K.axpby(x, None, 2.0, 0.0)      # a kernel of ours in front, on the same stream
+            _hip.check(L.iseg_allreduce_sum(comm, K.ptr(y), y.numel(), code, K.stream()), "iseg_allreduce_sum")
+            z = K.axpby(y, None, 0.5, 0.0)      # ... and one behind
+            torch.cuda.synchronize()
+            assert torch.equal(z, want)
+        assert L.iseg_allreduce_sum(comm, None, 0, K.F32, K.stream()) == 0      # empty message
+        assert L.iseg_allreduce_sum(comm, K.ptr(x), 8, 7, K.stream()) != 0      # unknown dtype is refused
+    finally:
+        _hip.check(L.iseg_comm_destroy(comm), "iseg_comm_destroy")
+    bad = C.c_void_p()
+    assert L.iseg_comm_init(C.byref(bad), 2, 2, uid) != 0      # rank outside the world
