@@ -192,18 +192,30 @@ class HighResolutionFuseModule(Layer):
 
     def call(self, inputs, training=None):
         x_list = list(inputs)
-        for i in range(len(self.fuse_branches)):
-            y = x_list[0] if i == 0 else self.fuse_branches[i][0](x_list[0], training=training)
-            for j in range(1, self.num_branches):
-                x = x_list[j]
+        nb, n_out = self.num_branches, len(self.fuse_branches)
+        sizes = [t.shape[1:3] for t in x_list]
+        # Every list slot has several readers (the fuse rows, and the caller for what is returned): one alias per reader, so that the
+        # readers' gradients are summed by our own kernel (F.fork).  Slot j is read in its input version by rows i <= j and in its fused
+        # version -- written back by row j -- by rows i > j and by the caller.
+        slots = []
+        for j in range(nb):
+            readers = (1 if j == 0 else min(j, n_out - 1) + 1) + (1 if j >= n_out else 0)
+            slots.append(list(F.fork(x_list[j], readers)))
+        for i in range(n_out):
+            y = slots[0].pop() if i == 0 else self.fuse_branches[i][0](slots[0].pop(), training=training)
+            for j in range(1, nb):
+                x = slots[j].pop()
                 if i != j:
                     x = self.fuse_branches[i][j](x, training=training)
                     if j > i:
-                        x = F.resize_bilinear(x, x_list[i].shape[1:3], align_corners=True)
-                last = j == self.num_branches - 1
-                y = F.add_relu(y, x) if last else F.add(y, x)
-            x_list[i] = y      # written back into the list the next branches read (the reference's behaviour, see the module docstring)
-        return x_list
+                        x = F.resize_bilinear(x, sizes[i], align_corners=True)
+                y = F.add_relu(y, x) if j == nb - 1 else F.add(y, x)
+            # written back into the list the next rows read (the reference's behaviour, see the module docstring)
+            assert not slots[i], "fuse bookkeeping: an input alias of this slot was left unread"
+            slots[i] = list(F.fork(y, (n_out - 1 - i) + 1))
+        out = [s.pop() for s in slots]
+        assert not any(slots), "fuse bookkeeping: unread aliases"
+        return out
 
 
 class HighResolutionModule(Layer):
