@@ -357,11 +357,48 @@ class _DWConvFn(Function):
         return dx, None, None, None
 
 
-def depthwise_conv2d(x, W, b=None, dilation=1):
+_DW_STRIDE_TABLES = {}
+
+
+def _dw_stride_tables(N, H, W, s, ke, device):
+    """row tables that pick the stride-s 'same' outputs out of the stride-1 'same' result: TF pads (out-1)*s + ke - H in total, the smaller half
+    in front, so output i sits at stride-1 position i*s + ((ke-1)//2 - pad_front)"""
+    key = (N, H, W, s, ke, str(device))
+    t = _DW_STRIDE_TABLES.get(key)
+    if t is None:
+        def axis(L):
+            out = -(-L // s)
+            front = max((out - 1) * s + ke - L, 0) // 2
+            return out, (ke - 1) // 2 - front
+
+        Ho, oh = axis(H)
+        Wo, ow = axis(W)
+        n = torch.arange(N).view(N, 1, 1)
+        src = (n * H + (torch.arange(Ho) * s + oh).view(1, Ho, 1)) * W + (torch.arange(Wo) * s + ow).view(1, 1, Wo)
+        fwd = src.reshape(-1).to(torch.int32)
+        bwd = torch.full((N * H * W,), -1, dtype=torch.int32)
+        bwd[fwd.long()] = torch.arange(fwd.numel(), dtype=torch.int32)
+        t = _DW_STRIDE_TABLES[key] = (fwd.to(device), bwd.to(device), Ho, Wo)
+    return t
+
+
+def depthwise_conv2d(x, W, b=None, dilation=1, strides=1):
+    """padding='same'.  Stride 1 is the hot path (ConvNeXt 7x7, SepConvBnReLU 3x3 dilated).  A strided layer (the stride-2 depthwise
+    convolutions of the separable / inverted-residual families) is the stride-1 result sampled at TF's 'same' positions by one row gather:
+    exact, s^2 times the arithmetic of a dedicated kernel -- a correctness path until such a family is on a measured configuration."""
     _check_act_dtype(x)
+    s = int(strides)
+    if s == 1:
+        if nn.dry_run():
+            return _dry(x.shape, x)
+        return _DWConvFn.apply(x, W, b, int(dilation))
+    N, H, Wd, C = x.shape
     if nn.dry_run():
-        return _dry(x.shape, x)
-    return _DWConvFn.apply(x, W, b, int(dilation))
+        return _dry((N, -(-H // s), -(-Wd // s), C), x)
+    ke = (W.shape[0] - 1) * int(dilation) + 1
+    fwd, bwd, Ho, Wo = _dw_stride_tables(N, H, Wd, s, ke, x.device)
+    y1 = _DWConvFn.apply(x, W, b, int(dilation))
+    return permute_rows(y1, fwd, bwd, (N, Ho, Wo, C))
 
 
 # ---------------------------------------------------------------------------------------------------------

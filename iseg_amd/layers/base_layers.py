@@ -112,12 +112,13 @@ class DepthwiseConv2D(Layer):
         self.built = True
 
     def call(self, inputs, training=None):
-        if _pair(self.strides) != (1, 1) or self.padding != "same" or self.kernel_size[0] != self.kernel_size[1]:
-            raise NotImplementedError("DepthwiseConv2D: only square kernels, stride 1, padding='same' are on the hot path")
+        st = _pair(self.strides)
+        if st[0] != st[1] or self.padding != "same" or self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] % 2 == 0:
+            raise NotImplementedError("DepthwiseConv2D: odd square kernels, isotropic strides and padding='same' only")
         d = _pair(self.dilation_rate)
         if d[0] != d[1]:
             raise NotImplementedError("DepthwiseConv2D: anisotropic dilation")
-        return F.depthwise_conv2d(inputs, self.depthwise_kernel, self.bias, d[0])
+        return F.depthwise_conv2d(inputs, self.depthwise_kernel, self.bias, d[0], strides=st[0])
 
 
 class LayerNormalization(Layer):

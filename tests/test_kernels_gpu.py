@@ -489,3 +489,42 @@ def test_gemm_dma_pipeline_strided_batch(cuda):
     qh = qr[:, :, :C].reshape(Bz, T, H, d).permute(0, 2, 1, 3)
     kh = qr[:, :, C:].reshape(Bz, T, H, d).permute(0, 2, 1, 3)
     close(P.reshape(Bz, H, T, T), 0.125 * (qh @ kh.transpose(-1, -2)), dt, "batched q k^T")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,k,s,dil", [((2, 16, 16, 32), 3, 2, 1), ((1, 15, 9, 16), 3, 2, 1), ((2, 12, 13, 8), 5, 2, 1), ((1, 17, 17, 24), 3, 3, 1),
+                                           ((2, 16, 10, 16), 3, 2, 2)])
+def test_strided_depthwise_conv_matches_oracle(cuda, dtype, shape, k, s, dil):
+    """keras DepthwiseConv2D(strides=s, padding="same") (the separable / inverted-residual families): TF's 'same' positions for even and odd
+    sizes, forward and both gradients"""
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+
+    nn.set_compute_dtype(dtype)
+    try:
+        g = torch.Generator().manual_seed(sum(shape) + 7 * k + s)
+        N, H, W, C = shape
+        x = torch.randn(shape, generator=g).to(dtype)
+        w = torch.randn(k, k, C, 1, generator=g) / k
+        b = torch.randn(C, generator=g) * 0.1
+        wp = torch.nn.Parameter(w.clone().cuda())
+        bp = torch.nn.Parameter(b.clone().cuda())
+        if dtype == torch.bfloat16:
+            wp.iseg_compute, bp.iseg_compute = None, None
+        xg = x.cuda().requires_grad_(True)
+        y = F.depthwise_conv2d(xg, wp, bp, dil, strides=s)
+        xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+        yr = O.depthwise_conv2d(xr, wr, br, s, dil, "same")
+        assert tuple(y.shape) == tuple(yr.shape)
+        dy = torch.randn(yr.shape, generator=g).to(dtype)
+        y.backward(dy.cuda())
+        yr.backward(dy.double())
+        tol = 1e-5 if dtype == torch.float32 else 2e-2
+
+        def rel(a, b_):
+            return (a.detach().cpu().double() - b_).abs().max().item() / max(b_.abs().max().item(), 1e-8)
+
+        assert rel(y, yr.detach()) < tol
+        assert rel(xg.grad, xr.grad) < tol and rel(wp.grad, wr.grad) < 2 * tol and rel(bp.grad, br.grad) < 2 * tol
+    finally:
+        nn.set_compute_dtype(torch.float32)
