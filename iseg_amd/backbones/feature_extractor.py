@@ -8,6 +8,7 @@ from .backbone_registry import backbone_registry_dict
 from .convnext import build_dilated_convnext, convnext_large, convnext_tiny, convnext_xlarge, convnext_xxlarge
 from .convnext_v2 import convnext_v2_huge, convnext_v2_large, convnext_v2_nano, convnext_v2_tiny
 from .hrnet import HRNetW32, HRNetW48
+from .mobilenetv2_common import MobileNetV2, build_atrous_mobilenetv2
 from .resnet_common import apply_multi_grid, build_atrous_resnet, resnet50, resnet101, resnet152
 
 
@@ -21,6 +22,7 @@ def _builtin_backbones():
         ss.CONVNEXT_V2_TINY: convnext_v2_tiny,
         ss.CONVNEXT_V2_LARGE: convnext_v2_large,
         ss.CONVNEXT_V2_HUGE: convnext_v2_huge,
+        ss.MOBILENETV2: MobileNetV2,
         ss.HRNET_W48: HRNetW48,
         ss.HRNET_W32: HRNetW32,
         ss.RESNET50: resnet50,
@@ -58,6 +60,8 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
     if ss.RESNET in name:
         build_atrous_resnet(backbone, output_stride=output_stride)
         apply_multi_grid(backbone, block_index=-1, grids=resnet_multi_grids)
+    elif name == ss.MOBILENETV2:
+        build_atrous_mobilenetv2(backbone, output_stride=output_stride)
     elif ss.CONVNEXT in name:
         build_dilated_convnext(backbone, output_stride=output_stride)
     # build by shape propagation (the reference runs backbone(tf.ones(image_shape)), :153-164)

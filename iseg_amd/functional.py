@@ -618,6 +618,28 @@ def gelu(x):
     return _ActFn.apply(x, K.ACT_GELU)
 
 
+class _Relu6Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        xc = _c(x)
+        ctx.save_for_backward(xc)
+        return K.clip_fwd(xc, 0.0, 6.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        return K.clip_bwd(xc, _c(dy), 0.0, 6.0)
+
+
+def relu6(x):
+    """tf.nn.relu6 (backbones/mobilenetv2_common.py:50,61,161,168) = clip to [0, 6]; the gradient passes inside the interval (TF's Relu6Grad is
+    strict at the two end points, the clip gradient is not: a difference on a set of measure zero)"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _Relu6Fn.apply(x)
+
+
 class _AddFn(Function):
     @staticmethod
     def forward(ctx, a, b):

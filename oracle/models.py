@@ -598,3 +598,53 @@ def hrnet_forward(w, x, stages, training=False, new_stats=None):
     size = x_list[0].shape[1:3]
     y = torch.cat([x_list[0]] + [O.resize_bilinear(t, size, align_corners=True) for t in x_list[1:]], dim=-1)
     return x_list + [y]
+
+
+# ------------------------------------------------------------------------------------------------------
+# MobileNetV2 (backbones/mobilenetv2_common.py): stride-2 blocks are restated literally -- ZeroPadding2D(correct_pad) followed by the
+# depthwise convolution with padding "valid" (:114-176) -- so that the product's 'same' stride-2 shortcut is checked against it.
+# ------------------------------------------------------------------------------------------------------
+MOBILENETV2_BLOCKS = [(16, 1, 1, 1), (24, 2, 6, 2), (32, 2, 6, 3), (64, 2, 6, 4), (96, 1, 6, 3), (160, 2, 6, 3), (320, 1, 6, 1)]      # filters, stride, expansion, repeats
+
+
+def mobilenetv2_forward(w, x, output_stride=32, training=False, new_stats=None):
+    """returns the endpoint list of MobileNetV2.call(return_endpoints=True) after build_atrous_mobilenetv2(output_stride)"""
+    def bn(name, y):
+        return _bn(w, name, y, training, 1e-3, new_stats=new_stats)
+
+    relu6 = lambda t: torch.clamp(t, 0.0, 6.0)      # noqa: E731
+    x = relu6(bn("bn_Conv1", O.conv2d(x, w["Conv1/kernel"], None, 2, 1, "same")))
+    endpoints = []
+    block_id, current_os, rate = 0, 2, 1
+    for filters, stride0, expansion, repeats in MOBILENETV2_BLOCKS:
+        for r in range(repeats):
+            original_stride = stride0 if r == 0 else 1
+            stride, dil = original_stride, 1
+            if original_stride > 1:      # build_atrous_mobilenetv2 :204-222
+                if current_os >= output_stride:
+                    rate *= original_stride
+                    stride, dil = 1, rate
+                else:
+                    current_os *= original_stride
+            else:
+                dil = rate
+            prefix = f"block_{block_id}_" if block_id else "expanded_conv_"
+            if original_stride > 1:
+                endpoints.append(x)
+            inp = x
+            y = x
+            if block_id:
+                y = relu6(bn(f"{prefix}expand_BN", O.conv2d(y, w[f"{prefix}expand/kernel"], None, 1, 1, "same")))
+            if stride == 2:
+                H, W = y.shape[1], y.shape[2]
+                pt, pl = 1 - (1 - H % 2), 1 - (1 - W % 2)      # correct_pad(., 3): (1 - adjust, 1) per axis
+                y = torch.nn.functional.pad(y, (0, 0, pl, 1, pt, 1))
+                y = O.depthwise_conv2d(y, w[f"{prefix}depthwise/depthwise_kernel"], None, 2, 1, "valid")
+            else:
+                y = O.depthwise_conv2d(y, w[f"{prefix}depthwise/depthwise_kernel"], None, 1, dil, "same")
+            y = relu6(bn(f"{prefix}depthwise_BN", y))
+            y = bn(f"{prefix}project_BN", O.conv2d(y, w[f"{prefix}project/kernel"], None, 1, 1, "same"))
+            x = inp + y if (inp.shape[-1] == y.shape[-1] and original_stride == 1) else y
+            block_id += 1
+    x = relu6(bn("Conv_1_bn", O.conv2d(x, w["Conv_1/kernel"], None, 1, 1, "same")))
+    return endpoints + [x]

@@ -332,3 +332,23 @@ def test_hrnet_registry_and_weight_names():
     total = sum(int(np.prod(s)) for s in shapes.values())
     assert 6.4e7 < total < 6.7e7      # HRNet-W48 backbone: ~65 M parameters
     assert len(bb.stages) == 3 and [len(s.modules_list) for s in bb.stages] == [1, 4, 3]
+
+
+def test_mobilenetv2_names_count_and_atrous_surgery():
+    """backbones/mobilenetv2_common.py: 2 223 872 trainable parameters at alpha = 1 (Keras' published count without the top), the Keras weight
+    names, and build_atrous_mobilenetv2's stride / rate edits (:204-222)"""
+    import numpy as np
+
+    from iseg_amd.backbones.feature_extractor import get_backbone
+    from iseg_amd.backbones.mobilenetv2_common import _make_divisible, correct_pad
+
+    bb = get_backbone("mobilenetv2", output_stride=8, return_endpoints=True, image_shape=(1, 64, 64, 3))
+    shapes = {p.iseg_name: tuple(p.shape) for p in bb.parameters()}
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 2223872
+    assert shapes["Conv1/kernel"] == (3, 3, 3, 32) and shapes["expanded_conv_depthwise/depthwise_kernel"] == (3, 3, 32, 1)
+    assert "expanded_conv_expand/kernel" not in shapes and shapes["block_1_expand/kernel"] == (1, 1, 16, 96)
+    assert shapes["block_16_project/kernel"] == (1, 1, 960, 320) and shapes["Conv_1/kernel"] == (1, 1, 320, 1280)
+    sr = [(b.strides, b.atrous_rates) for b in bb.blocks]
+    assert sr[1] == (2, 1) and sr[3] == (2, 1) and sr[6] == (1, 2) and sr[7] == (1, 2) and sr[13] == (1, 4) and sr[16] == (1, 4)
+    assert _make_divisible(32 * 0.35, 8) == 16 and _make_divisible(24 * 1.4, 8) == 32
+    assert correct_pad((None, 64, 63, 8), 3) == ((0, 1), (1, 1))
