@@ -557,6 +557,24 @@ int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1,
                           iseg_stream_t stream);
 int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled, const float* b1, void* g, void* dh, void* dy2,
                           int64_t M, int C, int dtype, iseg_stream_t stream);
+/* The same block's backward pass with NO [M, 4C] tensor in HBM (round 3; the training path uses this pair):
+ *   iseg_convnext_mlp_bwd_data  dy2 [M, C] only; dbr = rowscale[m / rows_per_group] * dout is formed while the rows are loaded
+ *                               (rowscale may be NULL)
+ *   iseg_convnext_mlp_wgrad     every parameter gradient of backbones/convnext.py:51-57 (pwconv1, pwconv2, gamma), ACCUMULATED into
+ *                               dW1 [C, 4C], db1 [4C], dW2 [4C, C], db2 [C], dgamma [C]: workgroups own 128 hidden units and a chunk of
+ *                               rows, recompute gelu(h) / dh for them and contract over the rows on the matrix cores; partial sums per
+ *                               row chunk in `ws` (iseg_convnext_mlp_wgrad_workspace_bytes), summed in chunk order by a second launch
+ *                               (deterministic).  With gamma: dW2 += (g^T dbr) gamma, dgamma += sum_k W2 o (g^T dbr) + b2 S,
+ *                               db2 += gamma S with S = column sums of dbr; gamma == NULL: dW2 += g^T dbr, db2 += S.  W2 / b2 / gamma
+ *                               are the fp32 masters.  mean != NULL: `y` is the LayerNorm INPUT y1 and y2 = (y1 - mean) rstd ln_gamma +
+ *                               ln_beta is formed while the rows are staged.  rowscale needs rows_per_group % 64 == 0. */
+int iseg_convnext_mlp_bwd_data(const void* y2, const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
+                               const float* b1, void* dy2, int64_t M, int C, int dtype, iseg_stream_t stream);
+size_t iseg_convnext_mlp_wgrad_workspace_bytes(int64_t M, int C);
+int iseg_convnext_mlp_wgrad(const void* y, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
+                            const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled, const float* b1,
+                            const float* W2, const float* b2, const float* gamma, float* dW1, float* db1, float* dW2, float* db2,
+                            float* dgamma, int64_t M, int C, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 #ifdef __cplusplus
 }

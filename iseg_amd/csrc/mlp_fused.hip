@@ -275,14 +275,18 @@ __device__ __forceinline__ void acc_to_row_pieces(const float* v, uint4& p0, uin
     p1 = make_uint4(d[4], d[5], d[6], d[7]);
 }
 
-template <int C, int SUB, int WAVES, int NSTAGES>
+// STORE = false: the data-gradient chain only (dy2); G and dH never leave the CU -- the weight gradients come from mlp_wgrad.hip, which
+// recomputes the hidden tile per hidden-unit slice.  `rowscale` (drop-path factor per group of rows_per_group rows) turns D = d(out) into
+// dbr while the rows are loaded.
+template <int C, int SUB, int WAVES, int NSTAGES, bool STORE>
 __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ D,
+                                                                      const float* __restrict__ rowscale, int64_t rows_per_group,
                                                                       const void* __restrict__ BW, const float* __restrict__ b1,
                                                                       bf16_t* __restrict__ Gout, bf16_t* __restrict__ DHout,
                                                                       bf16_t* __restrict__ DY, int64_t M) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
     constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
-    constexpr int STORES = 4 * SUB;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
+    constexpr int STORES = STORE ? 4 * SUB : 0;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float* const b1s = reinterpret_cast<float*>(smem + G::RING);
 
@@ -301,6 +305,13 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
         for (int kk = 0; kk < KK; ++kk) {
             yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
             df[kk] = *reinterpret_cast<const bf16x8*>(dp + 16 * kk);
+        }
+        if (rowscale) {
+            const float rs = rowscale[row / rows_per_group];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) df[kk][u] = (bf16_t)((float)df[kk][u] * rs);
         }
     }
     for (int i = tid; i < HID; i += 64 * WAVES) b1s[i] = b1[i];
@@ -377,15 +388,17 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(take(f0 + 2 * KK + 2 * cb + s), hf[s], acc[cb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            uint4 g0, g1, d0, d1;
-            acc_to_row_pieces(gv, g0, g1);
-            acc_to_row_pieces(dv, d0, d1);
-            if (row_ok) {
-                const int64_t o = row_o + 32 * (kt * SUB + sub);
-                *reinterpret_cast<uint4*>(Gout + o) = g0;
-                *reinterpret_cast<uint4*>(Gout + o + 16) = g1;
-                *reinterpret_cast<uint4*>(DHout + o) = d0;
-                *reinterpret_cast<uint4*>(DHout + o + 16) = d1;
+            if (STORE) {
+                uint4 g0, g1, d0, d1;
+                acc_to_row_pieces(gv, g0, g1);
+                acc_to_row_pieces(dv, d0, d1);
+                if (row_ok) {
+                    const int64_t o = row_o + 32 * (kt * SUB + sub);
+                    *reinterpret_cast<uint4*>(Gout + o) = g0;
+                    *reinterpret_cast<uint4*>(Gout + o + 16) = g1;
+                    *reinterpret_cast<uint4*>(DHout + o) = d0;
+                    *reinterpret_cast<uint4*>(DHout + o + 16) = d1;
+                }
             }
         }
     };
@@ -494,17 +507,18 @@ int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float*
     return iseg_check_launch("iseg_convnext_mlp_fwd");
 }
 
-template <int C, int SUB, int WAVES, int NSTAGES>
-int launch_mlp_bwd(const void* y2, const void* dbr, const void* BW, const float* b1, void* g, void* dh, void* dy2, int64_t M, hipStream_t s) {
+template <int C, int SUB, int WAVES, int NSTAGES, bool STORE>
+int launch_mlp_bwd(const void* y2, const void* dbr, const float* rowscale, int64_t rows_per_group, const void* BW, const float* b1, void* g,
+                   void* dh, void* dy2, int64_t M, hipStream_t s) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
     static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
     }();
     (void)raised;
     const int grid = (int)ceil_div64(M, 32 * WAVES);
-    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, (const bf16_t*)dbr, BW, b1,
-                       (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M);
+    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2,
+                       (const bf16_t*)dbr, rowscale, rows_per_group, BW, b1, (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M);
     return iseg_check_launch("iseg_convnext_mlp_bwd");
 }
 
@@ -549,7 +563,18 @@ extern "C" int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void
     ISEG_REQUIRE(y2 && dbr && bw_tiled && b1 && g && dh && dy2 && M > 0, "iseg_convnext_mlp_bwd: null operand or empty problem");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dbr | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)g | (uintptr_t)dh | (uintptr_t)dy2) & 15) == 0,
                  "iseg_convnext_mlp_bwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
-    if (C == 192) return launch_mlp_bwd<192, 1, 4, 3>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);
-    return launch_mlp_bwd<384, 1, 4, 2>(y2, dbr, bw_tiled, b1, g, dh, dy2, M, stream);      // 72-KiB slabs: a two-stage ring is what fits
+    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);
+    if (C == 192) return launch_mlp_bwd<192, 1, 4, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);
+    return launch_mlp_bwd<384, 1, 4, 2, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);      // 72-KiB slabs: a two-stage ring is what fits
+}
+
+extern "C" int iseg_convnext_mlp_bwd_data(const void* y2, const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
+                                          const float* b1, void* dy2, int64_t M, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dtype == ISEG_BF16 && (C == 96 || C == 192), "iseg_convnext_mlp_bwd_data: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(y2 && dout && bw_tiled && b1 && dy2 && M > 0, "iseg_convnext_mlp_bwd_data: null operand or empty problem");
+    ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_bwd_data: rowscale needs rows_per_group > 0");
+    ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dout | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)dy2) & 15) == 0,
+                 "iseg_convnext_mlp_bwd_data: operands must be 16-byte aligned");
+    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, stream);
+    return launch_mlp_bwd<192, 1, 4, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, stream);
 }

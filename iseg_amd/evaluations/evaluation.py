@@ -5,7 +5,7 @@ import torch
 from .. import dist, nn
 from ..core_model import SegFoundation
 from ..losses.catecrossentropy_ignore_label import catecrossentropy_ignore_label_loss
-from ..metrics.mean_iou import MeanIOU
+from ..metrics.mean_iou import MeanIOU, per_class_miou_to_mean_miou
 from ..metrics.seg_metric_wrapper import SegMetricWrapper
 
 
@@ -21,7 +21,12 @@ class _Mean:
         self.total = self.total + v.sum().reshape(1)
         self.count += v.numel()
 
+    def local_result(self):
+        """this rank's running mean, no exchange (progress lines)"""
+        return float(self.total) / max(float(self.count), 1.0)
+
     def result(self):
+        """COLLECTIVE: every rank must call it the same number of times"""
         t = torch.cat([self.total.to(nn.device()), torch.tensor([float(self.count)], device=nn.device())])
         dist.all_reduce_sum(t)
         return float(t[0]) / max(float(t[1]), 1.0)
@@ -67,17 +72,21 @@ def evaluate(distribute_strategy, model, data, batch_size, num_class, ignore_lab
             eval_step(inputs, model, scale_rates, flip, loss_func, loss_metrics, [iou_metrics], distribute_strategy)
             processed_count += int(inputs[0].shape[0])
             if verbose and dist.rank() == 0:
-                print("Processed : {:}, current loss = {:4f}, current IOU = {:.2f} %".format(processed_count, loss_metrics.result(),
-                                                                                            float(iou_metrics.result()) * 100))
+                # the progress line shows THIS rank's running values: ranks may hold different batch counts after ds.shard, so nothing
+                # inside the loop may be a collective (the reference prints the replica-merged value; the final figures below are merged)
+                print("Processed : {:}, current loss = {:4f}, current IOU = {:.2f} %".format(processed_count, loss_metrics.local_result(),
+                                                                                            float(iou_metrics.metric.local_result()) * 100))
+        # collectives: entered by every rank, once each, in this order
         mean_loss = loss_metrics.result()
-        mean_iou = iou_metrics.result()
+        per_class = iou_metrics.metric.per_class_result()
+        mean_iou = per_class_miou_to_mean_miou(*per_class)
         if dist.rank() == 0:
             print("-----------------------------------------------")
             print(f"Mean loss on val set : {mean_loss}")
             print(f"Mean IoU on val set : {float(mean_iou)}")
             print("-----------------------------------------------")
             print("Per-class IoU on val set :")
-            print(iou_metrics.metric.per_class_result())
+            print(per_class)
         evaluate.last_mean_loss = mean_loss
         loss_metrics.reset_state()
         iou_metrics.reset_states()

@@ -896,6 +896,9 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 # ConvNeXt block, fused:  x + drop_path(gamma * pw2(gelu(pw1(LN(dw7x7(x))))))     backbones/convnext.py:47-63
 # ---------------------------------------------------------------------------------------------------------
+_MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
+
+
 class _ConvNeXtBlockFn(Function):
     @staticmethod
     def forward(ctx, x, dw_kernel, dw_bias, ln_gamma, ln_beta, w1, b1, w2, b2, gamma, dil, eps, dp_mask):
@@ -950,13 +953,40 @@ class _ConvNeXtBlockFn(Function):
         M = N * H * W
         Kk = p.dw_kernel.shape[0]
         do2 = _c(dout).reshape(M, C)
+        cdt = xc.dtype
+        side = _SideQueue(xc.device)
+        if ctx.fused and _MLP_BWD_NO_HIDDEN and (dp_mask is None or (H * W) % 64 == 0):
+            # round 3: nothing [M, 4C]-shaped reaches HBM in the backward pass either.  One kernel carries the data gradient through the
+            # recomputed hidden tile; a second one (workgroups own 128 hidden units and a chunk of rows) recomputes it again and contracts
+            # over the rows for every parameter gradient of the MLP; the drop-path row factor and the column sums of dbr ride both
+            # (csrc/mlp_wgrad.hip) -- replaces rowscale + colsum + chain + two weight-gradient GEMMs + their split-K sums + layerscale_grads
+            bw = h
+            dy2 = K.convnext_mlp_bwd_data(y2, do2, bw, p.b1.data, dp_mask, H * W)
+            K.convnext_mlp_wgrad(y2, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None, _grad(p.w1),
+                                 _grad(p.b1), _grad(p.w2), _grad(p.b2), _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W)
+            del h, bw
+        else:
+            dy2 = _ConvNeXtBlockFn._mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc)
+            del h, g
+        dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
+        dy1 = dy1.reshape(N, H, W, C)
+        side.run(lambda: K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad), xc, dy1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            padb = (Kk - 1) * dil - pad
+            dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
+        side.join()
+        dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma)
+        return (dx,) + (None,) * 12
+
+    @staticmethod
+    def _mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc):
+        """the round-2 route: g / dh materialised ([M, 4C] each), two weight-gradient GEMMs; still the path of the un-fused stages (C >= 384)"""
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
         S = torch.empty(C, dtype=torch.float32, device=xc.device)      # column sums of dbr (layer-scale and bias gradients)
         s_on_gemm = p.gamma is not None and (ctx.fused or g is not None) and xc.dtype == torch.bfloat16 and 4 * C >= 768      # rides Z = g^T dbr below
         if not s_on_gemm:
             K.colsum(dbr, C, 0, 1, M, C, S)
-        cdt = xc.dtype
-        side = _SideQueue(xc.device)
         dy2 = None
         if ctx.fused:
             # h is the tiled weight buffer here: g = gelu(pre), dh = (dbr @ (W2 gamma)^T) * gelu'(pre), dy2 = dh @ W1^T in one launch
@@ -980,17 +1010,7 @@ class _ConvNeXtBlockFn(Function):
         side.run(param_grads, dbr, g, dh, y2)
         if not ctx.fused:
             dy2 = K.dense_dgrad(dh, nn.w(p.w1))                                # [M,C]
-        del g, dh
-        dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
-        dy1 = dy1.reshape(N, H, W, C)
-        side.run(lambda: K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad), xc, dy1)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            padb = (Kk - 1) * dil - pad
-            dx = K.dwconv2d(dy1, p.dw_kernel.data.reshape(Kk * Kk, C), None, Kk, dil, padb, padb, flip=True, add=_c(dout))
-        side.join()
-        dist.grads_ready(p.dw_kernel, p.dw_bias, p.ln_gamma, p.ln_beta, p.w1, p.b1, p.w2, p.b2, p.gamma)
-        return (dx,) + (None,) * 12
+        return dy2
 
 
 _GRN_FOLD_RATIO = int(os.environ.get("ISEG_V2_GRN_FOLD_RATIO", "1"))      # experiments: fold from HW * ratio >= 2 * (4C) on

@@ -257,6 +257,29 @@ def convnext_mlp_bwd(y2, dbr, bw_tiled, b1):
     return g, dh, dy2
 
 
+def convnext_mlp_bwd_data(y2, dout, bw_tiled, b1, rowscale=None, rows_per_group=0):
+    """dy2 = ((rowscale * dout) @ (W2 gamma)^T * gelu'(h)) @ W1^T with the hidden tile recomputed and kept on the CU (nothing [M, 4C] is written)"""
+    _require_cuda(y2, dout, bw_tiled)
+    M, Cc = y2.shape
+    dy2 = torch.empty((M, Cc), dtype=y2.dtype, device=y2.device)
+    _hip.call("iseg_convnext_mlp_bwd_data", ptr(y2), ptr(dout), ptr(rowscale), int(rows_per_group), ptr(bw_tiled), ptr(b1), ptr(dy2), M, Cc,
+              dt(y2), stream())
+    return dy2
+
+
+def convnext_mlp_wgrad(y, dout, bw_tiled, b1, W2, b2, gamma, dW1, db1, dW2, db2, dgamma, rowscale=None, rows_per_group=0, ln=None):
+    """all parameter gradients of the fused MLP accumulated into dW1 / db1 / dW2 / db2 / dgamma (csrc/mlp_wgrad.hip); ln = (mean, rstd,
+    ln_gamma, ln_beta) makes `y` the LayerNorm input"""
+    _require_cuda(y, dout, bw_tiled)
+    M, Cc = y.shape
+    need = _hip.lib().iseg_convnext_mlp_wgrad_workspace_bytes(M, Cc)
+    ws, wsb = workspace(need, y.device)
+    mean, rstd, lng, lnb = ln if ln is not None else (None, None, None, None)
+    _hip.call("iseg_convnext_mlp_wgrad", ptr(y), ptr(mean), ptr(rstd), ptr(lng), ptr(lnb), ptr(dout), ptr(rowscale), int(rows_per_group),
+              ptr(bw_tiled), ptr(b1), ptr(W2), ptr(b2), ptr(gamma), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dgamma), M, Cc, dt(y), ptr(ws),
+              wsb, stream())
+
+
 def layernorm_fwd(x2d, gamma, beta, eps, save_stats=True):
     _require_cuda(x2d)
     rows, Cc = x2d.shape

@@ -44,5 +44,10 @@ class MeanIOU:
         iou, n = self.per_class_result()
         return per_class_miou_to_mean_miou(iou, n)
 
+    def local_result(self):
+        """mean IoU of THIS replica's counts only -- no collective, safe to call from one rank (progress lines)"""
+        iou, n = get_per_class_miou(self.total_cm.reshape(self.num_classes, self.num_classes).cpu())
+        return per_class_miou_to_mean_miou(iou, n)
+
     def reset_states(self):
         self.total_cm.zero_()

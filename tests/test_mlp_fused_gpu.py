@@ -130,3 +130,92 @@ def test_convnext_mlp_prep_images(cuda):
             a4 = bw[slab, 2].reshape(C // 32, 2, 32, 16)[:, s_]
             want4 = W1.to(bf).float()[:, hid].reshape(C // 32, 32, 16)
             assert torch.equal(a4, want4)
+
+
+def _bwd_reference(y2b, doutb, rs_rows, W1, b1, W2, b2, gamma):
+    """fp64 restatement of the block's backward pass on the bf16-rounded operands the kernels see (hidden tile rounded to bf16 where the
+    kernels round it): dy2 and every parameter gradient of backbones/convnext.py:51-57"""
+    bf = torch.bfloat16
+    W1b = W1.to(bf).double()
+    W2e = ((W2 * gamma) if gamma is not None else W2).to(bf).double()
+    dbr = doutb.double()
+    if rs_rows is not None:
+        dbr = (doutb.float() * rs_rows[:, None]).to(bf).double()
+    h = (y2b.double() @ W1b + b1.double()).requires_grad_(True)
+    gr = O.gelu(h)
+    (dgelu,) = torch.autograd.grad(gr.sum(), h)
+    g = gr.detach().to(bf).double()
+    dh = ((dbr @ W2e.t()) * dgelu).to(bf).double()
+    dy2 = dh @ W1b.t()
+    Z = g.t() @ dbr
+    S = dbr.sum(0)
+    out = {"dy2": dy2, "dW1": y2b.double().t() @ dh, "db1": dh.sum(0)}
+    if gamma is not None:
+        out.update(dW2=Z * gamma.double(), dgamma=(W2.double() * Z).sum(0) + b2.double() * S, db2=gamma.double() * S)
+    else:
+        out.update(dW2=Z, db2=S)
+    return out
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M,groups,use_gamma", [(256, 1, True), (1024, 4, True), (4096 + 37, 0, False), (33, 0, True), (64 * 300, 5, True)])
+def test_convnext_mlp_bwd_without_hidden_tensors_matches_oracle(cuda, C, M, groups, use_gamma):
+    """iseg_convnext_mlp_bwd_data + iseg_convnext_mlp_wgrad (nothing [M, 4C]-shaped in HBM) against fp64 autograd; gradients accumulate
+    into their buffers; a second run reproduces the first bit for bit (fixed summation order)"""
+    from iseg_amd import kernels as K
+
+    y2, dout, W1, b1, W2, b2, gamma = _inputs(M, C, 77 + C + M)
+    if not use_gamma:
+        gamma = None
+    bf = torch.bfloat16
+    y2b, doutb = y2.to(bf), dout.to(bf)
+    rpg = M // groups if groups else 0
+    rs = (torch.arange(groups, dtype=torch.float32) * 0.5 + 0.25) if groups else None
+    rs_rows = rs[torch.arange(M) // rpg] if groups else None
+    dev = lambda t: None if t is None else t.cuda()
+    _, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), dev(gamma), backward=True)
+    ref = _bwd_reference(y2b, doutb, rs_rows, W1, b1, W2, b2, gamma)
+
+    def run():
+        grads = {k: torch.full(shape, 0.5, dtype=torch.float32, device="cuda") for k, shape in
+                 (("dW1", (C, 4 * C)), ("db1", (4 * C,)), ("dW2", (4 * C, C)), ("db2", (C,)), ("dgamma", (C,)))}
+        dy2 = K.convnext_mlp_bwd_data(y2b.cuda(), doutb.cuda(), bw, b1.cuda(), dev(rs), rpg)
+        K.convnext_mlp_wgrad(y2b.cuda(), doutb.cuda(), bw, b1.cuda(), W2.cuda(), b2.cuda(), dev(gamma), grads["dW1"], grads["db1"], grads["dW2"],
+                             grads["db2"], grads["dgamma"] if use_gamma else None, dev(rs), rpg)
+        return dy2, grads
+
+    dy2, grads = run()
+
+    def rel(a, b):
+        return (a.cpu().double() - b).abs().max().item() / max(b.abs().max().item(), 1e-8)
+
+    assert rel(dy2, ref["dy2"]) < 1.5e-2, rel(dy2, ref["dy2"])
+    for k in ("dW1", "db1", "dW2", "db2") + (("dgamma",) if use_gamma else ()):
+        got = grads[k].cpu().double() - 0.5      # the kernels accumulate into what was there
+        err = (got - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-8)
+        assert err < 6e-3, (k, err)
+    dy2b, grads2 = run()
+    assert torch.equal(dy2, dy2b)
+    for k in grads:
+        assert torch.equal(grads[k], grads2[k]), k
+
+
+def test_convnext_mlp_wgrad_layernorm_on_load(cuda):
+    """mean != NULL: the y operand is LayerNorm(y1) formed while the rows are staged -- same gradients as with y2 materialised"""
+    from iseg_amd import kernels as K
+
+    C, M = 96, 2048 + 64
+    y1, dout, W1, b1, W2, b2, gamma = _inputs(M, C, 901)
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    lng, lnb = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    y1b = y1.to(bf).cuda()
+    y2, mean, rstd = K.layernorm_fwd(y1b, lng.cuda(), lnb.cuda(), 1e-6)
+    _, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda(), backward=True)
+    res = []
+    for ln in (None, (mean, rstd, lng.cuda(), lnb.cuda())):
+        grads = [torch.zeros(s, dtype=torch.float32, device="cuda") for s in ((C, 4 * C), (4 * C,), (4 * C, C), (C,), (C,))]
+        K.convnext_mlp_wgrad(y2 if ln is None else y1b, dout.to(bf).cuda(), bw, b1.cuda(), W2.cuda(), b2.cuda(), gamma.cuda(), *grads, ln=ln)
+        res.append(grads)
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-3 * max(a.abs().max().item(), 1e-6)
