@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 storage (parity mode); the headline number is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph-step", action="store_true", help="replay the training step from one HIP graph (single GPU; no per-launch roofline timer)")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous + one all-reduce only (gloo when there is no GPU): tests the --gpus N self-launch path on CPU")
     return ap.parse_args()
@@ -286,7 +287,7 @@ def main():
     # Roofline: the last warm-up step times every GEMM launch with HIP events on the launch stream to find the dominant
     # (template, shape) group; the timed region then brackets only that group's launches (a few event pairs per step), so
     # the headline throughput is not taxed by ~300 event records per step.
-    want_roofline = rank == 0 and not args.no_roofline
+    want_roofline = rank == 0 and not args.no_roofline and not args.graph_step
     survey = None
     for i in range(args.warmup):
         if want_roofline and i == args.warmup - 1:
@@ -305,11 +306,19 @@ def main():
         # few microseconds, and 19 pairs per step had taxed the headline by 2.5 %
         timer = K.KernelTimer(only=dominant, every=4)
         K.KERNEL_TIMER[0] = timer
+    step_fn = trainer.train_step
+    if args.graph_step:
+        # the whole step replayed from one HIP graph (iseg_amd/graphs.py): capture happens here, outside the timed region
+        from iseg_amd.graphs import GraphedTrainStep
+
+        step_fn = GraphedTrainStep(trainer, warmup=0)
+        step_fn(x, y)
+        step_fn(x, y)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = trainer.train_step(x, y)
+        losses = step_fn(x, y)
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0

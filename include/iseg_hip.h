@@ -234,12 +234,14 @@ int iseg_accumulate_pair(const float* src, int n, float* dst0, float* dst1, iseg
 int iseg_scale_dev(const void* x, const float* s_dev, void* y, int64_t n, int dtype, iseg_stream_t stream);
 int iseg_rowscale(const void* x, const float* s, void* y, int64_t rows, int C, int64_t rows_per_group, int dtype,
                   iseg_stream_t stream);
-/* keras.layers.Dropout: y = x*mask/(1-rate); mask = f(seed, index) so backward = same call on dy */
-int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, int dtype, iseg_stream_t stream);
+/* keras.layers.Dropout: y = x*mask/(1-rate); mask = f(seed, index) so backward = same call on dy.
+ * seed_offset (device pointer, may be NULL) is added to `seed` by the kernel: a training step replayed from a HIP graph has frozen launch
+ * arguments, so its draw counter lives in device memory (iseg_amd/graphs.py); same meaning in the two drop-path entry points. */
+int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, const uint64_t* seed_offset, int dtype, iseg_stream_t stream);
 /* utils/drops.py:14-20: s[n] = floor(keep + u_n)/keep */
-int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, iseg_stream_t stream);
+int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, const uint64_t* seed_offset, iseg_stream_t stream);
 /* P masks of n samples each in one launch (s [P, n], keep_probs [P] on the device): the drop_path call sites of one training step */
-int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, iseg_stream_t stream);
+int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, const uint64_t* seed_offset, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
 /* keras.activations.relu / gelu where no GEMM epilogue is available; bwd: dx = dy*act'(aux) */
 int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, iseg_stream_t stream);

@@ -93,9 +93,9 @@ SIGNATURES = {
     "iseg_accumulate_pair": (_i, [_p, _i, _p, _p, _p]),
     "iseg_scale_dev": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_rowscale": (_i, [_p, _p, _p, _l, _i, _l, _i, _p]),
-    "iseg_dropout": (_i, [_p, _p, _l, _f, _u64, _i, _p]),
-    "iseg_drop_path_mask": (_i, [_p, _i, _f, _u64, _p]),
-    "iseg_drop_path_masks": (_i, [_p, _p, _i, _i, _u64, _p]),
+    "iseg_dropout": (_i, [_p, _p, _l, _f, _u64, _p, _i, _p]),
+    "iseg_drop_path_mask": (_i, [_p, _i, _f, _u64, _p, _p]),
+    "iseg_drop_path_masks": (_i, [_p, _p, _i, _i, _u64, _p, _p]),
     "iseg_fill_f32": (_i, [_p, _f, _l, _p]),
     "iseg_act_fwd": (_i, [_p, _p, _l, _i, _i, _p]),
     "iseg_act_bwd": (_i, [_p, _p, _p, _l, _i, _i, _p]),

@@ -285,7 +285,8 @@ __device__ __forceinline__ float uniform01(uint64_t seed, uint64_t idx) {
 
 // y = x * (u >= rate) / (1-rate); the mask is a pure function of (seed, element index): backward re-derives it
 template <class T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float rate, uint64_t seed) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float rate, uint64_t seed, const uint64_t* __restrict__ seed_offset) {
+    if (seed_offset) seed += *seed_offset;      // (a captured step: the launch arguments are frozen, the draw counter moves on in device memory)
     const float inv_keep = 1.0f / (1.0f - rate);
     const int64_t nv = n / 8;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
@@ -300,14 +301,16 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64
 }
 
 // per-sample drop-path factors: s[n] = floor(keep + u_n) / keep   (utils/drops.py:14-20)
-__global__ void drop_path_mask_kernel(float* __restrict__ s, int n, float keep, uint64_t seed) {
+__global__ void drop_path_mask_kernel(float* __restrict__ s, int n, float keep, uint64_t seed, const uint64_t* __restrict__ seed_offset) {
+    if (seed_offset) seed += *seed_offset;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) s[i] = floorf(keep + uniform01(seed, (uint64_t)i)) / keep;
 }
 
 // the masks of a whole training step in one launch: row p (one per drop_path call site, in call order) uses its own keep probability
 // and its own stream of the counter-based generator
-__global__ void drop_path_masks_kernel(float* __restrict__ s, const float* __restrict__ keep, int P, int n, uint64_t seed) {
+__global__ void drop_path_masks_kernel(float* __restrict__ s, const float* __restrict__ keep, int P, int n, uint64_t seed, const uint64_t* __restrict__ seed_offset) {
+    if (seed_offset) seed += *seed_offset;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P * n) return;
     const int p = i / n;
@@ -696,26 +699,26 @@ extern "C" int iseg_rowscale(const void* x, const float* s, void* y, int64_t row
     return iseg_check_launch("iseg_rowscale");
 }
 
-extern "C" int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, int dtype, hipStream_t stream) {
+extern "C" int iseg_dropout(const void* x, void* y, int64_t n, float rate, uint64_t seed, const uint64_t* seed_offset, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(x && y && rate >= 0.f && rate < 1.f, "iseg_dropout: bad arguments");
     const unsigned blocks = cap_blocks(ceil_div64(n, 8));
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n, rate,
-                           seed);
+                           seed, seed_offset);
     else
-        hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, n, rate, seed);
+        hipLaunchKernelGGL((dropout_kernel<float>), dim3(blocks), dim3(256), 0, stream, (const float*)x, (float*)y, n, rate, seed, seed_offset);
     return iseg_check_launch("iseg_dropout");
 }
 
-extern "C" int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, hipStream_t stream) {
+extern "C" int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, const uint64_t* seed_offset, hipStream_t stream) {
     ISEG_REQUIRE(s && n > 0 && keep_prob > 0.f && keep_prob <= 1.f, "iseg_drop_path_mask: bad arguments");
-    hipLaunchKernelGGL(drop_path_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, s, n, keep_prob, seed);
+    hipLaunchKernelGGL(drop_path_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, s, n, keep_prob, seed, seed_offset);
     return iseg_check_launch("iseg_drop_path_mask");
 }
 
-extern "C" int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, hipStream_t stream) {
+extern "C" int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, const uint64_t* seed_offset, hipStream_t stream) {
     ISEG_REQUIRE(s && keep_probs && P > 0 && n > 0, "iseg_drop_path_masks: bad arguments");
-    hipLaunchKernelGGL(drop_path_masks_kernel, dim3((P * n + 255) / 256), dim3(256), 0, stream, s, keep_probs, P, n, seed);
+    hipLaunchKernelGGL(drop_path_masks_kernel, dim3((P * n + 255) / 256), dim3(256), 0, stream, s, keep_probs, P, n, seed, seed_offset);
     return iseg_check_launch("iseg_drop_path_masks");
 }
 

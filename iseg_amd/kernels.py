@@ -503,15 +503,25 @@ def rowscale(x2d, s, rows_per_group):
     return y
 
 
+# Device-resident addend of every dropout / drop-path seed.  None outside graph capture; iseg_amd.graphs.GraphedTrainStep points it at a one-word
+# device buffer while it captures a training step and moves the word on before every replay, so the replayed launches (frozen
+# arguments) draw the numbers the eager step would have drawn.
+_SEED_OFFSET = [None]
+
+
+def set_seed_offset(t):
+    _SEED_OFFSET[0] = t
+
+
 def dropout(x, rate, seed):
     y = torch.empty_like(x)
-    _hip.call("iseg_dropout", ptr(x), ptr(y), x.numel(), rate, seed, dt(x), stream())
+    _hip.call("iseg_dropout", ptr(x), ptr(y), x.numel(), rate, seed, ptr(_SEED_OFFSET[0]), dt(x), stream())
     return y
 
 
 def drop_path_mask(n, keep_prob, seed, device):
     s = torch.empty(n, dtype=torch.float32, device=device)
-    _hip.call("iseg_drop_path_mask", ptr(s), n, keep_prob, seed, stream())
+    _hip.call("iseg_drop_path_mask", ptr(s), n, keep_prob, seed, ptr(_SEED_OFFSET[0]), stream())
     return s
 
 
@@ -519,7 +529,7 @@ def drop_path_masks(keep_probs_dev, n, seed):
     """[P, n] per-sample drop-path factors, row p with keep probability keep_probs_dev[p]: one launch for a whole step"""
     P = keep_probs_dev.numel()
     s = torch.empty((P, n), dtype=torch.float32, device=keep_probs_dev.device)
-    _hip.call("iseg_drop_path_masks", ptr(s), ptr(keep_probs_dev), P, n, seed, stream())
+    _hip.call("iseg_drop_path_masks", ptr(s), ptr(keep_probs_dev), P, n, seed, ptr(_SEED_OFFSET[0]), stream())
     return s
 
 

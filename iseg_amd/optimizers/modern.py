@@ -69,6 +69,8 @@ class _FlatOptimizer:
             self._hp_host = self._hp_host.pin_memory()
         self._slot = 0
         self.hp = self._hp_dev[0]
+        self._hp_fixed = None        # graph mode (fixed_hp_slot): the one device slot a captured step kernel reads
+        self._prepared = False       # prepare_step() already pushed this step's scalars (GraphedTrainStep does it outside the graph)
         seg_first = [o // 256 for (_, o, _) in store.segments] + [store.nblocks]
         self._seg_first_block = torch.tensor(seg_first, dtype=torch.int32, device=dev)
         self._norm_ws = None
@@ -85,12 +87,33 @@ class _FlatOptimizer:
             ev.synchronize()
         for i, v in enumerate(vals):
             self._hp_host[slot, i] = v
-        self.hp = self._hp_dev[slot]
+        # eager: the device slot rotates with the host slot; graph mode: always the same device words (the captured kernel's argument),
+        # filled by a stream-ordered copy from the rotating pinned slot in front of every replay
+        self.hp = self._hp_dev[slot] if self._hp_fixed is None else self._hp_fixed
         self.hp.copy_(self._hp_host[slot], non_blocking=True)
         if self.hp.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
             self._hp_events[slot] = ev
+
+    def fixed_hp_slot(self, on=True):
+        """graph mode: the step kernel reads its scalars from ONE device address (iseg_amd/graphs.py)"""
+        self._hp_fixed = torch.zeros(4, dtype=torch.float32, device=self.store.device) if on else None
+
+    def _hp_values(self):
+        raise NotImplementedError
+
+    def prepare_step(self):
+        """host half of apply_gradients(): this step's learning rate / bias correction / gradient scale / clip value on their way to the
+        device.  apply_gradients() calls it itself unless a graph runner already did (outside the captured region)."""
+        self._push_hp(self._hp_values())
+        self._prepared = True
+
+    def after_replayed_step(self):
+        """host bookkeeping of a step whose kernels were replayed from a graph"""
+        self.iterations += 1
+        self._prepared = False
+        nn.weights_changed()
 
     def _clip_tables(self, seg_l2=None):
         """(seg_sq, clipnorm, global_sq, global_clipnorm) for the step kernel; runs iseg_grad_sqnorm when a norm clip is configured"""
@@ -130,11 +153,16 @@ class AdamW(_FlatOptimizer):
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
         self.seg_wd = torch.tensor(wd, dtype=torch.float32, device=st.device)
 
-    def apply_gradients(self):
-        st = self.store
+    def _hp_values(self):
         t = self.iterations + 1
         corr = math.sqrt(1.0 - self.beta_2 ** t) / (1.0 - self.beta_1 ** t)
-        self._push_hp([self.current_lr(), corr, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
+        return [self.current_lr(), corr, self.grad_scale, self.clipvalue if self.clipvalue else 0.0]
+
+    def apply_gradients(self):
+        st = self.store
+        if not self._prepared:
+            self.prepare_step()
+        self._prepared = False
         seg_sq, cn, tot, gn = self._clip_tables()
         _hip.call("iseg_adamw_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(self.v),
                   K.ptr(self.vhat) if self.amsgrad else None, K.ptr(st.flat_bf16), K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult),
@@ -159,9 +187,14 @@ class SGD(_FlatOptimizer):
         self.seg_lr_mult = torch.tensor(lr_mult, dtype=torch.float32, device=st.device)
         self.seg_l2 = torch.tensor(l2, dtype=torch.float32, device=st.device)
 
+    def _hp_values(self):
+        return [self.current_lr(), 0.0, self.grad_scale, self.clipvalue if self.clipvalue else 0.0]
+
     def apply_gradients(self):
         st = self.store
-        self._push_hp([self.current_lr(), 0.0, self.grad_scale, self.clipvalue if self.clipvalue else 0.0])
+        if not self._prepared:
+            self.prepare_step()
+        self._prepared = False
         seg_sq, cn, tot, gn = self._clip_tables(self.seg_l2)
         _hip.call("iseg_sgd_momentum_step", K.ptr(st.flat_w), K.ptr(st.flat_g), K.ptr(self.m), K.ptr(st.flat_bf16),
                   K.ptr(st.seg_of_block), K.ptr(self.seg_lr_mult), K.ptr(self.seg_l2), K.ptr(self.hp), self.momentum, int(self.nesterov),
