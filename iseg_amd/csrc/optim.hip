@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ w, const
         const int seg = seg_of_block[b];
         if (seg < 0) continue;  // padding block
         const float lr_mult = seg_lr_mult[seg], wd = seg_wd[seg];
+        // a variable this optimizer does not own (MultiOptimizer routes it to another one) or a frozen one: no update, no decay -- and its
+        // gradient is not even read: NaN * 0 from another group's variable must not reach the weight through this pass
+        if (lr_mult == 0.f && wd == 0.f) continue;
         const float cf = clip_factor(clip, seg);
         const int64_t i = b * 256 + lane * 4;
         float4 w4 = *reinterpret_cast<const float4*>(w + i);
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const f
         const int seg = seg_of_block[b];
         if (seg < 0) continue;
         const float lr_mult = seg_lr_mult[seg], l2 = seg_l2[seg];
+        if (lr_mult == 0.f && l2 == 0.f) continue;      // not this optimizer's variable (see adamw_kernel): never touch it, never read its gradient
         const int64_t i = b * 256 + threadIdx.x;
         float wi = w[i];
         float gi = (g[i] * gscale + 2.f * l2 * wi) * clip_factor(clip, seg);

@@ -54,6 +54,12 @@ class GraphedCall:
                     return self.fn(x)
             e[1], e[2], e[3] = self._capture(x)
         graph, static_in, out = e[1], e[2], e[3]
+        # The K-contiguous kernel copies (nn.wt) are refreshed by a HOST-side version check; after the warm-up calls the versions match, so
+        # the capture holds no transpose launch and a replay never passes through wt() again.  After an optimizer step / load_weights /
+        # restore_checkpoint the copies are refreshed here, eagerly, in front of the replay (same stream: ordered).
+        from . import nn
+
+        nn.refresh_wt()
         static_in.copy_(x)
         graph.replay()
         return out      # (the captured output buffer: valid until the next call with this signature)

@@ -219,6 +219,17 @@ def _wt_rebuild():
                max_tiles=max(((k + 63) // 64) * ((n + 63) // 64) for (_, _, k, n) in rows), version=-1)
 
 
+def refresh_wt():
+    """bring every registered K-contiguous kernel copy up to date NOW (one launch) -- for callers that will not pass through wt() again
+    before the copies are read, i.e. the replay of a captured graph (iseg_amd/graphs.py)"""
+    if _WT["params"] and _WT["version"] != _WEIGHTS_VERSION[0]:
+        wt(_WT["params"][0])
+
+
+def weights_version():
+    return _WEIGHTS_VERSION[0]
+
+
 def wt(param):
     """[N][K] bf16 copy of the 2-D kernel `param` ([K][N]) under mixed precision, or None (fp32 compute, no shadow, not 2-D).  All registered
     kernels are re-transposed by ONE launch (iseg_transpose_batched) the first time any of them is asked for after a weight update."""

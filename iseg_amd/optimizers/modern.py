@@ -36,6 +36,9 @@ class _FlatOptimizer:
             self._build_tables()
 
     def _owns(self, p):
+        """this optimizer updates p: routed here (MultiOptimizer) and not frozen (p.iseg_frozen: no step, no decay, gradient never read)"""
+        if getattr(p, "iseg_frozen", False):
+            return False
         return self._owned is None or getattr(p, "iseg_name", None) in self._owned
 
     # Keras API

@@ -24,6 +24,9 @@ class TrainableModel:
         self.loss_weights = loss_weights or {}
         self.metrics = metrics or {}
         self.update_metrics = True
+        # keras.optimizers.Optimizer(gradient_transformers=[...]): functions applied to the gradients before the update.  Here a transformer
+        # takes the ParamStore (flat gradient buffer + per-parameter views) after the data-parallel sum and edits the gradients in place.
+        self.gradient_transformers = []
         if isinstance(optimizer, list):
             # several optimizers: the model names the layer groups (core_model.py:603, layers/core_model_ext.py:386-388 multi_optimizers_layers),
             # one group per optimizer, and the pairs become a MultiOptimizer (optimizers/multi_optimizer.py)
@@ -139,6 +142,8 @@ class TrainableModel:
             torch.autograd.backward(losses)
         self.reducer.finish()
         dist.set_active_reducer(None)
+        for fn in self.gradient_transformers:
+            fn(self.store)
         self.optimizer.grad_scale = 1.0 / dist.world_size()    # per-replica mean losses, summed grads -> global mean
         self.optimizer.apply_gradients()
         if self.update_metrics:

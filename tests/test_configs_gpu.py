@@ -72,6 +72,70 @@ def test_full_architectures_train_in_bf16(cuda, factory, size):
     assert tuple(logits.shape) == (2, size, size, 21) and torch.isfinite(logits).all()
 
 
+def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3):
+    """fp32 storage: logits < logit_tol abs and the argmax mask bit-exact against the oracle's whole-model forward, the mean ignore-label
+    loss within 1e-4, and selected weight gradients of that loss against fp64 autograd through the oracle"""
+    from iseg_amd import functional as F
+    from iseg_amd.losses.catecrossentropy_ignore_label import catecrossentropy_ignore_label_loss
+
+    w = OM.export_weights(model)
+    with torch.no_grad():
+        logits = model(x.cuda(), training=False)[0]
+        ref = oracle_fn(w, x.double())["logits"]
+    assert logits.dtype == torch.float32 and tuple(logits.shape) == tuple(ref.shape)
+    err = (logits.cpu().double() - ref).abs().max().item()
+    assert err < logit_tol, err
+    assert torch.equal(logits.argmax(-1).cpu(), O.argmax_first(ref))
+    loss_fn = catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, batch_size=x.shape[0])
+    got = float(loss_fn(y.cuda(), logits).mean())
+    want = OM.mean_ce_loss(ref, y).item()
+    assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (got, want)
+    # gradients: evaluation-mode graph (frozen BatchNorm statistics, no drop path / dropout) on both sides
+    params = {p.iseg_name: p for p in model.parameters()}
+    for p in params.values():
+        p.grad = None
+    wg = {k: (v.clone().requires_grad_(True) if k in grad_names else v) for k, v in w.items()}
+    OM.mean_ce_loss(oracle_fn(wg, x.double())["logits"], y).backward()
+    out = model(x.cuda(), training=False)[0]
+    with F.unit_loss_grad():
+        torch.autograd.backward([loss_fn.fused_mean(y.cuda(), out, 1.0)])
+    for name in grad_names:
+        g_ref = wg[name].grad
+        g = params[name].grad.cpu().double()
+        scale = max(g_ref.abs().max().item(), 1e-12)
+        assert (g - g_ref).abs().max().item() <= 5e-3 * scale, (name, (g - g_ref).abs().max().item(), scale)
+
+
+def test_cfg3_swin_tiny_fpn_whole_model_against_the_oracle(cuda):
+    """BASELINE config 3 at full depth (Swin-T 2/2/6/2, heads 3/6/12/24, window 7 + FPN + 1x1 head) on an odd size: 96x128 gives 24x32
+    tokens -> padded to 28x35 windows at stage 0 and 1-2 windows deeper down, every stage with its shift mask and patch-merging pad"""
+    from iseg_amd import heads, nn
+    from iseg_amd.data import synthetic_batch
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(heads.swin_tiny_fpn(build_input_size=(96, 128)), seed=7)
+    x, y = synthetic_batch(2, 96, 128, seed=14)
+    _whole_model_parity(model, lambda w, t: OM.swin_fpn_forward(w, t, training=False), x, y,
+                        ["patch_embed/proj/kernel", "layers/0/blocks/1/attn/relative_position_bias_table", "layers/2/blocks/3/mlp/fc1/kernel",
+                         "layers/1/downsample/reduction/kernel", "fpn_head/fpn/skip_conv_filters0/conv/kernel", "fpn_head/end_conv/bn/gamma",
+                         "seg/logits_conv/kernel"])
+
+
+def test_cfg5_intern_image_base_aspp_whole_model_against_the_oracle(cuda):
+    """BASELINE config 5 at full depth (InternImage-B: 112 channels, depths 4/4/21/4, DCNv3 groups 7/14/28/56, post-norm) + ASPP on an odd size"""
+    from iseg_amd import heads, nn
+    from iseg_amd.data import synthetic_batch
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(heads.intern_image_base_aspp(build_input_size=(96, 128), dropout_rate=0.0), seed=8)
+    x, y = synthetic_batch(1, 96, 128, seed=15)
+    _whole_model_parity(model, lambda w, t: OM.intern_image_aspp_forward(w, t, training=False), x, y,
+                        ["patch_embed/conv1/kernel", "block/0/layer/1/dcn/offset/kernel", "block/2/layer/10/mlp/fc1/kernel", "block/2/layer/20/gamma1",
+                         "block/1/downsample/conv/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"])
+
+
 def _flagship(size):
     from iseg_amd import nn
     from iseg_amd.heads import convnext_tiny_aspp
@@ -183,5 +247,11 @@ def test_graphed_inference_replays_bit_exact(cuda):
             got3 = g(x3)
         assert torch.equal(got3, eager(x3))
         assert len(g.entries) == 2 and all(e[1] is not None for e in g.entries.values())
+        # train-then-evaluate: after the weights change (optimizer step / load_weights / restore_checkpoint) a replay must read the new
+        # K-contiguous kernel copies of the un-fused ConvNeXt stages, which only a host-side version check refreshes
+        randomize_parameters(model, 6)
+        want4 = eager(x).clone()
+        assert not torch.equal(want4, want)
+        assert torch.equal(g(x), want4)
     finally:
         nn.set_compute_dtype(torch.float32)

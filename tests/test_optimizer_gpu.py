@@ -205,6 +205,34 @@ def test_multi_optimizer_routes_variables_by_layer(cuda):
         MultiOptimizer(optimizers_and_layers=[(AdamW(global_clipnorm=1.0), [ga]), (SGD(), [gb])]).build(store)
 
 
+def test_multi_optimizer_nan_gradient_stays_in_its_group(cuda):
+    """a NaN gradient on a variable owned by the AdamW group is scrubbed there (adamw.py:63-74) and must not reach the weight through the
+    SGD group's pass (learning-rate multiplier 0 for variables it does not own: NaN * 0 = NaN if the kernel computed them)"""
+    from iseg_amd.optimizers.modern import SGD, AdamW
+    from iseg_amd.optimizers.multi_optimizer import MultiOptimizer
+    from iseg_amd.param_store import ParamStore
+
+    ps = _params(4)
+    store = ParamStore(ps)
+    mo = MultiOptimizer(optimizers_and_layers=[(AdamW(learning_rate=1e-2, weight_decay=0.0), [_Holder(ps[:3])]),
+                                               (SGD(learning_rate=0.05, momentum=0.9), _Holder(ps[3:]))])
+    mo.build(store)
+    before = [p.data.clone() for p in ps]
+    gs = _grads(0, 11, nan=False)
+    for p, g in zip(ps, gs):
+        p.grad.copy_(g.cuda())
+    ps[0].grad.view(-1)[3] = float("nan")      # (only NaN is scrubbed: adamw.py:70 tf.where(is_nan(g), 0, g))
+    ps[1].grad.view(-1)[0] = float("nan")
+    mo.apply_gradients()
+    for p in ps:
+        assert torch.isfinite(p.data).all() and torch.isfinite(p.iseg_compute.float()).all(), p.iseg_name
+    sgd = mo.optimizer_specs[1]["optimizer"]
+    assert torch.isfinite(sgd.m).all()
+    # the scrubbed element behaves like a zero gradient: no movement on the first AdamW step without decay
+    assert ps[0].data.view(-1)[3] == before[0].view(-1)[3]
+    assert not torch.equal(ps[3].data, before[3])
+
+
 def test_trainer_takes_a_list_of_optimizers_through_multi_optimizers_layers(cuda):
     from iseg_amd import heads, nn
     from iseg_amd.data import synthetic_batch
