@@ -40,33 +40,100 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT a HIP / torch.cuda call (the launcher parent must not hold the device): the visibility list when
+    one is exported, else the kfd topology (a node with SIMDs is a GPU; CPU nodes report simd_count 0).  None when neither source exists."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return None
+    n = 0
+    for node in os.listdir(root):
+        try:
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent has not touched the GPU (no HIP call,
-    no torch.cuda.is_available()), the children are fresh interpreters with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (never an
-    exec of a process that initialised the GPU).  Rank 0 inherits stdout and prints the JSON line; the exit code is non-zero when any
-    rank fails."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent never touches the GPU (no HIP call, no
+    torch.cuda.*: the device count comes from the visibility list / kfd topology), the children are fresh interpreters with RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set (never an exec of a process that initialised the GPU).  Rank 0 inherits stdout and prints the JSON
+    line; every rank's stderr (and the other ranks' stdout) goes to its own log file, whose tail is shown when a rank fails.  A wall-clock
+    watchdog (ISEG_BENCH_TIMEOUT_S, default 900) kills the ranks that are left and exits non-zero, so a hung rank cannot hang the caller;
+    a rank that dies takes the others down after a short grace period instead of leaving them in a collective."""
     import socket
     import subprocess
+    import tempfile
 
     n = args.gpus
-    if not args.check_launch and torch.cuda.device_count() < n:
-        print(f"bench.py: --gpus {n} but this node exposes {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+    have = visible_gpu_count()
+    if not args.check_launch and have is not None and have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
         return 2
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
-    procs = []
+    log_dir = os.environ.get("ISEG_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="iseg_bench_")
+    os.makedirs(log_dir, exist_ok=True)
+    limit = float(os.environ.get("ISEG_BENCH_TIMEOUT_S", "900"))
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        log = open(os.path.join(log_dir, f"rank{r}.log"), "wb")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    codes = [p.wait() for p in procs]
+                                      stdout=None if r == 0 else log, stderr=log))
+    t0 = time.time()
+    failed_at = None
+    verdict = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.time()
+        if any(c not in (None, 0) for c in codes) and failed_at is None:
+            failed_at = now
+        hung = now - t0 > limit
+        if hung or (failed_at is not None and now - failed_at > 20.0):
+            why = f"no result after {limit:.0f} s" if hung else "a rank failed and the others did not exit within 20 s"
+            print(f"bench.py: {why}; terminating the remaining ranks (the children started here, by pid)", file=sys.stderr)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            verdict = 4 if hung else 1
+            break
+        time.sleep(0.2)
+    for log in logs:
+        log.close()
+    codes = [p.returncode for p in procs]
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return 1
+    if bad or verdict:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}; per-rank logs in {log_dir}", file=sys.stderr)
+        for r, _ in bad[:4]:
+            try:
+                with open(os.path.join(log_dir, f"rank{r}.log"), "rb") as f:
+                    tail = f.read()[-1500:].decode("utf-8", "replace")
+                print(f"---- rank {r} (tail) ----\n{tail}", file=sys.stderr)
+            except OSError:
+                pass
+        return verdict or 1
     return 0
 
 
@@ -82,7 +149,11 @@ def joined_ranks(device):
 def check_launch(args):
     from iseg_amd import dist
 
-    use_gpu = torch.cuda.device_count() >= max(args.gpus, 1) and torch.cuda.is_available()
+    use_gpu = (visible_gpu_count() or 0) >= max(args.gpus, 1) and torch.cuda.is_available()
+    if os.environ.get("ISEG_BENCH_TEST_HANG") == str(os.environ.get("RANK", "0")):      # (tests/test_bench_launch.py: the watchdog)
+        time.sleep(3600)
+    if os.environ.get("ISEG_BENCH_TEST_FAIL") == str(os.environ.get("RANK", "0")):
+        sys.exit(7)
     dist.init(backend=None if use_gpu else "gloo")
     n = joined_ranks(torch.device("cuda", dist.local_rank()) if use_gpu else torch.device("cpu"))
     if n != args.gpus:

@@ -82,7 +82,10 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
             load_h5_weight(backbone, weights_path, by_name=False)
         elif stem.endswith(".h5") or weights_path.endswith(".npz"):
             print(f"Load backbone weights {weights_path} as H5 format (name-based)")
-            load_h5_weight_by_name(backbone, weights_path)
+            if ss.RESNET in name:      # (:174-176) ResNets keep Keras' strict loader: by layer name, weights by position
+                load_h5_weight(backbone, weights_path)
+            else:
+                load_h5_weight_by_name(backbone, weights_path)
         elif weights_path.endswith(".ckpt") or weights_path.endswith(".keras"):
             raise NotImplementedError(f"{weights_path}: TensorFlow checkpoint / .keras archives need TensorFlow to read; export the "
                                       "backbone as .h5 there and convert it with tools/h5_to_npz.py")

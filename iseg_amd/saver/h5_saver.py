@@ -136,6 +136,42 @@ def load_weights_from_group_by_name(f, model, skip_mismatch=False):
     return len(pairs)
 
 
+def load_weights_from_group_by_name_strict(f, layers, skip_mismatch=False):
+    """keras load_weights_from_hdf5_group_by_name (utils/hdf5_utils.py:230-383), the route the reference keeps for ResNets
+    (backbones/feature_extractor.py:174-176 -> utils/keras_ops.py:107-122 with layers = get_all_layers(model)): a stored group goes to every
+    layer of that NAME, its arrays to the layer's weights BY POSITION -- count and shapes must agree.  No fuzzy search: two same-shaped
+    weights of one layer (BatchNormalization's gamma / beta / moving_mean / moving_variance) cannot change places."""
+    index = {}
+    for layer in layers:
+        if layer.name:
+            index.setdefault(layer.name, []).append(layer)
+    pairs = []
+    for k, name in enumerate(layer_names_of(f)):
+        values = list(load_subset_weights_kv_dict_from_hdf5_group(f[name]).values())
+        for layer in index.get(name, []):
+            symbolic = layer_weights(layer)
+            if len(values) != len(symbolic):
+                msg = (f"Weight count mismatch for layer #{k} (named {layer.name}). Layer expects {len(symbolic)} weight(s). "
+                       f"Received {len(values)} saved weight(s)")
+                if skip_mismatch:
+                    warnings.warn("Skipping loading weights for layer #{} (named {}) due to mismatch in number of weights.".format(k, layer.name))
+                    continue
+                raise ValueError(msg)
+            ok = True
+            for (wname, target), v in zip(symbolic, values):
+                if tuple(np.asarray(v).shape) != tuple(target.shape):
+                    msg = (f"Shape mismatch in layer #{k} (named {layer.name}) for weight {wname}. Weight expects shape {tuple(target.shape)}. "
+                           f"Received saved weight with shape {tuple(np.asarray(v).shape)}")
+                    if not skip_mismatch:
+                        raise ValueError(msg)
+                    warnings.warn("Skipping: " + msg)
+                    ok = False
+            if ok:
+                pairs.extend((target, v) for (_, target), v in zip(symbolic, values))
+    _assign(pairs)
+    return len(pairs)
+
+
 def load_h5_weight_by_name(model, path, skip_mismatch=False):
     """(:38-46) `path`: a Keras .h5 (needs h5py) or its .npz conversion (tools/h5_to_npz.py) or a file written by save_weights"""
     return load_weights_from_group_by_name(open_weights(path), model, skip_mismatch=skip_mismatch)

@@ -40,11 +40,13 @@ def set_bn_epsilon(model, epsilon=1e-3):
 def load_h5_weight(model, path, skip_mismatch=False, use_v2_behavior=False, by_name=True):
     """utils/keras_ops.py:107-127: Keras HDF5 weights (or their .npz conversion, saver/weights_file.py) into `model`, by layer name or
     -- by_name=False, the `.topology.h5` files of backbones/feature_extractor.py:167-169 -- by layer order"""
-    from ..saver import load_weights_from_group_by_name, load_weights_from_group_topological, open_weights
+    from ..saver import load_weights_from_group_by_name, load_weights_from_group_by_name_strict, load_weights_from_group_topological, open_weights
 
     f = open_weights(path)
     if by_name:
-        return load_weights_from_group_by_name(f, model, skip_mismatch=skip_mismatch)
+        if use_v2_behavior:      # (:115-116) the v2 loader = the fuzzy per-layer search of saver/h5_saver.py
+            return load_weights_from_group_by_name(f, model, skip_mismatch=skip_mismatch)
+        return load_weights_from_group_by_name_strict(f, get_all_layers(model), skip_mismatch=skip_mismatch)
     return load_weights_from_group_topological(f, model)
 
 

@@ -27,3 +27,40 @@ def test_world_size_mismatch_is_an_error():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
                        env=_env(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+
+
+def test_hung_rank_is_killed_by_the_watchdog(tmp_path):
+    """a rank that never comes back must not hang the caller: the wall-clock watchdog terminates the children and exits non-zero; every
+    rank leaves a log file"""
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TEST_HANG="1", ISEG_BENCH_TIMEOUT_S="25", ISEG_BENCH_LOG_DIR=str(tmp_path)), capture_output=True,
+                       text=True, timeout=200)
+    assert r.returncode == 4, (r.returncode, r.stderr[-1500:])
+    assert time.time() - t0 < 120
+    assert "terminating the remaining ranks" in r.stderr
+    assert sorted(os.listdir(tmp_path)) == ["rank0.log", "rank1.log"]
+
+
+def test_failed_rank_takes_the_job_down(tmp_path):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TEST_FAIL="1", ISEG_BENCH_TIMEOUT_S="120", ISEG_BENCH_LOG_DIR=str(tmp_path)), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1500:])
+    assert "(1, 7)" in r.stderr and "rank 1 (tail)" in r.stderr
+
+
+def test_launcher_parent_counts_gpus_without_touching_them():
+    """the parent decides from the visibility list / kfd topology, never from torch.cuda.* (which initialises the HIP runtime)"""
+    import re
+
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def self_launch"):src.index("def joined_ranks")]
+    assert not re.search(r"torch\.cuda\.", body.split('"""', 2)[2])
+    code = "import os, sys; sys.path.insert(0, %r); import bench; print(bench.visible_gpu_count())" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=_env(HIP_VISIBLE_DEVICES="0,1,2"), capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip().splitlines()[-1] == "3", out.stderr[-500:]
+    out = subprocess.run([sys.executable, "-c", code], env=_env(HIP_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=120)
+    assert out.stdout.strip().splitlines()[-1] == "0"

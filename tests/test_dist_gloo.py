@@ -97,3 +97,78 @@ def test_two_rank_gloo_reducer_broadcast_syncbn():
     assert all(p.exitcode == 0 for p in procs)
     for rank, ok_bcast, ok_red, ok_bn in res:
         assert ok_bcast and ok_red and ok_bn, (rank, ok_bcast, ok_red, ok_bn)
+
+
+def _eval_worker(rank, world, port, q):
+    """evaluate() under two ranks with RAGGED shards (3 batches -> rank 0 gets two, rank 1 gets one) and the progress line switched on:
+    every collective must be entered by every rank the same number of times (a rank-0-only metric read used to deadlock here).  The device
+    kernels are replaced by torch-CPU stand-ins INSIDE THIS TEST PROCESS only: what is under test is the collective protocol."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from iseg_amd import dist, nn
+    from iseg_amd.core_model import SegFoundation
+    from iseg_amd.data import synthetic_dataset
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.evaluations import evaluation as E
+    from iseg_amd.metrics.mean_iou import MeanIOU
+
+    nn.set_device("cpu")
+    dist.init(backend="gloo")
+
+    class Stub(SegFoundation):
+        def __init__(self):
+            torch.nn.Module.__init__(self)
+
+        def inference_with_multi_scales(self, images, training=False, scale_rates=(1.0,), flip=False):
+            # deterministic "logits": class = a function of the pixel values
+            c = (images.sum(-1, keepdim=True) * 3.0).floor().long() % 21
+            return torch.nn.functional.one_hot(c.squeeze(-1), 21).float() * 4.0
+
+    def cpu_loss(num_class=21, ignore_label=255, batch_size=2, reduction=False, **kw):
+        def fn(y_true, y_pred):
+            z = y_pred.reshape(-1, num_class)
+            y = y_true.reshape(-1).long()
+            keep = y != ignore_label
+            lp = torch.log_softmax(z, -1)
+            return torch.where(keep, -lp[torch.arange(len(y)), torch.where(keep, y, torch.zeros_like(y))], torch.zeros(len(y)))
+        return fn
+
+    def cpu_confusion(self, logits2d, labels1d, ignore_label):
+        pred = logits2d.argmax(-1)
+        keep = labels1d != ignore_label
+        idx = labels1d[keep].long() * self.num_classes + pred[keep]
+        self.total_cm += torch.bincount(idx, minlength=self.num_classes ** 2)
+
+    E.catecrossentropy_ignore_label_loss = cpu_loss
+    MeanIOU.update_from_logits = cpu_confusion
+    data = synthetic_dataset(5, 16, 16, seed=3)      # batch 2 -> 3 batches: ranks hold 2 and 1
+    miou = float(E.evaluate(Strategy(one_device=(world == 1)), Stub(), data, batch_size=2, num_class=21, ignore_label=255, scale_rates=[1.0],
+                            flip=False, val_image_count=5, verbose=1))
+    q.put((rank, miou, E.evaluate.last_mean_loss))
+    if dist.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def test_two_rank_evaluate_enters_every_collective_on_every_rank():
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0, "a rank hung or failed inside evaluate()"
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]      # both ranks report the merged figures
+    # single-process reference over the same five images
+    port1 = _free_port()
+    q1 = ctx.Queue()
+    p = ctx.Process(target=_eval_worker, args=(0, 1, port1, q1))
+    p.start()
+    p.join(timeout=240)
+    assert p.exitcode == 0
+    _, miou1, loss1 = q1.get(timeout=5)
+    assert abs(res[0][1] - miou1) < 1e-9 and abs(res[0][2] - loss1) < 1e-6

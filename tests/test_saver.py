@@ -139,3 +139,35 @@ def test_get_backbone_loads_weights_path_and_rejects_unknown_formats(tmp_path):
     with pytest.raises(ImportError, match="h5py"):
         (tmp_path / "real.h5").write_bytes(b"\x89HDF\r\n\x1a\n")
         get_backbone("convnext_tiny", image_shape=(1, 64, 64, 3), weights_path=str(tmp_path / "real.h5"))
+
+
+def test_resnet_takes_the_strict_by_name_route(tmp_path):
+    """backbones/feature_extractor.py:174-176: for a ResNet the stored arrays go to the layer of the same name BY POSITION (Keras'
+    load_weights_from_hdf5_group_by_name), so BatchNormalization's four same-shaped vectors cannot be swapped by a fuzzy name match -- also
+    when the file names them differently; a count mismatch raises"""
+    from iseg_amd.backbones.feature_extractor import get_backbone
+    from iseg_amd.utils.keras_ops import get_all_layers
+
+    nn.set_seed(21)
+    a = get_backbone("resnet50", image_shape=(1, 64, 64, 3), return_endpoints=True)
+    from tests.util_models import randomize_parameters
+
+    randomize_parameters(a, 21)
+    # one group per LEAF layer that owns weights (what save_model_to_h5(get_all_layers(model)) of the reference writes), weights renamed so
+    # that only their order identifies them
+    layers = {}
+    for layer in get_all_layers(a):
+        own = [(p.iseg_name, p) for p in layer.parameters(recurse=False)] + [(b.iseg_name, b) for b in layer.buffers(recurse=False)
+                                                                               if getattr(b, "iseg_name", None)]
+        if own:
+            layers[layer.name] = {f"w{i}:0": t.detach().cpu().numpy() for i, (_, t) in enumerate(own)}
+    path = write_npz(str(tmp_path / "resnet50.h5.npz"), layers)
+    nn.set_seed(22)
+    b = get_backbone("resnet50", image_shape=(1, 64, 64, 3), return_endpoints=True, weights_path=path)
+    sa, sb = _state(a), _state(b)
+    assert len(sa) > 200 and all(torch.equal(sa[k], sb[k]) for k in sa)
+    first = next(iter(layers))
+    broken = dict(layers)
+    broken[first] = dict(list(layers[first].items())[:-1]) if len(layers[first]) > 1 else {**layers[first], "extra:0": np.zeros(3, np.float32)}
+    with pytest.raises(ValueError, match="Weight count mismatch"):
+        get_backbone("resnet50", image_shape=(1, 64, 64, 3), return_endpoints=True, weights_path=write_npz(str(tmp_path / "broken.h5.npz"), broken))
