@@ -27,7 +27,60 @@ typedef const __attribute__((address_space(1))) void* glb_void_ptr;
 // swizzle key of a B-tile row (see the fragment read below: a 16-lane read group holds rows {x, 8+x, 16+x, 24+x} + const, x = 0..3)
 __device__ __forceinline__ int b_key(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4>
+// EK: epilogue kind known at compile time (0 = whatever the Epi struct says at run time).  The flagship's three fused epilogues get their
+// own instantiation: dead branches of epi_finish8 fold away, and a kernel trace / PMC pass can tell the forward product (gelu + gelu'
+// outputs) from the data gradient (x aux) -- with one symbol for both, rocprof's per-kernel traffic was a mean over two different epilogues.
+enum { EK_ANY = 0, EK_GELU_DERIV = 1, EK_MUL_AUX = 2, EK_BIAS_RESIDUAL = 3, EK_PLAIN = 4 };
+
+template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
+    if (EK == EK_GELU_DERIV) {          // bias -> gelu, second output gelu'(pre): pwconv1 forward of an un-fused ConvNeXt block
+        e.act = ISEG_ACT_GELU;
+        e.pre_deriv = 1;
+        e.residual = nullptr;
+        e.aux = nullptr;
+        e.colscale = nullptr;
+        e.rowscale = nullptr;
+        e.accumulate = 0;
+        e.alpha = 1.f;
+    } else if (EK == EK_MUL_AUX) {      // x aux (saved gelu'): pwconv2 data gradient
+        e.act = ISEG_ACT_MUL_AUX;
+        e.bias = nullptr;
+        e.pre_out = nullptr;
+        e.residual = nullptr;
+        e.colscale = nullptr;
+        e.rowscale = nullptr;
+        e.accumulate = 0;
+        e.alpha = 1.f;
+    } else if (EK == EK_PLAIN) {        // nothing fused: pwconv1 data gradient
+        e.act = ISEG_ACT_NONE;
+        e.bias = nullptr;
+        e.aux = nullptr;
+        e.pre_out = nullptr;
+        e.residual = nullptr;
+        e.colscale = nullptr;
+        e.rowscale = nullptr;
+        e.accumulate = 0;
+        e.alpha = 1.f;
+    } else if (EK == EK_BIAS_RESIDUAL) {      // bias, layer scale / drop-path factor (run time), + residual: pwconv2 forward
+        e.act = ISEG_ACT_NONE;
+        e.aux = nullptr;
+        e.pre_out = nullptr;
+        e.accumulate = 0;
+        e.alpha = 1.f;
+    }
+    return e;
+}
+
+inline int epi_kind(const Epi& e, const float* slabs) {
+    if (slabs || e.alpha != 1.f || e.accumulate) return EK_ANY;
+    if (e.act == ISEG_ACT_GELU && e.pre_out && e.pre_deriv && e.bias && !e.residual && !e.aux && !e.colscale && !e.rowscale) return EK_GELU_DERIV;
+    if (e.act == ISEG_ACT_MUL_AUX && e.aux && !e.bias && !e.pre_out && !e.residual && !e.colscale && !e.rowscale) return EK_MUL_AUX;
+    if (e.act == ISEG_ACT_NONE && e.bias && e.residual && !e.aux && !e.pre_out) return EK_BIAS_RESIDUAL;
+    if (e.act == ISEG_ACT_NONE && !e.bias && !e.residual && !e.aux && !e.pre_out && !e.colscale && !e.rowscale) return EK_PLAIN;
+    return EK_ANY;
+}
+
+template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
@@ -212,9 +265,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
                     *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(v);
                     *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(v + 4);
                 } else {
+                    const Epi ek = epi_known<EK>(epi);
                     EpiPrefetch<TO> pf;
-                    pf.load(epi, m, n, D, ldd);
-                    epi_finish8<TO>(epi, v, pf, m, n, D, ldd);
+                    pf.load(ek, m, n, D, ldd);
+                    epi_finish8<TO>(ek, v, pf, m, n, D, ldd);
                 }
             }
         }
@@ -238,7 +292,7 @@ inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
     return true;
 }
 
-template <int WM, int WN, int NS, class TO, int FN = 4>
+template <int WM, int WN, int NS, class TO, int FN = 4, int EK = EK_ANY>
 void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
     constexpr int BM = WM * 64, BN = WN * FN * 16;
     const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
@@ -248,11 +302,11 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
     dim3 grid(ntiles, nsplit, batch);
     constexpr int lds = NS * (BM + BN) * 128;
     static const bool raised = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     }();
     (void)raised;
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
                        (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
 }
 
@@ -332,15 +386,30 @@ inline int dma_form(const iseg_gemm_args* g, int nsplit) {
     return variant;
 }
 
+// one instantiation per fused epilogue kind for bf16 outputs (the other output type keeps the run-time epilogue)
+template <int WM, int WN, int NS, class TO, int FN>
+void launch_dma_kinds(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
+    if (sizeof(TO) == 2) {
+        switch (epi_kind(epi, slabs)) {
+            case EK_GELU_DERIV: launch_dma<WM, WN, NS, TO, FN, EK_GELU_DERIV>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN>(g, epi, nsplit, kps, slabs, s); return;
+            default: break;
+        }
+    }
+    launch_dma<WM, WN, NS, TO, FN>(g, epi, nsplit, kps, slabs, s);
+}
+
 template <class TO>
 void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     switch (dma_form(g, nsplit)) {
         case 1: launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s); break;
-        case 2: launch_dma<4, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
+        case 2: launch_dma_kinds<4, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 128: the flagship's stage-2 products
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 5: launch_dma_persistent<TO>(g, epi, kps, dma_cus(), s); break;
-        case 6: launch_dma<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;
-        default: launch_dma<2, 2, 3, TO>(g, epi, nsplit, kps, slabs, s); break;
+        case 6: launch_dma_kinds<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 192: stage 3
+        default: launch_dma_kinds<2, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s); break;
     }
 }
 

@@ -15,6 +15,10 @@
 // ds_read_b64_tr_b16.  Z and dW1T stay in registers (C / 2 per lane) over the whole row chunk; every workgroup writes one fp32 partial,
 // iseg_convnext_mlp_wgrad_finish sums the chunks in a fixed order (no atomics) and applies the layer-scale algebra.
 //
+// Measured (MI355X, stage 0: M = 262144, C = 96): 165 us + 30 us for the finish launch; the instruction stream is VALU-issue bound (141 VALU + 24
+// MFMA per 32-row block and wavefront, gelu + gelu' = 110 of them; SQ issue ~85 % busy with two wavefronts per SIMD), LDS 31 us, matrix cores
+// 31 us.  What did not help: requesting the next block's A fragments a phase early (202 vs 198 us), 128-row tiles (222 us).
+//
 // dbr = rowscale[sample] * d(out) is formed while the tile is staged (the drop-path row factor is constant inside a tile), and with
 // mean != NULL the y operand is LayerNorm(y1) formed the same way, so neither the scaled gradient nor the normalised activation has to
 // exist in HBM for this kernel.
@@ -228,11 +232,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float g, gd;
-#if defined(WG_KNOB) && (WG_KNOB & 1)
-                    g = hacc[b][r]; gd = hacc[b][r] * 0.5f;
-#else
                     gelu_sig_both(hacc[b][r], g, gd);
-#endif
                     const bf16_t dh = (bf16_t)(dacc[b][r] * gd);
                     gf[4 * b + r] = (bf16_t)g;
                     hf[4 * b + r] = dh;
@@ -251,13 +251,8 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
                 }
 #pragma unroll
                 for (int c = 0; c < CG; ++c) {
-#if defined(WG_KNOB) && (WG_KNOB & 2)
-                    zacc[c0 + c][0] += (float)bd[c][0] + (float)gf[0];
-                    wacc[c0 + c][0] += (float)by[c][0] + (float)hf[0];
-#else
                     zacc[c0 + c] = mfma16(gf, bd[c], zacc[c0 + c]);
                     wacc[c0 + c] = mfma16(hf, by[c], wacc[c0 + c]);
-#endif
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -268,20 +263,11 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
     commit(0, 0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
-#if defined(WG_KNOB) && (WG_KNOB & 4)
-        compute(0);
-#elif defined(WG_KNOB) && (WG_KNOB & 8)
-        issue(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        commit(t + 1, (t + 1) & 1);
-        __syncthreads();
-#else
         issue(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(t & 1);
         commit(t + 1, (t + 1) & 1);
         __syncthreads();
-#endif
     }
 
     // ---- partial results of this (chunk, hidden group) ----

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--graph-step", action="store_true", help="replay the train step from one HIP graph (iseg_amd/graphs.py GraphedTrainStep)")
     args = ap.parse_args()
     from iseg_amd import heads
     from iseg_amd.core_env import common_env_setup
@@ -54,8 +55,16 @@ def main():
                                                adamw_weight_decay=0.05))
             trainer = CoreTrain(helper, None).create_trainable_model(21, ignore_label=255, batch_size=batch)
 
-            def step():
-                return trainer.train_step(x, y)
+            if args.graph_step:
+                from iseg_amd.graphs import GraphedTrainStep
+
+                graphed = GraphedTrainStep(trainer, warmup=2)
+
+                def step():
+                    return graphed(x, y)
+            else:
+                def step():
+                    return trainer.train_step(x, y)
         else:
             def step():
                 with torch.no_grad():
@@ -72,6 +81,7 @@ def main():
                "images_per_sec": round(batch / dt, 2), "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2)}
         if training:
             rec["loss"] = round(float(out[0]), 4)
+            rec["step"] = "hip graph replay" if args.graph_step else "eager"
         print(json.dumps(rec), flush=True)
         del model, helper
         torch.cuda.empty_cache()
