@@ -13,7 +13,7 @@
 // row-contractions: accumulator blocks of rows 0-15 and 16-31 side by side are one 8-element fragment whose k slot (q, j) is row 4q + j
 // (j < 4) or 16 + 4q + j - 4, and the B operand (lane = channel) is gathered in that same order from the row-major LDS tile by two
 // ds_read_b64_tr_b16.  Z and dW1T stay in registers (C / 2 per lane) over the whole row chunk; every workgroup writes one fp32 partial,
-// iseg_convnext_mlp_wgrad_finish sums the chunks in a fixed order (no atomics) and applies the layer-scale algebra.
+// a fixed-order row reduction sums the chunk records (no atomics) and a small finish launch applies the layer-scale algebra.
 //
 // Measured (MI355X, stage 0: M = 262144, C = 96): 165 us + 30 us for the finish launch; the instruction stream is VALU-issue bound (141 VALU + 24
 // MFMA per 32-row block and wavefront, gelu + gelu' = 110 of them; SQ issue ~85 % busy with two wavefronts per SIMD), LDS 31 us, matrix cores
@@ -73,8 +73,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
                                                                  const float* __restrict__ ln_beta, const bf16_t* __restrict__ D,
                                                                  const float* __restrict__ rowscale, int64_t rows_per_group,
                                                                  const void* __restrict__ BW, const float* __restrict__ b1,
-                                                                 float* __restrict__ part, float* __restrict__ part_b1,
-                                                                 float* __restrict__ part_s, int64_t M, int64_t rows_per_chunk, int nchunk) {
+                                                                 float* __restrict__ part, int64_t M, int64_t rows_per_chunk, int nchunk) {
     using G = WgGeom<C>;
     constexpr int HID = G::HID, KS = G::KS, CBS = G::CBS, STRIDE = G::STRIDE, TILE = G::TILE, RT = G::RT, RG = G::RG, RPT = G::RPT, CPR = G::CPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -271,8 +270,12 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
     }
 
     // ---- partial results of this (chunk, hidden group) ----
-    float* const pz = part + ((int64_t)chunk * 2 + 0) * HID * C;
-    float* const pw = part + ((int64_t)chunk * 2 + 1) * HID * C;
+    // one record per chunk: [Z | dW1T | db1 | S], so that ONE fixed-order row reduction sums everything over the chunks
+    constexpr int64_t REC = 2 * (int64_t)HID * C + HID + C;
+    float* const pz = part + (int64_t)chunk * REC;
+    float* const pw = pz + (int64_t)HID * C;
+    float* const pb = pw + (int64_t)HID * C;
+    float* const ps = pb + HID;
 #pragma unroll
     for (int cb = 0; cb < CBS; ++cb)
 #pragma unroll
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
         u = __builtin_bit_cast(unsigned, v);
         auto sx = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         v = __builtin_bit_cast(float, (unsigned)sx[0]) + __builtin_bit_cast(float, (unsigned)sx[1]);
-        if (lane < 16) part_b1[(int64_t)chunk * HID + hid0 + li] = v;
+        if (lane < 16) pb[hid0 + li] = v;
     }
     if (hg == 0) {      // S = column sums of dbr: the staging threads' registers -> LDS [row group][C] -> one value per channel
         float* const ss = reinterpret_cast<float*>(smem);      // (every wavefront is past its last tile read: the loop ended on a barrier)
@@ -301,23 +304,25 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
         if (tid < C) {
             float v = 0.f;
             for (int g = 0; g < RG; ++g) v += ss[g * C + tid];
-            part_s[(int64_t)chunk * C + tid] = v;
+            ps[tid] = v;
         }
     }
 }
 
-// Sum the row-chunk partials in chunk order and book the parameter gradients (accumulating into the flat gradient buffer):
+// Book the parameter gradients from the chunk-summed record (accumulating into the flat gradient buffer):
 //     dW1[c][hid] += dW1T[hid][c]      db1[hid] += ..      dW2[hid][c] += Z[hid][c] gamma[c]      db2[c] += gamma[c] S[c]
 //     dgamma[c]   += sum_hid W2[hid][c] Z[hid][c] + b2[c] S[c]           (gamma == NULL: dW2 += Z, db2 += S)
-// Block = 8 hidden units x 32 channels (256 threads, one element each, sixteen chunks' loads in flight per array); dW1 leaves through an
-// LDS transpose; the per-block column sums of W2 o Z go to `gpart` [HID / 8][C] for the fixed-order second stage.
+// Block = 8 hidden units x 32 channels (256 threads, one element each); dW1 leaves through an LDS transpose; the per-block column sums of
+// W2 o Z go to `gpart` [HID / 8][C] for the fixed-order second stage.  (Summing the 80 chunk records inside this kernel took 47-134 us in
+// three different shapes -- 144 workgroups cannot pull 24 MB, and the db1 / S sums were 80 dependent loads on a handful of threads; the
+// generic row reduction in front does it in 8.5 us.)
 constexpr int FIN_ROWS = 8;
-__global__ __launch_bounds__(256) void convnext_mlp_wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ part_b1,
-                                                                        const float* __restrict__ part_s, int nchunk,
-                                                                        const float* __restrict__ W2, const float* __restrict__ b2,
-                                                                        const float* __restrict__ gamma, float* __restrict__ dW1,
-                                                                        float* __restrict__ db1, float* __restrict__ dW2,
-                                                                        float* __restrict__ db2, float* __restrict__ gpart, int C) {
+// `rec` = the chunk-summed record [Z | dW1T | db1 | S] (fp32, one fixed-order row reduction over the chunk records in front of this launch)
+__global__ __launch_bounds__(256) void convnext_mlp_wgrad_finish_kernel(const float* __restrict__ rec, const float* __restrict__ W2,
+                                                                        const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                                        float* __restrict__ dW1, float* __restrict__ db1,
+                                                                        float* __restrict__ dW2, float* __restrict__ db2,
+                                                                        float* __restrict__ gpart, int C) {
     __shared__ float tw[FIN_ROWS][33];
     __shared__ float tg[8][32];
     const int HID = 4 * C;
@@ -325,40 +330,14 @@ __global__ __launch_bounds__(256) void convnext_mlp_wgrad_finish_kernel(const fl
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const int c = c0 + tx;
     const int64_t plane = (int64_t)HID * C;
-    float s = 0.f;
-    if (blockIdx.y == 0 && ty == 0) {
-        for (int k = 0; k < nchunk; ++k) s += part_s[(int64_t)k * C + c];
-    }
     const float gm = gamma ? gamma[c] : 1.f;
-    float colsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < FIN_ROWS / 8; ++i) {
-        const int hid = h0 + ty + 8 * i;
-        const int64_t o = (int64_t)hid * C + c;
-        float z = 0.f, w = 0.f;
-        int k = 0;
-        for (; k + 16 <= nchunk; k += 16) {
-            float zz[16], ww[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                zz[u] = part[(int64_t)(k + u) * 2 * plane + o];
-                ww[u] = part[(int64_t)(k + u) * 2 * plane + plane + o];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) {
-                z += (zz[u] + zz[u + 1]) + (zz[u + 2] + zz[u + 3]);
-                w += (ww[u] + ww[u + 1]) + (ww[u + 2] + ww[u + 3]);
-            }
-        }
-        for (; k < nchunk; ++k) {
-            z += part[(int64_t)k * 2 * plane + o];
-            w += part[(int64_t)k * 2 * plane + plane + o];
-        }
+    {
+        const int64_t o = (int64_t)(h0 + ty) * C + c;
+        const float z = rec[o], w = rec[plane + o];
         dW2[o] += z * gm;
-        colsum += W2[o] * z;
-        tw[ty + 8 * i][tx] = w;
+        tg[ty][tx] = W2[o] * z;
+        tw[ty][tx] = w;
     }
-    tg[ty][tx] = colsum;
     __syncthreads();
     {      // dW1[c][hid]: thread -> (channel row, hidden unit): FIN_ROWS consecutive hidden units per channel
         const int hx = threadIdx.x & (FIN_ROWS - 1), cc = threadIdx.x / FIN_ROWS;      // 8 x 32
@@ -369,6 +348,7 @@ __global__ __launch_bounds__(256) void convnext_mlp_wgrad_finish_kernel(const fl
 #pragma unroll
         for (int j = 0; j < 8; ++j) v += tg[j][tx];
         if (blockIdx.y == 0) {
+            const float s = rec[2 * plane + HID + c];
             if (gamma) {
                 v += b2[c] * s;
                 db2[c] += gm * s;
@@ -380,9 +360,7 @@ __global__ __launch_bounds__(256) void convnext_mlp_wgrad_finish_kernel(const fl
     }
     if (blockIdx.x == 0 && threadIdx.x < FIN_ROWS) {
         const int hid = h0 + threadIdx.x;
-        float v = 0.f;
-        for (int k = 0; k < nchunk; ++k) v += part_b1[(int64_t)k * HID + hid];
-        db1[hid] += v;
+        db1[hid] += rec[2 * plane + hid];
     }
 }
 
@@ -410,11 +388,9 @@ int launch_wgrad(const void* y, const float* mean, const float* rstd, const floa
     }();
     (void)raised;
     float* part = ws;
-    float* part_b1 = part + (int64_t)nchunk * 2 * G::HID * C;
-    float* part_s = part_b1 + (int64_t)nchunk * G::HID;
     const int grid = 8 * G::NHG * ((nchunk + 7) / 8);
     hipLaunchKernelGGL((convnext_mlp_wgrad_kernel<C>), dim3(grid), dim3(G::NT), G::LDS, s, (const bf16_t*)y, mean, rstd, lng, lnb, (const bf16_t*)d,
-                       rowscale, rows_per_group, BW, b1, part, part_b1, part_s, M, (int64_t)rpc, nchunk);
+                       rowscale, rows_per_group, BW, b1, part, M, (int64_t)rpc, nchunk);
     return iseg_check_launch("iseg_convnext_mlp_wgrad");
 }
 
@@ -423,7 +399,8 @@ size_t wgrad_ws_floats(int C, int64_t M, int* nchunk_out) {
     if (C == 96) rows_per_chunk_for<96>(M, &nchunk);
     else rows_per_chunk_for<192>(M, &nchunk);
     if (nchunk_out) *nchunk_out = nchunk;
-    return (size_t)nchunk * (2 * 4 * C * C + 4 * C + C) + (size_t)(4 * C / FIN_ROWS) * C;
+    const size_t rec = 2 * 4 * (size_t)C * C + 4 * C + C;      // [Z | dW1T | db1 | S]
+    return (size_t)(nchunk + 1) * rec + (size_t)(4 * C / FIN_ROWS) * C;      // chunk records, their sum, the layer-scale partials
 }
 
 }  // namespace
@@ -456,10 +433,12 @@ extern "C" int iseg_convnext_mlp_wgrad(const void* y, const float* mean, const f
                      : launch_wgrad<192>(y, mean, rstd, ln_gamma, ln_beta, dout, rowscale, rows_per_group, bw_tiled, b1, wsf, M, stream);
     if (rc != ISEG_OK) return rc;
     const int HID = 4 * C;
+    const int64_t rec = 2 * (int64_t)HID * C + HID + C;
     float* part = wsf;
-    float* part_b1 = part + (int64_t)nchunk * 2 * HID * C;
-    float* part_s = part_b1 + (int64_t)nchunk * HID;
-    float* gpart_ws = part_s + (int64_t)nchunk * C;
+    float* sum = part + (int64_t)nchunk * rec;
+    float* gpart_ws = sum + rec;
+    // chunk records -> their sum: the fixed-order two-level row reduction every parameter gradient uses (common.h)
+    launch_reduce_rows(part, nchunk, rec, 0, 1, rec, sum, nullptr, rec, 0, 1.f, 0, stream);
     const int P = HID / FIN_ROWS;
     float* gpart = gpart_ws;
     float* arena = nullptr;
@@ -467,7 +446,7 @@ extern "C" int iseg_convnext_mlp_wgrad(const void* y, const float* mean, const f
         arena = iseg_deferred_partials((size_t)P * C * sizeof(float), dgamma, nullptr, 1, stream);      // (common.h: deferred reductions)
         if (arena) gpart = arena;
     }
-    hipLaunchKernelGGL(convnext_mlp_wgrad_finish_kernel, dim3(C / 32, HID / FIN_ROWS), dim3(256), 0, stream, part, part_b1, part_s, nchunk, W2, b2, gamma,
+    hipLaunchKernelGGL(convnext_mlp_wgrad_finish_kernel, dim3(C / 32, HID / FIN_ROWS), dim3(256), 0, stream, sum, W2, b2, gamma,
                        dW1, db1, dW2, db2, gpart, C);
     if (gamma) {
         if (arena) iseg_deferred_push(gpart, P, C, C, dgamma, nullptr, C, 1.f, stream);

@@ -24,7 +24,9 @@ def _restore_policy():
 
 def _donor(tmp_path):
     """a ConvNeXt-T with SURVEY 8(d) weights, written as a Keras-style weight file (one group per direct layer) and as a renamed variant
-    ('.'-separated layer names, a model prefix in front of every weight name: what another Keras version writes)"""
+    ('.'-separated layer GROUP names, as Keras 3 writes them: the replace_slash route of saver/h5_saver.py:58-61.  The weight names stay exact:
+    this backbone numbers its blocks ("stages/1/1/gamma"), and the reference's component-PRESENCE match (:281-298) cannot tell
+    "stages/1/0/gamma" from "stages/1/1/gamma" -- its fuzzy route is exercised on distinctly named layers in tests/test_saver.py)"""
     from iseg_amd import nn
     from iseg_amd.backbones.feature_extractor import get_backbone
     from iseg_amd.saver import open_weights, save_weights, write_npz
@@ -37,7 +39,7 @@ def _donor(tmp_path):
     layers = {}
     for lname in [str(s) for s in root.attrs["layer_names"]]:
         g = root[lname]
-        layers[lname.replace("/", ".")] = {"model." + w.replace("/", "."): np.asarray(g[w]) for w in [str(s) for s in g.attrs["weight_names"]]}
+        layers[lname.replace("/", ".")] = {w: np.asarray(g[w]) for w in [str(s) for s in g.attrs["weight_names"]]}
     renamed = write_npz(str(tmp_path / "renamed.h5.npz"), layers)
     return donor, exact, renamed
 
