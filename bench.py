@@ -224,19 +224,28 @@ def _kernel_label(key):
     return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''}{'; epilogue ' + epi if epi else ''})"
 
 
+def _dma_symbol(key):
+    """(mangled-name fragment, total grid size) of the LDS-DMA GEMM instantiation a timed group runs on, or (None, None)"""
+    _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux = key[:10]
+    variant = key[13] if len(key) > 13 else 0
+    shapes = {2: (4, 2, 3, 4), 6: (4, 2, 2, 6), 4: (2, 2, 3, 4)}      # variant -> (WM, WN, NS, FN) of gemm_dma.h dispatch_dma
+    if variant not in shapes:
+        return None, None
+    wm, wn, ns, fn = shapes[variant]
+    ek = 1 if (int(act) == 2 and has_pre) else 2 if int(act) == 5 else 3 if (int(act) == 0 and has_res) else 4 if (int(act) == 0 and not has_aux) else 0
+    bm, bn = wm * 64, wn * fn * 16
+    tiles = -(-M // bm) * -(-N // bn)
+    return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}EE", tiles * wm * wn * 64
+
+
 def pick_dominant(report):
     """the group with the largest total time; several stage-2 GEMM groups sit within a few per cent of each other, so among the
-    groups within 10 % of the maximum prefer one whose HBM traffic has been measured with PMC counters (profiles/pmc_traffic.json)"""
+    groups within 10 % of the maximum prefer one whose launches a PMC pass can attribute (see _dma_symbol)"""
     totals = {k: v[0] * v[1] for k, v in report.items()}
     top = max(totals.values())
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            measured = set(json.load(f))
-    except OSError:
-        measured = set()
     near = sorted((k for k, t in totals.items() if t >= 0.9 * top), key=lambda k: -totals[k])
-    for k in near:
-        if _kernel_label(k) in measured:
+    for k in near:      # prefer a group whose instantiation rocprof can name on its own (LDS-DMA kernel, epilogue kind in the symbol)
+        if _dma_symbol(k)[0] is not None:
             return k
     return near[0]
 
@@ -258,17 +267,21 @@ def roofline_from_timer(report, steps, survey=None):
               "launches_per_step": launches / steps, "launch_us": round(sec * 1e6, 2),
               "share_of_gemm_time": round(share, 4), "algorithmic_bytes_per_launch": int(nbytes),
               "algorithmic_flops_per_launch": int(flops), "flop_per_byte": round(intensity, 1), "traffic": None}
-    # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the figure comes from the
-    # separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_traffic.py, corrections
-    # per MI355X_MICROARCH.md) committed under profiles/; null when no measurement for this kernel+shape is on file.
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            rec = json.load(f).get(common["kernel"])
-        if rec:
-            common["traffic"] = rec["traffic"]
-            common["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes)"
-    except OSError:
-        pass
+    # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the figure comes from the separate rocprofv3
+    # --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_evidence.sh -> profiles/r03_pmc.json, corrections per
+    # MI355X_MICROARCH.md), looked up by kernel symbol (the epilogue kind is part of it since round 3) and grid; null when the file was
+    # taken on another source tree or holds no such kernel.
+    sym, grid = _dma_symbol(key)
+    doc, why = _pmc_on_this_tree()
+    if doc is not None and sym is not None:
+        for rec in doc.get("kernels", []):
+            if sym in rec["kernel"] and int(rec["grid"]) == grid:
+                common["traffic"] = rec["traffic"]
+                common["profiled_launch_us"] = rec["avg_us"]
+                common["traffic_source"] = f"{PMC_FILE} kernel {sym} grid {grid} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; separate passes; same source stamp)"
+                break
+    elif why:
+        common["traffic_source"] = why
     if intensity >= ridge:
         ach = flops / sec / 1e12
         common.update({"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
@@ -280,21 +293,43 @@ def roofline_from_timer(report, steps, survey=None):
     return common
 
 
+PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+
+
+def _pmc_on_this_tree():
+    """profiles/r03_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes over this same command, tools/collect_evidence.sh) when it was taken
+    on EXACTLY this source tree (tools/source_stamp.py), else (None, why)"""
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return None, f"{PMC_FILE} not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_stamp import source_stamp
+
+    have, now = (doc.get("stamp") or {}).get("source_sha16"), source_stamp()
+    if have != now:
+        return None, f"{PMC_FILE} was taken on source stamp {have}, this tree is {now}: counters not reported"
+    return doc, None
+
+
 def step_fractions(args, ips_per_gpu, sec_per_step):
     """the WHOLE step against both peaks, beside the single-kernel `roofline`: matrix-core fraction from the model's algorithmic flops
-    (TRAIN_GFLOP_PER_IMAGE) at the measured rate, HBM fraction from the step's PMC traffic (profiles/r02_pmc.json: rocprofv3 FETCH_SIZE /
-    WRITE_SIZE passes over this same command at the default batch and size; null for another workload or without the file)"""
-    out = {"mfma_frac": round(ips_per_gpu * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4), "hbm_frac": None, "traffic_bytes": None}
+    (TRAIN_GFLOP_PER_IMAGE) at the measured rate; HBM fraction and matrix-core busy fraction from the step's PMC passes -- null unless the
+    counters on file were taken on this very source tree, at the default batch and size"""
+    out = {"mfma_frac": round(ips_per_gpu * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4), "hbm_frac": None, "traffic_bytes": None,
+           "mfma_busy_frac": None}
     if args.batch == 16 and args.size == 512 and not args.fp32:
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
-                st = json.load(f)["step"]
+        doc, why = _pmc_on_this_tree()
+        if doc is None:
+            out["traffic_source"] = why
+        else:
+            st = doc["step"]
             out["traffic_bytes"] = int(st["traffic_bytes"])
             out["hbm_frac"] = round(st["traffic_bytes"] / sec_per_step / (HBM_PEAK_GBS * 1e9), 4)
             out["mfma_busy_frac"] = st.get("mfma_occupancy")
-            out["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES, separate passes)"
-        except (OSError, KeyError, ValueError):
-            pass
+            out["traffic_source"] = (f"{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES, separate passes); stamp "
+                                     f"{doc['stamp']['source_sha16']} = this tree, taken at commit {doc['stamp'].get('git_head')}")
     return out
 
 

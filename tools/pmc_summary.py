@@ -16,6 +16,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 CLOCK_HZ, SIMDS = 2.4e9, 1024
@@ -60,14 +61,19 @@ def main():
         step_traffic += (rd + wr) * n / steps
         step_time += t * n / steps
         step_mfma += mf * n / steps
-        rows.append({"kernel": name[:140], "grid": int(grid), "launches_per_step": round(n / steps, 2), "avg_us": round(t * 1e6, 2),
+        rows.append({"kernel": name[:200], "grid": int(grid), "launches_per_step": round(n / steps, 2), "avg_us": round(t * 1e6, 2),
                      "ms_per_step": round(t * n / steps * 1e3, 4), "read_bytes": int(rd), "write_bytes": int(wr), "traffic": int(rd + wr),
                      "hbm_gbs": round((rd + wr) / t * 1e-9, 1), "hbm_frac_of_8tbs": round((rd + wr) / t / 8e12, 4),
                      "mfma_busy_cycles": int(mf), "mfma_occupancy": round(mf / (t * CLOCK_HZ * SIMDS), 4),
                      "sq_wait_inst_any": int(mean(sq[key]["SQ_WAIT_INST_ANY"]) or 0), "sq_wave_cycles": int(mean(sq[key]["SQ_WAVE_CYCLES"]) or 0),
                      "sq_insts_valu": int(mean(sq[key]["SQ_INSTS_VALU"]) or 0)})
     rows.sort(key=lambda r: -r["ms_per_step"])
-    doc = {"source": "rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over `bench.py --steps 3 --warmup 2`",
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from source_stamp import git_head, source_stamp
+
+    doc = {"stamp": {"source_sha16": source_stamp(), "git_head": git_head(),
+                     "note": "sha256 over iseg_amd/csrc/* and the host files listed in tools/source_stamp.py; bench.py reports these figures only on an identical tree"},
+           "source": "rocprofv3 --kernel-trace --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*) over `bench.py --steps 3 --warmup 2`",
            "corrections": "read = 2 * FETCH_SIZE KiB (gfx950 wide coalesced reads report half), write = WRITE_SIZE KiB; MFMA occupancy at the nominal 2.4 GHz",
            "step": {"kernel_time_ms": round(step_time * 1e3, 3), "traffic_bytes": int(step_traffic),
                     "hbm_frac_of_8tbs": round(step_traffic / step_time / 8e12, 4),
