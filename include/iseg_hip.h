@@ -561,7 +561,7 @@ int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled,
                           int64_t M, int C, int dtype, iseg_stream_t stream);
 /* The same block's backward pass with NO [M, 4C] tensor in HBM (round 3; the training path uses this pair):
  *   iseg_convnext_mlp_bwd_data  dy2 [M, C] only; dbr = rowscale[m / rows_per_group] * dout is formed while the rows are loaded
- *                               (rowscale may be NULL)
+ *                               (rowscale may be NULL); mean != NULL: `y` is the LayerNorm input y1, normalised on load like in _wgrad
  *   iseg_convnext_mlp_wgrad     every parameter gradient of backbones/convnext.py:51-57 (pwconv1, pwconv2, gamma), ACCUMULATED into
  *                               dW1 [C, 4C], db1 [4C], dW2 [4C, C], db2 [C], dgamma [C]: workgroups own 128 hidden units and a chunk of
  *                               rows, recompute gelu(h) / dh for them and contract over the rows on the matrix cores; partial sums per
@@ -570,8 +570,14 @@ int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled,
  *                               db2 += gamma S with S = column sums of dbr; gamma == NULL: dW2 += g^T dbr, db2 += S.  W2 / b2 / gamma
  *                               are the fp32 masters.  mean != NULL: `y` is the LayerNorm INPUT y1 and y2 = (y1 - mean) rstd ln_gamma +
  *                               ln_beta is formed while the rows are staged.  rowscale needs rows_per_group % 64 == 0. */
-int iseg_convnext_mlp_bwd_data(const void* y2, const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
-                               const float* b1, void* dy2, int64_t M, int C, int dtype, iseg_stream_t stream);
+int iseg_convnext_mlp_bwd_data(const void* y, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
+                               const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled, const float* b1,
+                               void* dy2, int64_t M, int C, int dtype, iseg_stream_t stream);
+/* the forward kernel with keras.layers.LayerNormalization(epsilon) (backbones/convnext.py:27,49) folded into its row load: y1 = the
+ * depthwise convolution's output; mean / rstd [M] are written for the backward kernels; y2 never exists in HBM */
+int iseg_convnext_mlp_fwd_ln(const void* y1, const float* ln_gamma, const float* ln_beta, float eps, float* mean, float* rstd,
+                             const void* fw_tiled, const float* b1, const float* b2, const float* gamma, const float* rowscale,
+                             int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype, iseg_stream_t stream);
 size_t iseg_convnext_mlp_wgrad_workspace_bytes(int64_t M, int C);
 int iseg_convnext_mlp_wgrad(const void* y, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
                             const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled, const float* b1,

@@ -180,7 +180,8 @@ SIGNATURES = {
     "iseg_convnext_mlp_prep": (_i, [_p, _p, _p, _p, _p, _i, _p]),
     "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
-    "iseg_convnext_mlp_bwd_data": (_i, [_p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
+    "iseg_convnext_mlp_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
+    "iseg_convnext_mlp_fwd_ln": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_wgrad_workspace_bytes": (_z, [_l, _i]),
     "iseg_convnext_mlp_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
     "iseg_sgd_momentum_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _p, _f, _p, _f, _l, _p]),

@@ -34,6 +34,7 @@
 // C = 192; two wavefronts per SIMD let one's gelu overlap the other's MFMAs.
 #include "common.h"
 #include "iseg_hip.h"
+#include "mlp_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
                                                                const float* __restrict__ b1, const float* __restrict__ b2,
                                                                const float* __restrict__ gamma, const float* __restrict__ rowscale,
                                                                int64_t rows_per_group, const bf16_t* __restrict__ R, bf16_t* __restrict__ O,
-                                                               int64_t M) {
+                                                               int64_t M, MlpLayerNorm ln) {
     using G = MlpGeom<C, SUB, WAVES, 2, NSTAGES>;
     constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
         const bf16_t* yp = Y + row * C + 8 * h;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
+        // Y is the LayerNorm INPUT (ln.gamma != NULL): a row lives in the two lanes r and r + 32, so the statistics are an in-lane sum and one
+        // lane-half exchange; y2 never exists in HBM (round 3).  The row's mean / rstd are saved for the backward kernels.
+        if (ln.gamma) mlp_layernorm_rows<KK>(yf, ln, m0 + r < M ? m0 + r : -1, h, C);
     }
     for (int i = tid; i < HID; i += 64 * WAVES) b1s[i] = b1[i];
     // the loads above must have landed before the ring starts (keeps the compiler's own vmcnt bookkeeping out of the loop)
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
                                                                       const float* __restrict__ rowscale, int64_t rows_per_group,
                                                                       const void* __restrict__ BW, const float* __restrict__ b1,
                                                                       bf16_t* __restrict__ Gout, bf16_t* __restrict__ DHout,
-                                                                      bf16_t* __restrict__ DY, int64_t M) {
+                                                                      bf16_t* __restrict__ DY, int64_t M, MlpLayerNorm ln) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
     constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
     constexpr int STORES = STORE ? 4 * SUB : 0;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
             yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
             df[kk] = *reinterpret_cast<const bf16x8*>(dp + 16 * kk);
         }
+        if (ln.gamma) mlp_layernorm_apply_rows<KK>(yf, ln, row, h);      // Y = LayerNorm input, statistics saved by the forward kernel
         if (rowscale) {
             const float rs = rowscale[row / rows_per_group];
 #pragma unroll
@@ -494,7 +499,7 @@ __global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const flo
 
 template <int C, int SUB, int WAVES, int NSTAGES>
 int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float* b2, const float* gamma, const float* rowscale,
-                   int64_t rows_per_group, const void* residual, void* out, int64_t M, hipStream_t s) {
+                   int64_t rows_per_group, const void* residual, void* out, int64_t M, const MlpLayerNorm& ln, hipStream_t s) {
     using G = MlpGeom<C, SUB, WAVES, 2, NSTAGES>;
     static const bool raised = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_fwd_kernel<C, SUB, WAVES, NSTAGES>),
@@ -503,13 +508,13 @@ int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float*
     (void)raised;
     const int grid = (int)ceil_div64(M, 32 * WAVES);
     hipLaunchKernelGGL((convnext_mlp_fwd_kernel<C, SUB, WAVES, NSTAGES>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2, FW, b1, b2, gamma, rowscale,
-                       rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M);
+                       rows_per_group, (const bf16_t*)residual, (bf16_t*)out, M, ln);
     return iseg_check_launch("iseg_convnext_mlp_fwd");
 }
 
 template <int C, int SUB, int WAVES, int NSTAGES, bool STORE>
 int launch_mlp_bwd(const void* y2, const void* dbr, const float* rowscale, int64_t rows_per_group, const void* BW, const float* b1, void* g,
-                   void* dh, void* dy2, int64_t M, hipStream_t s) {
+                   void* dh, void* dy2, int64_t M, const MlpLayerNorm& ln, hipStream_t s) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
     static const bool raised = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>),
@@ -518,7 +523,7 @@ int launch_mlp_bwd(const void* y2, const void* dbr, const float* rowscale, int64
     (void)raised;
     const int grid = (int)ceil_div64(M, 32 * WAVES);
     hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2,
-                       (const bf16_t*)dbr, rowscale, rows_per_group, BW, b1, (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M);
+                       (const bf16_t*)dbr, rowscale, rows_per_group, BW, b1, (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M, ln);
     return iseg_check_launch("iseg_convnext_mlp_bwd");
 }
 
@@ -551,10 +556,25 @@ extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const
     ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_fwd: rowscale needs rows_per_group > 0");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)gamma) & 15) == 0,
                  "iseg_convnext_mlp_fwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_fwd<96, 2, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
-    if (C == 192) return launch_mlp_fwd<192, 1, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    const MlpLayerNorm none{};
+    if (C == 96) return launch_mlp_fwd<96, 2, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, none, stream);
+    if (C == 192) return launch_mlp_fwd<192, 1, 8, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, none, stream);
     // C = 384: 96 fragment + 192 accumulator registers per lane -> one wavefront per SIMD, 128-row workgroups
-    return launch_mlp_fwd<384, 1, 4, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, stream);
+    return launch_mlp_fwd<384, 1, 4, 3>(y2, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, none, stream);
+}
+
+extern "C" int iseg_convnext_mlp_fwd_ln(const void* y1, const float* ln_gamma, const float* ln_beta, float eps, float* mean, float* rstd,
+                                        const void* fw_tiled, const float* b1, const float* b2, const float* gamma, const float* rowscale,
+                                        int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dtype == ISEG_BF16 && (C == 96 || C == 192), "iseg_convnext_mlp_fwd_ln: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(y1 && ln_gamma && ln_beta && mean && rstd && fw_tiled && b1 && b2 && residual && out && M > 0,
+                 "iseg_convnext_mlp_fwd_ln: null operand or empty problem");
+    ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_fwd_ln: rowscale needs rows_per_group > 0");
+    ISEG_REQUIRE((((uintptr_t)y1 | (uintptr_t)fw_tiled | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)b1 | (uintptr_t)b2 | (uintptr_t)gamma |
+                   (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0, "iseg_convnext_mlp_fwd_ln: operands must be 16-byte aligned");
+    const MlpLayerNorm ln{ln_gamma, ln_beta, mean, rstd, eps};
+    if (C == 96) return launch_mlp_fwd<96, 2, 8, 3>(y1, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, ln, stream);
+    return launch_mlp_fwd<192, 1, 8, 3>(y1, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual, out, M, ln, stream);
 }
 
 extern "C" int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled, const float* b1, void* g, void* dh, void* dy2,
@@ -563,18 +583,23 @@ extern "C" int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void
     ISEG_REQUIRE(y2 && dbr && bw_tiled && b1 && g && dh && dy2 && M > 0, "iseg_convnext_mlp_bwd: null operand or empty problem");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dbr | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)g | (uintptr_t)dh | (uintptr_t)dy2) & 15) == 0,
                  "iseg_convnext_mlp_bwd: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);
-    if (C == 192) return launch_mlp_bwd<192, 1, 4, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);
-    return launch_mlp_bwd<384, 1, 4, 2, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, stream);      // 72-KiB slabs: a two-stage ring is what fits
+    const MlpLayerNorm none{};
+    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, none, stream);
+    if (C == 192) return launch_mlp_bwd<192, 1, 4, 3, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, none, stream);
+    return launch_mlp_bwd<384, 1, 4, 2, true>(y2, dbr, nullptr, 0, bw_tiled, b1, g, dh, dy2, M, none, stream);      // 72-KiB slabs: a two-stage ring is what fits
 }
 
-extern "C" int iseg_convnext_mlp_bwd_data(const void* y2, const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
+extern "C" int iseg_convnext_mlp_bwd_data(const void* y2, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
+                                          const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
                                           const float* b1, void* dy2, int64_t M, int C, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(dtype == ISEG_BF16 && (C == 96 || C == 192), "iseg_convnext_mlp_bwd_data: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
     ISEG_REQUIRE(y2 && dout && bw_tiled && b1 && dy2 && M > 0, "iseg_convnext_mlp_bwd_data: null operand or empty problem");
     ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_bwd_data: rowscale needs rows_per_group > 0");
     ISEG_REQUIRE((((uintptr_t)y2 | (uintptr_t)dout | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)dy2) & 15) == 0,
                  "iseg_convnext_mlp_bwd_data: operands must be 16-byte aligned");
-    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, stream);
-    return launch_mlp_bwd<192, 1, 4, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, stream);
+    ISEG_REQUIRE(!mean || (rstd && ln_gamma && ln_beta && (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0),
+                 "iseg_convnext_mlp_bwd_data: mean needs rstd and 16-byte aligned ln_gamma / ln_beta");
+    const MlpLayerNorm ln{mean ? ln_gamma : nullptr, ln_beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f};
+    if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, ln, stream);
+    return launch_mlp_bwd<192, 1, 4, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, ln, stream);
 }

@@ -896,6 +896,7 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 # ConvNeXt block, fused:  x + drop_path(gamma * pw2(gelu(pw1(LN(dw7x7(x))))))     backbones/convnext.py:47-63
 # ---------------------------------------------------------------------------------------------------------
+_MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: LayerNorm of the fused stages as its own kernel (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
 
@@ -912,7 +913,14 @@ class _ConvNeXtBlockFn(Function):
         pad = (Kk - 1) * dil // 2
         y1 = K.dwconv2d(xc, p.dw_kernel.data.reshape(Kk * Kk, C), p.dw_bias.data, Kk, dil, pad, pad)
         M = N * H * W
-        y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps)
+        ctx.fused = K.convnext_mlp_supported(C, xc.dtype)
+        # round 3: on the fused stages LayerNorm rides the MLP kernels' row loads (forward: statistics + normalisation, backward: normalisation
+        # from the saved statistics), so y2 is never written or read -- needs the backward route that keeps nothing [M, 4C]-shaped either
+        ctx.ln_on_load = ctx.fused and _MLP_LN_ON_LOAD and _MLP_BWD_NO_HIDDEN and (dp_mask is None or (H * W) % 64 == 0)
+        if ctx.ln_on_load:
+            y2 = mean = rstd = None
+        else:
+            y2, mean, rstd = K.layernorm_fwd(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps)
         grad = any(ctx.needs_input_grad)          # grad mode is off inside Function.forward; this is the tape's view
         # measured on MI355X (tools/kbench_gemm.py): writing both h and g = gelu(h) from the pw1 epilogue (175+83+117 us at
         # stage 0 for pw1/pw2/wgrad2) beats writing h only and re-deriving gelu(h) while staging the A operand of pw2 and of
@@ -920,12 +928,15 @@ class _ConvNeXtBlockFn(Function):
         # h holds gelu'(pre-activation), not the pre-activation: the pw1 epilogue has Phi and exp(-v^2/2) in hand for gelu anyway, and
         # the backward epilogue then costs one multiply instead of an erf per element (+50 us of VALU per 100 M elements, measured)
         gam = p.gamma.data if p.gamma is not None else None
-        ctx.fused = K.convnext_mlp_supported(C, xc.dtype)
         if ctx.fused:
             # wide stages (C = 96 / 192, bf16): the [M, 4C] hidden tile stays on the CU (csrc/mlp_fused.hip) and the backward pass
             # recomputes it, so nothing [M, 4C]-shaped is kept; `bw` holds the tiled weight images the backward chain streams
             fw, bw = K.convnext_mlp_prep(p.w1.data, p.w2.data, gam, backward=grad)
-            out = K.convnext_mlp_fwd(y2, fw, p.b1.data, p.b2.data, gam, dp_mask, H * W, xc.reshape(M, C))
+            if ctx.ln_on_load:
+                out, mean, rstd = K.convnext_mlp_fwd_ln(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps, fw, p.b1.data, p.b2.data, gam,
+                                                        dp_mask, H * W, xc.reshape(M, C))
+            else:
+                out = K.convnext_mlp_fwd(y2, fw, p.b1.data, p.b2.data, gam, dp_mask, H * W, xc.reshape(M, C))
             h, g = bw, None
         else:
             h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
@@ -961,9 +972,10 @@ class _ConvNeXtBlockFn(Function):
             # over the rows for every parameter gradient of the MLP; the drop-path row factor and the column sums of dbr ride both
             # (csrc/mlp_wgrad.hip) -- replaces rowscale + colsum + chain + two weight-gradient GEMMs + their split-K sums + layerscale_grads
             bw = h
-            dy2 = K.convnext_mlp_bwd_data(y2, do2, bw, p.b1.data, dp_mask, H * W)
-            K.convnext_mlp_wgrad(y2, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None, _grad(p.w1),
-                                 _grad(p.b1), _grad(p.w2), _grad(p.b2), _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W)
+            yop, ln = (y1.reshape(M, C), (mean, rstd, p.ln_gamma.data, p.ln_beta.data)) if ctx.ln_on_load else (y2, None)
+            dy2 = K.convnext_mlp_bwd_data(yop, do2, bw, p.b1.data, dp_mask, H * W, ln=ln)
+            K.convnext_mlp_wgrad(yop, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None, _grad(p.w1),
+                                 _grad(p.b1), _grad(p.w2), _grad(p.b2), _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W, ln=ln)
             del h, bw
         else:
             dy2 = _ConvNeXtBlockFn._mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc)

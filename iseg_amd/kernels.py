@@ -257,13 +257,27 @@ def convnext_mlp_bwd(y2, dbr, bw_tiled, b1):
     return g, dh, dy2
 
 
-def convnext_mlp_bwd_data(y2, dout, bw_tiled, b1, rowscale=None, rows_per_group=0):
-    """dy2 = ((rowscale * dout) @ (W2 gamma)^T * gelu'(h)) @ W1^T with the hidden tile recomputed and kept on the CU (nothing [M, 4C] is written)"""
-    _require_cuda(y2, dout, bw_tiled)
-    M, Cc = y2.shape
-    dy2 = torch.empty((M, Cc), dtype=y2.dtype, device=y2.device)
-    _hip.call("iseg_convnext_mlp_bwd_data", ptr(y2), ptr(dout), ptr(rowscale), int(rows_per_group), ptr(bw_tiled), ptr(b1), ptr(dy2), M, Cc,
-              dt(y2), stream())
+def convnext_mlp_fwd_ln(y1, ln_gamma, ln_beta, eps, fw_tiled, b1, b2, gamma, rowscale, rows_per_group, residual):
+    """convnext_mlp_fwd with LayerNorm(y1) formed while the rows are loaded: returns (out, mean, rstd); y2 is never written"""
+    _require_cuda(y1, fw_tiled, residual)
+    M, Cc = y1.shape
+    out = torch.empty((M, Cc), dtype=y1.dtype, device=y1.device)
+    mean = torch.empty(M, dtype=torch.float32, device=y1.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=y1.device)
+    _hip.call("iseg_convnext_mlp_fwd_ln", ptr(y1), ptr(ln_gamma), ptr(ln_beta), float(eps), ptr(mean), ptr(rstd), ptr(fw_tiled), ptr(b1), ptr(b2),
+              ptr(gamma), ptr(rowscale), int(rows_per_group), ptr(residual), ptr(out), M, Cc, dt(y1), stream())
+    return out, mean, rstd
+
+
+def convnext_mlp_bwd_data(y, dout, bw_tiled, b1, rowscale=None, rows_per_group=0, ln=None):
+    """dy2 = ((rowscale * dout) @ (W2 gamma)^T * gelu'(h)) @ W1^T with the hidden tile recomputed and kept on the CU (nothing [M, 4C] is
+    written); ln = (mean, rstd, ln_gamma, ln_beta) makes `y` the LayerNorm input"""
+    _require_cuda(y, dout, bw_tiled)
+    M, Cc = y.shape
+    dy2 = torch.empty((M, Cc), dtype=y.dtype, device=y.device)
+    mean, rstd, lng, lnb = ln if ln is not None else (None, None, None, None)
+    _hip.call("iseg_convnext_mlp_bwd_data", ptr(y), ptr(mean), ptr(rstd), ptr(lng), ptr(lnb), ptr(dout), ptr(rowscale), int(rows_per_group),
+              ptr(bw_tiled), ptr(b1), ptr(dy2), M, Cc, dt(y), stream())
     return dy2
 
 

@@ -219,3 +219,29 @@ def test_convnext_mlp_wgrad_layernorm_on_load(cuda):
         res.append(grads)
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-3 * max(a.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M", [256, 1000 + 37])
+def test_convnext_mlp_layernorm_on_load_matches_the_separate_kernel(cuda, C, M):
+    """iseg_convnext_mlp_fwd_ln / _bwd_data with LayerNorm folded into the row loads against LayerNorm kernel + the plain fused kernels:
+    same statistics (1e-6), same outputs to bf16 rounding of y2 (the fused path rounds the same values to bf16 in registers)"""
+    from iseg_amd import kernels as K
+
+    y1, res, W1, b1, W2, b2, gamma = _inputs(M, C, 321 + C + M)
+    g = torch.Generator().manual_seed(9)
+    lng, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    bf = torch.bfloat16
+    y1b, resb = (y1 * 1.7 + 0.3).to(bf).cuda(), res.to(bf).cuda()
+    rs = torch.tensor([0.5, 1.25], device="cuda")
+    rpg = -(-M // 2)
+    fw, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda(), backward=True)
+    y2, mean, rstd = K.layernorm_fwd(y1b, lng, lnb, 1e-6)
+    want = K.convnext_mlp_fwd(y2, fw, b1.cuda(), b2.cuda(), gamma.cuda(), rs, rpg, resb)
+    got, mean2, rstd2 = K.convnext_mlp_fwd_ln(y1b, lng, lnb, 1e-6, fw, b1.cuda(), b2.cuda(), gamma.cuda(), rs, rpg, resb)
+    assert (mean - mean2).abs().max().item() < 1e-5 and ((rstd - rstd2).abs() / rstd).max().item() < 1e-5
+    assert (got.float() - want.float()).abs().max().item() < 4e-2 * max(1.0, want.float().abs().max().item() / 4)
+    dout = torch.randn(M, C, generator=torch.Generator().manual_seed(4)).to(bf).cuda()
+    want_d = K.convnext_mlp_bwd_data(y2, dout, bw, b1.cuda(), rs, rpg)
+    got_d = K.convnext_mlp_bwd_data(y1b, dout, bw, b1.cuda(), rs, rpg, ln=(mean, rstd, lng, lnb))
+    assert (got_d.float() - want_d.float()).abs().max().item() < 2e-2 * max(1.0, want_d.float().abs().max().item())
