@@ -554,6 +554,10 @@ int iseg_convnext_mlp_supported(int C, int dtype);
 size_t iseg_convnext_mlp_tiled_bytes(int C, int backward);
 int iseg_convnext_mlp_prep(const float* W1, const float* W2, const float* gamma, void* fw_tiled, void* bw_tiled, int C,
                            iseg_stream_t stream);
+/* all per-weight-update derivations of a model's ConvNeXt blocks in one launch.  table (device): per entry 8 x int64
+ * {kind, p1, p2, p3, p4, p5, n, rows}: kind 1 = iseg_convnext_mlp_prep(W1 = p1, W2 = p2, gamma = p3 | 0, fw_tiled = p4, bw_tiled = p5 | 0, C = n);
+ * kind 0 = iseg_scale_cols_cast(src = p1, colscale = p3, dst(bf16) = p4, rows, cols = n).  max_elements sizes the grid. */
+int iseg_convnext_weight_prep_batched(const int64_t* table, int entries, int64_t max_elements, iseg_stream_t stream);
 int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1, const float* b2, const float* gamma,
                           const float* rowscale, int64_t rows_per_group, const void* residual, void* out, int64_t M, int C, int dtype,
                           iseg_stream_t stream);

@@ -472,11 +472,11 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
 }
 
 // fp32 master kernels -> the tiled bf16 images (see the header comment).  One thread per image element.
-__global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ gamma,
-                                         bf16_t* __restrict__ FW, bf16_t* __restrict__ BW, int C) {
+__device__ __forceinline__ void mlp_prep_elements(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                  bf16_t* __restrict__ FW, bf16_t* __restrict__ BW, int C, int first, int stride) {
     const int HID = 4 * C, per_img = C * 32, nslab = HID / 32;
     const int nfw = nslab * 2 * per_img, nbw = BW ? nslab * 3 * per_img : 0;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfw + nbw; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < nfw + nbw; e += stride) {
         const bool bw = e >= nfw;
         const int i = bw ? e - nfw : e, nimg = bw ? 3 : 2;
         const int slab = i / (nimg * per_img), rem = i % (nimg * per_img);
@@ -494,6 +494,30 @@ __global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const flo
             v = kind == 2 ? W2[(int64_t)hid * C + c] : W1[(int64_t)c * HID + hid];
         }
         (bw ? BW : FW)[i] = (bf16_t)v;
+    }
+}
+
+__global__ void convnext_mlp_prep_kernel(const float* __restrict__ W1, const float* __restrict__ W2, const float* __restrict__ gamma,
+                                         bf16_t* __restrict__ FW, bf16_t* __restrict__ BW, int C) {
+    mlp_prep_elements(W1, W2, gamma, FW, BW, C, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Every per-weight-update derivation of the ConvNeXt blocks in ONE launch (blockIdx.y = table entry): the tiled MLP images of the fused
+// stages (kind 1) and the layer-scale-folded bf16 kernels W2 * gamma of the un-fused stages' data gradients (kind 0) -- 18 launches of ~5 us
+// per step before.  Entry = 8 x int64: {kind, W1 | src, W2, gamma, FW | dst, BW, C | cols, rows}.
+__global__ void convnext_weight_prep_batched_kernel(const int64_t* __restrict__ table) {
+    const int64_t* e = table + 8 * blockIdx.y;
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (e[0] == 1) {
+        mlp_prep_elements(reinterpret_cast<const float*>(e[1]), reinterpret_cast<const float*>(e[2]), reinterpret_cast<const float*>(e[3]),
+                          reinterpret_cast<bf16_t*>(e[4]), reinterpret_cast<bf16_t*>(e[5]), (int)e[6], first, stride);
+    } else {
+        const float* src = reinterpret_cast<const float*>(e[1]);
+        const float* g = reinterpret_cast<const float*>(e[3]);
+        bf16_t* dst = reinterpret_cast<bf16_t*>(e[4]);
+        const int cols = (int)e[6];
+        const int64_t total = e[7] * cols;
+        for (int64_t i = first; i < total; i += stride) dst[i] = (bf16_t)(src[i] * g[i % cols]);
     }
 }
 
@@ -546,6 +570,14 @@ extern "C" int iseg_convnext_mlp_prep(const float* W1, const float* W2, const fl
     hipLaunchKernelGGL(convnext_mlp_prep_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, W1, W2, gamma, (bf16_t*)fw_tiled,
                        (bf16_t*)bw_tiled, C);
     return iseg_check_launch("iseg_convnext_mlp_prep");
+}
+
+extern "C" int iseg_convnext_weight_prep_batched(const int64_t* table, int entries, int64_t max_elements, hipStream_t stream) {
+    ISEG_REQUIRE(table && entries > 0 && max_elements > 0, "iseg_convnext_weight_prep_batched: bad arguments");
+    int64_t bx = (max_elements + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(convnext_weight_prep_batched_kernel, dim3((unsigned)bx, (unsigned)entries), dim3(256), 0, stream, table);
+    return iseg_check_launch("iseg_convnext_weight_prep_batched");
 }
 
 extern "C" int iseg_convnext_mlp_fwd(const void* y2, const void* fw_tiled, const float* b1, const float* b2, const float* gamma,

@@ -896,6 +896,7 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 # ConvNeXt block, fused:  x + drop_path(gamma * pw2(gelu(pw1(LN(dw7x7(x))))))     backbones/convnext.py:47-63
 # ---------------------------------------------------------------------------------------------------------
+_BATCHED_PREP = os.environ.get("ISEG_BATCHED_PREP", "1") == "1"      # 0: per-block prep launches (A/B measurements)
 _MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: LayerNorm of the fused stages as its own kernel (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
@@ -931,7 +932,10 @@ class _ConvNeXtBlockFn(Function):
         if ctx.fused:
             # wide stages (C = 96 / 192, bf16): the [M, 4C] hidden tile stays on the CU (csrc/mlp_fused.hip) and the backward pass
             # recomputes it, so nothing [M, 4C]-shaped is kept; `bw` holds the tiled weight images the backward chain streams
-            fw, bw = K.convnext_mlp_prep(p.w1.data, p.w2.data, gam, backward=grad)
+            if _BATCHED_PREP:      # one launch per weight update for every block of the model (nn.mlp_tiled)
+                fw, bw = nn.mlp_tiled(p.w1, p.w2, p.gamma)
+            else:
+                fw, bw = K.convnext_mlp_prep(p.w1.data, p.w2.data, gam, backward=grad)
             if ctx.ln_on_load:
                 out, mean, rstd = K.convnext_mlp_fwd_ln(y1.reshape(M, C), p.ln_gamma.data, p.ln_beta.data, eps, fw, p.b1.data, p.b2.data, gam,
                                                         dp_mask, H * W, xc.reshape(M, C))
@@ -1004,7 +1008,12 @@ class _ConvNeXtBlockFn(Function):
             # h is the tiled weight buffer here: g = gelu(pre), dh = (dbr @ (W2 gamma)^T) * gelu'(pre), dy2 = dh @ W1^T in one launch
             g, dh, dy2 = K.convnext_mlp_bwd(y2, dbr, h, p.b1.data)
         else:
-            w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt) if p.gamma is not None else nn.w(p.w2)
+            if p.gamma is None:
+                w2eff = nn.w(p.w2)
+            elif _BATCHED_PREP and cdt == torch.bfloat16:
+                w2eff = nn.w_colscaled(p.w2, p.gamma)
+            else:
+                w2eff = K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
             dh = K.dense_dgrad(dbr, w2eff, act=K.ACT_MUL_AUX, aux=h)          # [M,4C] = (dbr @ W2g^T) * gelu'(pre), h = gelu'(pre)
         del h
 

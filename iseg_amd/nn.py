@@ -254,6 +254,93 @@ def wt(param):
     return _WT["views"][i]
 
 
+# ---------------------------------------------------------------------------------------------------------
+# per-weight-update derivations of the ConvNeXt blocks (tiled MLP images, layer-scale-folded kernels): ONE launch per update for all blocks
+# ---------------------------------------------------------------------------------------------------------
+_PREP = {"version": -1, "entries": [], "index": {}, "table": None, "ptrs": None, "max": 0}
+
+
+def _prep_key(kind, params):
+    return (kind,) + tuple(id(p) for p in params)
+
+
+def _prep_request(kind, params, make):
+    """the derived buffers of (kind, params), refreshed by one batched launch the first time any of them is asked for after a weight update"""
+    import weakref
+
+    key = _prep_key(kind, params)
+    i = _PREP["index"].get(key)
+    if i is not None and any(r() is not p for r, p in zip(_PREP["entries"][i]["refs"], params)):
+        i = None      # an id was recycled by another parameter
+    if i is None:
+        # drop the entries of models that are gone (the registry must not keep them alive or re-derive them forever)
+        live = [e for e in _PREP["entries"] if all(r() is not None for r in e["refs"])]
+        _PREP["entries"] = live
+        _PREP["index"] = {e["key"]: j for j, e in enumerate(live)}
+        bufs = make()
+        _PREP["index"][key] = i = len(live)
+        live.append({"key": key, "kind": kind, "refs": [weakref.ref(p) for p in params], "bufs": bufs})
+        _PREP["table"] = None
+        _PREP["version"] = -1
+    if _PREP["version"] != _WEIGHTS_VERSION[0]:
+        _prep_refresh()
+    return _PREP["entries"][i]["bufs"]
+
+
+def _prep_rows(e):
+    ps = [r() for r in e["refs"]]
+    if e["kind"] == 1:
+        w1, w2, gamma = ps[0], ps[1], (ps[2] if len(ps) > 2 else None)
+        fw, bw = e["bufs"]
+        Cc = w1.shape[0]
+        return [1, w1.data.data_ptr(), w2.data.data_ptr(), gamma.data.data_ptr() if gamma is not None else 0, fw.data_ptr(),
+                bw.data_ptr() if bw is not None else 0, Cc, 0], 5 * 4 * Cc * Cc
+    w2, gamma = ps
+    (dst,) = e["bufs"]
+    rows, cols = w2.shape
+    return [0, w2.data.data_ptr(), 0, gamma.data.data_ptr(), dst.data_ptr(), 0, cols, rows], rows * cols
+
+
+def _prep_refresh():
+    from . import _hip
+    from . import kernels as K
+
+    rows, mx = [], 0
+    for e in _PREP["entries"]:
+        if any(r() is None for r in e["refs"]):
+            continue
+        r, n = _prep_rows(e)
+        rows.append(r)
+        mx = max(mx, n)
+    if not rows:
+        return
+    if _PREP["table"] is None or _PREP["ptrs"] != rows:      # first use, a new block, or a re-homed parameter
+        dev = _PREP["entries"][0]["bufs"][0].device
+        _PREP["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _PREP["ptrs"], _PREP["max"] = rows, mx
+    _hip.call("iseg_convnext_weight_prep_batched", K.ptr(_PREP["table"]), len(rows), int(_PREP["max"]), K.stream())
+    _PREP["version"] = _WEIGHTS_VERSION[0]
+
+
+def mlp_tiled(w1, w2, gamma):
+    """(fw_tiled, bw_tiled) of a fused ConvNeXt MLP (csrc/mlp_fused.hip images), valid for the current weights"""
+    def make():
+        from . import _hip
+
+        L = _hip.lib()
+        Cc = w1.shape[0]
+        dev = w1.device
+        return (torch.empty(L.iseg_convnext_mlp_tiled_bytes(Cc, 0) // 2, dtype=torch.bfloat16, device=dev),
+                torch.empty(L.iseg_convnext_mlp_tiled_bytes(Cc, 1) // 2, dtype=torch.bfloat16, device=dev))
+
+    return _prep_request(1, [w1, w2] + ([gamma] if gamma is not None else []), make)
+
+
+def w_colscaled(w2, gamma):
+    """bf16 copy of the 2-D kernel w2 with its columns scaled by gamma (layer scale folded into the data-gradient product)"""
+    return _prep_request(0, [w2, gamma], lambda: (torch.empty(tuple(w2.shape), dtype=torch.bfloat16, device=w2.device),))[0]
+
+
 _DRY = [False]
 
 
