@@ -253,13 +253,15 @@ class SwinTransformerModel(Layer):
         self.dropout_rate, self.attention_dropout_rate, self.drop_path_rate = dropout_rate, attention_dropout_rate, drop_path_rate
         self.norm_layer = norm_layer
         self.return_endpoints = return_endpoints
-        if use_absolute_pos_embed:
-            raise NotImplementedError("use_absolute_pos_embed (unused by every registered Swin variant)")
 
     def build(self, input_shape):
         channels = int(input_shape[-1])
         self.patch_embed = PatchEmbed(patch_size=self.patch_size, in_channels=channels, embed_filters=self.embed_dim,
                                       norm_layer=self.norm_layer if self.patch_norm else None, name="patch_embed")
+        if self.use_absolute_pos_embed:      # (:563-569) zeros, one vector per patch of the BUILD resolution
+            ph, pw = self.patch_size
+            self._ape_grid = (-(-int(input_shape[1]) // ph), -(-int(input_shape[2]) // pw))
+            self.absolute_pos_embed = self.add_weight("absolute_pos_embed", (1, self._ape_grid[0] * self._ape_grid[1], self.embed_dim), "zeros")
         self.pos_drop = Dropout(self.dropout_rate, name="postional_dropout")
         dpr = [float(x) for x in np.linspace(0.0, self.drop_path_rate, sum(self.depths))]
         layers = []
@@ -275,6 +277,10 @@ class SwinTransformerModel(Layer):
     def call(self, inputs, training=None):
         x = F.cast_input(inputs)
         x = self.patch_embed(x)
+        if self.use_absolute_pos_embed:      # (:606-607) x + reshape(absolute_pos_embed, shape(x)): only the build resolution fits, as in the reference
+            if tuple(x.shape[1:3]) != self._ape_grid:
+                raise ValueError(f"absolute_pos_embed was built for {self._ape_grid} patches, the input gives {tuple(x.shape[1:3])}")
+            x = F.add_batch_broadcast(x, self.absolute_pos_embed.reshape(1, x.shape[1], x.shape[2], x.shape[3]))
         endpoints = [x]
         x = self.pos_drop(x, training=training)
         for layer in self.basic_layers:

@@ -1569,12 +1569,12 @@ class _FlashAttentionFn(Function):
 
 class _AttentionFn(Function):
     @staticmethod
-    def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed, bias_window=0):
+    def forward(ctx, qkv, bias_table, heads, Cq, Cv, scale, bias_index, mask, windows, clip, drop_rate, seed, bias_window=0, want_probs=False):
         B, T, ld = qkv.shape
         assert ld == 2 * Cq + Cv
         qkv = _c(qkv)
         dq, dv = Cq // heads, Cv // heads
-        ctx.fused = (bias_table is not None and Cq == Cv and clip is None and drop_rate <= 0 and
+        ctx.fused = (bias_table is not None and Cq == Cv and clip is None and drop_rate <= 0 and not want_probs and
                      K.window_attention_supported(T, dq, qkv.dtype) and os.environ.get("ISEG_WINATTN", "1") != "0")
         if ctx.fused:      # Swin window attention: one wavefront per (window, head), probabilities never leave the CU
             bias = K.relpos_bias_gather(bias_table.data, bias_index, heads, T)
@@ -1612,10 +1612,14 @@ class _AttentionFn(Function):
         ctx.cfg = (heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp)
         ctx.bias_table, ctx.bias_index, ctx.bias_window = bias_table, bias_index, bias_window
         ctx.save_for_backward(qkv, P, Pd if Pd is not P else None)
+        if want_probs:      # the probabilities that multiply V (after dropout / clip), [B, heads, T, T]; no gradient flows through this output
+            probs = Pd.reshape(B, heads, T, Tp)[..., :T]
+            ctx.mark_non_differentiable(probs)
+            return O, probs
         return O
 
     @staticmethod
-    def backward(ctx, dO):
+    def backward(ctx, dO, *unused_dprobs):
         if ctx.fused:
             qkv, table = ctx.saved_tensors
             heads, _, _, scale = ctx.cfg[:4]
@@ -1668,7 +1672,7 @@ class _AttentionFn(Function):
 
 
 def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=None, mask=None, windows=1, clip=None,
-                     dropout_rate=0.0, training=False, bias_window=0):
+                     dropout_rate=0.0, training=False, bias_window=0, return_probs=False):
     """qkv [B, T, 2*Cq + Cv] (columns [q | k | v], each split into `heads` contiguous head slices) -> [B, T, Cv].
     bias_table [entries, heads] fp32 parameter + bias_index int32 [T*T]; mask fp32 [windows, T, T] (sample b uses mask
     b % windows); clip = (lo, hi) on the probabilities."""
@@ -1678,6 +1682,11 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
     if mask is not None and (_MAX_GRID_Z // heads) % windows != 0 and qkv.shape[0] * heads > _MAX_GRID_Z:
         raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
     rate = float(dropout_rate) if training else 0.0
+    if return_probs:
+        if nn.dry_run():
+            return _dry((qkv.shape[0], qkv.shape[1], Cv), qkv), _dry((qkv.shape[0], heads, qkv.shape[1], qkv.shape[1]), qkv)
+        return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip, rate,
+                                  next_seed() if rate > 0 else 0, int(bias_window), True)
     if (bias_table is None and mask is None and clip is None and rate <= 0 and Cq == Cv and
             K.attention_fwd_supported(Cq // heads, qkv.dtype) and os.environ.get("ISEG_FLASHATTN", "1") != "0"):
         # online-softmax kernels, no T x T tensor: forward only for inference, the recomputing forward / backward pair for training
@@ -1847,6 +1856,62 @@ class _PosEmbedResizeFn(Function):
         K.gemm(Wy, dt_, g[e:], Hi, Wi * C, Ho, lda=Hi, ldb=Wi * C, ldd=Wi * C, a_kcontig=0, b_kcontig=0, accumulate=True)
         dist.grads_ready(pos)
         return None, None, None, None, None
+
+
+_BICUBIC_MATRICES = {}
+
+
+def _bicubic_weights(out_size, in_size, device):
+    key = (int(out_size), int(in_size), str(device))
+    m = _BICUBIC_MATRICES.get(key)
+    if m is None:
+        from .utils.bicubic import bicubic_matrix
+
+        m = _BICUBIC_MATRICES[key] = torch.from_numpy(bicubic_matrix(int(out_size), int(in_size))).to(device)
+    return m
+
+
+class _ResizeBicubicFn(Function):
+    """tf.image.resize(images, size, method="bicubic") (utils/common.py:107-134 of the reference: half-pixel centres, Keys a = -0.5, no
+    antialias, fp32 result cast back to the input dtype): the separable map y[n] = Wy @ x[n] @ Wx^T as two strided-batch fp32 GEMMs with the
+    host-built tap matrices of utils/bicubic.py (the kernel of the ViT position-embedding resize).  The gradient is the transposed map."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        N, Hi, Wi, C = x.shape
+        xf = _c(x) if x.dtype == torch.float32 else K.cast(_c(x), torch.float32)
+        Wy, Wx = _bicubic_weights(Ho, Hi, x.device), _bicubic_weights(Wo, Wi, x.device)
+        t = torch.empty((N, Ho, Wi * C), dtype=torch.float32, device=x.device)
+        K.gemm(Wy, xf.reshape(N, Hi, Wi * C), t, Ho, Wi * C, Hi, lda=Hi, ldb=Wi * C, ldd=Wi * C, a_kcontig=1, b_kcontig=0, batch=N, batch_inner=1,
+               sa=(0, 0), sb=(Hi * Wi * C, 0), sd=(Ho * Wi * C, 0))
+        y = torch.empty((N, Ho, Wo, C), dtype=torch.float32, device=x.device)
+        K.gemm(Wx, t, y, Wo, C, Wi, lda=Wi, ldb=C, ldd=C, a_kcontig=1, b_kcontig=0, batch=N * Ho, batch_inner=1, sa=(0, 0), sb=(Wi * C, 0),
+               sd=(Wo * C, 0))
+        ctx.shape, ctx.dtype = (N, Hi, Wi, C), x.dtype
+        ctx.save_for_backward(Wy, Wx)
+        return y if x.dtype == torch.float32 else K.cast(y, x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        Wy, Wx = ctx.saved_tensors
+        N, Hi, Wi, C = ctx.shape
+        Ho, Wo = Wy.shape[0], Wx.shape[0]
+        d = _c(dy) if dy.dtype == torch.float32 else K.cast(_c(dy), torch.float32)
+        dt_ = torch.empty((N, Ho, Wi * C), dtype=torch.float32, device=dy.device)
+        K.gemm(Wx, d, dt_, Wi, C, Wo, lda=Wi, ldb=C, ldd=C, a_kcontig=0, b_kcontig=0, batch=N * Ho, batch_inner=1, sa=(0, 0), sb=(Wo * C, 0),
+               sd=(Wi * C, 0))
+        dx = torch.empty((N, Hi, Wi * C), dtype=torch.float32, device=dy.device)
+        K.gemm(Wy, dt_, dx, Hi, Wi * C, Ho, lda=Hi, ldb=Wi * C, ldd=Wi * C, a_kcontig=0, b_kcontig=0, batch=N, batch_inner=1, sa=(0, 0),
+               sb=(Ho * Wi * C, 0), sd=(Hi * Wi * C, 0))
+        dx = dx.reshape(N, Hi, Wi, C)
+        return (dx if ctx.dtype == torch.float32 else K.cast(dx, ctx.dtype)), None, None
+
+
+def resize_bicubic(x, size):
+    Ho, Wo = int(size[0]), int(size[1])
+    if nn.dry_run():
+        return _dry((x.shape[0], Ho, Wo, x.shape[3]), x)
+    return _ResizeBicubicFn.apply(x, Ho, Wo)
 
 
 def resize_pos_embed(pos, Wy, Wx, n_extra, out_dtype):

@@ -23,8 +23,7 @@ class MultiHeadSelfAttentionLayer(Layer):
         self.shared_qk_weights, self.shared_qk = shared_qk_weights, shared_qk
         self.use_dense_for_linear = use_dense_for_linear
         self.dropout_rate = dropout_rate
-        if return_attention_map:
-            raise NotImplementedError("return_attention_map: the probabilities stay inside the attention operator")
+        self.return_attention_map = bool(return_attention_map)
 
     def build(self, input_shape):
         channels = int(input_shape[-1])
@@ -49,21 +48,39 @@ class MultiHeadSelfAttentionLayer(Layer):
                 self.key_conv.kernel.data.copy_(self.query_conv.kernel.data)
         self.built = True
 
-    def compute_attention(self, query, key, value, training=None):
+    def compute_attention(self, query, key, value, attention_mask=None, training=None):
+        """(:108-151) attention_mask (1 = attend, 0 = masked; [HW, HW], [N, HW, HW] or [N, 1, HW, HW]) enters safed_softmax as
+        (1 - mask) * -1e9 (utils/op_utils.py:24-38); with return_attention_map the probabilities that multiply V -- after dropout and the
+        [1e-7, 1 - 1e-7] clip -- come back as a second result [N, heads, HW, HW] (no gradient flows through it)"""
+        import torch
+
         n, h, w, _ = query.shape
         cq, cv = query.shape[-1], value.shape[-1]
         query = F.replace_nan_or_inf(query, EPSILON)
         key = F.replace_nan_or_inf(key, EPSILON)
         qkv = F.concat([query, key, value]).reshape(n, h * w, 2 * cq + cv)
         scale = 1.0 / math.sqrt(cq // self.num_heads) if self.apply_scale else 1.0
-        x = F.attention_packed(qkv, self.num_heads, cq, cv, scale, clip=(EPSILON, 1.0 - EPSILON), dropout_rate=self.dropout_rate,
-                               training=bool(training))
-        x = x.reshape(n, h, w, cv)
-        return F.replace_nan_or_inf(x, EPSILON)
+        mask, windows = None, 1
+        if attention_mask is not None:
+            m = attention_mask.to(device=qkv.device, dtype=torch.float32)
+            if m.dim() == 4:
+                if m.shape[1] != 1:
+                    raise NotImplementedError("attention_mask per head: [N, 1, HW, HW], [N, HW, HW] or [HW, HW] are supported")
+                m = m[:, 0]
+            if m.dim() == 2:
+                m = m[None]
+            if tuple(m.shape[1:]) != (h * w, h * w) or m.shape[0] not in (1, n):
+                raise ValueError(f"attention_mask of shape {tuple(attention_mask.shape)} does not fit {n} x {h * w} x {h * w} scores")
+            mask, windows = ((1.0 - m) * -1e9).contiguous(), int(m.shape[0])
+        out = F.attention_packed(qkv, self.num_heads, cq, cv, scale, mask=mask, windows=windows, clip=(EPSILON, 1.0 - EPSILON),
+                                 dropout_rate=self.dropout_rate, training=bool(training), return_probs=self.return_attention_map)
+        x, probs = out if self.return_attention_map else (out, None)
+        x = F.replace_nan_or_inf(x.reshape(n, h, w, cv), EPSILON)
+        return (x, probs) if self.return_attention_map else x
 
     def call(self, inputs, key=None, value=None, attention_mask=None, training=None):
-        if attention_mask is not None:
-            raise NotImplementedError("attention_mask")
+        # (:153-203) the reference's call() accepts attention_mask but never hands it to compute_attention; neither does this one --
+        # compute_attention(..., attention_mask=...) is the entry that honours it
         query = inputs
         if key is None:
             key = query

@@ -41,7 +41,7 @@ def resize_image(images, size, method=None, name=None):
             raise NotImplementedError("nearest resize is provided for int32 label maps")
         return K.resize_nearest_i32(images.contiguous(), int(size[0]), int(size[1]))
     if method == "bicubic":
-        raise NotImplementedError("bicubic resize (ViT pos-embed) is not part of this round's hot path")
+        return F.resize_bicubic(images, size)
     raise ValueError("Not support")
 
 

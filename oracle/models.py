@@ -348,14 +348,17 @@ def swin_patch_merging(w, p, x):
     return O.dense(x, w[f"{p}/reduction/kernel"]).reshape(B, H2, W2, 2 * C)
 
 
-def swin_forward(w, x, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, patch=4, dp_factors=None):
-    """endpoints [patch_embed, l0, l1, l2, l3] (pre-downsample).  dp_factors[layer][block] = (f_attn, f_mlp) or None"""
+def swin_forward(w, x, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, patch=4, dp_factors=None, ape=None):
+    """endpoints [patch_embed, l0, l1, l2, l3] (pre-downsample).  dp_factors[layer][block] = (f_attn, f_mlp) or None; ape = name of the
+    absolute position embedding [1, patches, C] added to the patch embedding (backbones/swin.py:563-569,606-607) or None"""
     import torch.nn.functional as TF
 
     H, W = x.shape[1], x.shape[2]
     x = TF.pad(x, (0, 0, 0, (patch - W % patch) % patch, 0, (patch - H % patch) % patch))
     x = O.conv2d(x, w["patch_embed/proj/kernel"], w["patch_embed/proj/bias"], patch, 1, "valid")
     x = O.layer_norm(x, w["patch_embed/norm/gamma"], w["patch_embed/norm/beta"], 1e-5)
+    if ape is not None:
+        x = x + w[ape].reshape(x.shape)
     endpoints = [x]
     for li, depth in enumerate(depths):
         mask = swin_attention_mask(x.shape[1], x.shape[2], ws, ws // 2, x.dtype)

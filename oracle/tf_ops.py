@@ -436,8 +436,9 @@ def keras_mha_self(x, wq, bq, wk, bk, wv, bv, wo, bo):
     return torch.einsum("bqhd,hdc->bqc", ctx, wo) + bo
 
 
-def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7):
-    """layers/multihead_self_attention.py:106-150 on finite inputs: per-head softmax(q k^T / sqrt(d)), clip, context"""
+def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7, attention_mask=None, return_attention_map=False):
+    """layers/multihead_self_attention.py:106-150 on finite inputs: per-head softmax(q k^T / sqrt(d)), clip, context; attention_mask
+    (1 = attend) enters as (1 - mask) * -1e9 before the softmax (utils/op_utils.py:24-38 safed_softmax)"""
     N, H, W, Cq = q.shape
     Cv = v.shape[-1]
     qh = q.reshape(N, H * W, heads, Cq // heads).permute(0, 2, 1, 3)
@@ -446,9 +447,15 @@ def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7):
     a = qh @ kh
     if apply_scale:
         a = a / math.sqrt(Cq // heads)
+    if attention_mask is not None:
+        m = attention_mask.to(a.dtype)
+        while m.dim() < 4:
+            m = m[None] if m.dim() == 2 else m[:, None]
+        a = a + (1.0 - m) * -1e9
     a = torch.softmax(a, dim=-1)
     a = torch.clamp(a, eps, 1.0 - eps)
-    return (a @ vh).permute(0, 2, 1, 3).reshape(N, H, W, Cv)
+    out = (a @ vh).permute(0, 2, 1, 3).reshape(N, H, W, Cv)
+    return (out, a) if return_attention_map else out
 
 
 # ------------------------------------------------------------------------------------------------------

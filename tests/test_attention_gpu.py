@@ -187,6 +187,51 @@ def test_mhsa_layer(cuda, dtype):
         nn.set_compute_dtype(torch.float32)
 
 
+def test_mhsa_attention_mask_and_attention_map(cuda):
+    """compute_attention(attention_mask=...) (layers/multihead_self_attention.py:108-151, safed_softmax's additive mask) and
+    return_attention_map: the [N, heads, HW, HW] probabilities that multiply V; call() ignores its attention_mask argument like the
+    reference's (:153-203)"""
+    from iseg_amd import nn
+    from iseg_amd.layers.multihead_self_attention import MultiHeadSelfAttentionLayer
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    shape = (2, 4, 5, 32)
+    T = 20
+    layer = MultiHeadSelfAttentionLayer(num_heads=4, return_attention_map=True, name="mhsa_map")
+    _setup(layer, torch.empty(shape, dtype=torch.float32, device="cuda"))
+    x = rnd(shape, 3)
+    w = OM.export_weights(layer)
+
+    def conv1x1(name, t):
+        return O.conv2d(t, w[f"mhsa_map/{name}/kernel"], w.get(f"mhsa_map/{name}/bias"), 1, 1, "valid")
+
+    q, k, v = (conv1x1(n_, x.double()) for n_ in ("query_conv", "key_conv", "value_conv"))
+    g = torch.Generator().manual_seed(5)
+    for mask in (None, (torch.rand(T, T, generator=g) > 0.3).float(), (torch.rand(2, 1, T, T, generator=g) > 0.3).float()):
+        if mask is not None:
+            mask[..., torch.arange(T), torch.arange(T)] = 1.0      # every query keeps itself
+        with torch.no_grad():
+            qd, kd, vd = layer.query_conv(x.cuda()), layer.key_conv(x.cuda()), layer.value_conv(x.cuda())
+            y, amap = layer.compute_attention(qd, kd, vd, attention_mask=None if mask is None else mask.cuda())
+        yr, ar = O.mhsa_core(q, k, v, 4, attention_mask=mask, return_attention_map=True)
+        assert tuple(amap.shape) == (2, 4, T, T)
+        assert (y.cpu().double() - yr).abs().max().item() < 2e-5 * max(1.0, yr.abs().max().item())
+        assert (amap.cpu().double() - ar).abs().max().item() < 2e-6
+        if mask is not None:
+            m4 = mask if mask.dim() == 4 else mask[None, None]
+            assert float((amap.cpu() * (1 - m4)).max()) <= 1.1e-7      # masked keys sit at the clip floor
+    # call(): returns the pair; its attention_mask argument is dropped exactly like the reference's
+    y1, a1 = layer(x.cuda(), training=False)
+    y2, a2 = layer(x.cuda(), attention_mask=torch.zeros(T, T).cuda(), training=False)
+    assert torch.equal(y1, y2) and torch.equal(a1, a2)
+    # gradients still flow through the context output
+    xg = x.cuda().requires_grad_(True)
+    yy, _ = layer(xg, training=True)
+    yy.sum().backward()
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_vit_small(cuda, dtype):
     """a 2-layer member of the ViT family (same code path as ViT-B/16): bicubic position-embedding resize 4x4 -> 3x5, class
@@ -253,6 +298,35 @@ def test_swin_small(cuda, dtype):
         _check_grads(swin, w, 5e-4 if dtype == torch.float32 else 8e-2, l2=dtype != torch.float32)
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+def test_swin_absolute_position_embedding(cuda):
+    """use_absolute_pos_embed (backbones/swin.py:563-569,606-607): one vector per patch of the build resolution, added to the patch embedding;
+    another resolution does not fit (the reference's reshape fails the same way)"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import SwinTransformerModel
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    shape = (2, 56, 56, 3)
+    swin = SwinTransformerModel(embed_dim=32, depths=[2], num_heads=[2], window_size=7, drop_path_rate=0.0, use_absolute_pos_embed=True,
+                                return_endpoints=True, name="swin_ape")
+    _setup(swin, torch.empty(shape, dtype=torch.float32, device="cuda"))
+    assert tuple(swin.absolute_pos_embed.shape) == (1, 14 * 14, 32)
+    x = rnd(shape, 4)
+    eps = swin(x.cuda(), training=True)
+    w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(swin).items()}
+    ref = OM.swin_forward(w, x.double(), depths=(2,), heads=(2,), ws=7, ape="swin_ape/absolute_pos_embed")
+    for a, b in zip(eps, ref):
+        assert _rel(a, b.detach()) < 1e-4
+    dys = [rnd(tuple(r.shape), 7 + i) for i, r in enumerate(ref)]
+    torch.autograd.backward(list(eps), [d.cuda() for d in dys])
+    torch.autograd.backward(ref, [d.double() for d in dys])
+    g = swin.absolute_pos_embed.grad.cpu().double()
+    gr = w["swin_ape/absolute_pos_embed"].grad
+    assert (g - gr).abs().max().item() < 5e-4 * max(1.0, gr.abs().max().item())
+    with pytest.raises(ValueError):
+        swin(rnd((1, 60, 56, 3), 9).cuda(), training=False)
 
 
 @pytest.mark.parametrize("heads,B,ws,masked", [(6, 5, 7, False), (3, 18, 7, True), (12, 4, 5, False), (2, 7, 8, True)])

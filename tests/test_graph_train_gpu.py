@@ -9,6 +9,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+OPTIMIZER = ["adamw"]
+
+
 def _trainer(seed=3):
     from iseg_amd import nn
     from iseg_amd.core_env import common_env_setup
@@ -20,8 +23,8 @@ def _trainer(seed=3):
     strategy = common_env_setup(use_one_device_strategy=True, mixed_precision=True, random_seed=seed)
     model = convnext_tiny_aspp(build_input_size=(64, 64), drop_path_rate=0.2, dropout_rate=0.1)
     helper = model_common_setup(model, restore_checkpoint=False)
-    helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-3, end_lr=0.0, epoch_steps=20, train_epoch=1, warmup_steps=3, warmup_lr=1e-5,
-                                       optimizer="adamw", adamw_weight_decay=0.05))
+    helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-3 if OPTIMIZER[0] == "adamw" else 2e-2, end_lr=0.0, epoch_steps=20, train_epoch=1,
+                                       warmup_steps=3, warmup_lr=1e-5, optimizer=OPTIMIZER[0], adamw_weight_decay=0.05))
     return CoreTrain(helper, None).create_trainable_model(21, ignore_label=255, batch_size=4)
 
 
@@ -67,8 +70,14 @@ def test_seed_offset_equals_shifted_seed(cuda):
     assert not torch.equal(got[0], K.dropout(x, 0.3, seed))
 
 
-def test_graphed_train_steps_follow_eager(cuda):
+@pytest.mark.parametrize("optimizer,loss_tol,weight_tol", [("adamw", 2e-3, 0.5), ("sgd", 5e-4, 0.03)])
+def test_graphed_train_steps_follow_eager(cuda, optimizer, loss_tol, weight_tol):
+    """AdamW: the flagship's optimizer (its sign-like early steps amplify the last-bit run-to-run differences of the float-atomic reductions,
+    so the weights of two EAGER runs already sit ~0.15 of their movement apart: only the loss curve and the schedule are tight there);
+    SGD with momentum: no amplification, the weights must agree closely too"""
     from iseg_amd.data import synthetic_batch
+
+    OPTIMIZER[0] = optimizer
 
     batches = []
     for s in (5, 6, 7):
@@ -80,10 +89,10 @@ def test_graphed_train_steps_follow_eager(cuda):
     assert any(e.get("graph") is not None for e in step.entries.values()), "the step was never captured"
     assert ite == itg == 9
     for i, (a, b) in enumerate(zip(le, lg)):
-        assert abs(a - b) <= 2e-3 * abs(a), (i, le, lg)
+        assert abs(a - b) <= loss_tol * abs(a), (i, le, lg)
     assert len(set(lg)) == len(lg)      # drop-path / dropout draws and the batches differ from step to step
     rel = ((we - wg).norm() / (we - w0e).norm()).item()      # the weights moved the same way
-    assert rel < 0.15, rel
+    assert rel < weight_tol, rel
     assert cme is not None and int(cme.sum()) == int(cmg.sum())      # every step's pixels were counted once
     # the optimizer scalars the last replay read: learning rate of step 9 of the warm-up + poly schedule
     opt = step.tm.optimizer

@@ -276,3 +276,27 @@ def test_resize_bilinear_align_corners_matches_oracle(cuda, dtype, shape, size):
             assert torch.equal(y[:, 0, 0].cpu(), x[:, 0, 0]) and torch.equal(y[:, -1, -1].cpu(), x[:, -1, -1])
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resize_image_bicubic_matches_oracle(cuda, dtype):
+    """utils/common.py:107-134 resize_image(method="bicubic") = tf.image.resize bicubic (half-pixel centres, Keys a = -0.5, renormalised border
+    taps, 1/1024 coefficient table), up- and down-scaling on odd sizes, and its gradient (the transposed linear map)"""
+    from iseg_amd.utils.common import resize_image
+
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 7, 10, 16, generator=g)
+    for size in ((13, 17), (5, 6), (7, 10)):
+        xd = x.to(dtype).cuda().requires_grad_(True)
+        y = resize_image(xd, size, method="bicubic")
+        assert y.dtype == dtype and tuple(y.shape) == (2, size[0], size[1], 16)
+        xr = x.to(dtype).double().requires_grad_(True)
+        ref = O.resize_bicubic(xr, size)
+        tol = 2e-5 if dtype == torch.float32 else 3e-2
+        assert (y.detach().cpu().double() - ref.detach()).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+        dy = torch.randn(ref.shape, generator=g)
+        y.backward(dy.to(dtype).cuda())
+        ref.backward(dy.to(dtype).double())
+        assert (xd.grad.cpu().double() - xr.grad).abs().max().item() < tol * max(1.0, xr.grad.abs().max().item())
+    with pytest.raises(ValueError):
+        resize_image(x.cuda(), (4, 4), method="lanczos3")
