@@ -1629,7 +1629,7 @@ class _AttentionFn(Function):
                 K.relpos_bias_scatter_grad(dbias, T, ctx.bias_index, _grad(ctx.bias_table), heads, T, accumulate=True,
                                            window=ctx.bias_window)
                 dist.grads_ready(ctx.bias_table)
-            return (dqkv,) + (None,) * 12
+            return (dqkv,) + (None,) * 13
         qkv, P, Pd = ctx.saved_tensors
         heads, Cq, Cv, scale, windows, clip, drop_rate, seed, Tp = ctx.cfg
         B, T, ld = qkv.shape
@@ -1668,7 +1668,7 @@ class _AttentionFn(Function):
                    batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
             K.gemm(dP[z0:z1], qv[b0:b1], dkv[b0:b1], T, dq, T, lda=Tp, ldb=ld, ldd=ld, a_kcontig=0, b_kcontig=0, alpha=scale,
                    batch=nb, batch_inner=heads, sa=sP, sb=(T * ld, dq), sd=(T * ld, dq))
-        return dqkv, None, None, None, None, None, None, None, None, None, None, None, None
+        return (dqkv,) + (None,) * 13
 
 
 def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=None, mask=None, windows=1, clip=None,
@@ -1678,13 +1678,12 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
     b % windows); clip = (lo, hi) on the probabilities."""
     _check_act_dtype(qkv)
     if nn.dry_run():
-        return _dry((qkv.shape[0], qkv.shape[1], Cv), qkv)
+        out = _dry((qkv.shape[0], qkv.shape[1], Cv), qkv)
+        return (out, _dry((qkv.shape[0], heads, qkv.shape[1], qkv.shape[1]), qkv)) if return_probs else out
     if mask is not None and (_MAX_GRID_Z // heads) % windows != 0 and qkv.shape[0] * heads > _MAX_GRID_Z:
         raise NotImplementedError("attention_packed: chunked launch needs chunk sizes that are multiples of the window count")
     rate = float(dropout_rate) if training else 0.0
     if return_probs:
-        if nn.dry_run():
-            return _dry((qkv.shape[0], qkv.shape[1], Cv), qkv), _dry((qkv.shape[0], heads, qkv.shape[1], qkv.shape[1]), qkv)
         return _AttentionFn.apply(qkv, bias_table, int(heads), int(Cq), int(Cv), float(scale), bias_index, mask, int(windows), clip, rate,
                                   next_seed() if rate > 0 else 0, int(bias_window), True)
     if (bias_table is None and mask is None and clip is None and rate <= 0 and Cq == Cv and

@@ -358,7 +358,7 @@ def swin_forward(w, x, depths=(2, 2, 6, 2), heads=(3, 6, 12, 24), ws=7, patch=4,
     x = O.conv2d(x, w["patch_embed/proj/kernel"], w["patch_embed/proj/bias"], patch, 1, "valid")
     x = O.layer_norm(x, w["patch_embed/norm/gamma"], w["patch_embed/norm/beta"], 1e-5)
     if ape is not None:
-        x = x + w[ape].reshape(x.shape)
+        x = x + w[ape].reshape(1, *x.shape[1:])      # (the reference reshapes to shape(x): batch 1 only; the batch broadcast is the evident intent)
     endpoints = [x]
     for li, depth in enumerate(depths):
         mask = swin_attention_mask(x.shape[1], x.shape[2], ws, ws // 2, x.dtype)

@@ -200,7 +200,7 @@ def test_mhsa_attention_mask_and_attention_map(cuda):
     T = 20
     layer = MultiHeadSelfAttentionLayer(num_heads=4, return_attention_map=True, name="mhsa_map")
     _setup(layer, torch.empty(shape, dtype=torch.float32, device="cuda"))
-    x = rnd(shape, 3)
+    x = rnd(shape, 3).float()
     w = OM.export_weights(layer)
 
     def conv1x1(name, t):
@@ -313,20 +313,20 @@ def test_swin_absolute_position_embedding(cuda):
                                 return_endpoints=True, name="swin_ape")
     _setup(swin, torch.empty(shape, dtype=torch.float32, device="cuda"))
     assert tuple(swin.absolute_pos_embed.shape) == (1, 14 * 14, 32)
-    x = rnd(shape, 4)
+    x = rnd(shape, 4).float()
     eps = swin(x.cuda(), training=True)
     w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(swin).items()}
     ref = OM.swin_forward(w, x.double(), depths=(2,), heads=(2,), ws=7, ape="swin_ape/absolute_pos_embed")
     for a, b in zip(eps, ref):
         assert _rel(a, b.detach()) < 1e-4
-    dys = [rnd(tuple(r.shape), 7 + i) for i, r in enumerate(ref)]
+    dys = [rnd(tuple(r.shape), 7 + i).float() for i, r in enumerate(ref)]
     torch.autograd.backward(list(eps), [d.cuda() for d in dys])
     torch.autograd.backward(ref, [d.double() for d in dys])
     g = swin.absolute_pos_embed.grad.cpu().double()
     gr = w["swin_ape/absolute_pos_embed"].grad
     assert (g - gr).abs().max().item() < 5e-4 * max(1.0, gr.abs().max().item())
     with pytest.raises(ValueError):
-        swin(rnd((1, 60, 56, 3), 9).cuda(), training=False)
+        swin(rnd((1, 60, 56, 3), 9).float().cuda(), training=False)
 
 
 @pytest.mark.parametrize("heads,B,ws,masked", [(6, 5, 7, False), (3, 18, 7, True), (12, 4, 5, False), (2, 7, 8, True)])
