@@ -978,8 +978,9 @@ class _ConvNeXtBlockFn(Function):
             bw = h
             yop, ln = (y1.reshape(M, C), (mean, rstd, p.ln_gamma.data, p.ln_beta.data)) if ctx.ln_on_load else (y2, None)
             dy2 = K.convnext_mlp_bwd_data(yop, do2, bw, p.b1.data, dp_mask, H * W, ln=ln)
-            K.convnext_mlp_wgrad(yop, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None, _grad(p.w1),
-                                 _grad(p.b1), _grad(p.w2), _grad(p.b2), _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W, ln=ln)
+            side.run(lambda: K.convnext_mlp_wgrad(yop, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None,
+                                                  _grad(p.w1), _grad(p.b1), _grad(p.w2), _grad(p.b2),
+                                                  _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W, ln=ln), yop, do2)
             del h, bw
         else:
             dy2 = _ConvNeXtBlockFn._mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc)
@@ -1156,11 +1157,47 @@ _SIDE_STREAMS = {}
 
 
 def _side_enabled():
+    """independent work on extra HIP streams?  ISEG_SIDE_STREAM = 1 always, 0 never, auto (default) only while a HIP graph is being captured.
+    Eager (measured on the flagship step, interleaved A/B): 9.08 ms with one queue, 9.39 ms with two -- every fork / join is a pair of host-side
+    event calls.  Inside a captured graph the same forks are edges of the graph: replayed 9.11 ms with one queue, 8.98 ms with two (round 3),
+    so the graph runner gets the concurrency and the eager step does not pay for it."""
     import os
 
-    # measured on the flagship step (MI355X, 30 steps, interleaved A/B): 12.12 ms with one queue, 12.26 ms with two -- the narrow-stage
-    # kernels already overlap their tails on one stream and the extra event traffic costs more than the concurrency returns; off by default
-    return os.environ.get("ISEG_SIDE_STREAM", "0") == "1"
+    mode = os.environ.get("ISEG_SIDE_STREAM", "auto")
+    if mode == "1":
+        return True
+    if mode == "0" or not torch.cuda.is_available():
+        return False
+    return torch.cuda.is_current_stream_capturing()
+
+
+_BRANCH_STREAMS = {}
+
+
+def parallel_branches(fns, device=None):
+    """[fn() for fn in fns], each on its own HIP stream when side streams are enabled (_side_enabled): the branches of ASPP are five
+    independent conv -> BatchNorm -> ReLU chains of 64..256-workgroup kernels that leave most of the chip idle one at a time.  The autograd
+    engine replays each branch's backward on the stream its forward ran on, so the backward pass forks the same way."""
+    if len(fns) < 2 or not _side_enabled():
+        return [fn() for fn in fns]
+    main = torch.cuda.current_stream()
+    key = main.device.index
+    pool = _BRANCH_STREAMS.setdefault(key, [])
+    while len(pool) < len(fns):
+        pool.append(torch.cuda.Stream(device=main.device))
+    outs = []
+    for fn, st in zip(fns, pool):
+        st.wait_stream(main)
+        with torch.cuda.stream(st):
+            outs.append(fn())
+    capturing = torch.cuda.is_current_stream_capturing()
+    for o, st in zip(outs, pool):
+        main.wait_stream(st)
+        if not capturing:      # eager: tell the caching allocator that the main stream reads what a side stream allocated
+            for t in (o if isinstance(o, (list, tuple)) else [o]):
+                if torch.is_tensor(t):
+                    t.record_stream(main)
+    return outs
 
 
 class _SideQueue:

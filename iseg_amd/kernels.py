@@ -56,9 +56,14 @@ def workspace(nbytes, device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        size = int(nbytes * 1.25) + 1024
         if torch.cuda.is_current_stream_capturing():
-            raise _hip.HipCallError("workspace growth during hipGraph capture; run one eager warm-up step first")
-        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            if buf is not None:      # kernels already captured hold the old pointer: it must not go back to the pool
+                raise _hip.HipCallError("workspace growth during hipGraph capture; run one eager warm-up step first")
+            # a stream that first appears inside the capture (the side streams of functional.parallel_branches / _SideQueue): give it what
+            # the warmed-up streams of this device ended up needing, so that it never has to grow while the capture goes on
+            size = max([size] + [b.numel() for (d, _), b in _WS.items() if d == key[0]])
+        buf = torch.empty(size, dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf, buf.numel()
 

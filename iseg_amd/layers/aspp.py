@@ -34,12 +34,10 @@ class AtrousSpatialPyramidPooling(Layer):
         results = []
         branches = int(self.use_image_level) + int(self.use_pixel_level) + len(self.asp_convs)
         xs = list(F.fork(inputs, branches))      # one alias per branch: the branch gradients are summed by our own kernel
-        if self.use_image_level:
-            results.append(self.image_level_block(xs.pop(0), training=training))
-        if self.use_pixel_level:
-            results.append(self.pixel_level_block(xs.pop(0), training=training))
-        for conv in self.asp_convs:
-            results.append(conv(xs.pop(0), training=training))
+        blocks = ([self.image_level_block] if self.use_image_level else []) + ([self.pixel_level_block] if self.use_pixel_level else []) + \
+            list(self.asp_convs)
+        # independent chains: one HIP stream each inside a captured training step (F.parallel_branches), plain calls otherwise
+        results = F.parallel_branches([(lambda b=b, x=x: b(x, training=training)) for b, x in zip(blocks, xs)])
         return F.concat(results)
 
     # ---- data-parallel training: the branches' SyncBN statistics share one all-reduce (and one in backward) -----------------------

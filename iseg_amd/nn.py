@@ -205,7 +205,14 @@ def weights_changed():
 
 
 def _wt_rebuild():
-    shadows = [p.iseg_compute for p in _WT["params"]]
+    # the registry must not keep dropped models alive (or re-transpose their kernels forever): entries are weak references, dead ones go here
+    live = [r for r in _WT["params"] if r() is not None]
+    _WT["params"] = live
+    _WT["index"] = {id(r()): j for j, r in enumerate(live)}
+    shadows = [r().iseg_compute for r in live]
+    if not shadows:
+        _WT.update(buf=None, views=[], table=None, ptrs=[], max_tiles=0, version=-1)
+        return
     dev = shadows[0].device
     base = min(sh.data_ptr() for sh in shadows)
     total, rows = 0, []
@@ -219,11 +226,32 @@ def _wt_rebuild():
                max_tiles=max(((k + 63) // 64) * ((n + 63) // 64) for (_, _, k, n) in rows), version=-1)
 
 
+def register_wt(params):
+    """register every eligible 2-D kernel of `params` at once (ParamStore build): one rebuild instead of one per first use"""
+    import weakref
+
+    added = False
+    for p in params:
+        sh = getattr(p, "iseg_compute", None)
+        if sh is None or sh.dim() != 2 or not sh.is_cuda:
+            continue
+        i = _WT["index"].get(id(p))
+        if i is None or _WT["params"][i]() is not p:
+            _WT["index"][id(p)] = len(_WT["params"])
+            _WT["params"].append(weakref.ref(p))
+            added = True
+    if added:
+        _wt_rebuild()
+
+
 def refresh_wt():
     """bring every registered K-contiguous kernel copy up to date NOW (one launch) -- for callers that will not pass through wt() again
     before the copies are read, i.e. the replay of a captured graph (iseg_amd/graphs.py)"""
-    if _WT["params"] and _WT["version"] != _WEIGHTS_VERSION[0]:
-        wt(_WT["params"][0])
+    if _WT["version"] != _WEIGHTS_VERSION[0]:
+        for r in _WT["params"]:
+            if r() is not None:
+                wt(r())
+                break
 
 
 def weights_version():
@@ -239,13 +267,14 @@ def wt(param):
     if sh is None or sh.dim() != 2 or not sh.is_cuda:
         return None
     i = _WT["index"].get(id(param))
-    if i is None or _WT["params"][i] is not param:
-        _WT["index"][id(param)] = i = len(_WT["params"])
-        _WT["params"].append(param)
-        _wt_rebuild()
+    if i is None or i >= len(_WT["params"]) or _WT["params"][i]() is not param:      # new, or an id recycled after its owner died
+        register_wt([param])
+        i = _WT["index"][id(param)]
     if _WT["version"] != _WEIGHTS_VERSION[0]:
-        if any(p.iseg_compute.data_ptr() != q for p, q in zip(_WT["params"], _WT["ptrs"])):      # a new ParamStore re-homed the shadows
+        dead = any(r() is None for r in _WT["params"])
+        if dead or any(r().iseg_compute.data_ptr() != q for r, q in zip(_WT["params"], _WT["ptrs"])):      # a dropped model / a new ParamStore re-homed the shadows
             _wt_rebuild()
+            i = _WT["index"][id(param)]
         from . import _hip
         from . import kernels as K
 
