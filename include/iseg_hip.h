@@ -489,11 +489,21 @@ int iseg_attention_bwd(const void* qkv, const void* out, const void* dout, const
  * labels [B, Hs, Ws] int32 or NULL; params [B, iseg_augment_params_ints()] int32 on the device, per sample:
  * H, W (valid source size), newH, newW (after the scale), off_y, off_x (crop offset in the scaled + padded image), flip, n_erase (<= 5),
  * then n_erase x (y, x, h, w) in output coordinates.  The host draws them; the device only draws the erase noise (seed).
+ * Optional photometric table fparams [B, iseg_augment_params_floats()] float32 (NULL = none; round 3), per sample: brightness delta
+ * (augments/random_brightness_augment.py: + delta, clip [0, 256]; 0 = not executed), contrast factor (tf.image.adjust_contrast about the
+ * channel means in slots 2..4, which iseg_augment_channel_means fills from the scaled + brightness-adjusted image; 1 = not executed),
+ * saturation factor (1) and hue delta (0) (augments/random_photo_metric_distortions.py: contrast -> saturation -> hue -> clip), and the
+ * stddev of RandomNoisyEvalAugment's N(0, sigma) noise (evaluation pipeline: added after the padding, clip [0, 256]).  The photometric
+ * steps sit between the random scale and the padding (pipeline.py:129-134): pad and erased pixels are not touched by them.
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_augment_params_ints(void);
-int iseg_augment_crop_batch(const void* images, int image_dtype, const int32_t* labels, const int32_t* params, const float* mean_pixel,
-                            const float* norm_scale, const float* norm_shift, int ignore_label, float* out_images, int32_t* out_labels, int B,
-                            int Hs, int Ws, int crop_h, int crop_w, uint64_t seed, iseg_stream_t stream);
+int iseg_augment_params_floats(void);
+size_t iseg_augment_means_workspace_bytes(int B);
+int iseg_augment_channel_means(const void* images, int image_dtype, const int32_t* params, float* fparams, int B, int Hs, int Ws, void* ws,
+                               size_t ws_bytes, iseg_stream_t stream);
+int iseg_augment_crop_batch(const void* images, int image_dtype, const int32_t* labels, const int32_t* params, const float* fparams,
+                            const float* mean_pixel, const float* norm_scale, const float* norm_shift, int ignore_label, float* out_images,
+                            int32_t* out_labels, int B, int Hs, int Ws, int crop_h, int crop_w, uint64_t seed, iseg_stream_t stream);
 int iseg_normalize_image(const float* x, float* y, int64_t pixels, const float* norm_scale, const float* norm_shift, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -164,8 +164,11 @@ SIGNATURES = {
     "iseg_grad_sqnorm": (_i, [_p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _l, _i, _p]),
     "iseg_adamw_step": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _f, _p, _f, _p, _f, _l, _p]),
     "iseg_augment_params_ints": (_i, []),
-    "iseg_augment_crop_batch": (_i, [_p, _i, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _p, _p, _i, _i, _i, _i,
-                                     _i, _u64, _p]),
+    "iseg_augment_params_floats": (_i, []),
+    "iseg_augment_means_workspace_bytes": (_z, [_i]),
+    "iseg_augment_channel_means": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "iseg_augment_crop_batch": (_i, [_p, _i, _p, _p, _p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _p, _p, _i, _i, _i,
+                                     _i, _i, _u64, _p]),
     "iseg_normalize_image": (_i, [_p, _p, _l, C.POINTER(C.c_float), C.POINTER(C.c_float), _p]),
     "iseg_upsample_ce_supported": (_i, [_i, _i, _i, _i, _i]),
     "iseg_upsample_ce_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),

@@ -24,11 +24,13 @@ class StandardAugmentationsPipeline:
             eval_crop_width = crop_width
         if not training:
             crop_height, crop_width = eval_crop_height, eval_crop_width
-        for flag, what in ((max_resize_height or max_resize_width, "ResizeAugment"), (random_brightness, "RandomBrightnessAugment"),
-                           (photo_metric_distortions, "RandomPhotoMetricDistortions"), (random_jepg_quality, "RandomJEPGQualityAugment"),
-                           (random_noisy_eval_level > 1e-3, "RandomNoisyEvalAugment")):
+        for flag, what in ((max_resize_height or max_resize_width, "ResizeAugment (a second resampling pass in front of the random scale)"),
+                           (random_jepg_quality, "RandomJEPGQualityAugment (a JPEG codec round trip)")):
             if flag:
                 raise NotImplementedError(f"{what} is not part of the on-device pipeline (the standard recipe leaves it off)")
+        # optional photometric augmentations (:129-134, :160-164): drawn on the host like every other decision, applied by the gather kernel
+        self.random_brightness, self.photo_metric_distortions = bool(random_brightness), bool(photo_metric_distortions)
+        self.random_noisy_eval_level = float(random_noisy_eval_level)
         if min_scale_factor < 0 or min_scale_factor > max_scale_factor:
             raise ValueError("Unexpected value of min_scale_factor.")
         self.training, self.name = training, name
@@ -78,8 +80,32 @@ class StandardAugmentationsPipeline:
                 tab[b, 8 + 4 * e:12 + 4 * e] = r
         return tab
 
+    def draw_photometric(self, n):
+        """[n, iseg_augment_params_floats()] float32 or None: RandomBrightnessAugment(max_delta 32, p 0.5) (random_brightness_augment.py:12-28);
+        RandomPhotoMetricDistortions = contrast U(0.75, 1.25) p 0.5 -> saturation U(0.75, 1.25) p 0.5 -> hue U(-0.1, 0.1) always
+        (random_photo_metric_distortions.py:15-37); evaluation: RandomNoisyEvalAugment's stddev (random_noisy_eval_augment.py:12-30)"""
+        train_any = self.training and (self.random_brightness or self.photo_metric_distortions)
+        noisy = (not self.training) and self.random_noisy_eval_level > 1e-3
+        if not (train_any or noisy):
+            return None
+        tab = np.zeros((n, K.augment_params_floats()), dtype=np.float32)
+        tab[:, 1] = 1.0
+        tab[:, 5] = 1.0
+        for b in range(n):
+            if self.training and self.random_brightness and self.rng.random() <= 0.5:
+                tab[b, 0] = self.rng.uniform(-32.0, 32.0)
+            if self.training and self.photo_metric_distortions:
+                if self.rng.random() <= 0.5:
+                    tab[b, 1] = self.rng.uniform(0.75, 1.25)
+                if self.rng.random() <= 0.5:
+                    tab[b, 5] = self.rng.uniform(0.75, 1.25)
+                tab[b, 6] = self.rng.uniform(-0.1, 0.1)
+            if noisy:
+                tab[b, 7] = self.random_noisy_eval_level
+        return tab
+
     # ---- the batch on the device -----------------------------------------------------------------------------------------------------
-    def apply_batch(self, images, labels, sizes=None, params=None):
+    def apply_batch(self, images, labels, sizes=None, params=None, photometric="draw"):
         """images [B, Hs, Ws, 3] uint8 / float32 (samples smaller than Hs x Ws sit in the top-left corner, `sizes` = their (H, W)),
         labels [B, Hs, Ws] int32 or None  ->  (float32 [B, crop_h, crop_w, 3] normalised, int32 [B, crop_h, crop_w] or None)"""
         B, Hs, Ws, _ = images.shape
@@ -91,8 +117,16 @@ class StandardAugmentationsPipeline:
         scale, shift = norm_affine(self.input_norm_type)
         self._launches += 1
         seed = (nn.seed() * 0x9E3779B97F4A7C15 + self._launches * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
-        return K.augment_crop_batch(images, labels, torch.from_numpy(params).to(dev), self.mean_pixel, scale, shift, self.ignore_label,
-                                    self.target_height, self.target_width, seed)
+        if isinstance(photometric, str):
+            photometric = self.draw_photometric(B)
+        pdev = torch.from_numpy(params).to(dev)
+        fdev = None
+        if photometric is not None:
+            fdev = torch.from_numpy(np.ascontiguousarray(photometric, dtype=np.float32)).to(dev)
+            if bool((photometric[:, 1] != 1.0).any()):      # the contrast step needs the channel means of the scaled image
+                K.augment_channel_means(images, pdev, fdev)
+        return K.augment_crop_batch(images, labels, pdev, self.mean_pixel, scale, shift, self.ignore_label, self.target_height,
+                                    self.target_width, seed, fparams=fdev)
 
     def __call__(self, ds):
         """dataset -> dataset of augmented samples (batch of one through the same kernel), for code written against the tf.data form"""

@@ -603,8 +603,23 @@ def _f3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
 
-def augment_crop_batch(images, labels, params, mean_pixel, norm_scale, norm_shift, ignore_label, crop_h, crop_w, seed):
-    """scale -> pad -> crop -> flip -> erase -> normalise as one gather (data_process/pipeline.py:85-170); params: int32 [B, n] on the device"""
+def augment_params_floats():
+    return int(_hip.lib().iseg_augment_params_floats())
+
+
+def augment_channel_means(images, params, fparams):
+    """fill slots 2..4 of the photometric table with the channel means of each sample's scaled (+ brightness) image (tf.image.adjust_contrast)"""
+    _require_cuda(images, params, fparams)
+    B, Hs, Ws, _ = images.shape
+    need = _hip.lib().iseg_augment_means_workspace_bytes(B)
+    ws, wsb = workspace(need, images.device)
+    _hip.call("iseg_augment_channel_means", ptr(images.contiguous()), 0 if images.dtype == torch.float32 else 2, ptr(params), ptr(fparams), B, Hs, Ws,
+              ptr(ws), wsb, stream())
+
+
+def augment_crop_batch(images, labels, params, mean_pixel, norm_scale, norm_shift, ignore_label, crop_h, crop_w, seed, fparams=None):
+    """scale -> [brightness / contrast / saturation / hue] -> pad -> crop -> flip -> erase -> [eval noise] -> normalise as one gather
+    (data_process/pipeline.py:85-170); params: int32 [B, n], fparams: float32 [B, m] or None, both on the device"""
     _require_cuda(images, params)
     if images.dtype not in (torch.float32, torch.uint8):
         raise TypeError("augment_crop_batch takes float32 or uint8 images")
@@ -618,8 +633,8 @@ def augment_crop_batch(images, labels, params, mean_pixel, norm_scale, norm_shif
             lab = lab.to(torch.int32)
         out_lab = torch.empty((B, crop_h, crop_w), dtype=torch.int32, device=images.device)
     _hip.call("iseg_augment_crop_batch", ptr(images), 0 if images.dtype == torch.float32 else 2, ptr(lab), ptr(params.contiguous()),
-              _f3(mean_pixel), _f3(norm_scale), _f3(norm_shift), int(ignore_label), ptr(out), ptr(out_lab), B, Hs, Ws, int(crop_h), int(crop_w),
-              int(seed), stream())
+              ptr(fparams), _f3(mean_pixel), _f3(norm_scale), _f3(norm_shift), int(ignore_label), ptr(out), ptr(out_lab), B, Hs, Ws,
+              int(crop_h), int(crop_w), int(seed), stream())
     return out, out_lab
 
 

@@ -515,3 +515,54 @@ def dcnv3_op(x, offset, mask, kernel_size=(3, 3), strides=(1, 1), padding="SAME"
         out = out + xg[bidx, yy, xx] * ww.unsqueeze(-1)            # [P, B, HW, Cg]
     out = (out * m).sum(dim=0)                                      # [B, HW, Cg]
     return out.reshape(N, groups, Ho, Wo, group_channels).permute(0, 2, 3, 1, 4).reshape(N, Ho, Wo, groups * group_channels)
+
+
+# ---- photometric augmentations (data_process/augments/random_{brightness,contrast,saturation,hue}_augment.py) -------------------------------
+def adjust_contrast(x, factor):
+    """tf.image.adjust_contrast on a float image [H, W, C]: (x - mean_hw) * factor + mean_hw, per channel"""
+    x = np.asarray(x, dtype=np.float64)
+    mean = x.mean(axis=(0, 1), keepdims=True)
+    return (x - mean) * factor + mean
+
+
+def _per_pixel_hsv(x, fn):
+    """run fn(h, s, v) -> (h, s, v) on every pixel through the standard library's colorsys (an implementation independent of the kernel's);
+    colorsys wants v in any scale but divides by it, so the pixels go through on their own scale like tf's float kernels"""
+    import colorsys
+
+    x = np.asarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    for idx in np.ndindex(x.shape[:-1]):
+        r, g, b = x[idx]
+        mx = max(r, g, b)
+        if mx <= 0.0:                       # tf's rgb_to_hsv: s = 0 when v <= 0, hue 0
+            h, s, v = 0.0, 0.0, mx
+        else:
+            h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        h, s, v = fn(h, s, v)
+        out[idx] = colorsys.hsv_to_rgb(h, s, v)
+    return out
+
+
+def adjust_saturation(x, factor):
+    """tf.image.adjust_saturation (float image, no range conversion): S * factor clipped to [0, 1]"""
+    return _per_pixel_hsv(x, lambda h, s, v: (h, min(max(s * factor, 0.0), 1.0), v))
+
+
+def adjust_hue(x, delta):
+    """tf.image.adjust_hue: H + delta wrapped into [0, 1)"""
+    return _per_pixel_hsv(x, lambda h, s, v: ((h + delta) % 1.0, s, v))
+
+
+def photometric_sequence(x, brightness_delta=0.0, contrast=1.0, saturation=1.0, hue=0.0, distortions=False):
+    """RandomBrightnessAugment (:12-28: + delta, clip [0, 256]) then RandomPhotoMetricDistortions.contrast_first_forward
+    (random_photo_metric_distortions.py:15-37: contrast -> saturation -> hue, clip [0, 256]) on the drawn values"""
+    x = np.asarray(x, dtype=np.float64)
+    x = np.clip(x + brightness_delta, 0.0, 256.0)
+    if distortions:
+        if contrast != 1.0:
+            x = adjust_contrast(x, contrast)
+        if saturation != 1.0:
+            x = adjust_saturation(x, saturation)
+        x = np.clip(adjust_hue(x, hue), 0.0, 256.0)       # (RandomHueAugment clips too: the same clip twice)
+    return x

@@ -92,7 +92,9 @@ def test_scale_factors_are_the_discrete_grid_and_eval_only_pads(cuda):
     assert torch.equal(out[:, :20, :20], img) and bool((out[:, 20:] == 127.5).all()) and bool((out[:, :, 20:] == 127.5).all())
     assert bool((ol[:, :20, :20] == 1).all()) and bool((ol[:, 20:] == 255).all())
     with pytest.raises(NotImplementedError):
-        StandardAugmentationsPipeline(training=True, random_brightness=True)
+        StandardAugmentationsPipeline(training=True, random_jepg_quality=True)
+    with pytest.raises(NotImplementedError):
+        StandardAugmentationsPipeline(training=True, max_resize_height=256)
 
 
 def test_normalize_input_value_range(cuda):
@@ -107,3 +109,59 @@ def test_normalize_input_value_range(cuda):
     ks = normalize_input_value_range(x, InputNormTypes.KERAS_SCALE)
     assert (ks.cpu() - (x.cpu() / 255.0 - mean / 255.0) / (std / 255.0)).abs().max().item() < 1e-5
     assert normalize_input_value_range(x, InputNormTypes.NONE) is x
+
+
+def test_photometric_augmentations_follow_the_reference_sequence(cuda):
+    """RandomBrightnessAugment + RandomPhotoMetricDistortions between the random scale and the padding (pipeline.py:129-134), on the
+    drawn values, against the numpy restatement (oracle.tf_ops.photometric_sequence; HSV through the standard library's colorsys)"""
+    from iseg_amd.data_process import InputNormTypes, StandardAugmentationsPipeline, norm_affine
+
+    ch, cw = 24, 28
+    pipe = StandardAugmentationsPipeline(training=True, crop_height=ch, crop_width=cw, input_norm_type=InputNormTypes.ZERO_MEAN, seed=9,
+                                         random_brightness=True, photo_metric_distortions=True, random_erase=False)
+    rng = np.random.default_rng(4)
+    sizes = [(20, 30), (32, 32), (17, 25), (32, 19)]
+    imgs = rng.integers(0, 256, (len(sizes), 32, 32, 3)).astype(np.uint8)
+    imgs[1, :6] = 0                      # black and saturated rows: the max <= 0 and range == 0 corners of the HSV conversion
+    imgs[1, 6:9] = 255
+    labs = rng.integers(0, 21, (len(sizes), 32, 32)).astype(np.int32)
+    scale, shift = norm_affine(InputNormTypes.ZERO_MEAN)
+    saw = {"bright": 0, "contrast": 0, "sat": 0, "none_sat": 0}
+    for trial in range(5):
+        params, tab = pipe.draw(sizes), pipe.draw_photometric(len(sizes))
+        assert tab is not None and (np.abs(tab[:, 0]) <= 32).all() and (np.abs(tab[:, 6]) <= 0.1).all()
+        assert ((tab[:, 1] >= 0.75) & (tab[:, 1] <= 1.25) & (tab[:, 5] >= 0.75) & (tab[:, 5] <= 1.25)).all()
+        out, lab = pipe.apply_batch(torch.from_numpy(imgs).cuda(), torch.from_numpy(labs).cuda(), sizes, params=params, photometric=tab)
+        for b, (H, W) in enumerate(sizes):
+            p, f = params[b], tab[b]
+            saw["bright"] += int(f[0] != 0); saw["contrast"] += int(f[1] != 1); saw["sat"] += int(f[5] != 1); saw["none_sat"] += int(f[5] == 1)
+            nH, nW, oy, ox, flip = [int(v) for v in p[2:7]]
+            x = torch.from_numpy(imgs[b, :H, :W].astype(np.float64))[None]
+            if (nH, nW) != (H, W):
+                x = O.resize_bilinear(x, (nH, nW))
+            x = O.photometric_sequence(x[0].numpy(), float(f[0]), float(f[1]), float(f[5]), float(f[6]), distortions=True)
+            ph, pw = max(nH, ch), max(nW, cw)
+            xp = np.empty((ph, pw, 3)); xp[:] = np.asarray(pipe.mean_pixel, dtype=np.float64); xp[:nH, :nW] = x
+            xc = xp[oy:oy + ch, ox:ox + cw]
+            xc = (xc[:, ::-1] if flip else xc) * np.asarray(scale) + np.asarray(shift)
+            err = np.abs(out[b].cpu().double().numpy() - xc).max()
+            assert err <= 3e-4, (trial, b, err)      # fp32 HSV round trip on the [0, 256] scale through the 2/255 normalisation
+    assert all(v > 0 for v in saw.values()), saw
+
+
+def test_noisy_eval_adds_clipped_gaussian_noise_after_the_padding(cuda):
+    from iseg_amd.data_process import StandardAugmentationsPipeline
+
+    ev = StandardAugmentationsPipeline(training=False, crop_height=64, crop_width=64, random_noisy_eval_level=8.0)
+    img = torch.full((2, 48, 48, 3), 100.0).cuda()
+    out, _ = ev.apply_batch(img, torch.zeros(2, 48, 48, dtype=torch.int32).cuda())
+    d_img, d_pad = (out[:, :48, :48] - 100.0).flatten().cpu(), (out[:, 48:] - 127.5).flatten().cpu()      # (the padding is noised too: :160-164)
+    for d in (d_img, d_pad):
+        assert abs(d.mean().item()) < 0.5 and abs(d.std().item() - 8.0) < 0.4
+    assert abs(((d_img.abs() < 8.0).float().mean().item()) - 0.6827) < 0.02                                # a normal, not a uniform
+    dark, _ = ev.apply_batch(torch.zeros(1, 64, 64, 3).cuda(), torch.zeros(1, 64, 64, dtype=torch.int32).cuda())
+    assert dark.min().item() == 0.0 and 0.4 < (dark == 0).float().mean().item() < 0.6                      # clip [0, 256]
+    a, _ = ev.apply_batch(img, torch.zeros(2, 48, 48, dtype=torch.int32).cuda())
+    assert not torch.equal(a, out)                                                                         # a fresh draw per batch
+    quiet = StandardAugmentationsPipeline(training=False, crop_height=64, crop_width=64, random_noisy_eval_level=0.0005)
+    assert quiet.draw_photometric(2) is None

@@ -252,3 +252,24 @@ def test_resize_bilinear_align_corners_by_hand():
     assert torch.allclose(y, want, atol=1e-6)
     one = O.resize_bilinear(x, (1, 1), align_corners=True)
     assert one.shape == (1, 1, 1, 1) and float(one) == 0.0      # a single output samples the first corner
+
+
+def test_photometric_restatement_known_answers():
+    """tf.image.adjust_{contrast,saturation,hue} facts that hold by definition: primaries rotate into each other under a third of a hue
+    turn, saturation 0 is the max-channel grey, factor-1 / delta-0 are identities, contrast keeps the channel means"""
+    import numpy as np
+
+    from oracle import tf_ops as O
+
+    red = np.array([[[200.0, 0.0, 0.0]]])
+    assert np.allclose(O.adjust_hue(red, 1.0 / 3.0), [[[0.0, 200.0, 0.0]]], atol=1e-9)
+    assert np.allclose(O.adjust_hue(red, -1.0 / 3.0), [[[0.0, 0.0, 200.0]]], atol=1e-9)
+    x = np.random.default_rng(0).uniform(0, 255, (5, 7, 3))
+    assert np.allclose(O.adjust_hue(x, 0.0), x, atol=1e-9) and np.allclose(O.adjust_saturation(x, 1.0), x, atol=1e-9)
+    grey = O.adjust_saturation(x, 0.0)
+    assert np.allclose(grey, x.max(-1, keepdims=True).repeat(3, -1), atol=1e-9)
+    c = O.adjust_contrast(x, 1.25)
+    assert np.allclose(c.mean((0, 1)), x.mean((0, 1))) and np.allclose(c - c.mean((0, 1)), 1.25 * (x - x.mean((0, 1))))
+    assert np.allclose(O.adjust_saturation(np.array([[[-3.0, -1.0, -2.0]]]), 1.1), [[[-1.0, -1.0, -1.0]]])      # tf: S = 0 when max <= 0
+    full = O.photometric_sequence(x, brightness_delta=40.0, contrast=1.25, saturation=1.2, hue=0.05, distortions=True)
+    assert full.min() >= 0.0 and full.max() <= 256.0
