@@ -147,6 +147,19 @@ size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int W, int C, int 
 int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W, int C,
                              int K, int dil, int pad_t, int pad_l, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
+/* The same layer with strides = s (backbones/mobilenetv2.py:60-78 the 3x3 / s2 of an inverted residual block; the strided SepConvBnReLU of
+ * layers/model_builder.py), computed at the strided output positions only.  pad_t / pad_l: TF "same" front padding for (H, K, s, dil);
+ * Ho = ceil(H / s), Wo = ceil(W / s).  The data gradient is the gather over dy (a tap contributes where (h + pad_t - i*dil) is a multiple of
+ * s); the weight gradient sums fixed pixel partitions in a fixed order (deterministic) into dw [K*K, C] / db [C] (+= when accumulate). */
+int iseg_dwconv2d_strided_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int C, int K, int stride, int dil,
+                              int pad_t, int pad_l, int Ho, int Wo, int dtype, iseg_stream_t stream);
+int iseg_dwconv2d_strided_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int K, int stride, int dil, int pad_t,
+                                   int pad_l, int Ho, int Wo, int dtype, iseg_stream_t stream);
+size_t iseg_dwconv2d_strided_bwd_weight_workspace_bytes(int N, int Ho, int Wo, int C, int K);
+int iseg_dwconv2d_strided_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W, int C, int K,
+                                     int stride, int dil, int pad_t, int pad_l, int Ho, int Wo, int dtype, void* ws, size_t ws_bytes,
+                                     iseg_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * (Sync)BatchNorm, training mode: keras BatchNormalization(synchronized=True) as wired by
  * layers/normalizations.py:14-23,39-132; moments as layers/keras3/bn.py:10-73 / layers/syncbn.py:70-119.

@@ -12,6 +12,11 @@
 //   pass 1  data grad     dx[m', c]       = sum_{i,j,co} dy[n, (h + pt - i*dh)/sh, (w + pl - j*dw)/sw, co] * w[i,j,c,co]   m' = (n,h,w)
 //                                           (a tap contributes only where both quotients are exact and inside the output map)
 //   pass 2  weight grad   dw[(i,j,c), co] = sum_m        x[n, oh*sh + i*dh - pt, ow*sw + j*dw - pl, c] * dy[m, co]
+//   pass 3  data grad of a STRIDED convolution (dilation 1), by stride phase: the input pixels with h = a (mod sh), w = b (mod sw) only ever
+//           meet the taps i = (a + pt) mod sh + t*sh, j = (b + pl) mod sw + u*sw, and for those (h + pt - i) / sh = hq + (a + pt) / sh - t is
+//           exact -- so each of the sh*sw phases is a stride-1 gather over dy with its own (smaller) tap grid: no zero products on the matrix
+//           cores (the plain gather form of pass 1 multiplies 1 - 1/(sh*sw) zeros), no column buffer, no col2im pass.  All phases run in one
+//           launch (blockIdx.y); the epilogue scatters a phase's rows to their pixels of dx.
 //
 // Each pass is the register-staged MFMA main loop of gemm_impl.h (128 x BN tile, 8 wavefronts, v_mfma_f32_16x16x32_bf16, LDS
 // fragments by ds_read_b128 / ds_read_b64_tr_b16, per-wave epilogue slab) with the A stager replaced by a gather: the row part of
@@ -36,6 +41,31 @@ struct ConvP {
     int kw;
     int sh, sw, dh, dw, pt, pl;
     int groups;
+};
+
+// one stride phase of pass 3
+struct PhaseP {
+    int Hq, Wq;             // pixels of this phase per image: h = hq * sh + a, w = wq * sw + b
+    int a, b;
+    int q0h, q0w;           // dy row of tap t: hq + q0h - t
+    int Th, Tw;             // tap grid of the phase
+    int tap0;               // weight tap of (t, u): tap0 + t * sh * kw + u * sw
+    int M, K;               // rows (N * Hq * Wq) and reduction (Th * Tw * Cout_g) of the phase
+};
+constexpr int MAX_PHASES = 16;
+struct PhaseTable {
+    PhaseP ph[MAX_PHASES];
+    int H, W, sh, sw, kw;
+};
+struct NoPhases {};
+
+// GEMM row of a phase -> pixel of dx
+struct PhaseRows {
+    int hw, wq, H, W, sh, sw, a, b;
+    __device__ __forceinline__ int64_t operator()(int64_t m) const {
+        const int n = (int)(m / hw), rem = (int)(m % hw);
+        return ((int64_t)n * H + (rem / wq) * sh + a) * W + (rem % wq) * sw + b;
+    }
 };
 
 constexpr int INVALID = -(1 << 28);
@@ -116,8 +146,9 @@ template <int ROWS, int NT, int BK, int PASS> struct GatherStager : Stager<ROWS,
 template <int ROWS, int NT, int BK> struct TapWeightStager : Stager<ROWS, true, NT, BK> {
     using Base = Stager<ROWS, true, NT, BK>;
     using G = typename Base::G;
+    // (tw, tap0, tsh, tsw): reduction tap ij = (t, u) of a tw-wide tap grid reads weight tap tap0 + t * tsh + u * tsw (pass 1: the identity)
     __device__ __forceinline__ void load_taps(const bf16_t* __restrict__ wg, int64_t ld, int64_t tap_stride, int cout_g, int64_t n0, int64_t k0,
-                                              int64_t R, int64_t Kend, int tid) {
+                                              int64_t R, int64_t Kend, int tid, int tw, int tap0, int tsh, int tsw) {
 #pragma unroll
         for (int i = 0; i < Base::PER_THREAD; ++i) {
             const int c = tid + i * NT;
@@ -131,7 +162,8 @@ template <int ROWS, int NT, int BK> struct TapWeightStager : Stager<ROWS, true, 
                 for (int u = 0; u < 8; ++u) v[u] = (bf16_t)0.f;
                 if (row < R && kk < Kend) {
                     const int ij = (int)(kk / cout_g), co = (int)(kk % cout_g);
-                    v = *reinterpret_cast<const bf16x8*>(wg + ij * tap_stride + row * ld + co);
+                    const int tap = tap0 + (ij / tw) * tsh + (ij % tw) * tsw;
+                    v = *reinterpret_cast<const bf16x8*>(wg + tap * tap_stride + row * ld + co);
                 }
                 this->regs[i] = v;
             }
@@ -144,8 +176,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
                                                                   int64_t tap_stride, TO* __restrict__ D, int64_t ldd, int64_t d_group_stride,
                                                                   int64_t M, int64_t N, int64_t K, int tiles_n, int ntiles,
                                                                   int64_t k_per_split, float* __restrict__ slabs, int64_t slab_group_stride,
-                                                                  Epi epi, int vecD) {
-    constexpr bool AKC = PASS != 2, BKC = PASS == 1;
+                                                                  Epi epi, int vecD,
+                                                                  typename std::conditional<PASS == 3, PhaseTable, NoPhases>::type phases) {
+    constexpr bool AKC = PASS != 2, BKC = PASS == 1 || PASS == 3;
+    constexpr int GPASS = PASS == 3 ? 1 : PASS;      // a phase is a stride-1 data-gradient gather in quotient coordinates
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
     constexpr int TM = FM * 16, TN = FN * 16;
@@ -168,7 +202,23 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
     if (epi.bias) epi.bias += grp * N;
 
     int t, ksplit;
-    tile_and_split(ntiles, t, ksplit);
+    int tw = p.kw, tap0 = 0, tsh = p.kw, tsw = 1;
+    PhaseRows rows{};
+    if constexpr (PASS == 3) {
+        const PhaseP& ph = phases.ph[blockIdx.y];
+        M = ph.M;
+        K = ph.K;
+        k_per_split = K;
+        t = blockIdx.x;
+        ksplit = 0;
+        if ((int64_t)(t / tiles_n) * BM >= M) return;      // (workgroup-uniform: the grid is sized for the largest phase)
+        p.Hr = ph.Hq, p.Wr = ph.Wq, p.kw = ph.Tw, p.pt = ph.q0h, p.pl = ph.q0w;
+        p.sh = p.sw = p.dh = p.dw = 1;
+        tw = ph.Tw, tap0 = ph.tap0, tsh = phases.sh * phases.kw, tsw = phases.sw;
+        rows = PhaseRows{ph.Hq * ph.Wq, ph.Wq, phases.H, phases.W, phases.sh, phases.sw, ph.a, ph.b};
+    } else {
+        tile_and_split(ntiles, t, ksplit);
+    }
     const int tile_n = t % tiles_n, tile_m = t / tiles_n;
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int64_t kbeg = (int64_t)ksplit * k_per_split;
@@ -181,12 +231,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    GatherStager<BM, NT, BK, PASS> sa;
+    GatherStager<BM, NT, BK, GPASS> sa;
     typename std::conditional<BKC, TapWeightStager<BN, NT, BK>, Stager<BN, false, NT, BK>>::type sb;
     sa.prepare(p, m0, M, coff, tid);
 
     auto load_b = [&](int64_t k0) {
-        if constexpr (BKC) sb.load_taps(Bop, ldb, tap_stride, p.Cg, n0, k0, N, kend, tid);
+        if constexpr (BKC) sb.load_taps(Bop, ldb, tap_stride, p.Cg, n0, k0, N, kend, tid, tw, tap0, tsh, tsw);
         else sb.load(Bop, ldb, n0, k0, N, kend, true, tid);
     };
 
@@ -222,7 +272,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvP p, const 
             __syncthreads();
         }
     }
-    tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, false, vecD, ksplit);
+    if constexpr (PASS == 3) tile_epilogue<WM, WN, FM, FN, TO, PhaseRows>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, nullptr, epi, false, vecD, 0, rows);
+    else tile_epilogue<WM, WN, FM, FN, TO>(acc, smem, D, ldd, M, N, m0, n0, wm, wn, wid, lane, slabs, epi, false, vecD, ksplit);
 }
 
 struct Problem {
@@ -275,7 +326,7 @@ template <int PASS, class TO> int run(const Problem& q, void* ws, size_t ws_byte
         const int tiles_m = (int)ceil_div64(q.M, BM), tiles_n = (int)ceil_div64(q.N, BN);
         hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, FM, FN, PASS, 64, TO>), dim3(tiles_m * tiles_n, eff, q.groups), dim3(WM * WN * 64), 0, stream, q.p,
                            q.B, q.ldb, q.b_group_stride, q.tap_stride, (TO*)q.D, q.ldd, q.d_group_stride, q.M, q.N, q.K, tiles_n, tiles_m * tiles_n,
-                           kps, slabs, slab_group_stride, epi, vecD);
+                           kps, slabs, slab_group_stride, epi, vecD, NoPhases{});
     };
     struct T128 { enum { WM = 2, WN = 4, FM = 4, FN = 2 }; };
     struct T64 { enum { WM = 4, WN = 2, FM = 2, FN = 2 }; };
@@ -295,6 +346,61 @@ template <int PASS, class TO> int run(const Problem& q, void* ws, size_t ws_byte
     ga.accumulate = q.accumulate;
     ga.bias = q.bias;
     return gemm_reduce(&ga, epi, slabs, eff, q.M, stream);
+}
+
+// pass 3: every stride phase of a strided data gradient in one launch (grid.y = phase, grid.z = group); phases no tap reaches (kernel
+// smaller than the stride) keep the zeros dx is cleared to first
+int run_phases(const Problem& q, const iseg_conv_geom* g, hipStream_t stream, const char* what) {
+    PhaseTable tab{};
+    tab.H = g->H, tab.W = g->W, tab.sh = g->sh, tab.sw = g->sw, tab.kw = g->KW;
+    const int og = g->Cout / g->groups;
+    int count = 0;
+    int64_t maxM = 0;
+    bool holes = false;
+    for (int a = 0; a < g->sh; ++a)
+        for (int b = 0; b < g->sw; ++b) {
+            const int Hq = a < g->H ? (g->H - a + g->sh - 1) / g->sh : 0, Wq = b < g->W ? (g->W - b + g->sw - 1) / g->sw : 0;
+            if (Hq == 0 || Wq == 0) continue;
+            const int rh = (a + g->pt) % g->sh, rw = (b + g->pl) % g->sw;
+            const int Th = rh < g->KH ? (g->KH - rh + g->sh - 1) / g->sh : 0, Tw = rw < g->KW ? (g->KW - rw + g->sw - 1) / g->sw : 0;
+            if (Th == 0 || Tw == 0) {
+                holes = true;
+                continue;
+            }
+            PhaseP& ph = tab.ph[count++];
+            ph.Hq = Hq, ph.Wq = Wq, ph.a = a, ph.b = b;
+            ph.q0h = (a + g->pt) / g->sh, ph.q0w = (b + g->pl) / g->sw;
+            ph.Th = Th, ph.Tw = Tw;
+            ph.tap0 = rh * g->KW + rw;
+            ph.M = (int)((int64_t)g->N * Hq * Wq);
+            ph.K = Th * Tw * og;
+            if (ph.M > maxM) maxM = ph.M;
+        }
+    if (holes) {
+        const hipError_t e = hipMemsetAsync(q.D, 0, (size_t)g->N * g->H * g->W * g->Cin * sizeof(bf16_t), stream);
+        if (e != hipSuccess) {
+            iseg_set_error("%s: clearing dx failed: %s", what, hipGetErrorString(e));
+            return ISEG_ERR_HIP;
+        }
+    }
+    if (count == 0) return ISEG_OK;
+    Epi epi{};
+    epi.alpha = 1.f;
+    epi.batch_inner = 1;
+    const int vecD = ((uintptr_t)q.D % 16 == 0) && (q.ldd % 8 == 0) && (q.d_group_stride % 8 == 0) && (q.N % 4 == 0);
+    auto launch = [&](auto tile) {
+        constexpr int WM = decltype(tile)::WM, WN = decltype(tile)::WN, FM = decltype(tile)::FM, FN = decltype(tile)::FN;
+        constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
+        const int tiles_m = (int)ceil_div64(maxM, BM), tiles_n = (int)ceil_div64(q.N, BN);
+        hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, FM, FN, 3, 64, bf16_t>), dim3(tiles_m * tiles_n, count, q.groups), dim3(WM * WN * 64), 0, stream,
+                           q.p, q.B, q.ldb, q.b_group_stride, q.tap_stride, (bf16_t*)q.D, q.ldd, q.d_group_stride, maxM, q.N, (int64_t)0, tiles_n,
+                           tiles_m * tiles_n, (int64_t)0, (float*)nullptr, (int64_t)0, epi, vecD, tab);
+    };
+    struct T128 { enum { WM = 2, WN = 4, FM = 4, FN = 2 }; };
+    struct T64 { enum { WM = 4, WN = 2, FM = 2, FN = 2 }; };
+    if (q.N <= 64) launch(T64{});
+    else launch(T128{});
+    return iseg_check_launch(what);
 }
 
 bool geom_ok(const iseg_conv_geom* g) {
@@ -374,6 +480,9 @@ extern "C" int iseg_conv2d_igemm_bwd_data(const void* dy, const void* w, void* d
     q.d_group_stride = cg;
     q.out_dtype = ISEG_BF16;
     q.groups = g->groups;
+    // strided, undilated: one stride-1 gather per stride phase (pass 3) instead of the gather form that multiplies the zeros between the hits
+    if ((g->sh > 1 || g->sw > 1) && g->dh == 1 && g->dw == 1 && g->sh * g->sw <= MAX_PHASES)
+        return run_phases(q, g, stream, "iseg_conv2d_igemm_bwd_data");
     return run<1, bf16_t>(q, ws, ws_bytes, stream, "iseg_conv2d_igemm_bwd_data");
 }
 

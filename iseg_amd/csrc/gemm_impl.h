@@ -361,12 +361,18 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16_t* lds, int r0, int ks, i
     }
 }
 
+// the row of D (and of the fused operands) that GEMM row m lands in: the identity everywhere except the phase form of the strided
+// convolution data gradient (conv_igemm.hip), whose rows are the pixels of one stride phase scattered back into the NHWC map
+struct IdentityRows {
+    __device__ __forceinline__ int64_t operator()(int64_t m) const { return m; }
+};
+
 // ---- epilogue: accumulators -> per-wave LDS slab (fp32) -> 8-column coalesced rows ----
 // Shared by both main loops.  `smem` must be free (every wave past its last fragment read) and hold WM*WN*32*(FN*16+4) floats.
-template <int WM, int WN, int FM, int FN, class TO>
+template <int WM, int WN, int FM, int FN, class TO, class RowMap = IdentityRows>
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[FM][FN], char* smem, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                               int64_t m0, int64_t n0, int wm, int wn, int wid, int lane, float* __restrict__ slabs,
-                                              const Epi& epi, bool ones_row, int vecD, int ksplit) {
+                                              const Epi& epi, bool ones_row, int vecD, int ksplit, const RowMap rowmap = RowMap()) {
     constexpr int TM = FM * 16, TN = FN * 16;
     constexpr int EPI_ROWS = 32;
     constexpr int EPI_STRIDE = TN + 4;
@@ -411,6 +417,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[FM][FN], char* smem, 
                     *reinterpret_cast<float4*>(v[q]) = *reinterpret_cast<const float4*>(src);
                     *reinterpret_cast<float4*>(v[q] + 4) = *reinterpret_cast<const float4*>(src + 4);
                     kind[q] = split ? 1 : (mm[q] == M ? 4 : ((vecD && nn[q] + 8 <= N) ? 2 : 3));
+                    if (kind[q] == 2 || kind[q] == 3) mm[q] = rowmap(mm[q]);
                     if (kind[q] == 2) pf[q].load(epi, mm[q], nn[q], D, ldd);
                 }
             }

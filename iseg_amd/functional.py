@@ -195,6 +195,9 @@ def _conv_geometry(H, W, kh, kw, strides, dilation, padding):
     return Ho, Wo, pt, pl
 
 
+_IGEMM_PHASES = os.environ.get("ISEG_IGEMM_PHASES", "1") != "0"      # experiment knob: 0 = strided data gradients through GEMM + col2im
+
+
 class _Conv2dFn(Function):
     """Three routes: (1) 1x1 / stride 1 / one group on the activation as it lies = a plain GEMM; (2) bf16 storage with channels per
     group that are multiples of 8 = implicit GEMM on the matrix cores (csrc/conv_igemm.hip: the patch matrix is gathered while the
@@ -266,12 +269,17 @@ class _Conv2dFn(Function):
             dy4 = dy2.reshape(N, Ho, Wo, Cout)
             if W.requires_grad:
                 K.conv2d_igemm_bwd_weight(xc, dy4, _grad(W), g_, accumulate=True)
-            if need_dx and st == (1, 1):
+            patchify = (kh, kw) == st      # kernel == stride: the column buffer IS dx up to a permutation, one plain GEMM fills it
+            if need_dx and (st == (1, 1) or (di == (1, 1) and st[0] * st[1] <= 16 and _IGEMM_PHASES and not patchify)):
+                # stride 1: one gather over dy; strided and undilated: one stride-1 gather per stride phase, all phases in one launch, rows
+                # scattered to their pixels by the epilogue (csrc/conv_igemm.hip pass 3) -- no zero products, no column buffer, no col2im
+                # (ResNet's 3x3 / s2 at 64x64x128: 23 us against 40 us for GEMM + col2im)
                 dx = K.conv2d_igemm_bwd_data(dy4, nn.w(W), g_)
             elif need_dx:
-                # strided: only 1 / (sh * sw) of the (tap, pixel) pairs of the gather form are non-zero, and the MFMA cannot skip them
-                # (ConvNeXt's 2x2 / s2 downsample at 128x128: 115 us gathered vs ~50 us here).  dcol = dy @ W^T, then the gather-form
-                # col2im (deterministic; for kernel == stride a pure permutation)
+                # strided and dilated (1 / (sh * sw) of the (tap, pixel) pairs of the plain gather form are non-zero, and the MFMA cannot skip
+                # them), or kernel == stride (ConvNeXt's 2x2 / s2 downsamples: the LDS-DMA GEMM + permutation measures 35 / 29 us against
+                # 46 / 39 us for the phase launch at stages 1 / 2, equal at stage 0; tools/kbench_conv_strided.py): dcol = dy @ W^T, then the
+                # gather-form col2im (deterministic)
                 ldc = (Kd + 7) // 8 * 8
                 dx = torch.empty((N, H, Wd, Cin), dtype=cdt, device=dy.device) if groups > 1 else None
                 for g in range(groups):
@@ -357,35 +365,37 @@ class _DWConvFn(Function):
         return dx, None, None, None
 
 
-_DW_STRIDE_TABLES = {}
+class _DWConvStridedFn(Function):
+    """DepthwiseConv2D(strides = s, padding = 'same'): forward, data gradient (gather over dy) and weight gradient at the strided output
+    positions only (csrc/dwconv_strided.hip)"""
 
+    @staticmethod
+    def forward(ctx, x, W, b, dil, stride):
+        Kk, C = W.shape[0], W.shape[2]
+        xc = _c(x)
+        y = K.dwconv2d_strided(xc, W.data.reshape(Kk * Kk, C), b.data if b is not None else None, Kk, stride, dil)
+        ctx.W, ctx.b, ctx.dil, ctx.stride = W, b, dil, stride
+        ctx.save_for_backward(xc)
+        return y
 
-def _dw_stride_tables(N, H, W, s, ke, device):
-    """row tables that pick the stride-s 'same' outputs out of the stride-1 'same' result: TF pads (out-1)*s + ke - H in total, the smaller half
-    in front, so output i sits at stride-1 position i*s + ((ke-1)//2 - pad_front)"""
-    key = (N, H, W, s, ke, str(device))
-    t = _DW_STRIDE_TABLES.get(key)
-    if t is None:
-        def axis(L):
-            out = -(-L // s)
-            front = max((out - 1) * s + ke - L, 0) // 2
-            return out, (ke - 1) // 2 - front
-
-        Ho, oh = axis(H)
-        Wo, ow = axis(W)
-        n = torch.arange(N).view(N, 1, 1)
-        src = (n * H + (torch.arange(Ho) * s + oh).view(1, Ho, 1)) * W + (torch.arange(Wo) * s + ow).view(1, 1, Wo)
-        fwd = src.reshape(-1).to(torch.int32)
-        bwd = torch.full((N * H * W,), -1, dtype=torch.int32)
-        bwd[fwd.long()] = torch.arange(fwd.numel(), dtype=torch.int32)
-        t = _DW_STRIDE_TABLES[key] = (fwd.to(device), bwd.to(device), Ho, Wo)
-    return t
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        W, b, dil, stride = ctx.W, ctx.b, ctx.dil, ctx.stride
+        Kk, C = W.shape[0], W.shape[2]
+        dyc = _c(dy)
+        if W.requires_grad:
+            K.dwconv2d_strided_bwd_weight(xc, dyc, _grad(W).reshape(Kk * Kk, C), _grad(b) if b is not None else None, Kk, stride, dil)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.dwconv2d_strided_bwd_data(dyc, W.data.reshape(Kk * Kk, C), Kk, stride, dil, xc.shape[1], xc.shape[2])
+        dist.grads_ready(W, b)
+        return dx, None, None, None, None
 
 
 def depthwise_conv2d(x, W, b=None, dilation=1, strides=1):
-    """padding='same'.  Stride 1 is the hot path (ConvNeXt 7x7, SepConvBnReLU 3x3 dilated).  A strided layer (the stride-2 depthwise
-    convolutions of the separable / inverted-residual families) is the stride-1 result sampled at TF's 'same' positions by one row gather:
-    exact, s^2 times the arithmetic of a dedicated kernel -- a correctness path until such a family is on a measured configuration."""
+    """padding='same'.  Stride 1 is the hot path (ConvNeXt 7x7, SepConvBnReLU 3x3 dilated); a strided layer (the stride-2 depthwise
+    convolutions of the separable / inverted-residual families) runs the dedicated kernels that visit the strided outputs only."""
     _check_act_dtype(x)
     s = int(strides)
     if s == 1:
@@ -395,10 +405,7 @@ def depthwise_conv2d(x, W, b=None, dilation=1, strides=1):
     N, H, Wd, C = x.shape
     if nn.dry_run():
         return _dry((N, -(-H // s), -(-Wd // s), C), x)
-    ke = (W.shape[0] - 1) * int(dilation) + 1
-    fwd, bwd, Ho, Wo = _dw_stride_tables(N, H, Wd, s, ke, x.device)
-    y1 = _DWConvFn.apply(x, W, b, int(dilation))
-    return permute_rows(y1, fwd, bwd, (N, Ho, Wo, C))
+    return _DWConvStridedFn.apply(x, W, b, int(dilation), s)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -402,6 +402,39 @@ def dwconv2d_bwd_weight(x, dy, dw, db, K, dil, pad_t, pad_l, accumulate=True):
               dt(x), ptr(ws), wsb, stream())
 
 
+def dwconv2d_strided(x, w, bias, K, stride, dil):
+    """DepthwiseConv2D(strides=stride, padding='same') at the strided positions only; x [N,H,W,C], w [K*K, C] fp32"""
+    _require_cuda(x, w)
+    N, H, W, Cc = x.shape
+    Ho, pt = same_pad(H, K, stride, dil)
+    Wo, pl = same_pad(W, K, stride, dil)
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _hip.call("iseg_dwconv2d_strided_fwd", ptr(x), ptr(w), ptr(bias), ptr(y), N, H, W, Cc, K, stride, dil, pt, pl, Ho, Wo, dt(x), stream())
+    return y
+
+
+def dwconv2d_strided_bwd_data(dy, w, K, stride, dil, H, W):
+    _require_cuda(dy, w)
+    N, Ho, Wo, Cc = dy.shape
+    _, pt = same_pad(H, K, stride, dil)
+    _, pl = same_pad(W, K, stride, dil)
+    dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    _hip.call("iseg_dwconv2d_strided_bwd_data", ptr(dy), ptr(w), ptr(dx), N, H, W, Cc, K, stride, dil, pt, pl, Ho, Wo, dt(dy), stream())
+    return dx
+
+
+def dwconv2d_strided_bwd_weight(x, dy, dw, db, K, stride, dil, accumulate=True):
+    _require_cuda(x, dy, dw)
+    N, H, W, Cc = x.shape
+    _, Ho, Wo, _ = dy.shape
+    _, pt = same_pad(H, K, stride, dil)
+    _, pl = same_pad(W, K, stride, dil)
+    need = _hip.lib().iseg_dwconv2d_strided_bwd_weight_workspace_bytes(N, Ho, Wo, Cc, K)
+    ws, wsb = workspace(need, x.device)
+    _hip.call("iseg_dwconv2d_strided_bwd_weight", ptr(x), ptr(dy), ptr(dw), ptr(db), int(accumulate), N, H, W, Cc, K, stride, dil, pt, pl, Ho, Wo,
+              dt(x), ptr(ws), wsb, stream())
+
+
 # ---------------------------------------------------------------------------------------------------------
 # layout / elementwise
 # ---------------------------------------------------------------------------------------------------------

@@ -29,7 +29,10 @@ CASES = [
     ((1, 40, 40, 8), 3, 1, 18, 8, 1),
     ((1, 5, 5, 16), 3, 4, 1, 16, 1),
     ((2, 10, 10, 32), 3, 1, 1, 64, 4),       # grouped
-    ((2, 9, 9, 48), 3, 2, 2, 48, 3),
+    ((2, 9, 9, 48), 3, 2, 2, 48, 3),         # strided AND dilated: the plain gather form
+    ((2, 9, 9, 48), 3, 2, 1, 48, 3),         # grouped, strided: stride phases x groups in one launch
+    ((2, 33, 31, 64), 3, 2, 1, 128, 1),      # stride phases of unequal size, several row tiles each
+    ((1, 12, 12, 16), 2, 3, 1, 16, 1),       # kernel smaller than the stride: phases no tap reaches stay zero
     ((4, 32, 32, 128), 3, 1, 1, 128, 1),     # several tiles in M and a long weight-gradient reduction
 ]
 

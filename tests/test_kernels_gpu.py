@@ -493,7 +493,7 @@ def test_gemm_dma_pipeline_strided_batch(cuda):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,k,s,dil", [((2, 16, 16, 32), 3, 2, 1), ((1, 15, 9, 16), 3, 2, 1), ((2, 12, 13, 8), 5, 2, 1), ((1, 17, 17, 24), 3, 3, 1),
-                                           ((2, 16, 10, 16), 3, 2, 2)])
+                                           ((2, 16, 10, 16), 3, 2, 2), ((2, 30, 28, 40), 3, 2, 1), ((1, 14, 14, 8), 7, 2, 1)])
 def test_strided_depthwise_conv_matches_oracle(cuda, dtype, shape, k, s, dil):
     """keras DepthwiseConv2D(strides=s, padding="same") (the separable / inverted-residual families): TF's 'same' positions for even and odd
     sizes, forward and both gradients"""
@@ -526,5 +526,10 @@ def test_strided_depthwise_conv_matches_oracle(cuda, dtype, shape, k, s, dil):
 
         assert rel(y, yr.detach()) < tol
         assert rel(xg.grad, xr.grad) < tol and rel(wp.grad, wr.grad) < 2 * tol and rel(bp.grad, br.grad) < 2 * tol
+        # dedicated kernels (csrc/dwconv_strided.hip): fixed summation order -> a second backward pass reproduces the weight gradient exactly
+        first = wp.grad.clone()
+        wp.grad.zero_(); bp.grad.zero_()
+        F.depthwise_conv2d(xg, wp, bp, dil, strides=s).backward(dy.cuda())
+        assert torch.equal(wp.grad, first)
     finally:
         nn.set_compute_dtype(torch.float32)
