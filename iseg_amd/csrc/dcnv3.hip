@@ -20,6 +20,7 @@
 #include "iseg_hip.h"
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,102 @@ template <class T, int CV>
 __device__ __forceinline__ void ldv(const T* p, float* v) {
     if (CV == 8) load8<T>(p, v);
     else v[0] = to_f32(p[0]);
+}
+
+constexpr int DCN_PMAX = 9;                       // sampling points the pipelined kernels keep in registers (3 x 3)
+
+__device__ __forceinline__ void unpack_raw_bf16x8(const uint4& r, float* v) {
+    v[0] = __uint_as_float(r.x << 16), v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16), v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16), v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16), v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+
+template <class T, int CG> __device__ __forceinline__ void dcn_unpack_row(const uint4* raw, float* v) {
+    constexpr int RAW = CG * (int)sizeof(T) / 16;
+#pragma unroll
+    for (int r = 0; r < RAW; ++r) {
+        if constexpr (sizeof(T) == 2) unpack_raw_bf16x8(raw[r], v + r * 8);
+        else {
+            v[r * 4] = __uint_as_float(raw[r].x), v[r * 4 + 1] = __uint_as_float(raw[r].y);
+            v[r * 4 + 2] = __uint_as_float(raw[r].z), v[r * 4 + 3] = __uint_as_float(raw[r].w);
+        }
+    }
+}
+
+// Forward for the group widths of the reference's models (Cg 8 / 16, at most 3 x 3 points): a lane owns (pixel, group) and all Cg channels.
+// The kernel is a chain of dependent round trips (offsets -> tap -> four corner rows, per point), so the offsets and masks of all points are
+// loaded up front and the corner rows of point p + 1 are requested before point p is accumulated; loads are issued unconditionally from a
+// clamped address and masked afterwards.  8 x 128 x 128 x 112: 457 -> see DESIGN 5.1.
+template <class T, int CG>
+__global__ __launch_bounds__(256) void dcnv3_fwd_pipe_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
+                                                             T* __restrict__ y, DcnGeom g) {
+    constexpr int RAW = CG * (int)sizeof(T) / 16;
+    const int P = g.kh * g.kw;
+    const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gi = (int)(i % g.G);
+        int64_t t = i / g.G;
+        const int w = (int)(t % g.Wo);
+        t /= g.Wo;
+        const int h = (int)(t % g.Ho);
+        const int n = (int)(t / g.Ho);
+        float offs[DCN_PMAX][2], mk[DCN_PMAX];
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p) {
+            const int64_t e = i * P + (p < P ? p : P - 1);
+            offs[p][0] = to_f32(offset[e * 2]);
+            offs[p][1] = to_f32(offset[e * 2 + 1]);
+            mk[p] = to_f32(mask[e]);
+        }
+        uint4 nxt[4][RAW];
+        Tap ntp{};
+        bool nok[4] = {false, false, false, false};
+        auto request = [&](int p) {
+            ntp = dcn_tap(g, h, w, p, offs[p][0], offs[p][1]);
+            const int ys[4] = {ntp.y0, ntp.y1, ntp.y0, ntp.y1};
+            const int xs[4] = {ntp.x0, ntp.x0, ntp.x1, ntp.x1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t src = dcn_src(g, n, ys[k], xs[k]);
+                nok[k] = src >= 0;
+                const uint4* q = reinterpret_cast<const uint4*>(x + (src < 0 ? 0 : src) + gi * CG);
+#pragma unroll
+                for (int r = 0; r < RAW; ++r) nxt[k][r] = q[r];
+            }
+        };
+        request(0);
+        float acc[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p) {
+            if (p >= P) continue;
+            const Tap tp = ntp;
+            float v[4][CG];
+            bool ok[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ok[k] = nok[k];
+                dcn_unpack_row<T, CG>(nxt[k], v[k]);
+            }
+            if (p + 1 < P) request(p + 1);
+            const float m = mk[p];
+            const float wgt[4] = {ok[0] ? m * tp.dx1 * tp.dy1 : 0.f, ok[1] ? m * tp.dx1 * tp.dy0 : 0.f, ok[2] ? m * tp.dx0 * tp.dy1 : 0.f,
+                                  ok[3] ? m * tp.dx0 * tp.dy0 : 0.f};
+#pragma unroll
+            for (int c = 0; c < CG; ++c) {
+                // (the reference sums the four corners first and applies the mask to the sum; the product order differs in the last bit only)
+                float px = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) px = fmaf(wgt[k], v[k][c], px);
+                acc[c] += px;
+            }
+        }
+        T* yp = y + i * CG;
+#pragma unroll
+        for (int c0 = 0; c0 < CG; c0 += 8) store8<T>(yp + c0, acc + c0);
+    }
 }
 
 template <class T, int CV>
@@ -266,14 +363,23 @@ __device__ __forceinline__ unsigned long long dcn_to_fixed(float v256) {      //
     return ((unsigned long long)(unsigned)hi << 32) | lo;
 }
 
+// bf16 storage (FIX32): the window accumulates 32-bit integers on a per-workgroup power-of-two scale instead -- half the LDS (four workgroups
+// per CU), ds_add_u32 instead of ds_add_u64, a multiply + round per addend instead of the two-word split.  A cell receives at most
+// 256 pixels x 9 points x 4 corners < 2^14 addends, each bounded by B = max|dy| * max|mask| over the workgroup's lanes (bilinear weights
+// <= 1), so with scale = 2^(30 - e), B * 2^14 < 2^e, no sum can leave int32; every addend is rounded to 2^-16 of B or finer -- two orders
+// below the bf16 rounding of the result -- and integer adds commute, so the result is still independent of the order.
 template <class T, int CG>
 __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
                                                             const T* __restrict__ dy, T* __restrict__ doffset, T* __restrict__ dmask,
                                                             float* __restrict__ windows, unsigned long long* __restrict__ side,
                                                             int* __restrict__ side_used, DcnGeom g, DcnWin wn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long win_acc[];      // [WS*WS][CG], channel slot rotated by the pixel index
+    constexpr bool FIX32 = sizeof(T) == 2;
+    using Acc = typename std::conditional<FIX32, int, unsigned long long>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned long long win_raw[];
+    Acc* const win_acc = reinterpret_cast<Acc*>(win_raw);      // [WS*WS][CG], channel slot rotated by the pixel index
+    __shared__ float wave_max[4];
     constexpr int WPIX = DCN_WS * DCN_WS;
-    for (int i = threadIdx.x; i < WPIX * CG; i += 256) win_acc[i] = 0ull;
+    for (int i = threadIdx.x; i < WPIX * CG; i += 256) win_acc[i] = (Acc)0;
     int b = blockIdx.x;
     const int gi = b % g.G;
     b /= g.G;
@@ -292,12 +398,72 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
         for (int c0 = 0; c0 < CG; c0 += 8) ldv<T, 8>(dy + (pix * g.G + gi) * CG + c0, d + c0);
     }
     bool spilled = false;
+    // every sampling point's offsets and mask up front (one round trip instead of one per point; P <= DCN_PMAX is a condition of this path)
+    float offs[DCN_PMAX][2], mk[DCN_PMAX];
+#pragma unroll
+    for (int p = 0; p < DCN_PMAX; ++p) {
+        const int pp = p < P ? p : P - 1;
+        const int64_t e = live ? (pix * g.G + gi) * P + pp : 0;
+        offs[p][0] = to_f32(offset[e * 2]);
+        offs[p][1] = to_f32(offset[e * 2 + 1]);
+        mk[p] = to_f32(mask[e]);
+    }
+    float scale = 0.f, inv_scale = 0.f;
+    if constexpr (FIX32) {
+        float bd = 0.f, bm = 0.f;
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) bd = fmaxf(bd, fabsf(d[c]));
+#pragma unroll
+            for (int p = 0; p < DCN_PMAX; ++p) bm = fmaxf(bm, fabsf(mk[p]));
+        }
+        float bound = bd * bm;
+        if (!(bound < 3.0e38f)) bound = 3.0e38f;      // (inf / NaN gradients: the sums saturate instead of wrapping)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
+        if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = bound;
+        __syncthreads();
+        bound = fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]));
+        int e = 0;
+        (void)frexpf(bound, &e);                      // bound < 2^e
+        int k = 30 - 14 - e;
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        scale = bound > 0.f ? ldexpf(1.f, k) : 0.f;
+        inv_scale = bound > 0.f ? ldexpf(1.f, -k) : 0.f;
+    }
     __syncthreads();
-    for (int p = 0; p < P; ++p) {      // uniform: every lane of the workgroup is on the same sampling point
-        if (!live) continue;
-        const T* op = offset + ((pix * g.G + gi) * P + p) * 2;
-        const float m = to_f32(mask[(pix * g.G + gi) * P + p]);
-        const Tap tp = dcn_tap(g, h, w, p, to_f32(op[0]), to_f32(op[1]));
+    // the four corner rows of point p + 1 are requested before point p's dot products and atomics: loads are issued unconditionally from a
+    // clamped address (a branch per load would make the compiler wait for each) and masked afterwards
+    constexpr int RAW = CG * (int)sizeof(T) / 16;
+    uint4 nxt[4][RAW];
+    Tap ntp{};
+    int64_t nsrc[4] = {-1, -1, -1, -1};
+    auto request = [&](int p) {
+        ntp = dcn_tap(g, h, w, p, offs[p][0], offs[p][1]);
+        const int ys[4] = {ntp.y0, ntp.y1, ntp.y0, ntp.y1};
+        const int xs[4] = {ntp.x0, ntp.x0, ntp.x1, ntp.x1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            nsrc[k] = dcn_src(g, n, ys[k], xs[k]);
+            const uint4* q = reinterpret_cast<const uint4*>(x + (nsrc[k] < 0 ? 0 : nsrc[k]) + gi * CG);
+#pragma unroll
+            for (int r = 0; r < RAW; ++r) nxt[k][r] = q[r];
+        }
+    };
+    if (live) request(0);
+#pragma unroll
+    for (int p = 0; p < DCN_PMAX; ++p) {
+        if (p >= P || !live) continue;      // (P is uniform; dead lanes belong to partial edge tiles)
+        const Tap tp = ntp;
+        int64_t srcs[4];
+        float v[4][CG];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            srcs[k] = nsrc[k];
+            dcn_unpack_row<T, CG>(nxt[k], v[k]);
+        }
+        if (p + 1 < P) request(p + 1);
+        const float m = mk[p];
         const float wgt[4] = {tp.dx1 * tp.dy1, tp.dx1 * tp.dy0, tp.dx0 * tp.dy1, tp.dx0 * tp.dy0};
         const float wpx[4] = {-tp.dy1, -tp.dy0, tp.dy1, tp.dy0};
         const float wpy[4] = {-tp.dx1, tp.dx1, -tp.dx0, tp.dx0};
@@ -306,27 +472,31 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
         float gm = 0.f, gpx = 0.f, gpy = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int64_t src = dcn_src(g, n, ys[k], xs[k]);
-            if (src < 0) continue;
-            float v[CG];
-#pragma unroll
-            for (int c0 = 0; c0 < CG; c0 += 8) ldv<T, 8>(x + src + gi * CG + c0, v + c0);
+            if (srcs[k] < 0) continue;
             float dot = 0.f;
 #pragma unroll
-            for (int c = 0; c < CG; ++c) dot = fmaf(d[c], v[c], dot);
+            for (int c = 0; c < CG; ++c) dot = fmaf(d[c], v[k][c], dot);
             gm = fmaf(wgt[k], dot, gm);
             gpx = fmaf(wpx[k], dot, gpx);
             gpy = fmaf(wpy[k], dot, gpy);
-            const float coef = m * wgt[k] * DCN_FIX;
             const int lx = xs[k] - wx0, ly = ys[k] - wy0;
             if ((unsigned)lx < (unsigned)DCN_WS && (unsigned)ly < (unsigned)DCN_WS) {
                 const int wp = ly * DCN_WS + lx;
-                unsigned long long* dst = win_acc + wp * CG;
+                Acc* dst = win_acc + wp * CG;
+                if constexpr (FIX32) {
+                    const float c32 = m * wgt[k] * scale;
 #pragma unroll
-                for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + wp) & (CG - 1)), dcn_to_fixed(d[c] * coef));
+                    for (int c = 0; c < CG; ++c)      // round to nearest through the 1.5 * 2^23 binade: |addend| < 2^16 by the scale
+                        atomicAdd(dst + ((c + wp) & (CG - 1)), __float_as_int(fmaf(d[c], c32, 12582912.f)) - 0x4B400000);
+                } else {
+                    const float coef = m * wgt[k] * DCN_FIX;
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + wp) & (CG - 1)), dcn_to_fixed(d[c] * coef));
+                }
             } else {
                 spilled = true;
-                unsigned long long* dst = side + src + gi * CG;
+                const float coef = m * wgt[k] * DCN_FIX;
+                unsigned long long* dst = side + srcs[k] + gi * CG;
 #pragma unroll
                 for (int c = 0; c < CG; ++c) atomicAdd(dst + c, dcn_to_fixed(d[c] * coef));
             }
@@ -340,7 +510,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
     float* out = windows + (int64_t)blockIdx.x * WPIX * CG;
     for (int i = threadIdx.x; i < WPIX * CG; i += 256) {
         const int wp = i / CG, c = i % CG;
-        out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + wp) & (CG - 1))] * DCN_UNFIX);
+        if constexpr (FIX32) out[i] = (float)win_acc[wp * CG + ((c + wp) & (CG - 1))] * inv_scale;
+        else out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + wp) & (CG - 1))] * DCN_UNFIX);
     }
 }
 
@@ -514,6 +685,7 @@ static int make_geom(DcnGeom* g, int N, int H, int W, int G, int Cg, int kh, int
 // window geometry of the deterministic backward pass; ok = 0 when the zero-offset footprint of a tile does not fit the window
 static bool dcn_window(const DcnGeom& g, DcnWin* wn) {
     if (g.Cg != 8 && g.Cg != 16) return false;
+    if (g.kh * g.kw > DCN_PMAX) return false;
     if (g.Win <= 2 || g.Hin <= 2) return false;
     wn->tiles_y = (g.Ho + DCN_TS - 1) / DCN_TS;
     wn->tiles_x = (g.Wo + DCN_TS - 1) / DCN_TS;
@@ -559,13 +731,23 @@ extern "C" int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mas
 #define DCN_FWD(T, CV)                                                                                                              \
     hipLaunchKernelGGL((dcnv3_fwd_kernel<T, CV>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset,   \
                        (const T*)mask, (T*)y, g)
+#define DCN_FWD_PIPE(T, CG)                                                                                                         \
+    hipLaunchKernelGGL((dcnv3_fwd_pipe_kernel<T, CG>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset, \
+                       (const T*)mask, (T*)y, g)
+    static const bool allow_pipe = [] { const char* e = getenv("ISEG_DCN_FWD_PIPE"); return !e || atoi(e) != 0; }();
+    const bool pipe = allow_pipe && v8 && (Cg == 8 || Cg == 16) && kh * kw <= DCN_PMAX;
     if (dtype == ISEG_BF16) {
-        if (v8) DCN_FWD(bf16_t, 8);
+        if (pipe && Cg == 16) DCN_FWD_PIPE(bf16_t, 16);
+        else if (pipe) DCN_FWD_PIPE(bf16_t, 8);
+        else if (v8) DCN_FWD(bf16_t, 8);
         else DCN_FWD(bf16_t, 1);
     } else {
-        if (v8) DCN_FWD(float, 8);
+        if (pipe && Cg == 16) DCN_FWD_PIPE(float, 16);
+        else if (pipe) DCN_FWD_PIPE(float, 8);
+        else if (v8) DCN_FWD(float, 8);
         else DCN_FWD(float, 1);
     }
+#undef DCN_FWD_PIPE
 #undef DCN_FWD
     return iseg_check_launch("iseg_dcnv3_fwd");
 }
@@ -602,7 +784,7 @@ extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mas
         const int64_t n16 = (int64_t)(need - side_off) / 16;      // side buffer + flag
         hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)side, n16);
         const unsigned blocks = (unsigned)((int64_t)N * wn.tiles_y * wn.tiles_x * G);
-        const size_t lds = (size_t)DCN_WS * DCN_WS * Cg * sizeof(unsigned long long);
+        const size_t lds = (size_t)DCN_WS * DCN_WS * Cg * (dtype == ISEG_BF16 ? sizeof(int) : sizeof(unsigned long long));
 #define DCN_WIN(T, CG)                                                                                                                      \
     do {                                                                                                                                    \
         static const bool raised = [] {                                                                                                     \
