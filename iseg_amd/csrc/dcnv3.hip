@@ -376,7 +376,12 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
     constexpr bool FIX32 = sizeof(T) == 2;
     using Acc = typename std::conditional<FIX32, int, unsigned long long>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned long long win_raw[];
-    Acc* const win_acc = reinterpret_cast<Acc*>(win_raw);      // [WS*WS][CG], channel slot rotated by the pixel index
+    // [WS*WS][CG]; channel c of window pixel (ly, lx) sits in slot (c + ly + lx) mod CG: the lanes of one ds_add (a fixed channel, 16 x 4
+    // neighbouring output pixels, whose footprints step along ly for consecutive lanes and along lx for consecutive rows) then spread over all
+    // banks.  Rotating by the linear pixel index ly * 24 + lx instead put 16 consecutive lanes on two banks (24 * 16 words = 0 mod 32).
+    // (Kept unrolled over the points at 161 registers / three workgroups per CU: capped at 128 for a fourth it spills 54-66 registers and
+    // runs 1.5x slower, rolled or not.)
+    Acc* const win_acc = reinterpret_cast<Acc*>(win_raw);
     __shared__ float wave_max[4];
     constexpr int WPIX = DCN_WS * DCN_WS;
     for (int i = threadIdx.x; i < WPIX * CG; i += 256) win_acc[i] = (Acc)0;
@@ -481,17 +486,17 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
             gpy = fmaf(wpy[k], dot, gpy);
             const int lx = xs[k] - wx0, ly = ys[k] - wy0;
             if ((unsigned)lx < (unsigned)DCN_WS && (unsigned)ly < (unsigned)DCN_WS) {
-                const int wp = ly * DCN_WS + lx;
+                const int wp = ly * DCN_WS + lx, rot = ly + lx;      // (channel slot: see the note on the window layout above)
                 Acc* dst = win_acc + wp * CG;
                 if constexpr (FIX32) {
                     const float c32 = m * wgt[k] * scale;
 #pragma unroll
                     for (int c = 0; c < CG; ++c)      // round to nearest through the 1.5 * 2^23 binade: |addend| < 2^16 by the scale
-                        atomicAdd(dst + ((c + wp) & (CG - 1)), __float_as_int(fmaf(d[c], c32, 12582912.f)) - 0x4B400000);
+                        atomicAdd(dst + ((c + rot) & (CG - 1)), __float_as_int(fmaf(d[c], c32, 12582912.f)) - 0x4B400000);
                 } else {
                     const float coef = m * wgt[k] * DCN_FIX;
 #pragma unroll
-                    for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + wp) & (CG - 1)), dcn_to_fixed(d[c] * coef));
+                    for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + rot) & (CG - 1)), dcn_to_fixed(d[c] * coef));
                 }
             } else {
                 spilled = true;
@@ -509,9 +514,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
     __syncthreads();
     float* out = windows + (int64_t)blockIdx.x * WPIX * CG;
     for (int i = threadIdx.x; i < WPIX * CG; i += 256) {
-        const int wp = i / CG, c = i % CG;
-        if constexpr (FIX32) out[i] = (float)win_acc[wp * CG + ((c + wp) & (CG - 1))] * inv_scale;
-        else out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + wp) & (CG - 1))] * DCN_UNFIX);
+        const int wp = i / CG, c = i % CG, rot = wp / DCN_WS + wp % DCN_WS;
+        if constexpr (FIX32) out[i] = (float)win_acc[wp * CG + ((c + rot) & (CG - 1))] * inv_scale;
+        else out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + rot) & (CG - 1))] * DCN_UNFIX);
     }
 }
 

@@ -24,10 +24,11 @@ class StandardAugmentationsPipeline:
             eval_crop_width = crop_width
         if not training:
             crop_height, crop_width = eval_crop_height, eval_crop_width
-        for flag, what in ((max_resize_height or max_resize_width, "ResizeAugment (a second resampling pass in front of the random scale)"),
-                           (random_jepg_quality, "RandomJEPGQualityAugment (a JPEG codec round trip)")):
-            if flag:
-                raise NotImplementedError(f"{what} is not part of the on-device pipeline (the standard recipe leaves it off)")
+        if random_jepg_quality:
+            raise NotImplementedError("RandomJEPGQualityAugment (a JPEG codec round trip) is not part of the on-device pipeline "
+                                      "(the standard recipe leaves it off)")
+        # ResizeAugment (:118-119, augments/resize_augment.py): samples larger than the bound are resampled once in front of everything else
+        self.max_resize = (max_resize_height, max_resize_width) if (max_resize_height or max_resize_width) else None
         # optional photometric augmentations (:129-134, :160-164): drawn on the host like every other decision, applied by the gather kernel
         self.random_brightness, self.photo_metric_distortions = bool(random_brightness), bool(photo_metric_distortions)
         self.random_noisy_eval_level = float(random_noisy_eval_level)
@@ -104,6 +105,35 @@ class StandardAugmentationsPipeline:
                 tab[b, 7] = self.random_noisy_eval_level
         return tab
 
+    def resize_target(self, height, width):
+        """ResizeAugment.compuate_target_size (resize_augment.py:15-33) in its float32 arithmetic: never larger than the sample"""
+        max_h, max_w = self.max_resize
+        f = np.float32
+        th = min(int(max_h), height) if max_h else height
+        tw = int(f(width) * f(th) / f(height))
+        tw = min(int(max_w), tw) if max_w else tw
+        tw = min(width, tw)
+        th = int(f(height) * f(tw) / f(width))
+        return th, tw
+
+    def _resize_to_bound(self, images, labels, sizes):
+        """the optional first augmentation: bilinear image / nearest label, sample by sample (the targets differ), back into the padded batch
+        buffer (float32 from here on)"""
+        out = torch.zeros(images.shape, dtype=torch.float32, device=images.device)
+        lab = None if labels is None else labels.clone()
+        new_sizes = []
+        for b, (H, W) in enumerate(sizes):
+            th, tw = self.resize_target(H, W)
+            src = images[b:b + 1, :H, :W].to(torch.float32).contiguous()
+            if (th, tw) == (H, W):
+                out[b, :H, :W] = src[0]
+            else:
+                out[b, :th, :tw] = K.resize_bilinear(src, th, tw)[0]
+                if lab is not None:
+                    lab[b, :th, :tw] = K.resize_nearest_i32(labels[b:b + 1, :H, :W, None].contiguous(), th, tw)[0, :, :, 0]
+            new_sizes.append((th, tw))
+        return out, lab, new_sizes
+
     # ---- the batch on the device -----------------------------------------------------------------------------------------------------
     def apply_batch(self, images, labels, sizes=None, params=None, photometric="draw"):
         """images [B, Hs, Ws, 3] uint8 / float32 (samples smaller than Hs x Ws sit in the top-left corner, `sizes` = their (H, W)),
@@ -111,6 +141,8 @@ class StandardAugmentationsPipeline:
         B, Hs, Ws, _ = images.shape
         if sizes is None:
             sizes = [(Hs, Ws)] * B
+        if self.max_resize is not None:      # (`params`, when given, were drawn for the sizes AFTER this step: resize_target)
+            images, labels, sizes = self._resize_to_bound(images, labels, sizes)
         if params is None:
             params = self.draw(sizes)
         dev = images.device

@@ -80,18 +80,32 @@ class _CastFn(Function):
 # ---------------------------------------------------------------------------------------------------------
 # Dense / 1x1 conv:  y = act(x @ W + b)         keras.layers.Dense, Conv2D(1x1)
 # ---------------------------------------------------------------------------------------------------------
+_FWD_KCONTIG = os.environ.get("ISEG_FWD_KCONTIG", "1") != "0"      # experiment knob: 0 = forward products read the Keras [K][N] kernels
+
+
+def _kcontig_kernel(W, x2, Kd, N):
+    """the [N][K] copy of a forward product's kernel (nn.wt) when the LDS-DMA GEMM can take the product (csrc/gemm_dma.h dma_eligible: bf16,
+    K a multiple of 64 and >= 128, N a multiple of 8 and >= 64, M >= 64), else None: the register-staged kernel reads [K][N] as it lies"""
+    if not _FWD_KCONTIG or x2.dtype != torch.bfloat16 or Kd % 64 or Kd < 128 or N % 8 or N < 64 or x2.shape[0] < 64:
+        return None
+    return nn.wt(W, (Kd, N))
+
+
 class _DenseFn(Function):
     @staticmethod
     def forward(ctx, x, W, b, act, kshape=None):
         Kd, N = kshape if kshape is not None else (W.shape[-2], W.shape[-1])
         x2 = _c(x).reshape(-1, Kd)
-        Wc = nn.w(W).reshape(Kd, N)
         bias = b.data.reshape(-1) if b is not None else None
         pre = None
         need_grad = any(ctx.needs_input_grad)     # grad mode is off inside Function.forward; this is the tape's view
         if act == K.ACT_GELU and need_grad:
             pre = torch.empty((x2.shape[0], N), dtype=x2.dtype, device=x2.device)
-        y = K.dense_fwd(x2, Wc, bias, act=act, pre_out=pre)
+        Wt = _kcontig_kernel(W, x2, Kd, N)
+        if Wt is not None:
+            y = K.dense_fwd_t(x2, Wt, bias, act=act, pre_out=pre)
+        else:
+            y = K.dense_fwd(x2, nn.w(W).reshape(Kd, N), bias, act=act, pre_out=pre)
         ctx.act, ctx.W, ctx.b, ctx.kshape = act, W, b, (Kd, N)
         ctx.save_for_backward(x2, pre if act == K.ACT_GELU else (y if act == K.ACT_RELU else None))
         return y.reshape(*x.shape[:-1], N)
@@ -129,8 +143,16 @@ class _MlpGeluFn(Function):
         x2 = _c(x).reshape(-1, C)
         need_grad = any(ctx.needs_input_grad)
         d = torch.empty((x2.shape[0], Hd), dtype=x2.dtype, device=x2.device) if need_grad else None
-        g = K.dense_fwd(x2, nn.w(W1), b1.data if b1 is not None else None, act=K.ACT_GELU, pre_out=d, pre_deriv=need_grad)
-        y = K.dense_fwd(g, nn.w(W2), b2.data if b2 is not None else None)
+        W1t, W2t = _kcontig_kernel(W1, x2, C, Hd), None
+        if W1t is not None:
+            g = K.dense_fwd_t(x2, W1t, b1.data if b1 is not None else None, act=K.ACT_GELU, pre_out=d, pre_deriv=need_grad)
+            W2t = _kcontig_kernel(W2, g, Hd, N)
+        else:
+            g = K.dense_fwd(x2, nn.w(W1), b1.data if b1 is not None else None, act=K.ACT_GELU, pre_out=d, pre_deriv=need_grad)
+        if W2t is not None:
+            y = K.dense_fwd_t(g, W2t, b2.data if b2 is not None else None)
+        else:
+            y = K.dense_fwd(g, nn.w(W2), b2.data if b2 is not None else None)
         ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(x2, g if need_grad else None, d)
         return y.reshape(*x.shape[:-1], N)
@@ -218,9 +240,13 @@ class _Conv2dFn(Function):
         igemm = (not direct) and xc.dtype == cdt and K.conv2d_igemm_supported(geom, cdt)
         M = N * Ho * Wo
         if direct:
-            y = torch.empty((M, Cout), dtype=cdt, device=x.device)
-            K.gemm(xc.reshape(-1, Cin), nn.w(W).reshape(Cin, Cout), y, M, Cout, Cin, lda=Cin, ldb=Cout, ldd=Cout, a_kcontig=1, b_kcontig=0,
-                   bias=(b.data if b is not None else None))
+            Wt = _kcontig_kernel(W, xc.reshape(-1, Cin), Cin, Cout)
+            if Wt is not None:
+                y = K.dense_fwd_t(xc.reshape(-1, Cin), Wt, b.data if b is not None else None)
+            else:
+                y = torch.empty((M, Cout), dtype=cdt, device=x.device)
+                K.gemm(xc.reshape(-1, Cin), nn.w(W).reshape(Cin, Cout), y, M, Cout, Cin, lda=Cin, ldb=Cout, ldd=Cout, a_kcontig=1, b_kcontig=0,
+                       bias=(b.data if b is not None else None))
         elif igemm:
             y = K.conv2d_igemm_fwd(xc, nn.w(W), b.data if b is not None else None, geom)
         else:

@@ -216,8 +216,8 @@ def _wt_rebuild():
     dev = shadows[0].device
     base = min(sh.data_ptr() for sh in shadows)
     total, rows = 0, []
-    for sh in shadows:
-        k, n = sh.shape
+    for r, sh in zip(live, shadows):
+        k, n = getattr(r(), "iseg_kshape", None) or sh.shape      # (kernels with more than two axes: the [K, N] view their GEMM uses)
         rows.append([(sh.data_ptr() - base) // 2, total, k, n])
         total += (k * n + 7) // 8 * 8
     buf = torch.empty(total, dtype=torch.bfloat16, device=dev)
@@ -233,7 +233,7 @@ def register_wt(params):
     added = False
     for p in params:
         sh = getattr(p, "iseg_compute", None)
-        if sh is None or sh.dim() != 2 or not sh.is_cuda:
+        if sh is None or not sh.is_cuda or (sh.dim() != 2 and getattr(p, "iseg_kshape", None) is None):
             continue
         i = _WT["index"].get(id(p))
         if i is None or _WT["params"][i]() is not p:
@@ -258,14 +258,23 @@ def weights_version():
     return _WEIGHTS_VERSION[0]
 
 
-def wt(param):
-    """[N][K] bf16 copy of the 2-D kernel `param` ([K][N]) under mixed precision, or None (fp32 compute, no shadow, not 2-D).  All registered
-    kernels are re-transposed by ONE launch (iseg_transpose_batched) the first time any of them is asked for after a weight update."""
+def wt(param, kshape=None):
+    """[N][K] bf16 copy of the kernel `param` ([K][N]; `kshape` = the (K, N) view of a kernel with more axes: a 1x1 convolution's
+    [1, 1, Cin, Cout], keras MultiHeadAttention's [C, heads, d] / [heads, d, C]) under mixed precision, or None (fp32 compute, no shadow, no 2-D
+    view).  All registered kernels are re-transposed by ONE launch (iseg_transpose_batched) the first time any of them is asked for after a
+    weight update."""
     if compute_dtype() != torch.bfloat16:
         return None
     sh = getattr(param, "iseg_compute", None)
-    if sh is None or sh.dim() != 2 or not sh.is_cuda:
+    if sh is None or not sh.is_cuda:
         return None
+    if sh.dim() != 2:
+        kshape = kshape or getattr(param, "iseg_kshape", None)
+        if kshape is None or kshape[0] * kshape[1] != sh.numel() or not sh.is_contiguous():
+            return None
+        if getattr(param, "iseg_kshape", None) != tuple(kshape):
+            param.iseg_kshape = tuple(kshape)
+            _WT["index"].pop(id(param), None)      # (registered under another view: rebuild)
     i = _WT["index"].get(id(param))
     if i is None or i >= len(_WT["params"]) or _WT["params"][i]() is not param:      # new, or an id recycled after its owner died
         register_wt([param])

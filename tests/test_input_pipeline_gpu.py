@@ -93,8 +93,6 @@ def test_scale_factors_are_the_discrete_grid_and_eval_only_pads(cuda):
     assert bool((ol[:, :20, :20] == 1).all()) and bool((ol[:, 20:] == 255).all())
     with pytest.raises(NotImplementedError):
         StandardAugmentationsPipeline(training=True, random_jepg_quality=True)
-    with pytest.raises(NotImplementedError):
-        StandardAugmentationsPipeline(training=True, max_resize_height=256)
 
 
 def test_normalize_input_value_range(cuda):
@@ -165,3 +163,26 @@ def test_noisy_eval_adds_clipped_gaussian_noise_after_the_padding(cuda):
     assert not torch.equal(a, out)                                                                         # a fresh draw per batch
     quiet = StandardAugmentationsPipeline(training=False, crop_height=64, crop_width=64, random_noisy_eval_level=0.0005)
     assert quiet.draw_photometric(2) is None
+
+
+def test_resize_augment_bounds_the_sample_before_everything_else(cuda):
+    """ResizeAugment (augments/resize_augment.py:15-60): float32 target-size arithmetic, bilinear image / nearest label, then the usual padding"""
+    from iseg_amd.data_process import StandardAugmentationsPipeline
+
+    ev = StandardAugmentationsPipeline(training=False, crop_height=40, crop_width=40, max_resize_height=24, max_resize_width=20)
+    assert ev.resize_target(48, 36) == (24, 18) and ev.resize_target(30, 60) == (10, 20) and ev.resize_target(16, 12) == (16, 12)
+    assert ev.resize_target(37, 29) == (int(np.float32(37) * np.float32(18) / np.float32(29)), 18)
+    rng = np.random.default_rng(3)
+    sizes = [(48, 36), (30, 60), (16, 12), (37, 29)]
+    imgs = rng.integers(0, 256, (4, 48, 60, 3)).astype(np.uint8)
+    labs = rng.integers(0, 21, (4, 48, 60)).astype(np.int32)
+    out, lab = ev.apply_batch(torch.from_numpy(imgs).cuda(), torch.from_numpy(labs).cuda(), sizes)
+    for b, (H, W) in enumerate(sizes):
+        th, tw = ev.resize_target(H, W)
+        x = torch.from_numpy(imgs[b, :H, :W].astype(np.float64))[None]
+        y = torch.from_numpy(labs[b, :H, :W].astype(np.int64))[None, :, :, None]
+        if (th, tw) != (H, W):
+            x, y = O.resize_bilinear(x, (th, tw)), O.resize_nearest(y, (th, tw))
+        assert (out[b, :th, :tw].cpu().double() - x[0]).abs().max().item() < 1e-3
+        assert torch.equal(lab[b, :th, :tw].cpu().long(), y[0, :, :, 0])
+        assert bool((out[b, th:] == 127.5).all()) and bool((out[b, :, tw:] == 127.5).all()) and bool((lab[b, th:] == 255).all())
