@@ -449,6 +449,14 @@ size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int Cg, int kh
 int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset, void* dmask,
                    int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype,
                    void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* Centre-feature scale of the DCNv3 layer (layers/dcn_v3/dcn_v3.py:138-146; intern_image_huge): out = x (1 - s) + x_proj s with
+ * s [pixels, G] (the un-squashed output of center_feature_scale_proj) broadcast over the Cg channels of its group; backward: dx, dx_proj and
+ * ds [pixels, G] = sum_c dout (x_proj - x).  Cg in {8, 16}. */
+int iseg_dcn_center_blend_fwd(const void* x, const void* x_proj, const void* scale, void* out, int64_t pixels, int G, int Cg, int dtype,
+                              iseg_stream_t stream);
+int iseg_dcn_center_blend_bwd(const void* dout, const void* x, const void* x_proj, const void* scale, void* dx, void* dx_proj, void* dscale,
+                              int64_t pixels, int G, int Cg, int dtype, iseg_stream_t stream);
+
 /* out[c] (+)= sum_r a[r][c]*b[r][c]: gradient of the per-channel layer scale x * gamma (backbones/intern_image/
  * intern_image_layer.py:128,136,160,168) */
 int iseg_scale_cols(const void* x, const float* colscale, void* y, int64_t rows, int C, int dtype, iseg_stream_t stream);

@@ -69,6 +69,8 @@ SIGNATURES = {
     "iseg_dwconv2d_strided_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_dwconv2d_strided_bwd_weight_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "iseg_dwconv2d_strided_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "iseg_dcn_center_blend_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
+    "iseg_dcn_center_blend_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "iseg_bn_workspace_bytes": (_z, [_l, _i]),
     "iseg_bn_stats": (_i, [_p, _l, _p, _l, _i, _i, _p, _z, _p]),
     "iseg_bn_finalize": (_i, [_p, _i, _f, _f, _p, _p, _p, _p, _p]),

@@ -853,6 +853,94 @@ extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mas
     return iseg_check_launch("iseg_dcnv3_bwd");
 }
 
+// centre-feature scale of the DCNv3 layer (layers/dcn_v3/dcn_v3.py:138-146): out = x (1 - s) + x_proj s with one scale per (pixel, group),
+// broadcast over the group's channels.  A lane owns 8 channels of one (pixel, group); the backward's ds = sum_c dout (x_proj - x) meets the
+// other lanes of a 16-channel group through one DPP-free shuffle (Cg in {8, 16}).
+template <class T, int CG>
+__global__ __launch_bounds__(256) void dcn_center_blend_fwd_kernel(const T* __restrict__ x, const T* __restrict__ xp, const T* __restrict__ sc,
+                                                                   T* __restrict__ out, int64_t groups_total) {
+    constexpr int L = CG / 8;
+    const int64_t total = groups_total * L;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float s = to_f32(sc[i / L]);
+        float a[8], b[8];
+        load8<T>(x + i * 8, a);
+        load8<T>(xp + i * 8, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = fmaf(b[u] - a[u], s, a[u]);
+        store8<T>(out + i * 8, a);
+    }
+}
+
+template <class T, int CG>
+__global__ __launch_bounds__(256) void dcn_center_blend_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ xp,
+                                                                   const T* __restrict__ sc, T* __restrict__ dx, T* __restrict__ dxp,
+                                                                   T* __restrict__ ds, int64_t groups_total) {
+    constexpr int L = CG / 8;
+    const int64_t total = groups_total * L;
+    const int64_t padded = (total + 255) / 256 * 256;      // every lane of a wavefront takes part in the shuffle
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < padded; i += (int64_t)gridDim.x * 256) {
+        const bool live = i < total;
+        const int64_t j = live ? i : 0;
+        const float s = to_f32(sc[j / L]);
+        float d[8], a[8], b[8], ga[8], gb[8];
+        load8<T>(dout + j * 8, d);
+        load8<T>(x + j * 8, a);
+        load8<T>(xp + j * 8, b);
+        float dot = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            dot = fmaf(d[u], b[u] - a[u], dot);
+            ga[u] = d[u] * (1.f - s);
+            gb[u] = d[u] * s;
+        }
+        if (L == 2) dot += __shfl_xor(dot, 1);
+        if (live) {
+            store8<T>(dx + j * 8, ga);
+            store8<T>(dxp + j * 8, gb);
+            if (j % L == 0) ds[j / L] = from_f32<T>(dot);
+        }
+    }
+}
+
+extern "C" int iseg_dcn_center_blend_fwd(const void* x, const void* x_proj, const void* scale, void* out, int64_t pixels, int G, int Cg, int dtype,
+                                         hipStream_t stream) {
+    ISEG_REQUIRE(x && x_proj && scale && out && pixels > 0 && G > 0, "iseg_dcn_center_blend_fwd: bad arguments");
+    ISEG_REQUIRE(Cg == 8 || Cg == 16, "iseg_dcn_center_blend_fwd: group width %d (8 or 16)", Cg);
+    const int64_t groups_total = pixels * G;
+#define DCN_BLEND(T, CG)                                                                                                                    \
+    hipLaunchKernelGGL((dcn_center_blend_fwd_kernel<T, CG>), dim3(lane_blocks(groups_total * (CG / 8))), dim3(256), 0, stream, (const T*)x, \
+                       (const T*)x_proj, (const T*)scale, (T*)out, groups_total)
+    if (dtype == ISEG_BF16) {
+        if (Cg == 16) DCN_BLEND(bf16_t, 16);
+        else DCN_BLEND(bf16_t, 8);
+    } else {
+        if (Cg == 16) DCN_BLEND(float, 16);
+        else DCN_BLEND(float, 8);
+    }
+#undef DCN_BLEND
+    return iseg_check_launch("iseg_dcn_center_blend_fwd");
+}
+
+extern "C" int iseg_dcn_center_blend_bwd(const void* dout, const void* x, const void* x_proj, const void* scale, void* dx, void* dx_proj,
+                                         void* dscale, int64_t pixels, int G, int Cg, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dout && x && x_proj && scale && dx && dx_proj && dscale && pixels > 0 && G > 0, "iseg_dcn_center_blend_bwd: bad arguments");
+    ISEG_REQUIRE(Cg == 8 || Cg == 16, "iseg_dcn_center_blend_bwd: group width %d (8 or 16)", Cg);
+    const int64_t groups_total = pixels * G;
+#define DCN_BLEND(T, CG)                                                                                                                     \
+    hipLaunchKernelGGL((dcn_center_blend_bwd_kernel<T, CG>), dim3(lane_blocks(groups_total * (CG / 8))), dim3(256), 0, stream, (const T*)dout, \
+                       (const T*)x, (const T*)x_proj, (const T*)scale, (T*)dx, (T*)dx_proj, (T*)dscale, groups_total)
+    if (dtype == ISEG_BF16) {
+        if (Cg == 16) DCN_BLEND(bf16_t, 16);
+        else DCN_BLEND(bf16_t, 8);
+    } else {
+        if (Cg == 16) DCN_BLEND(float, 16);
+        else DCN_BLEND(float, 8);
+    }
+#undef DCN_BLEND
+    return iseg_check_launch("iseg_dcn_center_blend_bwd");
+}
+
 extern "C" size_t iseg_mul_colsum_workspace_bytes(int64_t rows, int C) { return (size_t)mc_blocks(rows) * C * sizeof(float); }
 
 extern "C" int iseg_mul_colsum(const void* a, const void* b, int64_t rows, int C, float* out, int accumulate, int dtype, void* ws,

@@ -2011,6 +2011,32 @@ class _Dcnv3Fn(Function):
         return dx, doff, dmask, None
 
 
+class _DcnCenterBlendFn(Function):
+    @staticmethod
+    def forward(ctx, x, x_proj, scale, G, Cg):
+        xc, pc, sc = _c(x), _c(x_proj), _c(scale)
+        ctx.save_for_backward(xc, pc, sc)
+        ctx.geom = (G, Cg)
+        return K.dcn_center_blend_fwd(xc, pc, sc, G, Cg)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, pc, sc = ctx.saved_tensors
+        dx, dxp, ds = K.dcn_center_blend_bwd(_c(dout), xc, pc, sc, *ctx.geom)
+        return dx, dxp, ds, None, None
+
+
+def dcn_center_blend(x, x_proj, scale, groups, group_channels):
+    """centre-feature scale of the DCNv3 layer (layers/dcn_v3/dcn_v3.py:138-146): x (1 - s) + x_proj s, s [N, H, W, groups] broadcast over
+    the channels of its group"""
+    _check_act_dtype(x)
+    if group_channels not in (8, 16):
+        raise NotImplementedError("dcn_center_blend: group widths 8 and 16 (the reference's models use 16)")
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _DcnCenterBlendFn.apply(x, x_proj, scale, int(groups), int(group_channels))
+
+
 def dcnv3_core(x, offset, mask, groups, group_channels, kernel_size=(3, 3), stride=1, dilation=1, pad=1, offset_scale=1.0):
     kh, kw = kernel_size
     if nn.dry_run():

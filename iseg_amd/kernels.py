@@ -1041,6 +1041,22 @@ def dcnv3_bwd(x, offset, mask, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale
     return dx, doff, dmask
 
 
+def dcn_center_blend_fwd(x, x_proj, scale, G, Cg):
+    """x (1 - s) + x_proj s, s [.., G] broadcast over each group's Cg channels"""
+    _require_cuda(x, x_proj, scale)
+    out = torch.empty_like(x)
+    _hip.call("iseg_dcn_center_blend_fwd", ptr(x), ptr(x_proj), ptr(scale), ptr(out), x.numel() // (G * Cg), G, Cg, dt(x), stream())
+    return out
+
+
+def dcn_center_blend_bwd(dout, x, x_proj, scale, G, Cg):
+    _require_cuda(dout, x, x_proj, scale)
+    dx, dxp, ds = torch.empty_like(x), torch.empty_like(x_proj), torch.empty_like(scale)
+    _hip.call("iseg_dcn_center_blend_bwd", ptr(dout), ptr(x), ptr(x_proj), ptr(scale), ptr(dx), ptr(dxp), ptr(ds), x.numel() // (G * Cg), G, Cg,
+              dt(x), stream())
+    return dx, dxp, ds
+
+
 def mul_colsum(a2d, b2d, out, accumulate=True):
     _require_cuda(a2d, b2d, out)
     rows, Cc = a2d.shape

@@ -21,8 +21,6 @@ class DeformableConvolutionV3(Layer):
         self.activation = activation
         self.groups, self.filters_per_group = groups, filters // groups
         self.center_feature_scale = center_feature_scale
-        if center_feature_scale:
-            raise NotImplementedError("center_feature_scale (only intern_image_huge uses it)")
 
     def build(self, input_shape):
         input_channel = int(input_shape[-1])
@@ -34,6 +32,8 @@ class DeformableConvolutionV3(Layer):
         self.mask = Dense(self.groups * k2, kernel_initializer="zeros", bias_initializer="zeros", name=f"{self.name}/mask")
         self.input_proj = Dense(input_channel, name=f"{self.name}/input_proj")
         self.output_proj = Dense(self.filters, name=f"{self.name}/output_proj")
+        if self.center_feature_scale:      # (:98-102; a plain Dense: this port applies no sigmoid to the scale)
+            self.center_feature_scale_proj = Dense(self.groups, name=f"{self.name}/center_feature_scale_proj")
         self.built = True
 
     def call(self, inputs, training=False):
@@ -42,10 +42,16 @@ class DeformableConvolutionV3(Layer):
         x1 = self.dw_norm(self.dw_conv(xb))
         if self.activation == "gelu":
             x1 = F.gelu(x1)
-        x1a, x1b = F.fork(x1, 2)
+        if self.center_feature_scale:
+            x1a, x1b, x1c = F.fork(x1, 3)
+            x_proj, x_proj_skip = F.fork(x_proj, 2)
+        else:
+            x1a, x1b = F.fork(x1, 2)
         offset = self.offset(x1a)
         mask = F.softmax_groups(self.mask(x1b), self.kernel_size * self.kernel_size)
         pad = self.kernel_size // 2 if self.padding.upper() == "SAME" else 0
         x = F.dcnv3_core(x_proj, offset, mask, self.groups, self.filters_per_group, (self.kernel_size, self.kernel_size),
                          self.strides, self.dilation_rate, pad, self.offset_scale)
+        if self.center_feature_scale:      # (:138-146) x (1 - s) + x_proj s, one s per (pixel, group)
+            x = F.dcn_center_blend(x, x_proj_skip, self.center_feature_scale_proj(x1c), self.groups, self.filters_per_group)
         return self.output_proj(x)

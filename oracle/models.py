@@ -383,6 +383,10 @@ def dcnv3_layer(w, p, x, groups, kernel_size=3, dw_kernel=None, offset_scale=1.0
     mask = O.dense(x1, w[f"{p}/mask/kernel"], w[f"{p}/mask/bias"])
     mask = torch.softmax(mask.reshape(N, H, W, groups, -1), dim=-1).reshape(N, H, W, -1)
     y = O.dcnv3_op(x_proj, offset, mask, (kernel_size, kernel_size), (1, 1), "SAME", (1, 1), groups, C // groups, offset_scale)
+    if f"{p}/center_feature_scale_proj/kernel" in w:      # layers/dcn_v3/dcn_v3.py:138-146 (no sigmoid in this port)
+        s = O.dense(x1, w[f"{p}/center_feature_scale_proj/kernel"], w[f"{p}/center_feature_scale_proj/bias"])
+        s = s.unsqueeze(-1).expand(N, H, W, groups, C // groups).reshape(N, H, W, C)
+        y = y * (1 - s) + x_proj * s
     return O.dense(y, w[f"{p}/output_proj/kernel"], w[f"{p}/output_proj/bias"])
 
 
@@ -410,7 +414,9 @@ def intern_image_layer(w, p, x, groups, post_norm, dp=None):
 
 
 def intern_image_forward(w, x, depths, groups, post_norm, dp_factors=None):
-    """endpoints [stem before 2nd stride, b0, b1, ...] (pre-downsample)"""
+    """endpoints [stem before 2nd stride, b0, b1, ...] (pre-downsample); the centre-feature scale of the DCNv3 layers is on when its
+    projection is among the weights (it also keeps the block norm under post-norm: intern_image_block.py:81,115)"""
+    center = any(k.endswith("center_feature_scale_proj/kernel") for k in w)
     def ln(p, t):
         return O.layer_norm(t, w[f"{p}/gamma"], w[f"{p}/beta"], 1e-6)
 
@@ -421,7 +427,7 @@ def intern_image_forward(w, x, depths, groups, post_norm, dp_factors=None):
         for li in range(depth):
             dp = None if dp_factors is None else dp_factors[bi][li]
             x = intern_image_layer(w, f"block/{bi}/layer/{li}", x, groups[bi], post_norm, dp)
-        if not post_norm:
+        if not post_norm or center:
             x = ln(f"block/{bi}/norm", x)
         endpoints.append(x)
         if bi < len(depths) - 1:

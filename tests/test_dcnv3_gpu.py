@@ -64,8 +64,9 @@ def test_dcnv3_zero_offsets_reproduce_the_reference_base_grid(cuda):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("post_norm", [False, True])
-def test_intern_image_small_member(cuda, dtype, post_norm):
+@pytest.mark.parametrize("post_norm,cfs", [(False, False), (True, False), (True, True)])
+def test_intern_image_small_member(cuda, dtype, post_norm, cfs):
+    """cfs: use_center_feature_scale (intern_image_huge: post-norm + centre-feature scale, layers/dcn_v3/dcn_v3.py:138-146)"""
     from iseg_amd import nn
     from iseg_amd.backbones.intern_image.intern_image import InternImage
     from iseg_amd.param_store import ParamStore
@@ -75,7 +76,7 @@ def test_intern_image_small_member(cuda, dtype, post_norm):
     try:
         shape = (2, 40, 56, 3)
         net = InternImage(stem_filters=32, depths=[1, 2], groups=[2, 4], drop_path_rate=0.2, layer_scale=1.0, use_post_norm=post_norm,
-                          return_endpoints=True, name="ii_test")
+                          use_center_feature_scale=cfs, return_endpoints=True, name="ii_test")
         with nn.dry_run_scope():
             net(torch.empty(shape, dtype=torch.float32, device="cuda"))
         net._iseg_store = ParamStore(list(net.parameters()))
