@@ -94,9 +94,15 @@ class Mlp(Layer):
         self.fc2 = Dense(out_features, name=f"{name}/fc2")
         self.dropout = Dropout(dropout_rate, name=f"{name}/dropout")
 
-    def call(self, inputs, training=None):
-        if self.fc1.built and self.fc2.built and (self.dropout.rate == 0.0 or not training):
-            return F.mlp_gelu(inputs, self.fc1.kernel, self.fc1.bias, self.fc2.kernel, self.fc2.bias)     # one tape node
+    def fusable(self, training):
+        return self.fc1.built and self.fc2.built and (self.dropout.rate == 0.0 or not training)
+
+    def call(self, inputs, training=None, residual=None, drop_path_mask=None):
+        """residual / drop_path_mask (fusable(training) only): residual + factor[sample] * mlp(inputs) from the second product's epilogue"""
+        if self.fusable(training):
+            return F.mlp_gelu(inputs, self.fc1.kernel, self.fc1.bias, self.fc2.kernel, self.fc2.bias, residual=residual,
+                              drop_path_mask=drop_path_mask)     # one tape node
+        assert residual is None and drop_path_mask is None
         x = self.fc1(inputs)                     # Dense + exact-erf GELU in the GEMM epilogue
         x = self.dropout(x, training=training)
         x = self.fc2(x)
@@ -163,8 +169,14 @@ class SwinTransformerBlock(Layer):
         attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
         x = F.permute_rows(attn_windows, rev, part, (n, h * w, c))         # reverse + roll back + crop
         x, skip = F.fork(F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0])), 2)
-        y = self.mlp(self.norm2(x), training=training)
-        x = F.add(skip, F.drop_path(y, self.drop_path_prob, training, mask=masks[1]))
+        if self.mlp.fusable(training):      # skip + drop_path(mlp(.)) out of the second product's epilogue
+            mask = None
+            if training and self.drop_path_prob != 0.0:
+                mask = masks[1] if masks[1] is not None else F.drop_path_factors(n, 1.0 - self.drop_path_prob, x.device)
+            x = self.mlp(self.norm2(x), training=training, residual=skip, drop_path_mask=mask)
+        else:
+            y = self.mlp(self.norm2(x), training=training)
+            x = F.add(skip, F.drop_path(y, self.drop_path_prob, training, mask=masks[1]))
         return x.reshape(n, h, w, c)
 
 

@@ -28,9 +28,16 @@ class MLPBlock(Layer):
         self.dense1_dropout = Dropout(self.dropout_rate, name="dense1_dropout")
         self.built = True
 
-    def call(self, inputs, training=None):
-        if (self.activation == "gelu" and self.dense0.built and self.dense1.built and (self.dropout_rate == 0.0 or not training)):
-            return F.mlp_gelu(inputs, self.dense0.kernel, self.dense0.bias, self.dense1.kernel, self.dense1.bias)      # one tape node
+    def fusable(self, training):
+        return (self.activation == "gelu" and self.built and self.dense0.built and self.dense1.built
+                and (self.dropout_rate == 0.0 or not training))
+
+    def call(self, inputs, training=None, residual=None, drop_path_mask=None):
+        """residual / drop_path_mask (fusable(training) only): residual + factor[sample] * mlp(inputs) from the second product's epilogue"""
+        if self.fusable(training):
+            return F.mlp_gelu(inputs, self.dense0.kernel, self.dense0.bias, self.dense1.kernel, self.dense1.bias, residual=residual,
+                              drop_path_mask=drop_path_mask)      # one tape node
+        assert residual is None and drop_path_mask is None
         x = self.dense0(inputs)
         x = self.dense0_dropout(x, training=training)
         x = self.dense1(x)
@@ -63,6 +70,11 @@ class TransformerBlock(Layer):
             x = F.drop_path(x, self.drop_path_rate, training, mask=masks[0])
         x, identity = F.fork(F.add(x, skip), 2)
         x = self.mlp_norm(x)
+        if self.mlp.fusable(training):      # identity + drop_path(mlp(.)) out of the second product's epilogue
+            mask = None
+            if self.drop_path_rate != 0.0 and training:
+                mask = masks[1] if masks[1] is not None else F.drop_path_factors(x.shape[0], 1.0 - self.drop_path_rate, x.device)
+            return self.mlp(x, training=training, residual=identity, drop_path_mask=mask)
         x = self.mlp(x, training=training)
         if self.drop_path_rate != 0.0 and training:
             x = F.drop_path(x, self.drop_path_rate, training, mask=masks[1])

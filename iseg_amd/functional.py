@@ -137,10 +137,15 @@ class _MlpGeluFn(Function):
     GEMM's data gradient multiplies by the saved derivative in its epilogue -- no elementwise activation-gradient pass."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2):
+    def forward(ctx, x, W1, b1, W2, b2, residual=None, rowscale=None):
+        """residual / rowscale: `residual + rowscale[sample] * mlp(x)` -- the block's drop-path factor and skip connection ride the second
+        product's epilogue (backbones/swin.py:233-236, backbones/vit.py:128-131) instead of a row-scale and an add kernel"""
         C, Hd = W1.shape[-2], W1.shape[-1]
         N = W2.shape[-1]
         x2 = _c(x).reshape(-1, C)
+        res2 = _c(residual).reshape(-1, N) if residual is not None else None
+        rpg = x2.shape[0] // rowscale.shape[0] if rowscale is not None else 0
+        ctx.rowscale, ctx.rpg = rowscale, rpg
         need_grad = any(ctx.needs_input_grad)
         d = torch.empty((x2.shape[0], Hd), dtype=x2.dtype, device=x2.device) if need_grad else None
         W1t, W2t = _kcontig_kernel(W1, x2, C, Hd), None
@@ -150,9 +155,9 @@ class _MlpGeluFn(Function):
         else:
             g = K.dense_fwd(x2, nn.w(W1), b1.data if b1 is not None else None, act=K.ACT_GELU, pre_out=d, pre_deriv=need_grad)
         if W2t is not None:
-            y = K.dense_fwd_t(g, W2t, b2.data if b2 is not None else None)
+            y = K.dense_fwd_t(g, W2t, b2.data if b2 is not None else None, rowscale=rowscale, rows_per_group=rpg, residual=res2)
         else:
-            y = K.dense_fwd(g, nn.w(W2), b2.data if b2 is not None else None)
+            y = K.dense_fwd(g, nn.w(W2), b2.data if b2 is not None else None, rowscale=rowscale, rows_per_group=rpg, residual=res2)
         ctx.params = (W1, b1, W2, b2)
         ctx.save_for_backward(x2, g if need_grad else None, d)
         return y.reshape(*x.shape[:-1], N)
@@ -162,7 +167,10 @@ class _MlpGeluFn(Function):
         x2, g, d = ctx.saved_tensors
         W1, b1, W2, b2 = ctx.params
         N = W2.shape[-1]
+        dres = dy if ctx.needs_input_grad[5] else None      # the skip connection passes the gradient through
         dy2 = _c(dy).reshape(-1, N)
+        if ctx.rowscale is not None:
+            dy2 = K.rowscale(dy2, ctx.rowscale, ctx.rpg)
         if W2.requires_grad:
             K.dense_wgrad(g, dy2, _grad(W2), bias_grad=(_grad(b2) if b2 is not None and b2.requires_grad else None))
         elif b2 is not None and b2.requires_grad:
@@ -176,15 +184,18 @@ class _MlpGeluFn(Function):
         if ctx.needs_input_grad[0]:
             dx = K.dense_dgrad(dh, nn.w(W1)).reshape(*dy.shape[:-1], W1.shape[-2])
         dist.grads_ready(W1, b1, W2, b2)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, dres, None
 
 
-def mlp_gelu(x, W1, b1, W2, b2):
-    """dense(gelu(dense(x, W1, b1)), W2, b2) with no dropout in between"""
+def mlp_gelu(x, W1, b1, W2, b2, residual=None, drop_path_mask=None):
+    """dense(gelu(dense(x, W1, b1)), W2, b2) with no dropout in between; with `residual`: residual + drop_path_mask[sample] * that (the
+    per-sample factors of utils/drops.py:8-22, None = no drop path), in the second product's epilogue"""
     _check_act_dtype(x)
     if nn.dry_run():
         return _dry((*x.shape[:-1], W2.shape[-1]), x)
-    return _MlpGeluFn.apply(x, W1, b1, W2, b2)
+    if residual is None and drop_path_mask is not None:
+        raise ValueError("mlp_gelu: drop_path_mask rides the residual epilogue")
+    return _MlpGeluFn.apply(x, W1, b1, W2, b2, residual, drop_path_mask)
 
 
 def dense(x, W, b=None, act=K.ACT_NONE, kshape=None):
