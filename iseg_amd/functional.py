@@ -1201,16 +1201,17 @@ _SIDE_STREAMS = {}
 
 
 def _side_enabled():
-    """independent work on extra HIP streams?  ISEG_SIDE_STREAM = 1 always, 0 never, auto (default) only while a HIP graph is being captured.
-    Eager (measured on the flagship step, interleaved A/B): 9.08 ms with one queue, 9.39 ms with two -- every fork / join is a pair of host-side
-    event calls.  Inside a captured graph the same forks are edges of the graph: replayed 9.11 ms with one queue, 8.98 ms with two (round 3),
-    so the graph runner gets the concurrency and the eager step does not pay for it."""
+    """independent work on extra HIP streams?  ISEG_SIDE_STREAM = 1 always, `capture` only while a HIP graph is being captured, 0 / unset never.
+    Eager (flagship step, interleaved A/B): 9.08 ms with one queue, 9.39 ms with two -- every fork / join is a pair of host-side event calls.
+    Inside a captured graph the forks are edges of the graph; measured replayed (one box, interleaved): flagship 9.12 / 9.16 ms with one queue,
+    9.17 / 9.17 ms with two (an earlier box: 9.11 vs 8.98); ResNet-50 + ASPP 8.18 vs 11.6 ms, InternImage-B 36.6 vs 45.9 ms, Swin-T equal -- the
+    runtime pays for every fork / join of a replayed graph, and the small-kernel models have hundreds.  Off by default."""
     import os
 
-    mode = os.environ.get("ISEG_SIDE_STREAM", "auto")
+    mode = os.environ.get("ISEG_SIDE_STREAM", "0")
     if mode == "1":
         return True
-    if mode == "0" or not torch.cuda.is_available():
+    if mode != "capture" or not torch.cuda.is_available():
         return False
     return torch.cuda.is_current_stream_capturing()
 
