@@ -380,7 +380,10 @@ def main():
     from iseg_amd import dist
     from iseg_amd.data import synthetic_batch
 
-    strategy, model, trainer = build_trainer(args)
+    import contextlib
+
+    with contextlib.redirect_stdout(sys.stderr):      # the reference's build-time chatter ("Use the random seed ...") mirrored by the host code:
+        strategy, model, trainer = build_trainer(args)      # stdout carries the ONE JSON line and nothing else
     rank = dist.rank()
     world = joined_ranks(torch.device("cuda", dist.local_rank()))
     if args.gpus != world:
