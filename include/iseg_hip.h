@@ -563,6 +563,12 @@ int iseg_conv2d_igemm_supported(const iseg_conv_geom* geom_h, int dtype);
 size_t iseg_conv2d_igemm_workspace_bytes(const iseg_conv_geom* geom_h, int pass);
 int iseg_conv2d_igemm_fwd(const void* x, const void* w, const float* bias, void* y, const iseg_conv_geom* geom_h, int dtype, void* ws,
                           size_t ws_bytes, iseg_stream_t stream);
+/* The forward pass on the LDS-DMA pipeline (csrc/conv_igemm_dma.h): `wt` is the K-contiguous copy [Cout][KH*KW*Cin] of the Keras kernel (what
+ * iseg_transpose_batched keeps per weight update); one group, Cin % 64 == 0, Cout % 8 == 0.  iseg_conv2d_igemm_bwd_data takes the same pipeline by
+ * itself for stride-1 problems with Cout % 64 == 0 (the Keras kernel already is K-contiguous for that product). */
+int iseg_conv2d_igemm_fwd_kt_supported(const iseg_conv_geom* g, int dtype);
+int iseg_conv2d_igemm_fwd_kt(const void* x, const void* wt, const float* bias, void* y, const iseg_conv_geom* g, int dtype, void* ws,
+                             size_t ws_bytes, iseg_stream_t stream);
 int iseg_conv2d_igemm_bwd_data(const void* dy, const void* w, void* dx, const iseg_conv_geom* geom_h, int dtype, void* ws, size_t ws_bytes,
                                iseg_stream_t stream);
 int iseg_conv2d_igemm_bwd_weight(const void* x, const void* dy, float* dw, int accumulate, const iseg_conv_geom* geom_h, int dtype, void* ws,

@@ -182,6 +182,8 @@ SIGNATURES = {
     "iseg_conv2d_igemm_supported": (_i, [C.POINTER(ConvGeom), _i]),
     "iseg_conv2d_igemm_workspace_bytes": (_z, [C.POINTER(ConvGeom), _i]),
     "iseg_conv2d_igemm_fwd": (_i, [_p, _p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),
+    "iseg_conv2d_igemm_fwd_kt": (_i, [_p, _p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),
+    "iseg_conv2d_igemm_fwd_kt_supported": (_i, [C.POINTER(ConvGeom), _i]),
     "iseg_conv2d_igemm_bwd_data": (_i, [_p, _p, _p, C.POINTER(ConvGeom), _i, _p, _z, _p]),
     "iseg_conv2d_igemm_bwd_weight": (_i, [_p, _p, _p, _i, C.POINTER(ConvGeom), _i, _p, _z, _p]),
     "iseg_convnext_mlp_supported": (_i, [_i, _i]),

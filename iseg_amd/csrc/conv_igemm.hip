@@ -70,6 +70,12 @@ struct PhaseRows {
 
 constexpr int INVALID = -(1 << 28);
 
+}  // namespace
+
+#include "conv_igemm_dma.h"
+
+namespace {
+
 // 8 consecutive channels `c` of pixel (nb + ih * Ws + iw) of the gathered tensor, or zeros
 __device__ __forceinline__ bf16x8 gather8(const ConvP& p, int nb, int ih, int iw, int c, bool ok) {
     bf16x8 v;
@@ -403,6 +409,74 @@ int run_phases(const Problem& q, const iseg_conv_geom* g, hipStream_t stream, co
     return iseg_check_launch(what);
 }
 
+// ---- LDS-DMA form (conv_igemm_dma.h): forward on the K-contiguous kernel copy, stride-1 data gradient on the Keras kernel ----
+static int igemm_dma_mode() {      // ISEG_IGEMM_DMA: 0 = never, 1 = whenever eligible (default)
+    static const int v = [] { const char* e = getenv("ISEG_IGEMM_DMA"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+bool dma_conv_eligible(const Problem& q, const iseg_conv_geom* g, int pass) {
+    if (!igemm_dma_mode() || g->groups != 1 || q.p.Cg % 64 != 0 || q.N % 8 != 0 || q.N < 64 || q.M < 64 || q.K < 128) return false;
+    if (pass == 1 && (g->sh != 1 || g->sw != 1)) return false;      // strided data gradients run by stride phase (pass 3)
+    if (((uintptr_t)q.p.src | (uintptr_t)q.B | (uintptr_t)q.D) % 16 || q.ldd % 8 || q.ldb % 8 || q.p.Cs % 8) return false;
+    if (q.bias && (uintptr_t)q.bias % 16) return false;
+    return true;
+}
+
+template <int PASS> int run_dma(const Problem& q, void* ws, size_t ws_bytes, hipStream_t stream, const char* what) {
+    static const int force_split = [] { const char* e = getenv("ISEG_IGEMM_DMA_SPLIT"); return e ? atoi(e) : 0; }();      // experiment knobs
+    static const int force_tile = [] { const char* e = getenv("ISEG_IGEMM_DMA_TILE"); return e ? atoi(e) : 0; }();
+    int nsplit = conv_splits(q.M, q.N, q.K, 1);
+    if (force_split > 0 && force_split <= nsplit) nsplit = force_split;
+    int64_t kps = q.K;
+    float* slabs = nullptr;
+    if (nsplit > 1) {
+        const size_t need = (size_t)nsplit * q.M * q.N * sizeof(float);
+        if (!ws || ws_bytes < need) {
+            iseg_set_error("%s: split-K needs %zu workspace bytes, got %zu", what, need, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        slabs = (float*)ws;
+        kps = ceil_div64(ceil_div64(q.K, nsplit), 64) * 64;
+    }
+    const int eff = (int)ceil_div64(q.K, kps);
+    Epi epi{};
+    epi.bias = q.bias;
+    epi.alpha = 1.f;
+    epi.accumulate = q.accumulate;
+    epi.batch_inner = 1;
+    auto launch = [&](auto tile) {
+        constexpr int WM = decltype(tile)::WM, WN = decltype(tile)::WN, NS = decltype(tile)::NS;
+        constexpr int BM = WM * 64, BN = WN * 64;
+        constexpr int lds = NS * (BM + BN) * 128;
+        const int tiles_m = (int)ceil_div64(q.M, BM), tiles_n = (int)ceil_div64(q.N, BN);
+        static const bool raised = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_dma_kernel<WM, WN, NS, PASS, bf16_t>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        }();
+        (void)raised;
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, NS, PASS, bf16_t>), dim3(tiles_m * tiles_n, eff, 1), dim3(WM * WN * 64), lds, stream, q.p, q.B,
+                           q.ldb, q.tap_stride, (bf16_t*)q.D, q.ldd, q.M, q.N, q.K, tiles_n, tiles_m * tiles_n, kps, slabs, epi);
+    };
+    struct T256 { enum { WM = 4, WN = 2, NS = 3 }; };
+    struct T128 { enum { WM = 2, WN = 2, NS = 2 }; };
+    if (force_tile == 1 || (force_tile == 0 && ceil_div64(q.M, 256) * ceil_div64(q.N, 128) * eff >= 192)) launch(T256{});
+    else launch(T128{});
+    if (!slabs) return iseg_check_launch(what);
+    iseg_gemm_args ga{};
+    ga.M = q.M;
+    ga.N = q.N;
+    ga.K = q.K;
+    ga.D = q.D;
+    ga.ldd = q.ldd;
+    ga.in_dtype = ISEG_BF16;
+    ga.out_dtype = q.out_dtype;
+    ga.alpha = 1.f;
+    ga.accumulate = q.accumulate;
+    ga.bias = q.bias;
+    return gemm_reduce(&ga, epi, slabs, eff, q.M, stream);
+}
+
 bool geom_ok(const iseg_conv_geom* g) {
     return g && g->N > 0 && g->H > 0 && g->W > 0 && g->Cin > 0 && g->Cout > 0 && g->KH > 0 && g->KW > 0 && g->sh > 0 && g->sw > 0 && g->dh > 0 &&
            g->dw > 0 && g->Ho > 0 && g->Wo > 0 && g->groups > 0 && g->Cin % g->groups == 0 && g->Cout % g->groups == 0;
@@ -461,6 +535,36 @@ extern "C" int iseg_conv2d_igemm_fwd(const void* x, const void* w, const float* 
     return run<0, bf16_t>(q, ws, ws_bytes, stream, "iseg_conv2d_igemm_fwd");
 }
 
+extern "C" int iseg_conv2d_igemm_fwd_kt(const void* x, const void* wt, const float* bias, void* y, const iseg_conv_geom* g, int dtype, void* ws,
+                                        size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(x && wt && y, "iseg_conv2d_igemm_fwd_kt: null operand");
+    CONV_COMMON("iseg_conv2d_igemm_fwd_kt");
+    Problem q{};
+    q.M = (int64_t)g->N * g->Ho * g->Wo;
+    q.N = og;
+    q.K = (int64_t)g->KH * g->KW * cg;
+    q.p = ConvP{(const bf16_t*)x, g->H, g->W, g->Cin, g->Ho, g->Wo, cg, g->KW, g->sh, g->sw, g->dh, g->dw, g->pt, g->pl, g->groups};
+    q.B = (const bf16_t*)wt;
+    q.ldb = q.K;
+    q.D = y;
+    q.ldd = g->Cout;
+    q.out_dtype = ISEG_BF16;
+    q.bias = bias;
+    q.groups = g->groups;
+    if (!dma_conv_eligible(q, g, 0)) {
+        iseg_set_error("iseg_conv2d_igemm_fwd_kt: one group, Cin %% 64 == 0, Cout %% 8 == 0 and >= 64, 16-byte aligned operands (Cin %d, Cout %d, groups %d)",
+                       g->Cin, g->Cout, g->groups);
+        return ISEG_ERR_UNSUPPORTED;
+    }
+    return run_dma<0>(q, ws, ws_bytes, stream, "iseg_conv2d_igemm_fwd_kt");
+}
+
+extern "C" int iseg_conv2d_igemm_fwd_kt_supported(const iseg_conv_geom* g, int dtype) {
+    if (!geom_ok(g) || dtype != ISEG_BF16 || !igemm_dma_mode()) return 0;
+    return g->groups == 1 && g->Cin % 64 == 0 && g->Cout % 8 == 0 && g->Cout >= 64 && (int64_t)g->N * g->Ho * g->Wo >= 64 &&
+           (int64_t)g->KH * g->KW * g->Cin >= 128;
+}
+
 extern "C" int iseg_conv2d_igemm_bwd_data(const void* dy, const void* w, void* dx, const iseg_conv_geom* g, int dtype, void* ws, size_t ws_bytes,
                                           hipStream_t stream) {
     ISEG_REQUIRE(dy && w && dx, "iseg_conv2d_igemm_bwd_data: null operand");
@@ -483,6 +587,7 @@ extern "C" int iseg_conv2d_igemm_bwd_data(const void* dy, const void* w, void* d
     // strided, undilated: one stride-1 gather per stride phase (pass 3) instead of the gather form that multiplies the zeros between the hits
     if ((g->sh > 1 || g->sw > 1) && g->dh == 1 && g->dw == 1 && g->sh * g->sw <= MAX_PHASES)
         return run_phases(q, g, stream, "iseg_conv2d_igemm_bwd_data");
+    if (dma_conv_eligible(q, g, 1)) return run_dma<1>(q, ws, ws_bytes, stream, "iseg_conv2d_igemm_bwd_data");
     return run<1, bf16_t>(q, ws, ws_bytes, stream, "iseg_conv2d_igemm_bwd_data");
 }
 

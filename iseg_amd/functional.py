@@ -259,7 +259,13 @@ class _Conv2dFn(Function):
                 K.gemm(xc.reshape(-1, Cin), nn.w(W).reshape(Cin, Cout), y, M, Cout, Cin, lda=Cin, ldb=Cout, ldd=Cout, a_kcontig=1, b_kcontig=0,
                        bias=(b.data if b is not None else None))
         elif igemm:
-            y = K.conv2d_igemm_fwd(xc, nn.w(W), b.data if b is not None else None, geom)
+            Wt = None
+            if _FWD_KCONTIG and K.conv2d_igemm_fwd_kt_supported(geom, cdt):      # LDS-DMA form on the K-contiguous kernel copy
+                Wt = nn.wt(W, (kh * kw * Cin, Cout))
+            if Wt is not None:
+                y = K.conv2d_igemm_fwd_kt(xc, Wt, b.data if b is not None else None, geom)
+            else:
+                y = K.conv2d_igemm_fwd(xc, nn.w(W), b.data if b is not None else None, geom)
         else:
             y = torch.empty((M, Cout), dtype=cdt, device=x.device)
             Kd, og = kh * kw * Cin_g, Cout // groups

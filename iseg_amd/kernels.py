@@ -498,6 +498,19 @@ def conv2d_igemm_fwd(x, w, bias, geom):
     return y
 
 
+def conv2d_igemm_fwd_kt_supported(geom, dtype):
+    return dtype in _DT and bool(_hip.lib().iseg_conv2d_igemm_fwd_kt_supported(C.byref(geom), _DT[dtype]))
+
+
+def conv2d_igemm_fwd_kt(x, wt, bias, geom):
+    """the forward pass on the LDS-DMA pipeline: wt = the K-contiguous kernel copy [Cout, KH*KW*Cin] (nn.wt)"""
+    _require_cuda(x, wt)
+    y = torch.empty((geom.N, geom.Ho, geom.Wo, geom.Cout), dtype=x.dtype, device=x.device)
+    ws, wsb = _conv_ws(geom, 0, x.device)
+    _hip.call("iseg_conv2d_igemm_fwd_kt", ptr(x), ptr(wt), ptr(bias), ptr(y), C.byref(geom), dt(x), ptr(ws), wsb, stream())
+    return y
+
+
 def conv2d_igemm_bwd_data(dy, w, geom):
     _require_cuda(dy, w)
     dx = torch.empty((geom.N, geom.H, geom.W, geom.Cin), dtype=dy.dtype, device=dy.device)

@@ -34,6 +34,10 @@ CASES = [
     ((2, 33, 31, 64), 3, 2, 1, 128, 1),      # stride phases of unequal size, several row tiles each
     ((1, 12, 12, 16), 2, 3, 1, 16, 1),       # kernel smaller than the stride: phases no tap reaches stay zero
     ((4, 32, 32, 128), 3, 1, 1, 128, 1),     # several tiles in M and a long weight-gradient reduction
+    ((2, 16, 16, 128), 3, 1, 4, 192, 1),     # LDS-DMA form (Cin, Cout multiples of 64): dilated, most of the halo
+    ((1, 16, 16, 768), 3, 1, 6, 256, 1),     # the flagship's ASPP branch (LDS-DMA form, split-K)
+    ((3, 17, 13, 64), 3, 2, 1, 128, 1),      # LDS-DMA forward with a stride on odd sizes; data gradient by stride phase
+    ((2, 12, 20, 192), 5, 1, 1, 64, 1),      # 5x5, rows not a multiple of the tile
 ]
 
 
@@ -59,6 +63,9 @@ def test_conv_igemm_three_passes(cuda, shape, kk, s, d, Cout, groups):
     yo = O.conv2d(xx, ww, b.double(), s, d, groups=groups)
     assert tuple(yo.shape) == (N, Ho, Wo, Cout) == tuple(y.shape)
     close(y, yo, BF, "igemm fwd")
+    if k.conv2d_igemm_fwd_kt_supported(geom, BF):      # the LDS-DMA form on the K-contiguous kernel copy [Cout, kh*kw*Cin]
+        wt = w.reshape(-1, Cout).t().contiguous()
+        close(k.conv2d_igemm_fwd_kt(x, wt, b.cuda(), geom), yo, BF, "igemm fwd (LDS-DMA)")
     dy, dyr = q(rnd((N, Ho, Wo, Cout), 4), BF)
     yo.backward(dyr)
     dx = k.conv2d_igemm_bwd_data(dy, w, geom)

@@ -25,5 +25,7 @@ x = torch.randn(N, S, S, Cin, device="cuda").to(BF)
 w = (torch.randn(k, k, Cin, Cout, device="cuda") * 0.02).to(BF)
 dy = torch.randn(N, Ho, Ho, Cout, device="cuda").to(BF)
 dw = torch.zeros(k, k, Cin, Cout, device="cuda")
-print(f"fwd {timeit(lambda: K.conv2d_igemm_fwd(x, w, None, geom)):.1f} us | bwd data {timeit(lambda: K.conv2d_igemm_bwd_data(dy, w, geom)):.1f} us | "
+wt = w.reshape(-1, Cout).t().contiguous()
+kt = f"{timeit(lambda: K.conv2d_igemm_fwd_kt(x, wt, None, geom)):.1f}" if K.conv2d_igemm_fwd_kt_supported(geom, BF) else "-"
+print(f"fwd {timeit(lambda: K.conv2d_igemm_fwd(x, w, None, geom)):.1f} us (LDS-DMA on the K-contiguous kernel: {kt}) | bwd data {timeit(lambda: K.conv2d_igemm_bwd_data(dy, w, geom)):.1f} us | "
       f"bwd weight {timeit(lambda: K.conv2d_igemm_bwd_weight(x, dy, dw, geom, accumulate=True)):.1f} us", flush=True)
