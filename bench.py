@@ -341,10 +341,13 @@ def cpu_baseline(args):
     from iseg_amd.heads import convnext_tiny_aspp
     from iseg_amd import nn
 
+    import contextlib
+
     prev = nn.device()
     nn.set_device("cpu")
     try:
-        m = convnext_tiny_aspp(num_class=21, build_input_size=(args.size, args.size))
+        with contextlib.redirect_stdout(sys.stderr):      # (build-time chatter: stdout carries the JSON line only)
+            m = convnext_tiny_aspp(num_class=21, build_input_size=(args.size, args.size))
     finally:
         nn.set_device(prev if prev.type != "cpu" else None)
     w = OM.export_weights(m, dtype=torch.float32)
