@@ -383,10 +383,13 @@ def main():
     from iseg_amd import dist
     from iseg_amd.data import synthetic_batch
 
-    import contextlib
-
-    with contextlib.redirect_stdout(sys.stderr):      # the reference's build-time chatter ("Use the random seed ...") mirrored by the host code:
-        strategy, model, trainer = build_trainer(args)      # stdout carries the ONE JSON line and nothing else
+    # stdout carries the ONE JSON line and nothing else: until that line is printed, file descriptor 1 points at stderr, so neither the
+    # reference's build-time chatter mirrored by the host code ("Use the random seed ...") nor a native library's banner (RCCL prints its
+    # version to stdout when the first communicator comes up) can land in front of it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    strategy, model, trainer = build_trainer(args)
     rank = dist.rank()
     world = joined_ranks(torch.device("cuda", dist.local_rank()))
     if args.gpus != world:
@@ -460,7 +463,10 @@ def main():
         res["roofline"] = roofline_from_timer(timer.report(), args.steps, survey_report)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args)
-    print(json.dumps(res))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
