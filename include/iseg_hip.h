@@ -614,6 +614,16 @@ int iseg_convnext_mlp_bwd(const void* y2, const void* dbr, const void* bw_tiled,
 int iseg_convnext_mlp_bwd_data(const void* y, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
                                const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled, const float* b1,
                                void* dy2, int64_t M, int C, int dtype, iseg_stream_t stream);
+
+/* The same chain carried through the LayerNorm in front of the MLP as well (LayerNorm on the row load, backbones/convnext.py:26-27,52): y1 is the
+ * LayerNorm INPUT, dy1 receives its gradient -- rstd (t - mean_c(t) - xhat mean_c(t xhat)), t = dy2 gamma -- and the column sums
+ * dgamma += sum_rows dy2 xhat, dbeta += sum_rows dy2 are added to dln_gamma / dln_beta (per-workgroup partial rows in ws, fixed-order sum;
+ * deferred when a reduction queue is open).  Replaces iseg_convnext_mlp_bwd_data + iseg_layernorm_bwd for the fused stages. */
+size_t iseg_convnext_mlp_bwd_data_ln_workspace_bytes(int64_t M, int C);
+int iseg_convnext_mlp_bwd_data_ln(const void* y1, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
+                                  const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled, const float* b1,
+                                  void* dy1, float* dln_gamma, float* dln_beta, int64_t M, int C, int dtype, void* ws, size_t ws_bytes,
+                                  iseg_stream_t stream);
 /* the forward kernel with keras.layers.LayerNormalization(epsilon) (backbones/convnext.py:27,49) folded into its row load: y1 = the
  * depthwise convolution's output; mean / rstd [M] are written for the backward kernels; y2 never exists in HBM */
 int iseg_convnext_mlp_fwd_ln(const void* y1, const float* ln_gamma, const float* ln_beta, float eps, float* mean, float* rstd,

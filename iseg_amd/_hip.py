@@ -192,6 +192,8 @@ SIGNATURES = {
     "iseg_convnext_mlp_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_bwd_data": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _l, _i, _i, _p]),
+    "iseg_convnext_mlp_bwd_data_ln_workspace_bytes": (_z, [_l, _i]),
+    "iseg_convnext_mlp_bwd_data_ln": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
     "iseg_convnext_weight_prep_batched": (_i, [_p, _i, _l, _p]),
     "iseg_convnext_mlp_fwd_ln": (_i, [_p, _p, _p, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p, _p, _l, _i, _i, _p]),
     "iseg_convnext_mlp_wgrad_workspace_bytes": (_z, [_l, _i]),

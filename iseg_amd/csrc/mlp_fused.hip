@@ -282,12 +282,15 @@ __device__ __forceinline__ void acc_to_row_pieces(const float* v, uint4& p0, uin
 // STORE = false: the data-gradient chain only (dy2); G and dH never leave the CU -- the weight gradients come from mlp_wgrad.hip, which
 // recomputes the hidden tile per hidden-unit slice.  `rowscale` (drop-path factor per group of rows_per_group rows) turns D = d(out) into
 // dbr while the rows are loaded.
-template <int C, int SUB, int WAVES, int NSTAGES, bool STORE>
+// LNB (with the LayerNorm on the row load, ln.gamma != NULL): the epilogue carries dy2 through the LayerNorm backward as well -- DY receives the
+// gradient of the LayerNorm INPUT and ln_partials [gridDim.x][2 C] this workgroup's column sums (dgamma | dbeta) -- see the epilogue.
+template <int C, int SUB, int WAVES, int NSTAGES, bool STORE, bool LNB = false>
 __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ D,
                                                                       const float* __restrict__ rowscale, int64_t rows_per_group,
                                                                       const void* __restrict__ BW, const float* __restrict__ b1,
                                                                       bf16_t* __restrict__ Gout, bf16_t* __restrict__ DHout,
-                                                                      bf16_t* __restrict__ DY, int64_t M, MlpLayerNorm ln) {
+                                                                      bf16_t* __restrict__ DY, int64_t M, MlpLayerNorm ln,
+                                                                      float* __restrict__ ln_partials) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
     constexpr int HID = G::HID, KK = G::KK, CB = G::CB, IMG = G::IMG, SLAB = G::SLAB, STAGE = G::STAGE, NST = G::NST, NS = G::NS;
     constexpr int STORES = STORE ? 4 * SUB : 0;         // 16-byte global stores per wavefront and ring stage (G, dH: two each per slab)
@@ -449,12 +452,12 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
     float* const slab = reinterpret_cast<float*>(smem + wid * OUT_SLAB);
     const int er = lane >> 1, eh = lane & 1;
     const int64_t m = m0 + er;
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
+    // lane (er, eh) <- columns 32 cb + 16 eh .. + 15 of row er of the wavefront's dy2 block (the slab is wave-private; LDS operations of a
+    // wavefront complete in order)
+    auto exchange = [&](int cb, float* v) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             *reinterpret_cast<float4*>(slab + r * 36 + 8 * i + 4 * h) = make_float4(acc[cb][4 * i], acc[cb][4 * i + 1], acc[cb][4 * i + 2], acc[cb][4 * i + 3]);
-        float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(slab + er * 36 + 16 * eh + 4 * i);
@@ -463,10 +466,113 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
             v[4 * i + 2] = t.z;
             v[4 * i + 3] = t.w;
         }
-        if (m < M) {
-            const int c0 = 32 * cb + 16 * eh;
-            store8<bf16_t>(DY + m * C + c0, v);
-            store8<bf16_t>(DY + m * C + c0 + 8, v + 8);
+    };
+    if constexpr (!LNB) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            float v[16];
+            exchange(cb, v);
+            if (m < M) {
+                const int c0 = 32 * cb + 16 * eh;
+                store8<bf16_t>(DY + m * C + c0, v);
+                store8<bf16_t>(DY + m * C + c0 + 8, v + 8);
+            }
+        }
+    } else {
+        // LayerNorm backward on the rows while they are here (keras LayerNormalization, the arithmetic of layernorm_bwd_kernel in norm.hip):
+        //   t = dy2 * gamma,  dy1 = rstd * (t - mean_c(t) - xhat * mean_c(t * xhat)),  dgamma += dy2 * xhat,  dbeta += dy2   (column sums)
+        // Two passes over the column blocks (the accumulators stay in registers, so the exchange is simply repeated): row sums first, then the
+        // outputs; the column sums go through the same slab -- a lane adds up 16 rows of one column, halves meet by one swap, wavefronts in
+        // wavefront order -- and leave as ONE partial row per workgroup for the fixed-order reduction: no atomics, bit-reproducible (the
+        // LayerNorm backward kernel this replaces combines its lanes by LDS float atomics).
+        // (every global operand of the epilogue is requested up front -- the row's LayerNorm input as raw bf16, its statistics, gamma through
+        // LDS: loaded where they are used, the 2 x CB dependent round trips cost 26 us per launch, more than the LayerNorm kernel they replace)
+        float* const lnacc = reinterpret_cast<float*>(smem + WAVES * OUT_SLAB);      // [WAVES][2][C]: inside the ring, which is free by now
+        float* const gam_s = lnacc + WAVES * 2 * C;                                  // [C]
+        const int64_t mr = m < M ? m : M - 1;
+        bf16x8 yraw[CB][2];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            yraw[cb][0] = *reinterpret_cast<const bf16x8*>(Y + mr * C + 32 * cb + 16 * eh);
+            yraw[cb][1] = *reinterpret_cast<const bf16x8*>(Y + mr * C + 32 * cb + 16 * eh + 8);
+        }
+        const float mean = ln.mean[mr], rstd = ln.rstd[mr];
+        for (int i = tid; i < WAVES * 2 * C; i += 64 * WAVES) lnacc[i] = 0.f;      // (an inactive wavefront's row stays zero)
+        for (int i = tid; i < C; i += 64 * WAVES) gam_s[i] = ln.gamma[i];
+        __syncthreads();
+        const bool live = active && m < M;
+        float s1 = 0.f, s2 = 0.f;
+        auto xhat16 = [&](int cb, float* xh) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                xh[u] = ((float)yraw[cb][0][u] - mean) * rstd;
+                xh[8 + u] = ((float)yraw[cb][1][u] - mean) * rstd;
+            }
+        };
+        auto gamma16 = [&](int c0, float* gm) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(gam_s + c0 + 4 * i);
+                gm[4 * i] = t.x, gm[4 * i + 1] = t.y, gm[4 * i + 2] = t.z, gm[4 * i + 3] = t.w;
+            }
+        };
+        if (active) {
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int c0 = 32 * cb + 16 * eh;
+                float v[16], xh[16], gm[16];
+                exchange(cb, v);
+                xhat16(cb, xh);
+                gamma16(c0, gm);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const float t = v[u] * gm[u];
+                    s1 += t;
+                    s2 = fmaf(t, xh[u], s2);
+                }
+            }
+            s1 += __shfl_xor(s1, 1);      // the two lanes of a row
+            s2 += __shfl_xor(s2, 1);
+            s1 *= 1.f / (float)C;
+            s2 *= 1.f / (float)C;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const int c0 = 32 * cb + 16 * eh;
+                float v[16], xh[16], gm[16], o[16];
+                exchange(cb, v);
+                xhat16(cb, xh);
+                gamma16(c0, gm);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (!live) v[u] = 0.f;      // rows past M add nothing to the column sums
+                    o[u] = rstd * (v[u] * gm[u] - s1 - xh[u] * s2);
+                }
+                if (live) {
+                    store8<bf16_t>(DY + m * C + c0, o);
+                    store8<bf16_t>(DY + m * C + c0 + 8, o + 8);
+                }
+                // column sums of dy2 * xhat (q = 0) and dy2 (q = 1) over the wavefront's 32 rows
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<float4*>(slab + er * 36 + 16 * eh + 4 * i) =
+                            q == 0 ? make_float4(v[4 * i] * xh[4 * i], v[4 * i + 1] * xh[4 * i + 1], v[4 * i + 2] * xh[4 * i + 2], v[4 * i + 3] * xh[4 * i + 3])
+                                   : make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+                    float cs = 0.f;
+#pragma unroll
+                    for (int rr = 0; rr < 16; ++rr) cs += slab[(16 * h + rr) * 36 + r];      // lane (r = column, h = row half)
+                    cs += __shfl_xor(cs, 32);
+                    if (h == 0) lnacc[(wid * 2 + q) * C + 32 * cb + r] = cs;      // this wavefront's row: no atomics, the sum below is ordered
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * C; i += 64 * WAVES) {
+            float t = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) t += lnacc[wv * 2 * C + i];      // wavefront order: bit-reproducible
+            ln_partials[(int64_t)blockIdx.x * 2 * C + i] = t;
         }
     }
 }
@@ -536,18 +642,19 @@ int launch_mlp_fwd(const void* y2, const void* FW, const float* b1, const float*
     return iseg_check_launch("iseg_convnext_mlp_fwd");
 }
 
-template <int C, int SUB, int WAVES, int NSTAGES, bool STORE>
+template <int C, int SUB, int WAVES, int NSTAGES, bool STORE, bool LNB = false>
 int launch_mlp_bwd(const void* y2, const void* dbr, const float* rowscale, int64_t rows_per_group, const void* BW, const float* b1, void* g,
-                   void* dh, void* dy2, int64_t M, const MlpLayerNorm& ln, hipStream_t s) {
+                   void* dh, void* dy2, int64_t M, const MlpLayerNorm& ln, hipStream_t s, float* ln_partials = nullptr) {
     using G = MlpGeom<C, SUB, WAVES, 3, NSTAGES>;
+    static_assert(!LNB || G::RING >= WAVES * OUT_SLAB + (WAVES * 2 + 1) * C * 4, "the column sums and gamma sit behind the epilogue slabs inside the ring");
     static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE, LNB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
     }();
     (void)raised;
     const int grid = (int)ceil_div64(M, 32 * WAVES);
-    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2,
-                       (const bf16_t*)dbr, rowscale, rows_per_group, BW, b1, (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M, ln);
+    hipLaunchKernelGGL((convnext_mlp_bwd_kernel<C, SUB, WAVES, NSTAGES, STORE, LNB>), dim3(grid), dim3(64 * WAVES), G::LDS, s, (const bf16_t*)y2,
+                       (const bf16_t*)dbr, rowscale, rows_per_group, BW, b1, (bf16_t*)g, (bf16_t*)dh, (bf16_t*)dy2, M, ln, ln_partials);
     return iseg_check_launch("iseg_convnext_mlp_bwd");
 }
 
@@ -634,4 +741,41 @@ extern "C" int iseg_convnext_mlp_bwd_data(const void* y2, const float* mean, con
     const MlpLayerNorm ln{mean ? ln_gamma : nullptr, ln_beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f};
     if (C == 96) return launch_mlp_bwd<96, 2, 8, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, ln, stream);
     return launch_mlp_bwd<192, 1, 4, 3, false>(y2, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy2, M, ln, stream);
+}
+
+static int64_t mlp_bwd_blocks(int64_t M, int C) { return ceil_div64(M, 32 * (C == 96 ? 8 : 4)); }
+
+extern "C" size_t iseg_convnext_mlp_bwd_data_ln_workspace_bytes(int64_t M, int C) {
+    return (C == 96 || C == 192) && M > 0 ? (size_t)mlp_bwd_blocks(M, C) * 2 * C * sizeof(float) : 0;
+}
+
+extern "C" int iseg_convnext_mlp_bwd_data_ln(const void* y1, const float* mean, const float* rstd, const float* ln_gamma, const float* ln_beta,
+                                             const void* dout, const float* rowscale, int64_t rows_per_group, const void* bw_tiled,
+                                             const float* b1, void* dy1, float* dln_gamma, float* dln_beta, int64_t M, int C, int dtype,
+                                             void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dtype == ISEG_BF16 && (C == 96 || C == 192), "iseg_convnext_mlp_bwd_data_ln: bf16 storage with C = 96 or 192 only (C = %d, dtype = %d)", C, dtype);
+    ISEG_REQUIRE(y1 && mean && rstd && ln_gamma && ln_beta && dout && bw_tiled && b1 && dy1 && dln_gamma && dln_beta && M > 0,
+                 "iseg_convnext_mlp_bwd_data_ln: null operand or empty problem");
+    ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_convnext_mlp_bwd_data_ln: rowscale needs rows_per_group > 0");
+    ISEG_REQUIRE((((uintptr_t)y1 | (uintptr_t)dout | (uintptr_t)bw_tiled | (uintptr_t)b1 | (uintptr_t)dy1 | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0,
+                 "iseg_convnext_mlp_bwd_data_ln: operands must be 16-byte aligned");
+    const size_t need = iseg_convnext_mlp_bwd_data_ln_workspace_bytes(M, C);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_convnext_mlp_bwd_data_ln: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const MlpLayerNorm ln{ln_gamma, ln_beta, const_cast<float*>(mean), const_cast<float*>(rstd), 0.f};
+    // dgamma | dbeta: the workgroups' partial rows, summed in fixed order into the gradient buffers (queued when the caller defers reductions)
+    float* partials = (float*)ws;
+    float* const arena = iseg_deferred_partials(need, dln_gamma, dln_beta, 1, stream);
+    if (arena) partials = arena;
+    const int rc = C == 96 ? launch_mlp_bwd<96, 2, 8, 3, false, true>(y1, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy1, M, ln,
+                                                                       stream, partials)
+                           : launch_mlp_bwd<192, 1, 4, 3, false, true>(y1, dout, rowscale, rows_per_group, bw_tiled, b1, nullptr, nullptr, dy1, M, ln,
+                                                                        stream, partials);
+    if (rc != ISEG_OK) return rc;
+    const int blocks = (int)mlp_bwd_blocks(M, C);
+    if (arena) iseg_deferred_push(partials, blocks, 2 * C, 2 * C, dln_gamma, dln_beta, C, 1.f, stream);
+    else launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, dln_gamma, dln_beta, C, 0, 1.f, 1, stream);
+    return iseg_check_launch("iseg_convnext_mlp_bwd_data_ln");
 }

@@ -948,6 +948,7 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 _BATCHED_PREP = os.environ.get("ISEG_BATCHED_PREP", "1") == "1"      # 0: per-block prep launches (A/B measurements)
 _MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: LayerNorm of the fused stages as its own kernel (A/B measurements)
+_MLP_LN_BWD_FUSED = os.environ.get("ISEG_MLP_LN_BWD_FUSED", "1") == "1"      # 0: LayerNorm backward of the fused stages as its own kernel (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
 
@@ -1027,15 +1028,21 @@ class _ConvNeXtBlockFn(Function):
             # (csrc/mlp_wgrad.hip) -- replaces rowscale + colsum + chain + two weight-gradient GEMMs + their split-K sums + layerscale_grads
             bw = h
             yop, ln = (y1.reshape(M, C), (mean, rstd, p.ln_gamma.data, p.ln_beta.data)) if ctx.ln_on_load else (y2, None)
-            dy2 = K.convnext_mlp_bwd_data(yop, do2, bw, p.b1.data, dp_mask, H * W, ln=ln)
+            dy1 = dy2 = None
+            if ln is not None and _MLP_LN_BWD_FUSED:      # the chain kernel's epilogue carries the rows through the LayerNorm backward too
+                dy1 = K.convnext_mlp_bwd_data_ln(yop, do2, bw, p.b1.data, ln, _grad(p.ln_gamma), _grad(p.ln_beta), dp_mask, H * W)
+            else:
+                dy2 = K.convnext_mlp_bwd_data(yop, do2, bw, p.b1.data, dp_mask, H * W, ln=ln)
             side.run(lambda: K.convnext_mlp_wgrad(yop, do2, bw, p.b1.data, p.w2.data, p.b2.data, p.gamma.data if p.gamma is not None else None,
                                                   _grad(p.w1), _grad(p.b1), _grad(p.w2), _grad(p.b2),
                                                   _grad(p.gamma) if p.gamma is not None else None, dp_mask, H * W, ln=ln), yop, do2)
             del h, bw
         else:
+            dy1 = None
             dy2 = _ConvNeXtBlockFn._mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc)
             del h, g
-        dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
+        if dy1 is None:
+            dy1 = K.layernorm_bwd(dy2, y1.reshape(M, C), p.ln_gamma.data, mean, rstd, _grad(p.ln_gamma), _grad(p.ln_beta))
         dy1 = dy1.reshape(N, H, W, C)
         side.run(lambda: K.dwconv2d_bwd_weight(xc, dy1, _grad(p.dw_kernel).reshape(Kk * Kk, C), _grad(p.dw_bias), Kk, dil, pad, pad), xc, dy1)
         dx = None

@@ -286,6 +286,20 @@ def convnext_mlp_bwd_data(y, dout, bw_tiled, b1, rowscale=None, rows_per_group=0
     return dy2
 
 
+def convnext_mlp_bwd_data_ln(y1, dout, bw_tiled, b1, ln, dln_gamma, dln_beta, rowscale=None, rows_per_group=0):
+    """convnext_mlp_bwd_data carried through the LayerNorm in front of the MLP: returns the gradient of the LayerNorm INPUT y1 and adds the
+    LayerNorm parameter gradients to dln_gamma / dln_beta; ln = (mean, rstd, ln_gamma, ln_beta)"""
+    _require_cuda(y1, dout, bw_tiled, dln_gamma, dln_beta)
+    M, Cc = y1.shape
+    dy1 = torch.empty((M, Cc), dtype=y1.dtype, device=y1.device)
+    mean, rstd, lng, lnb = ln
+    need = _hip.lib().iseg_convnext_mlp_bwd_data_ln_workspace_bytes(M, Cc)
+    ws, wsb = workspace(need, y1.device)
+    _hip.call("iseg_convnext_mlp_bwd_data_ln", ptr(y1), ptr(mean), ptr(rstd), ptr(lng), ptr(lnb), ptr(dout), ptr(rowscale), int(rows_per_group),
+              ptr(bw_tiled), ptr(b1), ptr(dy1), ptr(dln_gamma), ptr(dln_beta), M, Cc, dt(y1), ptr(ws), wsb, stream())
+    return dy1
+
+
 def convnext_mlp_wgrad(y, dout, bw_tiled, b1, W2, b2, gamma, dW1, db1, dW2, db2, dgamma, rowscale=None, rows_per_group=0, ln=None):
     """all parameter gradients of the fused MLP accumulated into dW1 / db1 / dW2 / db2 / dgamma (csrc/mlp_wgrad.hip); ln = (mean, rstd,
     ln_gamma, ln_beta) makes `y` the LayerNorm input"""

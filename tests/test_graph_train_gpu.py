@@ -70,11 +70,13 @@ def test_seed_offset_equals_shifted_seed(cuda):
     assert not torch.equal(got[0], K.dropout(x, 0.3, seed))
 
 
-@pytest.mark.parametrize("optimizer,loss_tol,weight_tol", [("adamw", 2e-3, 0.5), ("sgd", 5e-4, 0.03)])
+@pytest.mark.parametrize("optimizer,loss_tol,weight_tol", [("adamw", 2e-3, 0.5), ("sgd", 5e-4, 0.08)])
 def test_graphed_train_steps_follow_eager(cuda, optimizer, loss_tol, weight_tol):
     """AdamW: the flagship's optimizer (its sign-like early steps amplify the last-bit run-to-run differences of the float-atomic reductions,
     so the weights of two EAGER runs already sit ~0.15 of their movement apart: only the loss curve and the schedule are tight there);
-    SGD with momentum: no amplification, the weights must agree closely too"""
+    SGD with momentum: no such amplification, the weights must agree closely too -- closely = the eager run-to-run band: the remaining LDS
+    float atomics (BatchNorm / depthwise / column-sum parameter gradients) leave two eager runs 0.03-0.05 of their weight movement apart after
+    nine steps about one time in three, and bit-identical the other times"""
     from iseg_amd.data import synthetic_batch
 
     OPTIMIZER[0] = optimizer

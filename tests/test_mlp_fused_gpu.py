@@ -245,3 +245,44 @@ def test_convnext_mlp_layernorm_on_load_matches_the_separate_kernel(cuda, C, M):
     want_d = K.convnext_mlp_bwd_data(y2, dout, bw, b1.cuda(), rs, rpg)
     got_d = K.convnext_mlp_bwd_data(y1b, dout, bw, b1.cuda(), rs, rpg, ln=(mean, rstd, lng, lnb))
     assert (got_d.float() - want_d.float()).abs().max().item() < 2e-2 * max(1.0, want_d.float().abs().max().item())
+
+
+@pytest.mark.parametrize("C", [96, 192])
+@pytest.mark.parametrize("M", [256, 1000 + 37, 4096 + 8])
+def test_convnext_mlp_chain_through_the_layernorm_backward(cuda, C, M):
+    """iseg_convnext_mlp_bwd_data_ln: the chain kernel's epilogue carries dy2 through the LayerNorm backward (gradient of the LayerNorm input,
+    dgamma / dbeta as per-workgroup partial rows summed in fixed order) -- against the chain kernel followed by the LayerNorm backward kernel,
+    and against the fp64 formula on the chain's dy2"""
+    from iseg_amd import kernels as K
+
+    y1, _, W1, b1, W2, b2, gamma = _inputs(M, C, 77 + C + M)
+    g = torch.Generator().manual_seed(19)
+    lng, lnb = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.2).cuda()
+    bf = torch.bfloat16
+    y1b = (y1 * 1.7 + 0.3).to(bf).cuda()
+    rs = torch.tensor([0.5, 1.25], device="cuda")
+    rpg = -(-M // 2)
+    _, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda(), backward=True)
+    _, mean, rstd = K.layernorm_fwd(y1b, lng, lnb, 1e-6)
+    ln = (mean, rstd, lng, lnb)
+    dout = torch.randn(M, C, generator=torch.Generator().manual_seed(4)).to(bf).cuda()
+    dy2 = K.convnext_mlp_bwd_data(y1b, dout, bw, b1.cuda(), rs, rpg, ln=ln)
+    dg_want, db_want = torch.full((C,), 0.25, device="cuda"), torch.full((C,), -0.5, device="cuda")
+    want = K.layernorm_bwd(dy2, y1b, lng, mean, rstd, dg_want, db_want)
+    dg, db = torch.full((C,), 0.25, device="cuda"), torch.full((C,), -0.5, device="cuda")      # (accumulated into: the gradient buffers are live)
+    got = K.convnext_mlp_bwd_data_ln(y1b, dout, bw, b1.cuda(), ln, dg, db, rs, rpg)
+    # fp64 formula on the bf16-rounded dy2 the separate route hands over (the fused route keeps fp32 rows: differences are bf16 roundings of dy2)
+    d, x = dy2.double().cpu(), y1b.double().cpu()
+    xh = (x - mean.double().cpu()[:, None]) * rstd.double().cpu()[:, None]
+    t = d * lng.double().cpu()
+    ref = rstd.double().cpu()[:, None] * (t - t.mean(1, keepdim=True) - xh * (t * xh).mean(1, keepdim=True))
+    scale = max(1.0, ref.abs().max().item())
+    assert (got.double().cpu() - ref).abs().max().item() < 2e-2 * scale
+    assert (got.float() - want.float()).abs().max().item() < 2e-2 * scale
+    dg_ref, db_ref = (d * xh).sum(0) + 0.25, d.sum(0) - 0.5
+    for a, b_, r in ((dg, dg_want, dg_ref), (db, db_want, db_ref)):
+        tol = 5e-3 * max(1.0, r.abs().max().item())
+        assert (a.double().cpu() - r).abs().max().item() < tol and (a - b_).abs().max().item() < tol
+    dg2, db2 = torch.full((C,), 0.25, device="cuda"), torch.full((C,), -0.5, device="cuda")
+    got2 = K.convnext_mlp_bwd_data_ln(y1b, dout, bw, b1.cuda(), ln, dg2, db2, rs, rpg)
+    assert torch.equal(got, got2) and torch.equal(dg, dg2) and torch.equal(db, db2)      # no atomics anywhere: bit-reproducible
