@@ -24,7 +24,7 @@ def test_evaluate_matches_oracle_miou_and_loss(cuda):
     model._iseg_store = ParamStore(list(model.parameters()))
     randomize_parameters(model, 2)
     data = synthetic_dataset(3, 64, 64, seed=11)      # batch 2 -> batches of 2, 1 (drop_remainder=False)
-    scales = [0.75, 1.0]
+    scales = [0.75, 1.0]      # (every scale x flip is one more fp64 oracle forward per image on the host)
     miou = evaluate(Strategy(one_device=True), model, data, batch_size=2, num_class=21, ignore_label=255, scale_rates=scales, flip=True,
                     val_image_count=3, verbose=0)
     w = OM.export_weights(model)
