@@ -270,6 +270,11 @@ size_t iseg_layerscale_grads_workspace_bytes(int K, int N);
 int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S, float* dW2,
                           float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
                           iseg_stream_t stream);
+/* The same from the UNREDUCED split-K slabs of the product Z = g^T dout (iseg_gemm with defer_reduce on an orientation that carries the
+ * ones-row: slabs [nslabs][K + 1][N] fp32, row K = column sums of dout): Z and S are formed in slab order while they are read, so the slab-sum
+ * launch and the Z tensor disappear.  N % 4 == 0. */
+int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2, float* dgamma,
+                                float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* ---------------------------------------------------------------------------------------------------------
  * tf.image.resize (half-pixel, no antialias): utils/common.py:107-134 resize_image
  * --------------------------------------------------------------------------------------------------------- */

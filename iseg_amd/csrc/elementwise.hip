@@ -416,6 +416,63 @@ __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __r
     }
 }
 
+// The same bookkeeping straight from the split-K slabs of the weight-gradient product Z = g^T dout (iseg_gemm with a deferred reduction:
+// slabs [nslabs][K + 1][N] fp32, row K = the virtual ones-row = column sums of dout): Z and S are summed in slab order while they are loaded,
+// so neither the slab-sum launch nor the Z tensor exists.  A lane owns four consecutive columns (16-byte loads), blocks are 16 columns-quads x
+// 16 row lanes over a strip of rows; partial column dots per block row as in the kernel above.
+__global__ __launch_bounds__(256) void layerscale_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
+                                                               const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                               const float* __restrict__ b2, float* __restrict__ dW2, float* __restrict__ db2,
+                                                               float* __restrict__ partials, int Kdim, int Ndim, int accumulate) {
+    __shared__ float4 red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int n = (blockIdx.x * 16 + tx) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < Ndim) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + n);
+        for (int k = blockIdx.y * 16 + ty; k < Kdim; k += gridDim.y * 16) {
+            const int64_t o = (int64_t)k * Ndim + n;
+            float4 z = *reinterpret_cast<const float4*>(slabs + o);
+            for (int q = 1; q < nslabs; ++q) {      // slab order: the sum the reduction kernel would have formed
+                const float4 t = *reinterpret_cast<const float4*>(slabs + q * slab_stride + o);
+                z.x += t.x, z.y += t.y, z.z += t.z, z.w += t.w;
+            }
+            const float4 w = *reinterpret_cast<const float4*>(W2 + o);
+            s.x = fmaf(w.x, z.x, s.x), s.y = fmaf(w.y, z.y, s.y), s.z = fmaf(w.z, z.z, s.z), s.w = fmaf(w.w, z.w, s.w);
+            float4 v = make_float4(z.x * g.x, z.y * g.y, z.z * g.z, z.w * g.w);
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(dW2 + o);
+                v.x += old.x, v.y += old.y, v.z += old.z, v.w += old.w;
+            }
+            *reinterpret_cast<float4*>(dW2 + o) = v;
+        }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < Ndim) {
+        float4 part = red[0][tx];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) part.x += red[i][tx].x, part.y += red[i][tx].y, part.z += red[i][tx].z, part.w += red[i][tx].w;
+        if (blockIdx.y == 0) {      // the S terms ride the first partial row (S = the ones-row of the slabs, summed in slab order)
+            const int64_t o = (int64_t)Kdim * Ndim + n;
+            float4 S = *reinterpret_cast<const float4*>(slabs + o);
+            for (int q = 1; q < nslabs; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(slabs + q * slab_stride + o);
+                S.x += t.x, S.y += t.y, S.z += t.z, S.w += t.w;
+            }
+            const float4 g = *reinterpret_cast<const float4*>(gamma + n), b = *reinterpret_cast<const float4*>(b2 + n);
+            part.x = fmaf(b.x, S.x, part.x), part.y = fmaf(b.y, S.y, part.y), part.z = fmaf(b.z, S.z, part.z), part.w = fmaf(b.w, S.w, part.w);
+            float4 dbv = make_float4(g.x * S.x, g.y * S.y, g.z * S.z, g.w * S.w);
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(db2 + n);
+                dbv.x += old.x, dbv.y += old.y, dbv.z += old.z, dbv.w += old.w;
+            }
+            *reinterpret_cast<float4*>(db2 + n) = dbv;
+        }
+        *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.y * Ndim + n) = part;
+    }
+}
+
 static int layerscale_ksplits(int K) {
     int p = K / 32;
     if (p > 64) p = 64;
@@ -736,7 +793,10 @@ extern "C" int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, hi
 }
 
 extern "C" size_t iseg_layerscale_grads_workspace_bytes(int K, int N) {
-    return (size_t)layerscale_ksplits(K) * N * sizeof(float);
+    int p = K / 16;      // (the slab form's finer row strips; the tensor form uses the first layerscale_ksplits(K) rows of it)
+    if (p > 128) p = 128;
+    if (p < layerscale_ksplits(K)) p = layerscale_ksplits(K);
+    return (size_t)p * N * sizeof(float);
 }
 
 extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S,
@@ -756,6 +816,32 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
     if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
     else launch_reduce_rows((const float*)ws, P, N, 0, 1, N, dgamma, nullptr, N, 0, 1.f, accumulate, stream);
     return iseg_check_launch("iseg_layerscale_grads");
+}
+
+extern "C" int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                           float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                           hipStream_t stream) {
+    ISEG_REQUIRE(slabs && nslabs >= 1 && W2 && b2 && gamma && dW2 && dgamma && db2, "iseg_layerscale_grads_slabs: null pointer");
+    ISEG_REQUIRE(N % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)W2 | (uintptr_t)b2 | (uintptr_t)gamma | (uintptr_t)dW2 | (uintptr_t)db2) & 15) == 0,
+                 "iseg_layerscale_grads_slabs: N %% 4 == 0 and 16-byte aligned operands");
+    // (one row strip of 16 per block row where the partial buffer allows it: 13 slab loads per element are latency, more lanes hide it --
+    // 1536 x 384 from 13 slabs: 17.7 us with K / 32 block rows)
+    int P = K / 16;
+    if ((size_t)P * N * sizeof(float) > ws_bytes) P = layerscale_ksplits(K);
+    if (P > 128) P = 128;
+    if (P < 1) P = 1;
+    const size_t need = (size_t)P * N * sizeof(float);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_layerscale_grads_slabs: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    float* const arena = iseg_deferred_partials(need, dgamma, nullptr, accumulate, stream);
+    if (arena) ws = arena;
+    hipLaunchKernelGGL(layerscale_slabs_kernel, dim3((N / 4 + 15) / 16, P), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2, gamma, b2,
+                       dW2, db2, (float*)ws, K, N, accumulate);
+    if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
+    else launch_reduce_rows((const float*)ws, P, N, 0, 1, N, dgamma, nullptr, N, 0, 1.f, accumulate, stream);
+    return iseg_check_launch("iseg_layerscale_grads_slabs");
 }
 
 extern "C" int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, hipStream_t stream) {

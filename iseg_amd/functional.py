@@ -948,6 +948,7 @@ def concat(xs):
 # ---------------------------------------------------------------------------------------------------------
 _BATCHED_PREP = os.environ.get("ISEG_BATCHED_PREP", "1") == "1"      # 0: per-block prep launches (A/B measurements)
 _MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: LayerNorm of the fused stages as its own kernel (A/B measurements)
+_LAYERSCALE_FROM_SLABS = os.environ.get("ISEG_LAYERSCALE_FROM_SLABS", "1") == "1"      # 0: slab sum + Z tensor + layer-scale kernel (A/B measurements)
 _MLP_LN_BWD_FUSED = os.environ.get("ISEG_MLP_LN_BWD_FUSED", "1") == "1"      # 0: LayerNorm backward of the fused stages as its own kernel (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
@@ -1078,9 +1079,13 @@ class _ConvNeXtBlockFn(Function):
         # --- side: pw2 + layer scale from Z = g^T dbr and S = colsum(dbr) (no pass over [M,C] for gamma), then dW1 (+ db1)
         def param_grads():
             if p.gamma is not None:
-                Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
-                K.dense_wgrad(g, dbr, Z, accumulate=False, bias_grad=S if s_on_gemm else None)      # Z = gelu(h)^T dbr (+ S from its ones-row)
-                K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+                sl = K.dense_wgrad_slabs(g, dbr) if (s_on_gemm and _LAYERSCALE_FROM_SLABS) else None
+                if sl is not None:      # the layer-scale kernel sums the split-K slabs of Z (and its ones-row S) while it reads them
+                    K.layerscale_grads_slabs(sl[0], sl[1], p.w2.data, p.b2.data, p.gamma.data, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+                else:
+                    Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
+                    K.dense_wgrad(g, dbr, Z, accumulate=False, bias_grad=S if s_on_gemm else None)      # Z = gelu(h)^T dbr (+ S from its ones-row)
+                    K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
             else:
                 K.dense_wgrad(g, dbr, _grad(p.w2))
                 K.axpby(S, _grad(p.b2), 1.0, 1.0, out=_grad(p.b2))

@@ -221,6 +221,43 @@ def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE, b
                 colsum_accumulate=accumulate)
 
 
+def dense_wgrad_slabs(x2d, dy2d):
+    """the weight-gradient product X^T dY with its bias-gradient ones-row, stopped in front of the slab sum: (slabs [n, K + 1, N] fp32, n) for a
+    consumer that sums the split-K slabs while it reads them (layerscale_grads_slabs), or None when the problem is not split / cannot carry
+    the ones-row"""
+    M, K = x2d.shape
+    N = dy2d.shape[1]
+    if not wgrad_can_fuse_bias(x2d) or N % 4 != 0:
+        return None
+    _require_cuda(x2d, dy2d)
+    g = GemmArgs()
+    dummy = torch.empty(1, dtype=torch.float32, device=x2d.device)      # (never written: the problem stops at its slabs)
+    g.A, g.lda, g.a_kcontig = ptr(x2d), x2d.stride(0), 0
+    g.B, g.ldb, g.b_kcontig = ptr(dy2d), dy2d.stride(0), 0
+    g.D, g.ldd = ptr(dummy), N
+    g.M, g.N, g.K = K, N, M
+    g.in_dtype, g.out_dtype = dt(x2d), 0
+    g.alpha, g.accumulate = 1.0, 0
+    g.colsum_out, g.colsum_accumulate = ptr(dummy), 0
+    g.batch, g.batch_inner = 1, 1
+    L = _hip.lib()
+    need = L.iseg_gemm_workspace_bytes(C.byref(g))
+    if need == 0:
+        return None
+    nsplit = need // ((K + 1) * N * 4)
+    kps = -(-(-(-M // nsplit)) // 128) * 128
+    eff = -(-M // kps)
+    slabs = torch.empty(need // 4, dtype=torch.float32, device=x2d.device)      # (its own buffer: the consumer's partials use the workspace)
+    g.defer_reduce = 1
+    timer = KERNEL_TIMER[0]
+    if timer is not None:
+        timer.begin(("gemm", 0, 0, int(K), int(N), int(M), 0, False, False, False, x2d.dtype, torch.float32, True, int(L.iseg_gemm_variant(C.byref(g)))))
+    _hip.check(L.iseg_gemm(C.byref(g), ptr(slabs), need, stream()), "iseg_gemm")
+    if timer is not None:
+        timer.end()
+    return slabs, int(eff)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------------------------
@@ -649,6 +686,15 @@ def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
     need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
     ws, wsb = workspace(need, Z.device)
     _hip.call("iseg_layerscale_grads", ptr(Z), ptr(W2), ptr(b2), ptr(gamma), ptr(S), ptr(dW2), ptr(dgamma), ptr(db2), Kd, Nd,
+              int(accumulate), ptr(ws), wsb, stream())
+
+
+def layerscale_grads_slabs(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, accumulate=True):
+    """layerscale_grads from the unreduced split-K slabs of Z = g^T dout (dense_wgrad_slabs): Z and S = colsum(dout) are summed on load"""
+    Kd, Nd = W2.shape
+    need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
+    ws, wsb = workspace(need, slabs.device)
+    _hip.call("iseg_layerscale_grads_slabs", ptr(slabs), int(nslabs), ptr(W2), ptr(b2), ptr(gamma), ptr(dW2), ptr(dgamma), ptr(db2), Kd, Nd,
               int(accumulate), ptr(ws), wsb, stream())
 
 

@@ -135,3 +135,34 @@ def test_deferred_gradient_reductions_match_immediate_ones(cuda):
         assert torch.allclose(flat, ref, rtol=2e-5, atol=1e-3), (flat - ref).abs().max().item()
         assert torch.allclose(outside, ref_out, rtol=2e-5, atol=1e-3)
     assert not K._DEFER["active"]
+
+
+def test_layerscale_grads_from_split_k_slabs(cuda):
+    """iseg_layerscale_grads_slabs sums the weight-gradient product's split-K slabs (and their ones-row S) while it reads them: same dW2 / dgamma /
+    db2 as slab sum -> Z -> iseg_layerscale_grads, and both against the fp64 formulas of backbones/convnext.py:56-57"""
+    from iseg_amd import kernels as K
+
+    torch.manual_seed(3)
+    M, Kd, Nd = 16384, 1536, 384
+    g = (torch.randn(M, Kd) * 0.5).to(torch.bfloat16).cuda()
+    dbr = (torch.randn(M, Nd) * 0.1).to(torch.bfloat16).cuda()
+    W2, b2, gamma = torch.randn(Kd, Nd).cuda() * 0.05, torch.randn(Nd).cuda() * 0.1, (torch.rand(Nd) + 0.5).cuda()
+    sl = K.dense_wgrad_slabs(g, dbr)
+    assert sl is not None and sl[1] > 1, "the flagship's stage-2 product must be split"
+    outs = []
+    for route in ("slabs", "tensor"):
+        dW2, dg, db = torch.full((Kd, Nd), 0.5, device="cuda"), torch.full((Nd,), -1.0, device="cuda"), torch.full((Nd,), 2.0, device="cuda")
+        if route == "slabs":
+            K.layerscale_grads_slabs(sl[0], sl[1], W2, b2, gamma, dW2, dg, db)
+        else:
+            Z, S = torch.empty(Kd, Nd, device="cuda"), torch.empty(Nd, device="cuda")
+            K.dense_wgrad(g, dbr, Z, accumulate=False, bias_grad=S)
+            K.layerscale_grads(Z, W2, b2, gamma, S, dW2, dg, db)
+        outs.append((dW2, dg, db))
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+    Zr = g.double().cpu().t() @ dbr.double().cpu()
+    Sr = dbr.double().cpu().sum(0)
+    want = (Zr * gamma.double().cpu() + 0.5, (W2.double().cpu() * Zr).sum(0) + b2.double().cpu() * Sr - 1.0, gamma.double().cpu() * Sr + 2.0)
+    for a, r in zip(outs[0], want):
+        assert (a.double().cpu() - r).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item())
