@@ -114,6 +114,9 @@ typedef struct iseg_gemm_args {
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
+/* slabs a deferred split problem really writes ([slab][M (+1 with colsum_out)][N] fp32 in the workspace): <= iseg_gemm_splits, the K range is cut
+ * into multiples of 128 -- for a consumer that sums the slabs itself (iseg_layerscale_grads_slabs) */
+int iseg_gemm_slabs(const iseg_gemm_args* args_h);
 /* which main loop iseg_gemm runs for this problem (profiling labels): 0 = register-staged gemm_bf16_kernel / fp32 kernel,
    1..4 = LDS-DMA pipeline gemm_bf16_dma_kernel with tile 128x64 / 256x128 / 128x128 (2 stages) / 128x128 (3 stages),
    5 = 256x128 persistent (one workgroup per CU walks several tiles), 6 = 256x192 (2 stages) */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "iseg_version": (_i, []),
     "iseg_last_error": (_z, [C.c_char_p, _z]),
     "iseg_gemm_splits": (_i, [C.POINTER(GemmArgs)]),
+    "iseg_gemm_slabs": (_i, [C.POINTER(GemmArgs)]),
     "iseg_gemm_variant": (_i, [C.POINTER(GemmArgs)]),
     "iseg_gemm_workspace_bytes": (_z, [C.POINTER(GemmArgs)]),
     "iseg_gemm": (_i, [C.POINTER(GemmArgs), _p, _z, _p]),

@@ -149,6 +149,15 @@ extern "C" int iseg_gemm_splits(const iseg_gemm_args* g) {
     return choose_split(g, g->in_dtype == ISEG_BF16 ? 128 : 64);
 }
 
+// slabs a split problem really writes: the K range is cut into 128-element multiples, so it can be fewer than iseg_gemm_splits
+extern "C" int iseg_gemm_slabs(const iseg_gemm_args* g) {
+    if (!g) return 0;
+    const int nsplit = iseg_gemm_splits(g);
+    if (nsplit <= 1) return 1;
+    const int64_t kps = ceil_div64(ceil_div64(g->K, nsplit), 128) * 128;
+    return (int)ceil_div64(g->K, kps);
+}
+
 extern "C" int iseg_gemm_variant(const iseg_gemm_args* g) {
     if (!g || g->in_dtype != ISEG_BF16) return 0;
     const int nsplit = iseg_gemm_splits(g);

@@ -244,9 +244,7 @@ def dense_wgrad_slabs(x2d, dy2d):
     need = L.iseg_gemm_workspace_bytes(C.byref(g))
     if need == 0:
         return None
-    nsplit = need // ((K + 1) * N * 4)
-    kps = -(-(-(-M // nsplit)) // 128) * 128
-    eff = -(-M // kps)
+    eff = int(L.iseg_gemm_slabs(C.byref(g)))
     slabs = torch.empty(need // 4, dtype=torch.float32, device=x2d.device)      # (its own buffer: the consumer's partials use the workspace)
     g.defer_reduce = 1
     timer = KERNEL_TIMER[0]
