@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     }
 }
 
-// Wide variant for few, long partial rows (split-K slabs of the big weight gradients: n ~ 10^5..10^6, P <= 32): a lane owns
+// Wide variant for long partial rows (split-K slabs of the big weight gradients, chunk records: n ~ 10^5..10^6, P <= 128): a lane owns
 // four consecutive columns (16-B loads, 1 KiB per wave per row) and walks the P rows in order -- same fixed summation order
 // for every element, no LDS.  Requires pstride % 4 == 0, n % 4 == 0, n0 % 4 == 0 and 16-B aligned bases (checked on the host).
 template <int TAG>
@@ -198,7 +198,10 @@ static inline void launch_reduce_rows(const float* partials, int P, int64_t pstr
                                       float* out0, float* out1, int64_t n0, int64_t bstride_out, float scale, int accumulate,
                                       hipStream_t stream) {
     const bool aligned = (((uintptr_t)partials | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0;
-    if (batch == 1 && P <= 32 && n >= 32768 && n % 4 == 0 && n0 % 4 == 0 && pstride % 4 == 0 && aligned) {
+    // (up to 128 partial rows: the chunk records of the fused-stage weight gradients are 40 / 80 rows of 0.3 M floats -- the 16 x 16 kernel below
+    // reads them in 64-byte segments at 2.8 TB/s; flagship 8.91 -> 8.87 ms.  ISEG_REDUCE_WIDE_MAXP overrides.)
+    static const int wide_max_p = [] { const char* e = getenv("ISEG_REDUCE_WIDE_MAXP"); return e ? atoi(e) : 128; }();
+    if (batch == 1 && P <= wide_max_p && n >= 32768 && n % 4 == 0 && n0 % 4 == 0 && pstride % 4 == 0 && aligned) {
         hipLaunchKernelGGL((reduce_rows_wide_kernel<0>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, partials, P,
                            pstride, n, out0, out1, n0, scale, accumulate);
         return;
