@@ -215,10 +215,22 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ x,
     }
 }
 
-// gradients: dx (fp32, atomics; zero-initialised by the caller), doffset, dmask (written once per (n,h,w,g,p))
+// 2^-40 fixed point (int64) for every input-gradient accumulator of this file: integer adds commute, so atomics give the same bits whatever
+// the order (the reference's default is a deterministic step, core_env.py:39-48).  |v| < 2^23, resolution 9.1e-13.
+constexpr float DCN_FIX = 256.f;                  // 2^8: high word = floor(v * 2^8), low word = fract * 2^32
+constexpr double DCN_UNFIX = 1.0 / 1099511627776.0;      // 2^-40
+__device__ __forceinline__ unsigned long long dcn_to_fixed(float v256) {      // v256 = value * 2^8
+    const float fl = floorf(v256);
+    const int hi = (int)fl;                                     // saturating
+    const unsigned lo = (unsigned)((v256 - fl) * 4294967296.f);
+    return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+
+// gradients: dx accumulated as int64 fixed point by global integer atomics into a zeroed workspace (order-free), converted to fp32 by
+// dcn_unfix_kernel; doffset, dmask written once per (n,h,w,g,p)
 template <class T, int CV>
 __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
-                                                        const T* __restrict__ dy, float* __restrict__ dx, T* __restrict__ doffset,
+                                                        const T* __restrict__ dy, unsigned long long* __restrict__ dx, T* __restrict__ doffset,
                                                         T* __restrict__ dmask, DcnGeom g) {
     const int P = g.kh * g.kw;
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
 #pragma unroll
                     for (int u = 0; u < CV; ++u) {
                         dot = fmaf(d[u], v[u], dot);
-                        atomicAdd(dx + src + gi * g.Cg + c0 + u, d[u] * m * wgt[k]);
+                        atomicAdd(dx + src + gi * g.Cg + c0 + u, dcn_to_fixed(d[u] * m * wgt[k] * DCN_FIX));
                     }
                 }
                 gm = fmaf(wgt[k], dot, gm);
@@ -276,8 +288,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
 // dmask / doffset are log2(LC) shuffles.  The tap geometry is recomputed by each of the LC lanes (cheap ALU).
 template <class T, int LC>
 __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__ x, const T* __restrict__ offset,
-                                                           const T* __restrict__ mask, const T* __restrict__ dy, float* __restrict__ dx,
-                                                           T* __restrict__ doffset, T* __restrict__ dmask, DcnGeom g) {
+                                                           const T* __restrict__ mask, const T* __restrict__ dy,
+                                                           unsigned long long* __restrict__ dx, T* __restrict__ doffset,
+                                                           T* __restrict__ dmask, DcnGeom g) {
     const int P = g.kh * g.kw;
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;          // (pixel, group) items
     const int c = threadIdx.x % LC;
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
                 if (src < 0) continue;        // uniform across the LC lanes of an item
                 const float v = to_f32(x[src + gi * g.Cg + c]);
                 const float dv = d * v;       // this lane's share of sum_c dy[c] * xp[corner][c]
-                atomicAdd(dx + src + gi * g.Cg + c, dm * wgt[k]);
+                atomicAdd(dx + src + gi * g.Cg + c, dcn_to_fixed(dm * wgt[k] * DCN_FIX));
                 gm = fmaf(wgt[k], dv, gm);
                 gpx = fmaf(wpx[k], dv, gpx);
                 gpy = fmaf(wpy[k], dv, gpy);
@@ -341,8 +354,6 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
 // Values are clamped to |v| < 2^23 by the fixed-point conversion (resolution 9.1e-13).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int DCN_TS = 16, DCN_WS = 24;
-constexpr float DCN_FIX = 256.f;                  // 2^8: high word = floor(v * 2^8), low word = fract * 2^32
-constexpr double DCN_UNFIX = 1.0 / 1099511627776.0;      // 2^-40
 
 struct DcnWin {
     int tiles_y, tiles_x;      // output tiles
@@ -354,13 +365,6 @@ __device__ __forceinline__ int dcn_win_x0(const DcnGeom& g, const DcnWin& wn, in
 }
 __device__ __forceinline__ int dcn_win_y0(const DcnGeom& g, const DcnWin& wn, int tx) {
     return (tx * DCN_TS * g.stride * (g.Hin - 2)) / g.Win + wn.c0y - wn.ry;
-}
-
-__device__ __forceinline__ unsigned long long dcn_to_fixed(float v256) {      // v256 = value * 2^8
-    const float fl = floorf(v256);
-    const int hi = (int)fl;                                     // saturating
-    const unsigned lo = (unsigned)((v256 - fl) * 4294967296.f);
-    return ((unsigned long long)(unsigned)hi << 32) | lo;
 }
 
 // bf16 storage (FIX32): the window accumulates 32-bit integers on a per-workgroup power-of-two scale instead -- half the LDS (four workgroups
@@ -572,6 +576,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
     }
 }
 
+__global__ __launch_bounds__(256) void dcn_unfix_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ dx, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = (float)((double)(long long)acc[i] * DCN_UNFIX);
+}
+
 __global__ __launch_bounds__(256) void dcn_zero_kernel(uint4* __restrict__ p, int64_t n16) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -591,15 +599,13 @@ __global__ __launch_bounds__(256) void mul_colsum_partial_kernel(const T* __rest
 }
 
 // the same for C % 8 == 0: a lane owns an 8-channel chunk and every (256 / chunks)-th row, four row loads of both operands in
-// flight per trip; lanes of a chunk meet through LDS atomics (order differs only inside a block's few adders), blocks through the
-// fixed-order partial reduction.  The scalar kernel above ran 56 us per call on InternImage-B (66 calls per step).
+// flight per trip; lanes of a chunk meet through one LDS slab row per row lane summed in row order (no float atomics), blocks through
+// the fixed-order partial reduction.  The scalar kernel above ran 56 us per call on InternImage-B (66 calls per step).
 template <class T>
 __global__ __launch_bounds__(256) void mul_colsum_partial_vec_kernel(const T* __restrict__ a, const T* __restrict__ b, int64_t rows,
                                                                      int C, float* __restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) float lds_mc[];  // [C]
+    extern __shared__ __attribute__((aligned(16))) float lds_mc[];  // [rows per iteration][C]
     const int nch = C / 8;
-    for (int i = threadIdx.x; i < C; i += 256) lds_mc[i] = 0.f;
-    __syncthreads();
     const int tpc = nch < 256 ? nch : 256;
     const int rpi = 256 / tpc;
     const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
@@ -629,11 +635,21 @@ __global__ __launch_bounds__(256) void mul_colsum_partial_vec_kernel(const T* __
                 for (int u = 0; u < 8; ++u) s[u] = fmaf(va[u], vb[u], s[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&lds_mc[c * 8 + u], s[u]);
+            for (int u = 0; u < 8; ++u) lds_mc[(size_t)tr * C + c * 8 + u] = s[u];
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) partials[(int64_t)blockIdx.x * C + i] = lds_mc[i];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        float a = lds_mc[i];
+        for (int t = 1; t < rpi; ++t) a += lds_mc[(size_t)t * C + i];
+        partials[(int64_t)blockIdx.x * C + i] = a;
+    }
+}
+
+static size_t mc_slab_bytes(int C) {
+    const int nch = C / 8;
+    const int tpc = nch < 256 ? nch : 256;
+    return (size_t)(256 / tpc) * C * sizeof(float);
 }
 
 // y[r][c] = x[r][c] * s[c]   (per-channel layer scale in the storage dtype)
@@ -762,9 +778,11 @@ extern "C" size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int
     DcnGeom g;
     if (make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd_workspace_bytes") != ISEG_OK) return 0;
     DcnWin wn;
-    if (!dcn_window(g, &wn)) return 0;
+    const size_t fallback = (size_t)N * H * W * G * Cg * sizeof(unsigned long long);      // int64 accumulators of the general kernels
+    if (!dcn_window(g, &wn)) return fallback;
     size_t so, fo;
-    return dcn_win_bytes(g, wn, &so, &fo);
+    const size_t win = dcn_win_bytes(g, wn, &so, &fo);
+    return win > fallback ? win : fallback;      // (ISEG_DCN_BWD_WIN=0 sends window geometries down the general route too)
 }
 
 extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset,
@@ -815,20 +833,28 @@ extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mas
             hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<8>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, dx_f32, g, wn);
         return iseg_check_launch("iseg_dcnv3_bwd");
     }
-    // fallback (other group widths, footprints wider than the window): fp32 atomics into a zeroed dx
+    // general route (other group widths, footprints wider than the window): int64 fixed-point atomics into a zeroed workspace, then one
+    // conversion pass -- order-free like the window kernels
+    const int64_t nel = (int64_t)N * H * W * G * Cg;
     {
-        const int64_t n16 = (int64_t)N * H * W * G * Cg * 4 / 16, rem = ((int64_t)N * H * W * G * Cg * 4) % 16;
-        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16 + 1)), dim3(256), 0, stream, (uint4*)dx_f32, n16);
-        if (rem) (void)hipMemsetAsync((char*)dx_f32 + n16 * 16, 0, rem, stream);
+        const size_t need = (size_t)nel * sizeof(unsigned long long);
+        if (!ws || ws_bytes < need) {
+            iseg_set_error("iseg_dcnv3_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        const int64_t n16 = (int64_t)need / 16;
+        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16 + 1)), dim3(256), 0, stream, (uint4*)ws, n16);
+        if (need % 16) (void)hipMemsetAsync((char*)ws + n16 * 16, 0, need % 16, stream);
     }
+    unsigned long long* const acc = (unsigned long long*)ws;
     const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
     const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
 #define DCN_BWD(T, CV)                                                                                                              \
     hipLaunchKernelGGL((dcnv3_bwd_kernel<T, CV>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset,   \
-                       (const T*)mask, (const T*)dy, dx_f32, (T*)doffset, (T*)dmask, g)
+                       (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, g)
 #define DCN_BWD_CL(T, LC)                                                                                                            \
     hipLaunchKernelGGL((dcnv3_bwd_cl_kernel<T, LC>), dim3(lane_blocks(lanes * LC)), dim3(256), 0, stream, (const T*)x,              \
-                       (const T*)offset, (const T*)mask, (const T*)dy, dx_f32, (T*)doffset, (T*)dmask, g)
+                       (const T*)offset, (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, g)
 #define DCN_BWD_CL_ANY(T)                    \
     do {                                     \
         if (Cg == 4) DCN_BWD_CL(T, 4);       \
@@ -850,6 +876,7 @@ extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mas
 #undef DCN_BWD_CL_ANY
 #undef DCN_BWD_CL
 #undef DCN_BWD
+    hipLaunchKernelGGL(dcn_unfix_kernel, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel);
     return iseg_check_launch("iseg_dcnv3_bwd");
 }
 
@@ -955,10 +982,10 @@ extern "C" int iseg_mul_colsum(const void* a, const void* b, int64_t rows, int C
     }
     const bool vec = C % 8 == 0 && ((uintptr_t)a | (uintptr_t)b) % 16 == 0;
     if (vec && dtype == ISEG_BF16)
-        hipLaunchKernelGGL((mul_colsum_partial_vec_kernel<bf16_t>), dim3(blocks), dim3(256), (size_t)C * sizeof(float), stream,
+        hipLaunchKernelGGL((mul_colsum_partial_vec_kernel<bf16_t>), dim3(blocks), dim3(256), mc_slab_bytes(C), stream,
                            (const bf16_t*)a, (const bf16_t*)b, rows, C, (float*)ws);
     else if (vec)
-        hipLaunchKernelGGL((mul_colsum_partial_vec_kernel<float>), dim3(blocks), dim3(256), (size_t)C * sizeof(float), stream,
+        hipLaunchKernelGGL((mul_colsum_partial_vec_kernel<float>), dim3(blocks), dim3(256), mc_slab_bytes(C), stream,
                            (const float*)a, (const float*)b, rows, C, (float*)ws);
     else if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((mul_colsum_partial_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)a, (const bf16_t*)b,

@@ -318,12 +318,10 @@ template <class T, int K, int CV, bool DIL1>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                 float* __restrict__ partials, int N, int H, int W, int C,
                                                                 int dil, int pad_t, int pad_l, int gs, int rt, int wseg, int ipl) {
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [(K*K+1)][gs*CV]
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [rt][(K*K+1)][gs*CV]: one slab per item lane, summed in lane order
     const int sc = gs * CV;
     const int slab_c0 = blockIdx.y * sc;
     const int nred = (K * K + 1) * sc;
-    for (int i = threadIdx.x; i < nred; i += blockDim.x) red[i] = 0.f;
-    __syncthreads();
     const int cg = threadIdx.x % gs;
     const int kh = (threadIdx.x / gs) % K;
     const int rl = threadIdx.x / (gs * K);
@@ -431,13 +429,16 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
                 }
             }
         }
+        // no float atomics (the step is bit-reproducible, core_env.py:39-48): lane (cg, kh, rl) owns K taps of slab rl -- every cell of the
+        // rt slabs is written exactly once (lanes that ran out of items store their zeros) -- and the slabs are summed in lane order below
+        float* mine = red + (size_t)rl * nred;
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int u = 0; u < CV; ++u) atomicAdd(&red[(kh * K + j) * sc + cg * CV + u], acc[j][u]);
+            for (int u = 0; u < CV; ++u) mine[(kh * K + j) * sc + cg * CV + u] = acc[j][u];
         if (kh == 0) {
 #pragma unroll
-            for (int u = 0; u < CV; ++u) atomicAdd(&red[K * K * sc + cg * CV + u], accb[u]);
+            for (int u = 0; u < CV; ++u) mine[K * K * sc + cg * CV + u] = accb[u];
         }
     }
     __syncthreads();
@@ -445,7 +446,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     float* out = partials + (int64_t)blockIdx.x * (K * K + 1) * C;
     for (int i = threadIdx.x; i < nred; i += blockDim.x) {
         const int tap = i / sc, c = i % sc;
-        out[(int64_t)tap * C + slab_c0 + c] = red[i];
+        float a = red[i];
+        for (int r = 1; r < rt; ++r) a += red[(size_t)r * nred + i];
+        out[(int64_t)tap * C + slab_c0 + c] = a;
     }
 }
 
@@ -464,10 +467,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_lds_kernel(const T* __r
     const int IH = TH + K - 1, IW = BWW + K - 1;
     T* xt = reinterpret_cast<T*>(smem_bw);                                   // [IH][IW][sc]
     T* dt = xt + (size_t)IH * IW * sc;                                       // [TH][BWW][sc]
-    float* red = reinterpret_cast<float*>(dt + (size_t)TH * BWW * sc);       // [(K*K+1)][sc]
+    float* red = reinterpret_cast<float*>(smem_bw);                          // [rt][(K*K+1)][sc]: over the tiles once the last one is consumed
     const int slab_c0 = blockIdx.y * sc;
     const int nred = (K * K + 1) * sc;
-    for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
     const int cg = threadIdx.x % gs;
     const int kh = (threadIdx.x / gs) % K;
     const int rl = threadIdx.x / (gs * K);
@@ -555,21 +557,24 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_lds_kernel(const T* __r
         }
     }
     __syncthreads();
-    if (worker) {
+    if (worker) {      // one slab per tile-row lane, every cell written once, summed in lane order (no float atomics: bit-reproducible)
+        float* mine = red + (size_t)rl * nred;
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&red[(kh * K + j) * sc + cg * 8 + u], acc[j][u]);
+            for (int u = 0; u < 8; ++u) mine[(kh * K + j) * sc + cg * 8 + u] = acc[j][u];
         if (kh == 0) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) atomicAdd(&red[K * K * sc + cg * 8 + u], accb[u]);
+            for (int u = 0; u < 8; ++u) mine[K * K * sc + cg * 8 + u] = accb[u];
         }
     }
     __syncthreads();
     float* out = partials + (int64_t)blockIdx.x * (K * K + 1) * C;
     for (int i = threadIdx.x; i < nred; i += 256) {
         const int tap = i / sc, c = i % sc;
-        out[(int64_t)tap * C + slab_c0 + c] = red[i];
+        float a = red[i];
+        for (int r = 1; r < rt; ++r) a += red[(size_t)r * nred + i];
+        out[(int64_t)tap * C + slab_c0 + c] = a;
     }
 }
 
@@ -1012,7 +1017,9 @@ static BwGeom bw_geom(int N, int H, int W, int C, int K, int dil, size_t elem) {
         }
         int rt = 256 / (gs * K);
         if (rt > H) rt = H;
-        const size_t bytes = ((size_t)(rt + K - 1) * (BWW + K - 1) + (size_t)rt * BWW) * gs * 8 * elem + (size_t)(K * K + 1) * gs * 8 * 4;
+        const size_t tile_bytes = ((size_t)(rt + K - 1) * (BWW + K - 1) + (size_t)rt * BWW) * gs * 8 * elem;
+        const size_t slab_bytes = (size_t)rt * (K * K + 1) * gs * 8 * 4;      // the per-lane sum slabs reuse the tile area
+        const size_t bytes = tile_bytes > slab_bytes ? tile_bytes : slab_bytes;
         if (rt >= 1 && bytes <= 80 * 1024) {
             g.lds = 1;
             g.cv = 8;
@@ -1122,7 +1129,7 @@ int launch_fwd_cv(const void* x, const float* w, const float* bias, const void* 
 template <class T, int K, int CV>
 void launch_bw(const void* x, const void* dy, float* ws, int N, int H, int W, int C, int dil, int pad_t, int pad_l, const BwGeom& g,
                hipStream_t s) {
-    const size_t lds = (size_t)(K * K + 1) * g.gs * CV * sizeof(float);
+    const size_t lds = (size_t)g.rt * (K * K + 1) * g.gs * CV * sizeof(float);
     if (dil == 1)
         hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, K, CV, true>), dim3(g.bx, g.slabs), dim3(256), lds, s, (const T*)x,
                            (const T*)dy, ws, N, H, W, C, dil, pad_t, pad_l, g.gs, g.rt, g.wseg, g.ipl);

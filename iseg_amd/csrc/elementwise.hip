@@ -129,11 +129,9 @@ __global__ void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, in
 template <class T, int V>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ldx, int64_t bsx,
                                                              float* __restrict__ partials, int64_t rows, int C) {
-    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [C]
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [rows per iteration][C]: one slab row per row lane, summed in row order
     const int b = blockIdx.y;
     const int nch = C / V;
-    for (int i = threadIdx.x; i < C; i += 256) lds_s[i] = 0.f;
-    __syncthreads();
     const int tpc = nch < 256 ? nch : 256;
     const int rpi = 256 / tpc;
     const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
@@ -167,13 +165,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
                     s[0] += to_f32(xb[r * ldx + c]);
                 }
             }
+            // (no float atomics: every cell of slab rows 0..rpi-1 is written exactly once, the sum below runs in row order -- bit-reproducible)
 #pragma unroll
-            for (int u = 0; u < V; ++u) atomicAdd(&lds_s[c * V + u], s[u]);
+            for (int u = 0; u < V; ++u) lds_s[(size_t)tr * C + c * V + u] = s[u];
         }
     }
     __syncthreads();
     float* out = partials + ((int64_t)b * gridDim.x + blockIdx.x) * C;
-    for (int i = threadIdx.x; i < C; i += 256) out[i] = lds_s[i];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        float a = lds_s[i];
+        for (int t = 1; t < rpi; ++t) a += lds_s[(size_t)t * C + i];
+        out[i] = a;
+    }
+}
+
+static size_t colsum_slab_bytes(int C, int V) {
+    const int nch = C / V;
+    const int tpc = nch < 256 ? nch : 256;
+    return (size_t)(256 / tpc) * C * sizeof(float);
 }
 
 static int colsum_blocks(int64_t rows, int C, int V) {
@@ -687,7 +696,7 @@ extern "C" int iseg_colsum(const void* x, int64_t ldx, int64_t batch_stride, int
     }
     float* const arena = batch == 1 ? iseg_deferred_partials(need, out, nullptr, accumulate, stream) : nullptr;      // (see common.h: deferred reductions)
     if (arena) ws = arena;
-    const size_t lds = (size_t)C * sizeof(float);
+    const size_t lds = colsum_slab_bytes(C, V);
 #define COLSUM(T, VV)                                                                                                  \
     hipLaunchKernelGGL((colsum_partial_kernel<T, VV>), dim3(P, batch), dim3(256), lds, stream, (const T*)x, ldx, batch_stride, \
                        (float*)ws, rows, C)

@@ -194,27 +194,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
-    // block-level combine (LDS float atomics; order differs run to run only inside one block's 4*rpw adders)
+    // block-level combine in a FIXED order (bit-reproducible; reference default use_deterministic=True, core_env.py:39-48): the row sub-groups
+    // of a wavefront meet by lane exchanges, then wavefront 0 stores its sums and wavefronts 1..3 add theirs one after the other
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-        const int c = li + i * lpr;
-        if (c < nchunks) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                float a = dg[i][u], b = db[i][u];
-                // combine the rows-per-wave sub-groups first (same channel, lanes li + k*lpr)
-                for (int o = lpr; o < 64; o <<= 1) {
-                    a += __shfl_xor(a, o, 64);
-                    b += __shfl_xor(b, o, 64);
-                }
-                if (sub == 0) {
-                    atomicAdd(&lds_part[c * 8 + u], a);
-                    atomicAdd(&lds_part[C + c * 8 + u], b);
-                }
+        for (int u = 0; u < 8; ++u) {
+            // combine the rows-per-wave sub-groups first (same channel, lanes li + k*lpr)
+            for (int o = lpr; o < 64; o <<= 1) {
+                dg[i][u] += __shfl_xor(dg[i][u], o, 64);
+                db[i][u] += __shfl_xor(db[i][u], o, 64);
             }
         }
     }
-    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+        if (wid == w && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < CPL; ++i) {
+                const int c = li + i * lpr;
+                if (c < nchunks) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        lds_part[c * 8 + u] += dg[i][u];
+                        lds_part[C + c * 8 + u] += db[i][u];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
     float* out = partials + (int64_t)blockIdx.x * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_part[i];
 }
@@ -227,11 +235,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ partials,
                                                        int64_t rows, int C, float* __restrict__ count_out) {
-    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [2][C]
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];  // [rows per iteration][2][C]: one slab row per adder, summed in row order
     const int nchunks = C / 8;
     if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = (float)rows;      // packed[2C]: this replica's element count per channel
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lds_s[i] = 0.f;
-    __syncthreads();
     // thread t handles chunk (t % tpc) of rows (t / tpc) + k*rows_per_iter
     const int tpc = nchunks < 256 ? nchunks : 256;  // threads across channels
     const int rpi = 256 / tpc;                      // rows per iteration per block
@@ -265,16 +271,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
                     q[u] += v[u] * v[u];
                 }
             }
+            float* slab = lds_s + (size_t)tr * 2 * C;      // (every cell of slab rows 0..rpi-1 is written exactly once)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                atomicAdd(&lds_s[c * 8 + u], s[u]);
-                atomicAdd(&lds_s[C + c * 8 + u], q[u]);
+                slab[c * 8 + u] = s[u];
+                slab[C + c * 8 + u] = q[u];
             }
         }
     }
     __syncthreads();
     float* out = partials + (int64_t)blockIdx.x * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_s[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float a = lds_s[i];
+        for (int t = 1; t < rpi; ++t) a += lds_s[(size_t)t * 2 * C + i];
+        out[i] = a;
+    }
 }
 
 // packed[0:C]=sum, [C:2C]=sumsq, [2C]=count  ->  mean/var(biased), then update moving stats
@@ -379,10 +390,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             int64_t ldx, const T* __restrict__ y, int64_t ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ partials, int64_t rows, int C, int relu) {
-    extern __shared__ __attribute__((aligned(16))) float lds_s[];
+    extern __shared__ __attribute__((aligned(16))) float lds_s[];      // [rows per iteration][2][C], as in bn_stats_kernel
     const int nchunks = C / 8;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) lds_s[i] = 0.f;
-    __syncthreads();
     const int tpc = nchunks < 256 ? nchunks : 256;
     const int rpi = 256 / tpc;
     const int tc = threadIdx.x % tpc, tr = threadIdx.x / tpc;
@@ -429,16 +438,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                     q[u] += d[u] * (xv[u] - m[u]) * rs[u];
                 }
             }
+            float* slab = lds_s + (size_t)tr * 2 * C;      // (every cell of slab rows 0..rpi-1 is written exactly once)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                atomicAdd(&lds_s[c * 8 + u], s[u]);
-                atomicAdd(&lds_s[C + c * 8 + u], q[u]);
+                slab[c * 8 + u] = s[u];
+                slab[C + c * 8 + u] = q[u];
             }
         }
     }
     __syncthreads();
     float* out = partials + (int64_t)blockIdx.x * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_s[i];
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float a = lds_s[i];
+        for (int t = 1; t < rpi; ++t) a += lds_s[(size_t)t * 2 * C + i];
+        out[i] = a;
+    }
 }
 
 // dx = gamma*rstd * (dz - sum_dz/n - xhat*sum_dzxhat/n) ; sums[0:C]=sum dz, [C:2C]=sum dz*xhat (already all-reduced)
@@ -600,6 +614,13 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
     return iseg_check_launch("iseg_layernorm_bwd");
 }
 
+// LDS of the two BatchNorm reduction kernels: one [2][C] slab row per row lane of the workgroup
+static size_t bn_slab_bytes(int C) {
+    const int nchunks = C / 8;
+    const int tpc = nchunks < 256 ? nchunks : 256;
+    return (size_t)(256 / tpc) * 2 * C * sizeof(float);
+}
+
 static int bn_blocks(int64_t rows, int C) {
     const int nchunks = C / 8;
     const int tpc = nchunks < 256 ? nchunks : 256;
@@ -623,7 +644,7 @@ extern "C" int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t 
         iseg_set_error("iseg_bn_stats: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const size_t lds = bn_slab_bytes(C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)x, ldx, (float*)ws,
                            rows, C, packed + 2 * C);
@@ -687,7 +708,7 @@ extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
         iseg_set_error("iseg_bn_bwd_reduce: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const size_t lds = bn_slab_bytes(C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)dy, lddy,
                            (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);

@@ -20,7 +20,7 @@ class GraphedCall:
     def __init__(self, fn, warmup=2):
         self.fn = fn
         self.warmup = int(warmup)
-        self.entries = {}      # signature -> [calls so far, graph, static input, static output]
+        self.entries = {}      # signature -> [calls so far, graph, static input, static output, buffer generation at capture]
 
     @staticmethod
     def _signature(x):
@@ -40,26 +40,39 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         return graph, static_in, out
 
+    @staticmethod
+    def _refresh_derived_weights():
+        """The K-contiguous kernel copies (nn.wt) and the ConvNeXt blocks' tiled / layer-scale-folded images (nn.mlp_tiled, nn.w_colscaled) are
+        refreshed by HOST-side version checks; after the warm-up calls the versions match, so the capture holds none of those launches and a
+        replay never passes through the checks again.  After an optimizer step / load_weights / restore_checkpoint they are refreshed here,
+        eagerly, in front of the replay (same stream: ordered).  Returns the generation of the buffers behind them."""
+        from . import nn
+
+        nn.refresh_wt()
+        nn.refresh_prep()
+        return nn.buffers_generation()
+
     def __call__(self, x):
         if not (torch.is_tensor(x) and x.is_cuda):
             raise TypeError("GraphedCall takes one device tensor")
         sig = self._signature(x)
         e = self.entries.get(sig)
         if e is None:
-            e = self.entries[sig] = [0, None, None, None]
+            e = self.entries[sig] = [0, None, None, None, -1]
+        if e[1] is not None and self._refresh_derived_weights() != e[4]:
+            # the buffers the graph points into were re-allocated since the capture (a model dropped or built, a parameter registered):
+            # drop the graph, run this call eagerly and capture again on the next one
+            e[0], e[1], e[2], e[3] = self.warmup, None, None, None
+            with torch.no_grad():
+                return self.fn(x)
         if e[1] is None:
             e[0] += 1
             if e[0] <= self.warmup:      # eager: builds layers, transposed kernel copies, tiling plans
                 with torch.no_grad():
                     return self.fn(x)
             e[1], e[2], e[3] = self._capture(x)
+            e[4] = self._refresh_derived_weights()
         graph, static_in, out = e[1], e[2], e[3]
-        # The K-contiguous kernel copies (nn.wt) are refreshed by a HOST-side version check; after the warm-up calls the versions match, so
-        # the capture holds no transpose launch and a replay never passes through wt() again.  After an optimizer step / load_weights /
-        # restore_checkpoint the copies are refreshed here, eagerly, in front of the replay (same stream: ordered).
-        from . import nn
-
-        nn.refresh_wt()
         static_in.copy_(x)
         graph.replay()
         return out      # (the captured output buffer: valid until the next call with this signature)
@@ -136,7 +149,9 @@ class GraphedTrainStep:
         opt.iterations = it0
         opt._prepared = False
         torch.cuda.current_stream().wait_stream(side)
-        return dict(graph=graph, sx=sx, sy=sy, losses=losses, seed_off=seed_off, counter0=counter0, draws=draws,
+        from . import nn
+
+        return dict(graph=graph, sx=sx, sy=sy, losses=losses, seed_off=seed_off, counter0=counter0, draws=draws, generation=nn.buffers_generation(),
                     off_host=torch.zeros(8, dtype=torch.int64).pin_memory(), off_events=[None] * 8, off_slot=0), eager_losses
 
     def __call__(self, x, y):
@@ -155,6 +170,13 @@ class GraphedTrainStep:
             captured, eager_losses = self._capture(x, y)      # this call's step ran eagerly inside; replays start with the next call
             e.update(captured)
             return eager_losses
+        from . import nn
+
+        if e["generation"] != nn.buffers_generation():
+            # the derived-weight buffers / pointer tables the captured launches point into were re-allocated (another model built or dropped):
+            # this step runs eagerly -- which also rebuilds them -- and the next call captures again
+            self.entries[sig] = dict(calls=self.warmup, graph=None)
+            return self.tm.train_step(x, y)
         return self._replay(e, x, y)
 
     def _replay(self, e, x, y):

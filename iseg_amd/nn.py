@@ -199,6 +199,17 @@ _WEIGHTS_VERSION = [0]
 _WT = {"version": -1, "params": [], "index": {}, "buf": None, "views": [], "table": None, "base": 0, "max_tiles": 0, "ptrs": []}
 
 
+# Generation of the DEVICE BUFFERS behind wt() / mlp_tiled() / w_colscaled(): bumped whenever one of them (or a pointer table) is re-allocated --
+# a model was dropped or added, a parameter registered, a kernel view changed.  A captured HIP graph holds raw pointers into those buffers, so the
+# graph runners (iseg_amd/graphs.py) remember the generation they captured under and capture again when it has moved; replaying across a
+# re-allocation would read and write freed memory without any error.
+_BUFFERS_GENERATION = [0]
+
+
+def buffers_generation():
+    return _BUFFERS_GENERATION[0]
+
+
 def weights_changed():
     """the bf16 compute copies were rewritten (optimizer step, ParamStore.sync_shadow): transposed copies are stale"""
     _WEIGHTS_VERSION[0] += 1
@@ -209,6 +220,7 @@ def _wt_rebuild():
     live = [r for r in _WT["params"] if r() is not None]
     _WT["params"] = live
     _WT["index"] = {id(r()): j for j, r in enumerate(live)}
+    _BUFFERS_GENERATION[0] += 1
     shadows = [r().iseg_compute for r in live]
     if not shadows:
         _WT.update(buf=None, views=[], table=None, ptrs=[], max_tiles=0, version=-1)
@@ -252,6 +264,13 @@ def refresh_wt():
             if r() is not None:
                 wt(r())
                 break
+
+
+def refresh_prep():
+    """the same for the per-update derivations of the ConvNeXt blocks (tiled MLP images, layer-scale-folded kernels): a replayed inference
+    graph reads them without passing through mlp_tiled() / w_colscaled(), whose host-side version check is what refreshes them"""
+    if _PREP["entries"] and _PREP["version"] != _WEIGHTS_VERSION[0]:
+        _prep_refresh()
 
 
 def weights_version():
@@ -318,6 +337,7 @@ def _prep_request(kind, params, make):
         bufs = make()
         _PREP["index"][key] = i = len(live)
         live.append({"key": key, "kind": kind, "refs": [weakref.ref(p) for p in params], "bufs": bufs})
+        _BUFFERS_GENERATION[0] += 1
         _PREP["table"] = None
         _PREP["version"] = -1
     if _PREP["version"] != _WEIGHTS_VERSION[0]:
@@ -353,6 +373,7 @@ def _prep_refresh():
     if not rows:
         return
     if _PREP["table"] is None or _PREP["ptrs"] != rows:      # first use, a new block, or a re-homed parameter
+        _BUFFERS_GENERATION[0] += 1
         dev = _PREP["entries"][0]["bufs"][0].device
         _PREP["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
         _PREP["ptrs"], _PREP["max"] = rows, mx

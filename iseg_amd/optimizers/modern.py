@@ -36,9 +36,8 @@ class _FlatOptimizer:
             self._build_tables()
 
     def _owns(self, p):
-        """this optimizer updates p: routed here (MultiOptimizer) and not frozen (p.iseg_frozen: no step, no decay, gradient never read)"""
-        if getattr(p, "iseg_frozen", False):
-            return False
+        """this optimizer updates p: routed here (MultiOptimizer).  Frozen variables (Keras `layer.trainable = False`) are `requires_grad = False`
+        parameters: the tables below give them learning-rate multiplier 0 and no decay"""
         return self._owned is None or getattr(p, "iseg_name", None) in self._owned
 
     # Keras API
@@ -101,7 +100,15 @@ class _FlatOptimizer:
 
     def fixed_hp_slot(self, on=True):
         """graph mode: the step kernel reads its scalars from ONE device address (iseg_amd/graphs.py)"""
-        self._hp_fixed = torch.zeros(4, dtype=torch.float32, device=self.store.device) if on else None
+        # ONE slot for the optimizer's lifetime: every captured graph (one per input signature) holds this address, so a second capture must not
+        # replace it -- the first graph would keep reading a freed slot that prepare_step() no longer fills.  Switching graph mode off only
+        # parks it (`_hp_fixed_slot` stays alive for the graphs that still point at it).
+        if on:
+            if getattr(self, "_hp_fixed_slot", None) is None:
+                self._hp_fixed_slot = torch.zeros(4, dtype=torch.float32, device=self.store.device)
+            self._hp_fixed = self._hp_fixed_slot
+        else:
+            self._hp_fixed = None
 
     def _hp_values(self):
         raise NotImplementedError

@@ -249,9 +249,23 @@ def test_graphed_inference_replays_bit_exact(cuda):
         assert len(g.entries) == 2 and all(e[1] is not None for e in g.entries.values())
         # train-then-evaluate: after the weights change (optimizer step / load_weights / restore_checkpoint) a replay must read the new
         # K-contiguous kernel copies of the un-fused ConvNeXt stages, which only a host-side version check refreshes
+        # (and the fused stages' tiled MLP images / layer-scale-folded kernels, nn.mlp_tiled / nn.w_colscaled): the REPLAY comes first -- an eager
+        # forward in front of it would refresh those buffers in place and hide a replay that does not
         randomize_parameters(model, 6)
+        got4 = g(x).clone()
         want4 = eager(x).clone()
         assert not torch.equal(want4, want)
-        assert torch.equal(g(x), want4)
+        assert torch.equal(got4, want4)
+        assert all(e[1] is not None for e in g.entries.values())      # still replays: no buffer was re-allocated by the weight change
+        # a second model registers its kernels: the derived-weight buffers are re-allocated, the old graph's pointers dangle -> the runner must
+        # notice (nn.buffers_generation), run eagerly once and capture again
+        other = heads.convnext_tiny_aspp(build_input_size=(64, 64))
+        other._iseg_store = ParamStore(list(other.parameters()))
+        randomize_parameters(other, 7)
+        with torch.no_grad():
+            inference_with_sliding_window(x, other, training=False, windows_size=(64, 64))
+        for i in range(3):
+            assert torch.equal(g(x), want4), i
+        del other
     finally:
         nn.set_compute_dtype(torch.float32)

@@ -147,3 +147,26 @@ def test_dcnv3_backward_windows_and_side_buffer(cuda, dtype, shape, G, spread):
     close(dm, mr.grad, dtype, "dcnv3 dmask", f32_tol=2e-5, bf16_tol=2e-2)
     dx2, doff2, dm2 = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
     assert torch.equal(dx, dx2) and torch.equal(doff, doff2) and torch.equal(dm, dm2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,G", [((2, 21, 19, 24), 3), ((1, 17, 23, 12), 4), ((1, 30, 26, 8), 2)])
+def test_dcnv3_general_backward_is_bit_identical_and_right(cuda, dtype, shape, G):
+    """the window route (8 per group) and the group widths it does not serve (4 per group: a lane per channel; 3: a lane per group): the input gradient is
+    accumulated by int64 fixed-point atomics (round 4: no float atomics), so repeated calls give the same bits; values against the oracle"""
+    from iseg_amd import kernels as K
+
+    N, H, W, C = shape
+    Cg = C // G
+    x, xr = q(rnd(shape, 21), dtype)
+    off, offr = q(rnd((N, H, W, G * 9 * 2), 22) * 2.0, dtype)
+    m, mr = q(torch.softmax(rnd((N, H, W, G, 9), 23), -1).reshape(N, H, W, G * 9), dtype)
+    dy, dyr = q(rnd(shape, 24), dtype)
+    for t in (xr, offr, mr):
+        t.requires_grad_(True)
+    O.dcnv3_op(xr, offr, mr, (3, 3), (1, 1), "SAME", (1, 1), G, Cg, 1.0).backward(dyr)
+    outs = [K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0) for _ in range(3)]
+    close(outs[0][0], xr.grad, torch.float32, "dcnv3 dx", f32_tol=2e-5 if dtype == torch.float32 else 2e-2)
+    close(outs[0][2], mr.grad, dtype, "dcnv3 dmask", f32_tol=2e-5, bf16_tol=2e-2)
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
