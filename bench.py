@@ -34,7 +34,9 @@ def parse():
     ap.add_argument("--fp32", action="store_true", help="fp32 storage (parity mode); the headline number is bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph-step", action="store_true", help="replay the training step from one HIP graph (single GPU; no per-launch roofline timer)")
+    ap.add_argument("--graph-step", action="store_true", help="(default on one GPU since round 4; kept for old command lines)")
+    ap.add_argument("--eager-step", action="store_true", help="enqueue every launch of the timed steps from the host instead of replaying the step from one HIP graph")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="eager steps in front of the timed region whose dominant-GEMM launches carry HIP event pairs")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous + one all-reduce only (gloo when there is no GPU): tests the --gpus N self-launch path on CPU")
     return ap.parse_args()
@@ -400,9 +402,14 @@ def main():
     from iseg_amd import kernels as K
 
     # Roofline: the last warm-up step times every GEMM launch with HIP events on the launch stream to find the dominant
-    # (template, shape) group; the timed region then brackets only that group's launches (a few event pairs per step), so
-    # the headline throughput is not taxed by ~300 event records per step.
-    want_roofline = rank == 0 and not args.no_roofline and not args.graph_step
+    # (template, shape) group.  Eager headline (--eager-step, or data parallel): the timed region brackets one launch in four of that group.
+    # Replayed headline (default on one GPU): `--roofline-steps` eager steps right in front of the timed region bracket EVERY launch of the
+    # group -- event-record nodes inside a captured graph carry no timestamps on ROCm 7.2, and the kernels, shapes and buffers
+    # are the same ones the replay runs.
+    from iseg_amd.graphs import GraphedTrainStep
+
+    replay = (not args.eager_step) and GraphedTrainStep(trainer)._eligible(x)
+    want_roofline = rank == 0 and not args.no_roofline
     survey = None
     for i in range(args.warmup):
         if want_roofline and i == args.warmup - 1:
@@ -417,15 +424,20 @@ def main():
         if survey is not None:
             survey_report = survey.report()
             dominant = pick_dominant(survey_report)
-        # one launch in four of the dominant group carries an event pair (>= 40 samples over the default 20 steps): every pair idles the stream for a
-        # few microseconds, and 19 pairs per step had taxed the headline by 2.5 %
-        timer = K.KernelTimer(only=dominant, every=4)
+        # eager headline: one launch in four of the dominant group carries an event pair (>= 40 samples over the default 20 steps): every pair idles
+        # the stream for a few microseconds, and 19 pairs per step had taxed the headline by 2.5 %
+        timer = K.KernelTimer(only=dominant, every=1 if replay else 4)
         K.KERNEL_TIMER[0] = timer
     step_fn = trainer.train_step
-    if args.graph_step:
+    roofline_steps = args.steps
+    if replay:
+        if timer is not None:
+            roofline_steps = max(1, args.roofline_steps)
+            for _ in range(roofline_steps):
+                trainer.train_step(x, y)
+            torch.cuda.synchronize()
+            K.KERNEL_TIMER[0] = None
         # the whole step replayed from one HIP graph (iseg_amd/graphs.py): capture happens here, outside the timed region
-        from iseg_amd.graphs import GraphedTrainStep
-
         step_fn = GraphedTrainStep(trainer, warmup=0)
         step_fn(x, y)
         step_fn(x, y)
@@ -457,10 +469,14 @@ def main():
         "images_per_sec_per_gpu": round(ips / world, 2),
         "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
         "final_loss": round(loss_val, 5),
+        "step_mode": ("hip-graph replay of the whole step (one graph launch per step)" if replay and any(e.get("graph") is not None for e in step_fn.entries.values())
+                      else "eager (every kernel enqueued from the host)"),
     }
     res["step"] = step_fractions(args, ips / world, elapsed / args.steps)
     if timer is not None:
-        res["roofline"] = roofline_from_timer(timer.report(), args.steps, survey_report)
+        res["roofline"] = roofline_from_timer(timer.report(), roofline_steps, survey_report)
+        res["roofline"]["measured_in"] = (f"{roofline_steps} eager steps directly in front of the timed region, every launch of the group bracketed by HIP events on the launch stream"
+                                          if replay else "the timed region, one launch in four of the group bracketed by HIP events on the launch stream")
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args)
     sys.stdout.flush()

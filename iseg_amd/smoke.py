@@ -1,17 +1,21 @@
 """A tiny invocation of the flagship hot path (ConvNeXt-T + ASPP through CoreTrain's compiled model) on cuda:0, checked against
-the CPU oracle: forward logits / argmax masks, then the loss curve of five AdamW steps.
+the CPU oracle: forward logits / argmax masks, then the loss curve of four AdamW steps at SURVEY section 8(c)'s bar (1e-4 relative).
 
-Why a curve and not "the loss went down": with lr 1e-3 on two 64x64 images the restatement itself climbs for the first steps
-(3.098 -> 3.25 -> 3.32 -> 3.19 at Keras' default epsilon 1e-7), so monotone decrease was never a property of this path.  Both
-curves are asserted to 1e-3: epsilon 1e-4 as it is, and Keras' default 1e-7 (optimizers/modern/adamw.py:13-59) with the gradient elements
-below 1e-4 of the model's largest (the oracle's fp64 gradient decides, step by step) zeroed on BOTH sides through
-TrainableModel.gradient_transformers: at 1e-7 Adam is scale-free, so those elements move by +-lr with the sign of fp32 rounding noise
-(oracle/models.py ConvNeXtASPPAdamWSteps has the measured sensitivity: 1.8e-2 without the mask, 3.5e-5 with it)."""
+Learning rate 1e-4 (bench.py's): with 1e-3 on two 64x64 images the restatement itself climbs for the first steps (3.098 -> 3.25 -> 3.32 ->
+3.19) -- an unstable regime in which the optimisation amplifies ANY perturbation by an order of magnitude per step (round 4 measured it with
+SGD, which divides by nothing: fp32-vs-fp64 rounding, 1e-7 of the loss at step 1, grows 7x per step at lr 2e-2 and not at all at 5e-3,
+tests/test_model_gpu.py::test_train_steps_follow_oracle_sgd); rounds 1-3 compared curves there and needed a 1e-3 band.  Both curves are
+asserted: epsilon 1e-4 as it is, and Keras' default 1e-7 (optimizers/modern/adamw.py:13-59) with the gradient elements below 1e-4 of the model's
+largest (the oracle's fp64 gradient decides, step by step) zeroed on BOTH sides through TrainableModel.gradient_transformers: at 1e-7 Adam is
+scale-free, so those elements move by +-lr with the sign of fp32 rounding noise (oracle/models.py ConvNeXtASPPAdamWSteps has the measured
+sensitivity); the masked fraction is printed."""
 import re
 
 import torch
 
 ZERO_GRADIENT_TAU = 1e-4
+LEARNING_RATE = 1e-4
+CURVE_TOLERANCE = 1e-4
 
 
 def _build(strategy, eps):
@@ -22,7 +26,7 @@ def _build(strategy, eps):
 
     model = convnext_tiny_aspp(num_class=21, build_input_size=(64, 64), drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0)
     helper = model_common_setup(model, restore_checkpoint=False)
-    opt = get_optimizer(strategy, initial_lr=1e-3, optimizer="adamw", epoch_steps=10, train_epoch=1, adamw_weight_decay=0.05)
+    opt = get_optimizer(strategy, initial_lr=LEARNING_RATE, optimizer="adamw", epoch_steps=10, train_epoch=1, adamw_weight_decay=0.05)
     opt.epsilon = eps
     helper.set_optimizer(opt)
     trainer = CoreTrain(helper, None).create_trainable_model(21, batch_size=2)
@@ -39,7 +43,7 @@ def _oracle_steps(model, x, y, eps, tau):
     names = [p.iseg_name for p in model.parameters()]
     return OM.ConvNeXtASPPAdamWSteps(
         w, x.cpu().double(), y.cpu(), names,
-        lambda s: O.warmup_poly_decay(s, 1e-3, 10, end_lr=0.0, warmup_steps=0, warmup_lr=0.0, power=0.9),
+        lambda s: O.warmup_poly_decay(s, LEARNING_RATE, 10, end_lr=0.0, warmup_steps=0, warmup_lr=0.0, power=0.9),
         lambda k: 0.0 if any(re.search(n, k) for n in excl) else 0.05, eps=eps, tau=tau)
 
 
@@ -74,6 +78,7 @@ def run_smoke(steps=4):
         if tau > 0:
             trainer.gradient_transformers.append(keep_well_conditioned)
         got, want, dropped = [], [], 0
+        total = sum(p.numel() for p in params.values())
         for _ in range(steps):
             loss, step_masks = oracle.forward_backward()
             want.append(loss)
@@ -85,7 +90,7 @@ def run_smoke(steps=4):
             oracle.apply()
         torch.cuda.synchronize()
         rel = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want))
-        print(f"smoke: AdamW epsilon {eps:g}" + (f" (gradient elements below {tau:g} of the largest zeroed on both sides: {dropped} in the last step)" if tau else "") +
+        print(f"smoke: AdamW epsilon {eps:g}" + (f" (gradient elements below {tau:g} of the largest zeroed on both sides: {dropped} of {total} = {100.0 * dropped / total:.1f} % in the last step)" if tau else "") +
               f": loss curve HIP {[round(v, 5) for v in got]} oracle {[round(v, 5) for v in want]} max rel diff {rel:.2e}")
-        assert all(v == v for v in got) and rel < 1e-3, (got, want)
+        assert all(v == v for v in got) and rel < CURVE_TOLERANCE, (rel, got, want)
     print("smoke OK")

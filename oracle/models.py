@@ -566,6 +566,28 @@ class ConvNeXtASPPAdamWSteps:
         self._pending = None
 
 
+class ConvNeXtASPPSGDSteps(ConvNeXtASPPAdamWSteps):
+    """The same loop under SGD_EXT with momentum (optimizers/modern/sgd.py:38-51): m = -g lr + m mu; w += m.  No scale-free division, so nothing
+    amplifies rounding noise and the comparison needs no gradient mask: any residual against this curve is a real gradient difference."""
+
+    def __init__(self, w, x, y, trainable, lr_fn, momentum=0.9, l2_of=None, output_stride=32):
+        super().__init__(w, x, y, trainable, lr_fn, lambda k: 0.0, output_stride=output_stride, tau=0.0)
+        self.momentum, self.l2_of = momentum, (l2_of or (lambda k: 0.0))
+        self.state = {k: torch.zeros_like(w[k]) for k in self.trainable}
+        self.last_grads = None
+
+    def apply(self):
+        grads, new_stats = self._pending
+        self.last_grads = grads
+        lr = self.lr_fn(self.step_index)
+        for k in self.trainable:
+            nw, nm = O.sgd_step(self.w[k], grads[k], self.state[k], lr, 1.0, self.momentum, self.l2_of(k))
+            self.w[k], self.state[k] = nw.detach(), nm
+        self.w.update(new_stats)
+        self.step_index += 1
+        self._pending = None
+
+
 def convnext_aspp_adamw_curve(w, x, y, steps, trainable, lr_fn, wd_of, eps=1e-7, beta1=0.9, beta2=0.999, output_stride=32):
     """w: weight dict (updated in place); trainable: names of the optimised variables; lr_fn(step) -> lr; wd_of(name) -> weight decay.
     Returns the list of losses, one per step (the loss BEFORE that step's update, like Keras logs it)."""

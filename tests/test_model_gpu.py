@@ -152,6 +152,52 @@ def test_train_steps_follow_oracle_adamw(cuda, eps, tau):
     assert got[-1] < got[0]
 
 
+def test_train_steps_follow_oracle_sgd(cuda):
+    """SURVEY section 8(c)'s bar: 5 optimisation steps on a fixed batch (fp32 storage, drop-path / dropout 0, SGD with momentum 0.9 as
+    optimizers/modern/sgd.py:12-51, NO gradient mask -- 0 % of the gradient elements are masked) reproduce the restatement's loss curve to 1e-4
+    relative and its weight movement to 1e-3.  SGD divides by nothing, so this separates "a gradient is slightly wrong" from "the AdamW comparison
+    is ill-conditioned" (test_train_steps_follow_oracle_adamw); the HIP side is bit-reproducible (tests/test_graph_train_gpu.py), so the residual
+    is a property of the arithmetic, not of the run.  Learning rate 5e-3: at 2e-2 this model's optimisation is unstable (the fp32-vs-fp64
+    rounding difference of step 1 grows 7x per step on BOTH sides of any comparison: measured weight-movement gap 1e-4, 3e-5, 2e-4, ..., 1.2e-2 after
+    five steps with the loss still inside 1e-4), which is a property of the problem, not of either implementation."""
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.trainer import TrainableModel
+
+    model = _setup(torch.float32)
+    x, y = synthetic_batch(2, 64, 64, seed=9)
+    lr0 = 5e-3
+    opt = get_optimizer(Strategy(one_device=True), initial_lr=lr0, end_lr=0.0, epoch_steps=10, train_epoch=1, optimizer="sgd", sgd_momentum_rate=0.9)
+    tm = TrainableModel(model, optimizer=opt, loss=model.custom_losses(21, 255, 2), loss_weights=model.custom_losses_weights(),
+                        metrics=model.custom_metrics(21, 255))
+    params = {p.iseg_name: p for p in model.parameters()}
+    w0 = {k: v.detach().cpu().double().clone() for k, v in params.items()}
+    oracle = OM.ConvNeXtASPPSGDSteps(OM.export_weights(model), x.double(), y, list(params),
+                                     lambda s: O.warmup_poly_decay(s, lr0, 10, end_lr=0.0, warmup_steps=0, warmup_lr=0.0, power=0.9), momentum=0.9)
+    got, want = [], []
+    xc, yc = x.cuda(), y.cuda()
+    for step in range(5):
+        want.append(oracle.forward_backward()[0])
+        got.append(float(tm.train_step(xc, yc)[0]))
+        if step == 0:      # per-variable gradients of step 1 against fp64, worst first: the message of a failure names the variable
+            worst = []
+            gmax = max(g.abs().max().item() for g in oracle._pending[0].values())
+            for k, p in params.items():
+                gr = oracle._pending[0][k]
+                d = (p.grad.detach().cpu().double().reshape(gr.shape) - gr).abs().max().item()
+                worst.append((d / max(gr.abs().max().item(), 1e-3 * gmax), k))
+            worst.sort(reverse=True)
+            assert worst[0][0] < 2e-3, worst[:5]
+        oracle.apply()
+    rel = [abs(a - b) / max(abs(b), 1e-6) for a, b in zip(got, want)]
+    assert max(rel) < 1e-5, (rel, got, want)
+    assert got[-1] < got[0]
+    num = sum(((params[k].detach().cpu().double().reshape(oracle.w[k].shape) - oracle.w[k]) ** 2).sum().item() for k in params)
+    den = sum(((oracle.w[k] - w0[k].reshape(oracle.w[k].shape)) ** 2).sum().item() for k in params)
+    assert (num / den) ** 0.5 < 1e-3, (num / den) ** 0.5
+
+
 def test_bf16_forward_close_and_training_decreases_loss(cuda):
     from iseg_amd.core_optimizer import get_optimizer
     from iseg_amd.data import synthetic_batch
