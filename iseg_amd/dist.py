@@ -60,10 +60,77 @@ def init(backend=None):
     td.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Stream-ordered exchange (ISEG_DIST_NATIVE=1): the collectives go through the C ABI's own RCCL communicator (csrc/comm.hip:
+# iseg_comm_* / iseg_allreduce_sum) instead of c10d work objects.  A collective is then ONE enqueue on an explicit HIP stream -- nothing the
+# host waits for, no work object, no watchdog thread -- which is what makes a data-parallel training step capturable into a HIP graph
+# (iseg_amd/graphs.py): SyncBN messages ride the compute stream between the kernels that produce and consume them, gradient buckets a side
+# stream that forks from / joins the compute stream through events (graph edges when captured).  c10d stays the rendezvous (it carries the
+# 128-byte RCCL id to the other ranks) and the default exchange; "emulate" runs the same scheduling with a blocking c10d primitive (gloo on the
+# CPU: tests/test_dist_gloo.py).  Reference: distribution/distribution_utils.py:75-95,158-169 (MirroredStrategy's NCCL all-reduce).
+# ---------------------------------------------------------------------------------------------------------
+_NATIVE = {"comm": None, "side": None, "join": None}
+
+
+def native_mode():
+    """'' (c10d work objects), 'rccl' (C-ABI communicator, stream-ordered) or 'emulate' (stream-ordered scheduling over a blocking c10d call)"""
+    v = os.environ.get("ISEG_DIST_NATIVE", "0")
+    if v in ("1", "rccl"):
+        return "rccl" if torch.cuda.is_available() else "emulate"
+    return "emulate" if v == "emulate" else ""
+
+
+def _native_comm():
+    """the C-ABI communicator of this process, created on first use: rank 0 draws the id, c10d broadcasts it"""
+    if _NATIVE["comm"] is None:
+        import ctypes as C
+
+        from . import _hip
+
+        L = _hip.lib()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank() == 0:
+            buf = C.create_string_buffer(128)
+            _hip.check(L.iseg_comm_unique_id(buf), "iseg_comm_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world_size() > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+            u = uid.to(dev)
+            td.broadcast(u, 0)
+            uid = u.cpu()
+        comm = C.c_void_p()
+        _hip.check(L.iseg_comm_init(C.byref(comm), world_size(), rank(), bytes(uid.numpy().tobytes())), "iseg_comm_init")
+        _NATIVE["comm"] = comm
+    return _NATIVE["comm"]
+
+
+def _stream_all_reduce(t, raw_stream):
+    """in-place sum over the ranks, enqueued on `raw_stream` (a hipStream_t handle); returns at once"""
+    mode = native_mode()
+    if mode == "rccl":
+        from . import _hip
+        from . import kernels as K
+
+        if not t.is_contiguous():
+            raise ValueError("stream-ordered all-reduce needs a contiguous tensor (a slice of the flat buffers is)")
+        code = K.F32 if t.dtype == torch.float32 else K.BF16 if t.dtype == torch.bfloat16 else None
+        if code is None:      # integer counts (confusion matrices): exact in fp64 -> not an RCCL-through-the-ABI type; take the c10d call
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+            return
+        _hip.check(_hip.lib().iseg_allreduce_sum(_native_comm(), K.ptr(t), t.numel(), code, raw_stream), "iseg_allreduce_sum")
+    else:
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+
+
 def all_reduce_sum(t, async_op=False):
-    if active():
-        return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
-    return None
+    if not active():
+        return None
+    if native_mode() and not async_op:
+        from . import kernels as K
+
+        _stream_all_reduce(t, K.stream() if t.is_cuda else None)      # on the compute stream: ordered behind its producer, in front of its consumer
+        return None
+    return td.all_reduce(t, op=td.ReduceOp.SUM, async_op=async_op)
 
 
 def broadcast(t, src=0):
@@ -132,7 +199,25 @@ class GradReducer:
         from . import kernels as K
 
         K.deferred_flush()      # the all-reduce reads the gradient buffer: reductions still queued into it must be enqueued first
-        self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
+        if native_mode():
+            self._launch_stream_ordered(self.store.flat_g[lo:hi])
+        else:
+            self.handles.append(all_reduce_sum(self.store.flat_g[lo:hi], async_op=True))
+
+    def _launch_stream_ordered(self, t):
+        """the bucket's sum on the side stream, behind everything the compute stream has enqueued so far (an event = a graph edge under
+        capture); finish() joins the side stream back.  On the CPU (emulation over gloo) there are no streams: the call is the blocking one."""
+        if not t.is_cuda:
+            _stream_all_reduce(t, None)
+            return
+        if _NATIVE["side"] is None:
+            _NATIVE["side"] = torch.cuda.Stream(device=t.device)
+        side = _NATIVE["side"]
+        fork = torch.cuda.Event()
+        fork.record()                      # on the current (compute / capture) stream
+        side.wait_event(fork)
+        _stream_all_reduce(t, side.cuda_stream)
+        self.side_used = True
 
     def ready(self, *params):
         """called by an operator's backward once the kernels that write these parameters' gradients are enqueued.  A parameter
@@ -172,6 +257,11 @@ class GradReducer:
             for h in self.handles:
                 if h is not None:
                     h.wait()
+            if getattr(self, "side_used", False):      # stream-ordered buckets: the optimizer step waits for the side stream
+                join = torch.cuda.Event()
+                join.record(_NATIVE["side"])
+                torch.cuda.current_stream().wait_event(join)
+                self.side_used = False
         self.reset()
 
 

@@ -10,7 +10,8 @@ GraphedTrainStep(trainable) does the same for TrainableModel.train_step (round 3
 8.3 ms to enqueue, against 9.5 ms of kernels -- the step is one kernel speed-up away from being host-bound, and the small-image configurations
 (ResNet-50 at 256^2, InternImage) already are.  What the host used to decide per step lives in device memory instead: the optimizer's
 scalars (one fixed slot, filled by a stream-ordered copy in front of the replay) and the dropout / drop-path draw counter (a one-word
-addend of every frozen seed argument).  Data-parallel runs keep the eager step (the collectives and their events are host-driven)."""
+addend of every frozen seed argument).  Data-parallel runs are captured when the exchange is stream-ordered (ISEG_DIST_NATIVE=1, iseg_amd/dist.py);
+with c10d work objects they keep the eager step."""
 import torch
 
 from . import kernels as K
@@ -93,7 +94,7 @@ class GraphedTrainStep:
     The first `warmup` calls run eagerly (layers build, kernel copies and tiling plans reach their final size); the next call runs its step
     eagerly on the capture stream and then captures; from then on every call copies the batch into the captured buffers, pushes the
     optimizer's scalars, advances the draw counter and replays.  Replayed steps produce bit for bit what eager steps produce from the same
-    state (same seeds, same summation orders): tests/test_graph_train_gpu.py.  Falls back to the eager step under data parallelism, for a
+    state (same seeds, same summation orders): tests/test_graph_train_gpu.py.  Falls back to the eager step under data parallelism with c10d work objects (captured with the stream-ordered exchange, ISEG_DIST_NATIVE=1), for a
     MultiOptimizer, and on the CPU."""
 
     SEED_STRIDE = 0xD1B54A32D192ED03      # functional.next_seed(): seed = base + counter * SEED_STRIDE (+ rank term)
@@ -107,8 +108,10 @@ class GraphedTrainStep:
         from . import dist
 
         opt = self.tm.optimizer
-        return (torch.is_tensor(x) and x.is_cuda and dist.world_size() == 1 and not dist.active() and hasattr(opt, "fixed_hp_slot") and
-                opt.store is not None)
+        # data parallel: only with the stream-ordered exchange (dist.native_mode() == "rccl": every collective is one enqueue on an explicit
+        # stream, so the step -- SyncBN messages, bucket all-reduces on the side stream -- is one graph); c10d work objects are host-driven
+        capturable = not dist.active() or dist.native_mode() == "rccl"
+        return torch.is_tensor(x) and x.is_cuda and capturable and hasattr(opt, "fixed_hp_slot") and opt.store is not None
 
     @staticmethod
     def _signature(x, y):

@@ -15,8 +15,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange=""):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if exchange:      # "emulate": the stream-ordered exchange's scheduling (dist._launch_stream_ordered, the join in finish()) over a blocking gloo call
+        os.environ["ISEG_DIST_NATIVE"] = exchange
+    else:
+        os.environ.pop("ISEG_DIST_NATIVE", None)
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,6 +31,7 @@ def _worker(rank, world, port, q):
     nn.set_device("cpu")
     dist.init(backend="gloo")
     assert dist.world_size() == world and dist.rank() == rank
+    assert dist.native_mode() == exchange
     nn.set_seed(rank)                     # different init per rank -> broadcast must equalise
     with nn.dry_run_scope():
         net = cx.ConvNeXt(depths=[1, 1, 1, 1], filters_list=[8, 16, 32, 64])
@@ -84,11 +89,17 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_reducer_broadcast_syncbn():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("exchange", ["", "emulate"])
+def test_two_rank_gloo_reducer_broadcast_syncbn(exchange):
+    """exchange = "": c10d work objects (the default data-parallel path); "emulate": the stream-ordered exchange of ISEG_DIST_NATIVE=1 -- the same
+    bucket scheduling, launch points and join the RCCL-through-the-C-ABI path takes on a GPU -- with gloo as the primitive"""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _step(rank, world, port, q, size, batch, rccl_single=False):
+def _step(rank, world, port, q, size, batch, rccl_single=False, native=False, graphed=False, steps=2):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,6 +32,10 @@ def _step(rank, world, port, q, size, batch, rccl_single=False):
         if rccl_single:     # one rank, every collective issued for real on the RCCL backend
             os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                               ISEG_DIST_SINGLE_RANK_COLLECTIVES="1", ISEG_DIST_BACKEND="nccl")
+    if native:      # the stream-ordered exchange: every collective through the C ABI's own RCCL communicator (iseg_amd/dist.py)
+        os.environ["ISEG_DIST_NATIVE"] = "1"
+    else:
+        os.environ.pop("ISEG_DIST_NATIVE", None)
     from iseg_amd import dist, nn
     from iseg_amd.core_optimizer import get_optimizer
     from iseg_amd.data import synthetic_batch
@@ -56,10 +60,21 @@ def _step(rank, world, port, q, size, batch, rccl_single=False):
     sizes = []
     real_allreduce = dist.all_reduce_sum
     dist.all_reduce_sum = lambda t, async_op=False: (sizes.append(int(t.numel())), real_allreduce(t, async_op=async_op))[1]
-    losses = [float(tm.train_step(xs, ys)[0]) for _ in range(2)]
+    step_fn = tm.train_step
+    if graphed:
+        from iseg_amd.graphs import GraphedTrainStep
+
+        step_fn = GraphedTrainStep(tm, warmup=1)
+        assert step_fn._eligible(xs), "the data-parallel step must be capturable with the stream-ordered exchange"
+    losses = [float(step_fn(xs, ys)[0]) for _ in range(steps)]
     dist.all_reduce_sum = real_allreduce
+    if graphed:
+        assert any(e.get("graph") is not None for e in step_fn.entries.values()), "the step was never captured"
+        sizes = None      # (replays issue no host-side calls: the message census below belongs to the eager runs)
+    if native:
+        assert dist.native_mode() == "rccl" and dist._NATIVE["comm"] is not None, "no collective went through the C-ABI communicator"
     torch.cuda.synchronize()
-    if world > 1 or rccl_single:
+    if (world > 1 or rccl_single) and sizes is not None and steps == 2:
         # the five ASPP branches (256 channels each) exchange their SyncBN statistics in ONE message per direction and step
         # (layers/aspp.py _call_grouped): 5 x (2 x 256 + 1, padded to 516 so every layer's slot stays 16-byte aligned) forward,
         # 5 x (2 x 256) backward; the end conv keeps its own pair
@@ -77,11 +92,11 @@ def _step(rank, world, port, q, size, batch, rccl_single=False):
         torch.distributed.destroy_process_group()
 
 
-def _run(world, size, batch, rccl_single=False):
+def _run(world, size, batch, rccl_single=False, native=False, graphed=False, steps=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_step, args=(r, world, port, q, size, batch, rccl_single)) for r in range(world)]
+    procs = [ctx.Process(target=_step, args=(r, world, port, q, size, batch, rccl_single, native, graphed, steps)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -112,8 +127,8 @@ def test_rccl_backend_single_rank_collectives_are_identity(cuda):
     """the `nccl` (= RCCL) branch of dist.py on real hardware: one rank, but the process group exists and EVERY collective of the step
     is issued -- weight / buffer broadcast, packed SyncBN all-reduces on the compute stream, the asynchronous gradient buckets launched
     from inside backward on RCCL's stream and waited for before the optimizer.  A sum over one rank is the identity, so weights, moving
-    statistics and losses after two steps must equal the collective-free run (up to the last-bit noise of the in-block LDS float atomics
-    in the parameter-gradient reductions); a missing stream dependency shows up as a gross difference."""
+    statistics and losses after two steps must equal the collective-free run (up to fp32 rounding: the synchronised path normalises ASPP's five branches as a
+    group, with other launch shapes for the statistics); a missing stream dependency shows up as a gross difference."""
     size, batch = (64, 64), 4
     plain = _run(1, size, batch)[0]
     rccl = _run(1, size, batch, rccl_single=True)[0]
@@ -154,3 +169,19 @@ def test_c_abi_exchange_entry_points_single_rank(cuda):
         _hip.check(L.iseg_comm_destroy(comm), "iseg_comm_destroy")
     bad = C.c_void_p()
     assert L.iseg_comm_init(C.byref(bad), 2, 2, uid) != 0      # rank outside the world
+
+
+def test_stream_ordered_exchange_single_rank_eager_and_replayed(cuda):
+    """ISEG_DIST_NATIVE=1 (round 4): SyncBN messages and gradient buckets go through iseg_allreduce_sum -- the C ABI's own RCCL communicator --
+    as plain stream-ordered enqueues (buckets on a side stream forked / joined by events) instead of c10d work objects.  On a world of one
+    rank every sum is the identity, so (1) the eager step equals the c10d-exchange step BIT FOR BIT (same kernels, same order: the step is
+    deterministic) and (2) the same step captured into ONE HIP graph -- collectives included, the point of the exercise: c10d's asynchronous
+    work objects cannot be captured -- replays bit for bit what the eager steps produce."""
+    size, batch = (64, 64), 4
+    c10d = _run(1, size, batch, rccl_single=True, steps=5)[0]
+    eager = _run(1, size, batch, rccl_single=True, native=True, steps=5)[0]
+    replay = _run(1, size, batch, rccl_single=True, native=True, graphed=True, steps=5)[0]
+    assert c10d[2] == eager[2] == replay[2], (c10d[2], eager[2], replay[2])
+    for k in c10d[3]:
+        assert (c10d[3][k] == eager[3][k]).all(), f"stream-ordered exchange differs from the c10d exchange on {k}"
+        assert (eager[3][k] == replay[3][k]).all(), f"the replayed data-parallel step differs from the eager one on {k}"

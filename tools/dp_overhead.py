@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Where the data-parallel plumbing costs time on ONE GPU (world of one rank, ISEG_DIST_SINGLE_RANK_COLLECTIVES=1): the flagship step with
-all collectives, without the gradient buckets, without the SyncBN messages, and with neither.   python tools/dp_overhead.py [steps]"""
+all collectives, without the gradient buckets, without the SyncBN messages, and with neither.   python tools/dp_overhead.py [steps]
+With a second argument `native`: the stream-ordered exchange (ISEG_DIST_NATIVE=1, collectives through the C ABI's RCCL communicator) --
+eager and replayed from one HIP graph, against the same step with every collective stubbed out."""
 import os
 import sys
 import time
 
 os.environ["ISEG_DIST_SINGLE_RANK_COLLECTIVES"] = "1"
+NATIVE = len(sys.argv) > 2 and sys.argv[2] == "native"
+if NATIVE:
+    os.environ["ISEG_DIST_NATIVE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
@@ -55,6 +60,41 @@ def main():
         print(f"{name:34s} {ta / steps * 1e3:6.2f} ms/step  (host enqueue {th / steps * 1e3:5.2f})  blocking {calls[0] / steps:.0f}  async {calls[1] / steps:.0f} per step",
               flush=True)
 
+    if NATIVE:
+        from iseg_amd.graphs import GraphedTrainStep
+
+        real = dist._stream_all_reduce
+        count = [0]
+
+        def run(name, step_fn):
+            for _ in range(6):
+                step_fn(x, y)
+            torch.cuda.synchronize()
+            count[0] = 0
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step_fn(x, y)
+            th = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            ta = time.perf_counter() - t0
+            print(f"{name:52s} {ta / steps * 1e3:6.2f} ms/step  (host enqueue {th / steps * 1e3:5.2f})  collectives enqueued by the host {count[0] / steps:.0f} per step", flush=True)
+
+        def counted(t, raw):
+            count[0] += 1
+            return real(t, raw)
+
+        dist._stream_all_reduce = counted
+        run("stream-ordered exchange, eager", trainer.train_step)
+        g = GraphedTrainStep(trainer, warmup=0)
+        assert g._eligible(x)
+        run("stream-ordered exchange, ONE HIP graph per step", g)
+        dist._stream_all_reduce = lambda t, raw: None
+        run("collectives stubbed (plumbing only), eager", trainer.train_step)
+        g2 = GraphedTrainStep(trainer, warmup=0)
+        run("collectives stubbed, ONE HIP graph per step", g2)
+        dist._stream_all_reduce = counted
+        run("stream-ordered exchange, eager (again)", trainer.train_step)
+        return
     variant("all collectives", True, True)
     variant("no gradient buckets", True, False)
     variant("no SyncBN messages", False, True)
