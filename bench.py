@@ -270,7 +270,7 @@ def roofline_from_timer(report, steps, survey=None):
               "share_of_gemm_time": round(share, 4), "algorithmic_bytes_per_launch": int(nbytes),
               "algorithmic_flops_per_launch": int(flops), "flop_per_byte": round(intensity, 1), "traffic": None}
     # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the figure comes from the separate rocprofv3
-    # --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_evidence.sh -> profiles/r03_pmc.json, corrections per
+    # --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_evidence.sh -> profiles/r04_pmc.json, corrections per
     # MI355X_MICROARCH.md), looked up by kernel symbol (the epilogue kind is part of it since round 3) and grid; null when the file was
     # taken on another source tree or holds no such kernel.
     sym, grid = _dma_symbol(key)
@@ -295,11 +295,11 @@ def roofline_from_timer(report, steps, survey=None):
     return common
 
 
-PMC_FILE = os.path.join("profiles", "r03_pmc.json")
+PMC_FILE = os.path.join("profiles", "r04_pmc.json")
 
 
 def _pmc_on_this_tree():
-    """profiles/r03_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes over this same command, tools/collect_evidence.sh) when it was taken
+    """profiles/r04_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes over this same command, tools/collect_evidence.sh) when it was taken
     on EXACTLY this source tree (tools/source_stamp.py), else (None, why)"""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
@@ -439,8 +439,14 @@ def main():
             K.KERNEL_TIMER[0] = None
         # the whole step replayed from one HIP graph (iseg_amd/graphs.py): capture happens here, outside the timed region
         step_fn = GraphedTrainStep(trainer, warmup=0)
-        step_fn(x, y)
-        step_fn(x, y)
+        try:
+            step_fn(x, y)
+            step_fn(x, y)
+        except Exception as e:      # a capture that fails must not cost the measurement: the eager step is the same kernels, enqueued by the host
+            print(f"bench.py: capturing the step into a HIP graph failed ({type(e).__name__}: {e}); timing the eager step instead", file=sys.stderr)
+            torch.cuda.synchronize()
+            step_fn, replay = trainer.train_step, False
+            step_fn(x, y)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -469,7 +475,7 @@ def main():
         "images_per_sec_per_gpu": round(ips / world, 2),
         "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
         "final_loss": round(loss_val, 5),
-        "step_mode": ("hip-graph replay of the whole step (one graph launch per step)" if replay and any(e.get("graph") is not None for e in step_fn.entries.values())
+        "step_mode": ("hip-graph replay of the whole step (one graph launch per step)" if replay and any(e.get("graph") is not None for e in getattr(step_fn, "entries", {}).values())
                       else "eager (every kernel enqueued from the host)"),
     }
     res["step"] = step_fractions(args, ips / world, elapsed / args.steps)
