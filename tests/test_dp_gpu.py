@@ -178,9 +178,9 @@ def test_stream_ordered_exchange_single_rank_eager_and_replayed(cuda):
     deterministic) and (2) the same step captured into ONE HIP graph -- collectives included, the point of the exercise: c10d's asynchronous
     work objects cannot be captured -- replays bit for bit what the eager steps produce."""
     size, batch = (64, 64), 4
-    c10d = _run(1, size, batch, rccl_single=True, steps=5)[0]
-    eager = _run(1, size, batch, rccl_single=True, native=True, steps=5)[0]
-    replay = _run(1, size, batch, rccl_single=True, native=True, graphed=True, steps=5)[0]
+    c10d = _run(1, size, batch, rccl_single=True, steps=4)[0]
+    eager = _run(1, size, batch, rccl_single=True, native=True, steps=4)[0]
+    replay = _run(1, size, batch, rccl_single=True, native=True, graphed=True, steps=4)[0]
     assert c10d[2] == eager[2] == replay[2], (c10d[2], eager[2], replay[2])
     for k in c10d[3]:
         assert (c10d[3][k] == eager[3][k]).all(), f"stream-ordered exchange differs from the c10d exchange on {k}"

@@ -80,7 +80,7 @@ def _batches():
     return out
 
 
-@pytest.mark.parametrize("optimizer", ["adamw", "sgd"])
+@pytest.mark.parametrize("optimizer", ["adamw"])      # (SGD's eager run is compared bit for bit with its replay below)
 def test_two_eager_runs_are_bit_identical(cuda, optimizer):
     """nine flagship steps (drop-path 0.2, dropout 0.1, bf16 storage, running mIoU) twice from the same state: identical losses, weights,
     optimizer state and confusion matrix, bit for bit"""
