@@ -782,7 +782,8 @@ static BwDmaGeom bw_dma_geom(int N, int H, int W, int C, int K, int dil, size_t 
     const int64_t ntiles = (int64_t)N * g.tiles_h * g.tiles_w;
     if (ntiles >= (1ll << 30)) return g;
     // two resident workgroups per CU: ~512 in flight; every workgroup of a slab gets the same number of tiles (+-1)
-    int64_t cap = 512 / g.slabs;
+    static const int slots = env_int("ISEG_DW_BW_DMA_SLOTS", 512);
+    int64_t cap = slots / g.slabs;
     if (cap < 8) cap = 8;
     const int64_t rounds = ceil_div64(ntiles, cap);
     int64_t bx = ceil_div64(ntiles, rounds);

@@ -26,3 +26,6 @@ print(os.environ.get("TAG"), " | ".join(out), flush=True)
 for dma in ("1", "0"):
     env = dict(os.environ, ISEG_DW_BW_DMA=dma, ISEG_DW_FWD_DMA=dma, TAG=f"dma={dma}")
     subprocess.run([sys.executable, "-c", code], env=env)
+for slots in sys.argv[1:]:      # extra arguments: resident-workgroup targets of the DMA-tiled weight gradient (ISEG_DW_BW_DMA_SLOTS)
+    env = dict(os.environ, ISEG_DW_BW_DMA_SLOTS=slots, TAG=f"dma=1 bw slots={slots}")
+    subprocess.run([sys.executable, "-c", code], env=env)
