@@ -9,7 +9,10 @@ def common_env_setup(run_eagerly=False, gpu_memory_growth=True, cuda_visible_dev
     set_random_seed(random_seed)
     use_tpu = tpu_name is not None
     print(f"Using TPU: {use_tpu}")
-    print(f"use_deterministic = {use_deterministic}")
+    # use_deterministic (reference: enable_op_determinism(), core_env.py:39-48, default True): honoured unconditionally -- no kernel of the step
+    # uses a floating-point atomic (every cross-lane / cross-workgroup sum runs in a fixed order; integer atomics commute), so two runs from the
+    # same state give the same bits (tests/test_graph_train_gpu.py).  False changes nothing: there is no faster non-deterministic variant to opt into.
+    print(f"use_deterministic = {use_deterministic} (the MI355X path is bit-reproducible either way)")
     strategy = get_distribution_strategy(gpu_memory_growth=gpu_memory_growth, cuda_visible_devices=cuda_visible_devices,
                                          use_tpu=use_tpu, tpu_name=tpu_name, use_one_device_strategy=use_one_device_strategy)
     if mixed_precision:
