@@ -777,17 +777,25 @@ class _RowScaleFn(Function):
 
 
 class _DropPathPool:
-    """The drop-path call sites of a training step draw from ONE launch: the first step records the (samples, keep probability)
-    sequence, every later step replays it -- one [P, n] tensor of factors, rows handed out in call order.  A step that asks for
-    something else (another batch size, eval in between) simply falls back to one launch per call and re-records."""
+    """The drop-path call sites of a training step draw from ONE launch: the first step with a given sample count records the
+    (samples, keep probability) sequence, every later step with that sample count replays it -- one [P, n] tensor of factors, rows handed
+    out in call order.  Plans are kept PER SAMPLE COUNT (round 4): a smaller last batch, or a second crop size of a graphed trainer, no longer
+    throws the plan away -- which had made the step after every switch draw one seed per call site instead of one per step, i.e. made the
+    random stream depend on the order of batch shapes (and a replayed graph, which froze the pooled form, disagree with the eager run).  A step
+    whose sequence differs from its plan (eval in between, a changed model) falls back to one launch per call and re-records."""
 
     def __init__(self):
-        self.active, self.plan, self.rec, self.masks, self.cursor, self.keeps = False, None, None, None, 0, None
+        self.active, self.plans, self.rec, self.masks, self.cursor, self.keeps, self.plan = False, {}, None, None, 0, {}, None
 
     def begin(self):
-        if self.rec and self.rec != self.plan:
-            self.plan, self.keeps = list(self.rec), None
-        self.active, self.rec, self.cursor, self.masks = True, [], 0, None
+        if self.rec:      # file the previous step's sequence under its sample count
+            counts = {q[0] for q in self.rec}
+            if len(counts) == 1:
+                n = next(iter(counts))
+                if self.plans.get(n) != self.rec:
+                    self.plans[n] = list(self.rec)
+                    self.keeps.pop(n, None)
+        self.active, self.rec, self.cursor, self.masks, self.plan = True, [], 0, None, None
 
     def end(self):
         self.active = False
@@ -798,14 +806,18 @@ class _DropPathPool:
             return K.drop_path_mask(n, keep, next_seed(), device)
         self.rec.append((n, keep))
         k = self.cursor
-        if self.plan is not None and k < len(self.plan) and self.plan[k] == (n, keep) and all(q[0] == n for q in self.plan):
+        if k == 0 and self.masks is None and len(self.rec) == 1:
+            self.plan = self.plans.get(n)
+        plan = self.plan
+        if plan is not None and k < len(plan) and plan[k] == (n, keep):
             if self.masks is None:
-                if self.keeps is None or self.keeps.device != device:
-                    self.keeps = torch.tensor([q[1] for q in self.plan], dtype=torch.float32, device=device)
-                self.masks = K.drop_path_masks(self.keeps, n, next_seed())
+                keeps = self.keeps.get(n)
+                if keeps is None or keeps.device != device:
+                    keeps = self.keeps[n] = torch.tensor([q[1] for q in plan], dtype=torch.float32, device=device)
+                self.masks = K.drop_path_masks(keeps, n, next_seed())
             self.cursor = k + 1
             return self.masks[k]
-        self.plan = None      # the sequence changed: individual launches until the next step re-records it
+        self.plan = None      # the sequence differs from the plan: individual launches until the next step has re-recorded it
         return K.drop_path_mask(n, keep, next_seed(), device)
 
 

@@ -115,3 +115,27 @@ def test_graphed_train_steps_follow_eager(cuda, optimizer):
     want_lr = opt.current_lr()
     opt.iterations += 1
     assert abs(float(opt._hp_fixed[0]) - want_lr) <= 1e-7 * want_lr
+
+
+def test_two_input_signatures_share_the_optimizer_slot(cuda):
+    """a second input signature (here: a smaller last batch) captures a second graph; both graphs read the optimizer's scalars -- learning rate,
+    bias correction -- from the SAME fixed device slot, so replays of the first graph after the second capture still follow the eager run bit for
+    bit (a fresh slot per capture left the first graph reading a freed address: round-3 advisor finding)"""
+    from iseg_amd.data import synthetic_batch
+
+    OPTIMIZER[0] = "adamw"
+    big, small = [], []
+    for s in (5, 6):
+        x, y = synthetic_batch(4, 64, 64, seed=s)
+        big.append((x.cuda(), y.cuda()))
+        x, y = synthetic_batch(2, 64, 64, seed=10 + s)
+        small.append((x.cuda(), y.cuda()))
+    order = [big[0], big[1], big[0], small[0], small[1], small[0], big[1], small[1], big[0], big[1], small[0]]
+    le, we, ite, cme, _, w0e = _run(False, len(order), order)
+    lg, wg, itg, cmg, step, w0g = _run(True, len(order), order)
+    assert torch.equal(w0e, w0g)
+    graphs = [e for e in step.entries.values() if e.get("graph") is not None]
+    assert len(graphs) == 2, "both signatures must have been captured"
+    assert le == lg, (le, lg)
+    assert torch.equal(we, wg), float((we - wg).abs().max())
+    assert torch.equal(cme, cmg)

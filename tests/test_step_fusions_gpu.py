@@ -29,9 +29,17 @@ def test_drop_path_pool_serves_a_step_from_one_launch(cuda):
         assert not torch.equal(per_step[1][2], per_step[2][2])          # a new draw each step
         kept = torch.stack([F.drop_path_factors(4096, 0.5, torch.device("cuda:0")) for _ in range(1)])[0]
         assert 0.4 < (kept > 0).float().mean().item() < 0.6
-        with F.drop_path_pool():                                          # another batch size: falls back, then re-records
+        with F.drop_path_pool():                                          # another batch size: records its own plan, the first one stays
             a = F.drop_path_factors(32, 0.9, torch.device("cuda:0"))
         assert tuple(a.shape) == (32,)
+        # plans are kept per sample count (round 4): switching back and forth costs no extra launches and no extra seeds -- the random stream of a
+        # step does not depend on the batch shapes of the steps before it (a replayed graph freezes the pooled form)
+        del launches[:]
+        for n in (64, 32, 64, 32):
+            with F.drop_path_pool():
+                got = [F.drop_path_factors(n, k, torch.device("cuda:0")) for k in (keeps if n == 64 else [0.9])]
+            assert all(tuple(m.shape) == (n,) for m in got)
+        assert launches == ["many"] * 4, launches
     finally:
         K.drop_path_mask, K.drop_path_masks = real_one, real_many
 
