@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 OPTIMIZER = ["adamw"]
+CLIPNORM = [None]
 
 
 def _trainer(seed=3):
@@ -24,7 +25,7 @@ def _trainer(seed=3):
     model = convnext_tiny_aspp(build_input_size=(64, 64), drop_path_rate=0.2, dropout_rate=0.1)
     helper = model_common_setup(model, restore_checkpoint=False)
     helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-3 if OPTIMIZER[0] == "adamw" else 2e-2, end_lr=0.0, epoch_steps=20, train_epoch=1,
-                                       warmup_steps=3, warmup_lr=1e-5, optimizer=OPTIMIZER[0], adamw_weight_decay=0.05))
+                                       warmup_steps=3, warmup_lr=1e-5, optimizer=OPTIMIZER[0], adamw_weight_decay=0.05, clipnorm=CLIPNORM[0]))
     return CoreTrain(helper, None).create_trainable_model(21, ignore_label=255, batch_size=4)
 
 
@@ -139,3 +140,23 @@ def test_two_input_signatures_share_the_optimizer_slot(cuda):
     assert le == lg, (le, lg)
     assert torch.equal(we, wg), float((we - wg).abs().max())
     assert torch.equal(cme, cmg)
+
+
+def test_graphed_step_with_per_variable_norm_clipping(cuda):
+    """clipnorm (Keras' per-variable norm clip, AdamW_EXT._clip_gradients with its NaN scrub: optimizers/modern/adamw.py:63-74) adds the squared-norm
+    reduction in front of the step kernel; captured with the rest of the step it must replay the eager run bit for bit, and it must bite (the curve
+    differs from the unclipped one)"""
+    OPTIMIZER[0] = "adamw"
+    batches = _batches()
+    try:
+        CLIPNORM[0] = None
+        plain = _run(False, 6, batches)[0]
+        CLIPNORM[0] = 0.05
+        le, we, _, cme, _, w0e = _run(False, 6, batches)
+        lg, wg, _, cmg, step, w0g = _run(True, 6, batches)
+    finally:
+        CLIPNORM[0] = None
+    assert any(e.get("graph") is not None for e in step.entries.values()), "the step was never captured"
+    assert le == lg, (le, lg)
+    assert torch.equal(we, wg) and torch.equal(cme, cmg)
+    assert le != plain, "the clip changed nothing: too loose to exercise the norm reduction"
