@@ -24,6 +24,11 @@ class TrainableModel:
         self.loss_weights = loss_weights or {}
         self.metrics = metrics or {}
         self.update_metrics = True
+        # jit_compile (Keras: compile the train function with XLA; core_train.py:86-91 passes it through model.compile): the MI355X counterpart of a
+        # traced, compiled step is the step replayed from ONE HIP graph (iseg_amd/graphs.py).  True -> fit() replays; None / False -> eager launches.
+        # The replay produces the bits of the eager step, so the switch changes speed only.
+        self.jit_compile = bool(jit_compile)
+        self._graphed_step = None
         # keras.optimizers.Optimizer(gradient_transformers=[...]): functions applied to the gradients before the update.  Here a transformer
         # takes the ParamStore (flat gradient buffer + per-parameter views) after the data-parallel sum and edits the gradients in place.
         self.gradient_transformers = []
@@ -184,6 +189,13 @@ class TrainableModel:
             verbose=1, validation_freq=1, log_every=50):
         it = iter(train_ds)
         history = []
+        step_fn = self.train_step
+        if self.jit_compile:
+            if self._graphed_step is None:
+                from .graphs import GraphedTrainStep
+
+                self._graphed_step = GraphedTrainStep(self)      # (falls back to the eager step where a capture is not possible: CPU, c10d data parallelism)
+            step_fn = self._graphed_step
         for epoch in range(initial_epoch, epochs):
             for cb in callbacks:
                 cb.on_epoch_begin(epoch)
@@ -191,7 +203,7 @@ class TrainableModel:
             running = None
             for step in range(steps_per_epoch):
                 x, y = next(it)
-                losses = self.train_step(x, y)
+                losses = step_fn(x, y)
                 if verbose and (step + 1) % log_every == 0:
                     vals = [float(l) for l in losses]          # the only host sync, once per log interval
                     print(f"epoch {epoch} step {step + 1}/{steps_per_epoch} loss {sum(vals):.5f} lr {self.optimizer.current_lr():.3e}")

@@ -86,3 +86,49 @@ def test_restore_refuses_a_mismatching_checkpoint(cuda, tmp_path):
     with pytest.raises(ValueError):
         hb.restore_checkpoint()
     assert hb.restore_checkpoint(skip_mismatch=True) == p2
+
+
+def test_jit_compile_replays_the_step_from_a_hip_graph_with_identical_results(cuda, tmp_path):
+    """CoreTrain.train(jit_compile=True) (core_train.py:86-91: Keras compiles the train function): here the step is replayed from one HIP graph.
+    Same seeds, same data order -> the history (losses, mIoU) and the weights of the compiled run equal the eager run's, bit for bit."""
+    from iseg_amd import functional as F
+    from iseg_amd.core_env import common_env_setup
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.core_train import CoreTrain
+    from iseg_amd.data import synthetic_dataset
+    from iseg_amd.modelhelper import model_common_setup
+
+    size = (64, 64)
+
+    def run(jit):
+        F._RNG_COUNTER[0] = 0
+        F._DROP_PATH_POOL.__init__()
+        strategy = common_env_setup(use_one_device_strategy=True, mixed_precision=True, random_seed=0)
+        model = _model(size)
+        helper = model_common_setup(model, restore_checkpoint=False, checkpoint_dir=None)
+        helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-3, end_lr=0.0, epoch_steps=4, train_epoch=2, optimizer="adamw",
+                                           adamw_weight_decay=0.01))
+        trainer = CoreTrain(helper, synthetic_dataset(16, size[0], size[1], seed=5), None)
+        history = trainer.train(strategy, num_class=21, ignore_label=255, batch_size=2, shuffle_rate=4, epoch_steps=4, train_epoches=2, verbose=0,
+                                jit_compile=jit)
+        torch.cuda.synchronize()
+        return history, {p.iseg_name: p.detach().clone() for p in model.parameters()}
+
+    from iseg_amd import graphs
+
+    captures = []
+    real_capture = graphs.GraphedTrainStep._capture
+    graphs.GraphedTrainStep._capture = lambda self, x, y: (captures.append(tuple(x.shape)), real_capture(self, x, y))[1]
+    try:
+        h0, w0 = run(None)
+        assert not captures
+        h1, w1 = run(True)
+    finally:
+        graphs.GraphedTrainStep._capture = real_capture
+        from iseg_amd import nn
+
+        nn.set_compute_dtype(torch.float32)
+    assert len(captures) == 1, f"jit_compile=True must capture the step once, captured {captures}"
+    assert h0 == h1, (h0, h1)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
