@@ -319,3 +319,73 @@ def test_cfg2_at_the_benchmark_shape(cuda):
     assert losses[-1] < losses[0], losses
     cm = tm._metrics_for(0)[0].metric.total_cm
     assert int(cm.sum()) == 4 * int((y != 255).sum())
+
+
+@pytest.mark.parametrize("size,batch", [((65, 97), 3), ((129, 129), 2)])
+def test_cfg2_odd_crop_sizes_fp32_parity_and_bf16_training(cuda, size, batch):
+    """the reference's default crop is 513 x 513 (data_process/pipeline.py crop_height / crop_width): odd planes all the way down (129 -> 65 -> 33 ->
+    17 at 513), i.e. ragged tiles in every tiled kernel (DMA depthwise tiles, fused-MLP row blocks, implicit-GEMM halos, the fused upsample + loss
+    tail).  fp32 storage against the oracle (logits 1e-3, argmax bit-exact, loss 1e-4); bf16 storage against the fp32-storage HIP run of the same
+    weights: logits within bf16 tolerance, every parameter gradient (frozen BatchNorm statistics) within 20 % in L2 (measured <= 12 %: bf16 rounding
+    through 18 blocks; a mishandled ragged tile is an O(1) error), and
+    three optimisation steps stay finite."""
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+    from iseg_amd.core_optimizer import get_optimizer
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.distribution.distribution_utils import Strategy
+    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.trainer import TrainableModel
+
+    x, y = synthetic_batch(batch, size[0], size[1], seed=41)
+    xc, yc = x.cuda(), y.cuda()
+    model = _flagship(size)
+    with torch.no_grad():
+        f32 = model(xc, training=False)[0]
+    ref = OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=False)["logits"]
+    assert tuple(f32.shape) == (batch, size[0], size[1], 21)
+    assert (f32.cpu().double() - ref).abs().max().item() < 1e-3
+    got_arg, ref_arg = f32.argmax(-1).cpu(), O.argmax_first(ref)
+    differ = got_arg != ref_arg
+    if bool(differ.any()):
+        # a pixel may only differ where the ORACLE's own decision is a numerical tie: the margin between its two largest logits below the fp32
+        # rounding of the logits (the bilinear x32 upsampling of an odd plane produces exact-arithmetic ties between neighbouring classes)
+        top2 = ref.topk(2, dim=-1).values
+        margin = (top2[..., 0] - top2[..., 1])[differ]
+        assert margin.max().item() < 1e-5, (int(differ.sum()), margin.max().item())
+
+    def grads_of(m, training=True):
+        m._iseg_store.zero_grad()
+        logits = m(xc, training=training)[0]
+        loss = F.softmax_ce_mean(logits, yc, 21, 255)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {p.iseg_name: p.grad.detach().float().clone() for p in m.parameters()}
+
+    loss32, g32 = grads_of(model)
+    ref_loss = OM.mean_ce_loss(OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=True)["logits"], y).item()
+    assert abs(loss32 - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
+    # gradients with FROZEN BatchNorm statistics: at these crops the head normalises over 3 x 4 x batch positions, and batch statistics over a few
+    # dozen bf16-rounded rows turn rounding into 15-20 % of the head's gradients at ANY plane shape -- the comparison is about ragged tiles, which the
+    # frozen-statistics pass walks just the same
+    _, g32 = grads_of(model, training=False)
+    scale = f32.abs().max().item()
+    del model
+    nn.set_compute_dtype(torch.bfloat16)
+    bm = _prep(convnext_tiny_aspp(build_input_size=size, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0), seed=2)
+    with torch.no_grad():
+        b16 = bm(xc, training=False)[0]
+    assert (b16.float() - f32).abs().max().item() < 0.06 * scale
+    loss16, _ = grads_of(bm)
+    assert abs(loss16 - loss32) < 2e-2 * abs(loss32)
+    _, g16 = grads_of(bm, training=False)
+    gmax = max(v.norm().item() for v in g32.values())
+    errs = {k: (g16[k] - v).norm().item() / max(v.norm().item(), 1e-3 * gmax) for k, v in g32.items()}
+    print("bf16 vs fp32 gradient error, largest first:", sorted(((round(e, 4), k) for k, e in errs.items()), reverse=True)[:8])
+    bad = {k: round(e, 4) for k, e in errs.items() if not e < 0.2}      # (measured: up to 0.12 at the stem, the far end of 18 bf16 blocks; a dropped tile is O(1))
+    assert not bad, bad
+    opt = get_optimizer(Strategy(one_device=True), initial_lr=1e-4, end_lr=0.0, epoch_steps=100, train_epoch=1, optimizer="adamw", adamw_weight_decay=0.05)
+    tm = TrainableModel(bm, optimizer=opt, loss=bm.custom_losses(21, 255, batch), loss_weights=bm.custom_losses_weights(), metrics=bm.custom_metrics(21, 255))
+    losses = [float(tm.train_step(xc, yc)[0]) for _ in range(3)]
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert int(tm._metrics_for(0)[0].metric.total_cm.sum()) == 3 * int((y != 255).sum())
