@@ -321,11 +321,12 @@ def test_cfg2_at_the_benchmark_shape(cuda):
     assert int(cm.sum()) == 4 * int((y != 255).sum())
 
 
-@pytest.mark.parametrize("size,batch", [((65, 97), 3), ((129, 129), 2)])
-def test_cfg2_odd_crop_sizes_fp32_parity_and_bf16_training(cuda, size, batch):
+@pytest.mark.parametrize("size,batch,os_", [((65, 97), 3, 32), ((129, 129), 2, 32), ((96, 64), 2, 16), ((64, 64), 2, 8)])
+def test_cfg2_odd_crops_and_output_strides_fp32_parity_and_bf16_training(cuda, size, batch, os_):
     """the reference's default crop is 513 x 513 (data_process/pipeline.py crop_height / crop_width): odd planes all the way down (129 -> 65 -> 33 ->
     17 at 513), i.e. ragged tiles in every tiled kernel (DMA depthwise tiles, fused-MLP row blocks, implicit-GEMM halos, the fused upsample + loss
-    tail).  fp32 storage against the oracle (logits 1e-3, argmax bit-exact, loss 1e-4); bf16 storage against the fp32-storage HIP run of the same
+    tail); the output-stride 16 / 8 cases run the dilated depthwise kernels (build_dilated_convnext, backbones/convnext.py:245-266) and ASPP's scaled
+    rates in both storage types.  fp32 storage against the oracle (logits 1e-3, argmax bit-exact, loss 1e-4); bf16 storage against the fp32-storage HIP run of the same
     weights: logits within bf16 tolerance, every parameter gradient (frozen BatchNorm statistics) within 20 % in L2 (measured <= 12 %: bf16 rounding
     through 18 blocks; a mishandled ragged tile is an O(1) error), and
     three optimisation steps stay finite."""
@@ -339,10 +340,12 @@ def test_cfg2_odd_crop_sizes_fp32_parity_and_bf16_training(cuda, size, batch):
 
     x, y = synthetic_batch(batch, size[0], size[1], seed=41)
     xc, yc = x.cuda(), y.cuda()
-    model = _flagship(size)
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(convnext_tiny_aspp(build_input_size=size, output_stride=os_, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0), seed=2)
     with torch.no_grad():
         f32 = model(xc, training=False)[0]
-    ref = OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=False)["logits"]
+    ref = OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=False, output_stride=os_)["logits"]
     assert tuple(f32.shape) == (batch, size[0], size[1], 21)
     assert (f32.cpu().double() - ref).abs().max().item() < 1e-3
     got_arg, ref_arg = f32.argmax(-1).cpu(), O.argmax_first(ref)
@@ -363,7 +366,7 @@ def test_cfg2_odd_crop_sizes_fp32_parity_and_bf16_training(cuda, size, batch):
         return float(loss), {p.iseg_name: p.grad.detach().float().clone() for p in m.parameters()}
 
     loss32, g32 = grads_of(model)
-    ref_loss = OM.mean_ce_loss(OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=True)["logits"], y).item()
+    ref_loss = OM.mean_ce_loss(OM.convnext_aspp_forward(OM.export_weights(model), x.double(), training=True, output_stride=os_)["logits"], y).item()
     assert abs(loss32 - ref_loss) < 1e-4 * max(1.0, abs(ref_loss))
     # gradients with FROZEN BatchNorm statistics: at these crops the head normalises over 3 x 4 x batch positions, and batch statistics over a few
     # dozen bf16-rounded rows turn rounding into 15-20 % of the head's gradients at ANY plane shape -- the comparison is about ragged tiles, which the
@@ -372,7 +375,7 @@ def test_cfg2_odd_crop_sizes_fp32_parity_and_bf16_training(cuda, size, batch):
     scale = f32.abs().max().item()
     del model
     nn.set_compute_dtype(torch.bfloat16)
-    bm = _prep(convnext_tiny_aspp(build_input_size=size, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0), seed=2)
+    bm = _prep(convnext_tiny_aspp(build_input_size=size, output_stride=os_, drop_path_rate=0.0, dropout_rate=0.0, layer_scale_init_value=1.0), seed=2)
     with torch.no_grad():
         b16 = bm(xc, training=False)[0]
     assert (b16.float() - f32).abs().max().item() < 0.06 * scale
