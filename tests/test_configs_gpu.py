@@ -328,7 +328,7 @@ def test_cfg2_at_the_benchmark_shape(cuda):
     assert int(cm.sum()) == 4 * int((y != 255).sum())
 
 
-@pytest.mark.parametrize("size,batch,os_", [((65, 97), 3, 32), ((129, 129), 2, 32), ((96, 64), 2, 16), ((64, 64), 2, 8)])
+@pytest.mark.parametrize("size,batch,os_", [((129, 97), 2, 32), ((96, 64), 2, 16), ((64, 64), 2, 8)])
 def test_cfg2_odd_crops_and_output_strides_fp32_parity_and_bf16_training(cuda, size, batch, os_):
     """the reference's default crop is 513 x 513 (data_process/pipeline.py crop_height / crop_width): odd planes all the way down (129 -> 65 -> 33 ->
     17 at 513), i.e. ragged tiles in every tiled kernel (DMA depthwise tiles, fused-MLP row blocks, implicit-GEMM halos, the fused upsample + loss
