@@ -114,7 +114,7 @@ def _stream_all_reduce(t, raw_stream):
         if not t.is_contiguous():
             raise ValueError("stream-ordered all-reduce needs a contiguous tensor (a slice of the flat buffers is)")
         code = K.F32 if t.dtype == torch.float32 else K.BF16 if t.dtype == torch.bfloat16 else None
-        if code is None:      # integer counts (confusion matrices): exact in fp64 -> not an RCCL-through-the-ABI type; take the c10d call
+        if code is None or not t.is_cuda:      # integer counts (confusion matrices) and host tensors: not for the C ABI's device entry; take the c10d call
             td.all_reduce(t, op=td.ReduceOp.SUM)
             return
         _hip.check(_hip.lib().iseg_allreduce_sum(_native_comm(), K.ptr(t), t.numel(), code, raw_stream), "iseg_allreduce_sum")
