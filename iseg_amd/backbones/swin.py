@@ -168,13 +168,21 @@ class SwinTransformerBlock(Layer):
         x_windows = F.permute_rows(x, part, rev, (n_win, ws * ws, c))      # pad + roll + partition
         attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
         x = F.permute_rows(attn_windows, rev, part, (n, h * w, c))         # reverse + roll back + crop
-        x, skip = F.fork(F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0])), 2)
+        x = F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0]))
         if self.mlp.fusable(training):      # skip + drop_path(mlp(.)) out of the second product's epilogue
             mask = None
             if training and self.drop_path_prob != 0.0:
                 mask = masks[1] if masks[1] is not None else F.drop_path_factors(n, 1.0 - self.drop_path_prob, x.device)
-            x = self.mlp(self.norm2(x), training=training, residual=skip, drop_path_mask=mask)
+            fc1, fc2 = self.mlp.fc1, self.mlp.fc2
+            params = (self.norm2.gamma, self.norm2.beta, fc1.kernel, fc1.bias, fc2.kernel, fc2.bias)
+            if not nn.dry_run() and F.ln_mlp_residual_supported(x, params, mask):
+                # stages of 96 / 192 channels: norm2 + MLP + drop path + skip as ONE node on the fused ConvNeXt-MLP kernels
+                x = F.ln_mlp_residual(x, self.norm2.gamma, self.norm2.beta, self.norm2.epsilon, fc1.kernel, fc1.bias, fc2.kernel, fc2.bias, mask)
+            else:
+                x, skip = F.fork(x, 2)
+                x = self.mlp(self.norm2(x), training=training, residual=skip, drop_path_mask=mask)
         else:
+            x, skip = F.fork(x, 2)
             y = self.mlp(self.norm2(x), training=training)
             x = F.add(skip, F.drop_path(y, self.drop_path_prob, training, mask=masks[1]))
         return x.reshape(n, h, w, c)

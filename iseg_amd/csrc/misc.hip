@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void finite_minmax_kernel(const T* __restrict_
     if (threadIdx.x == 0) {
         lo = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
         hi = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-        atomicMin(&mm[0], f2ord(lo));
-        atomicMax(&mm[1], f2ord(hi));
+        // 4096 workgroups x 2 atomics on two addresses serialise (97 us whatever the tensor size, Swin-T + FPN): look first, and only a workgroup that
+        // would move the running value sends its atomic -- after the first arrivals almost none does.  A stale look costs one needless atomic, never a
+        // wrong result (min / max are order independent).
+        const unsigned olo = f2ord(lo), ohi = f2ord(hi);
+        if (olo < __hip_atomic_load(&mm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[0], olo);
+        if (ohi > __hip_atomic_load(&mm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[1], ohi);
     }
 }
 
@@ -454,12 +458,16 @@ extern "C" int iseg_replace_nan_or_inf(const void* x, void* y, int64_t n, float 
     }
     unsigned* mm = (unsigned*)ws;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, stream, mm);
+    // the min / max pass: at most four workgroups per CU (each ends in up to two atomics on the same two words), eight elements per lane and trip
+    int64_t rb = ceil_div64(ceil_div64(n, 8), 256);
+    if (rb > 1024) rb = 1024;
+    const unsigned red_blocks = (unsigned)rb;
     if (dtype == ISEG_BF16) {
-        hipLaunchKernelGGL((finite_minmax_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, n, nan_value, mm);
+        hipLaunchKernelGGL((finite_minmax_kernel<bf16_t>), dim3(red_blocks), dim3(256), 0, stream, (const bf16_t*)x, n, nan_value, mm);
         hipLaunchKernelGGL((sanitize_apply_kernel<bf16_t>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const bf16_t*)x, (bf16_t*)y, n,
                            nan_value, mm);
     } else {
-        hipLaunchKernelGGL((finite_minmax_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const float*)x, n, nan_value, mm);
+        hipLaunchKernelGGL((finite_minmax_kernel<float>), dim3(red_blocks), dim3(256), 0, stream, (const float*)x, n, nan_value, mm);
         hipLaunchKernelGGL((sanitize_apply_kernel<float>), dim3(ew_blocks(n)), dim3(256), 0, stream, (const float*)x, (float*)y, n,
                            nan_value, mm);
     }

@@ -303,30 +303,66 @@ __global__ void bn_finalize_kernel(const float* __restrict__ packed, int C, floa
     if (moving_var) moving_var[c] = moving_var[c] * momentum + var * (1.f - momentum);
 }
 
+// Strip mapping of the element-wise BatchNorm kernels: thread (tc, tr) owns channel chunk(s) tc, tc + tpc, ... (eight channels each) and rows
+// blockIdx * rpi + tr, + gridDim * rpi, ... -- the per-channel constants (statistics, gamma, beta; in the packed form two divisions and an rsqrt per
+// channel) are derived once per chunk instead of once per 16 bytes of x (bn_apply_packed ran at 2.9 TB/s on those divisions, 5.5 without them).
+struct BnStrip {
+    int nchunks, tpc, rpi, tc, tr;
+    bool active;
+    __device__ __forceinline__ BnStrip(int C) {
+        nchunks = C / 8;
+        tpc = nchunks < 256 ? nchunks : 256;
+        rpi = 256 / tpc;
+        tc = threadIdx.x % tpc;
+        tr = threadIdx.x / tpc;
+        active = tr < rpi;
+    }
+};
+
 // y = act((x-mean)*rstd*gamma+beta), y may be a channel slice of a wider (concat) buffer
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, T* __restrict__ y, int64_t ldy,
                                                        int64_t rows, int C, int relu) {
-    const int nchunks = C / 8;
-    const int64_t total = rows * nchunks;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / nchunks;
-        const int c = (int)(i % nchunks) * 8;
-        float v[8], m[8], s[8], g[8], b[8];
-        load8<T>(x + r * ldx + c, v);
+    const BnStrip st(C);
+    if (!st.active) return;
+    const int64_t rstep = (int64_t)gridDim.x * st.rpi;
+    for (int cc = st.tc; cc < st.nchunks; cc += st.tpc) {
+        const int c = cc * 8;
+        float m[8], s[8], g[8], b[8];
         load8<float>(mean + c, m);
         load8<float>(rstd + c, s);
         load8<float>(gamma + c, g);
         load8<float>(beta + c, b);
+        int64_t r = (int64_t)blockIdx.x * st.rpi + st.tr;
+        constexpr int UB = 4;
+        for (; r + (UB - 1) * rstep < rows; r += UB * rstep) {
+            float v[UB][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
-            if (relu) o = fmaxf(o, 0.f);
-            v[u] = o;
+            for (int k = 0; k < UB; ++k) load8<T>(x + (r + k * rstep) * ldx + c, v[k]);
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float o = (v[k][u] - m[u]) * s[u] * g[u] + b[u];
+                    if (relu) o = fmaxf(o, 0.f);
+                    v[k][u] = o;
+                }
+                store8<T>(y + (r + k * rstep) * ldy + c, v[k]);
+            }
         }
-        store8<T>(y + r * ldy + c, v);
+        for (; r < rows; r += rstep) {
+            float v[8];
+            load8<T>(x + r * ldx + c, v);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
+                if (relu) o = fmaxf(o, 0.f);
+                v[u] = o;
+            }
+            store8<T>(y + r * ldy + c, v);
+        }
     }
 }
 
@@ -338,14 +374,13 @@ __global__ __launch_bounds__(256) void bn_apply_packed_kernel(const T* __restric
                                                               float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ moving_mean,
                                                               float* __restrict__ moving_var, T* __restrict__ y, int64_t ldy, int64_t rows, int C,
                                                               int relu) {
-    const int nchunks = C / 8;
-    const int64_t total = rows * nchunks;
+    const BnStrip st(C);
+    if (!st.active) return;
     const float n = packed[2 * C];
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / nchunks;
-        const int c = (int)(i % nchunks) * 8;
-        float v[8], m[8], s[8], g[8], b[8], var[8];
-        load8<T>(x + r * ldx + c, v);
+    const int64_t rstep = (int64_t)gridDim.x * st.rpi;
+    for (int cc = st.tc; cc < st.nchunks; cc += st.tpc) {
+        const int c = cc * 8;
+        float m[8], s[8], g[8], b[8], var[8];
         load8<float>(packed + c, m);
         load8<float>(packed + C + c, var);
         load8<float>(gamma + c, g);
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(256) void bn_apply_packed_kernel(const T* __restric
             var[u] = fmaxf(var[u] / n - m[u] * m[u], 0.f);
             s[u] = rsqrtf(var[u] + eps);
         }
-        if (r == 0) {
+        if (blockIdx.x == 0 && st.tr == 0) {      // the lane that owns row 0 of this chunk
             store8<float>(mean + c, m);
             store8<float>(rstd + c, s);
             if (moving_mean) {
@@ -374,13 +409,34 @@ __global__ __launch_bounds__(256) void bn_apply_packed_kernel(const T* __restric
                 store8<float>(moving_var + c, mv);
             }
         }
+        int64_t r = (int64_t)blockIdx.x * st.rpi + st.tr;
+        constexpr int UB = 4;
+        for (; r + (UB - 1) * rstep < rows; r += UB * rstep) {
+            float v[UB][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
-            if (relu) o = fmaxf(o, 0.f);
-            v[u] = o;
+            for (int k = 0; k < UB; ++k) load8<T>(x + (r + k * rstep) * ldx + c, v[k]);
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    float o = (v[k][u] - m[u]) * s[u] * g[u] + b[u];
+                    if (relu) o = fmaxf(o, 0.f);
+                    v[k][u] = o;
+                }
+                store8<T>(y + (r + k * rstep) * ldy + c, v[k]);
+            }
         }
-        store8<T>(y + r * ldy + c, v);
+        for (; r < rows; r += rstep) {
+            float v[8];
+            load8<T>(x + r * ldx + c, v);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float o = (v[u] - m[u]) * s[u] * g[u] + b[u];
+                if (relu) o = fmaxf(o, 0.f);
+                v[u] = o;
+            }
+            store8<T>(y + r * ldy + c, v);
+        }
     }
 }
 
@@ -455,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// dx = gamma*rstd * (dz - sum_dz/n - xhat*sum_dzxhat/n) ; sums[0:C]=sum dz, [C:2C]=sum dz*xhat (already all-reduced)
+// dx = gamma*rstd * (dz - sum_dz/n - xhat*sum_dzxhat/n) ; sums[0:C]=sum dz, [C:2C]=sum dz*xhat (already all-reduced).  Strip mapping (BnStrip).
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
                                                            int64_t ldx, const T* __restrict__ y, int64_t ldy,
@@ -463,48 +519,70 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float inv_n, T* __restrict__ dx, int64_t lddx, int64_t rows, int C,
                                                            int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int nchunks = C / 8;
-    const int64_t total = rows * nchunks;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / nchunks;
-        const int c = (int)(i % nchunks) * 8;
-        float d[8], xv[8], m[8], rs[8], g[8], s1[8], s2[8];
-        if (r == 0 && (dgamma || dbeta)) {      // the lane that owns row 0 of a chunk also books the parameter gradients (dbeta | dgamma = sums)
-            float a[8], acc[8];
-            if (dbeta) {
-                load8<float>(sums + c, a);
-                load8<float>(dbeta + c, acc);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += a[u];
-                store8<float>(dbeta + c, acc);
-            }
-            if (dgamma) {
-                load8<float>(sums + C + c, a);
-                load8<float>(dgamma + c, acc);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += a[u];
-                store8<float>(dgamma + c, acc);
-            }
-        }
-        load8<T>(dy + r * lddy + c, d);
-        load8<T>(x + r * ldx + c, xv);
-        if (relu) {
-            float yv[8];
-            load8<T>(y + r * ldy + c, yv);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
-        }
+    const BnStrip st(C);
+    if (!st.active) return;
+    const int64_t rstep = (int64_t)gridDim.x * st.rpi;
+    for (int cc = st.tc; cc < st.nchunks; cc += st.tpc) {
+        const int c = cc * 8;
+        float m[8], rs[8], g[8], s1[8], s2[8];
         load8<float>(mean + c, m);
         load8<float>(rstd + c, rs);
         load8<float>(gamma + c, g);
         load8<float>(sums + c, s1);
         load8<float>(sums + C + c, s2);
+        if (blockIdx.x == 0 && st.tr == 0 && (dgamma || dbeta)) {   // the lane that owns row 0 of a chunk also books the parameter gradients (dbeta | dgamma = sums)
+            float acc[8];
+            if (dbeta) {
+                load8<float>(dbeta + c, acc);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float xh = (xv[u] - m[u]) * rs[u];
-            d[u] = g[u] * rs[u] * (d[u] - s1[u] * inv_n - xh * s2[u] * inv_n);
+                for (int u = 0; u < 8; ++u) acc[u] += s1[u];
+                store8<float>(dbeta + c, acc);
+            }
+            if (dgamma) {
+                load8<float>(dgamma + c, acc);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += s2[u];
+                store8<float>(dgamma + c, acc);
+            }
         }
-        store8<T>(dx + r * lddx + c, d);
+        int64_t r = (int64_t)blockIdx.x * st.rpi + st.tr;
+        constexpr int UB = 2;
+        for (; r + (UB - 1) * rstep < rows; r += UB * rstep) {
+            float d[UB][8], xv[UB][8], yv[UB][8];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                load8<T>(dy + (r + k * rstep) * lddy + c, d[k]);
+                load8<T>(x + (r + k * rstep) * ldx + c, xv[k]);
+                if (relu) load8<T>(y + (r + k * rstep) * ldy + c, yv[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float dv = (relu && !(yv[k][u] > 0.f)) ? 0.f : d[k][u];
+                    const float xh = (xv[k][u] - m[u]) * rs[u];
+                    d[k][u] = g[u] * rs[u] * (dv - s1[u] * inv_n - xh * s2[u] * inv_n);
+                }
+                store8<T>(dx + (r + k * rstep) * lddx + c, d[k]);
+            }
+        }
+        for (; r < rows; r += rstep) {
+            float d[8], xv[8];
+            load8<T>(dy + r * lddy + c, d);
+            load8<T>(x + r * ldx + c, xv);
+            if (relu) {
+                float yv[8];
+                load8<T>(y + r * ldy + c, yv);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float xh = (xv[u] - m[u]) * rs[u];
+                d[u] = g[u] * rs[u] * (d[u] - s1[u] * inv_n - xh * s2[u] * inv_n);
+            }
+            store8<T>(dx + r * lddx + c, d);
+        }
     }
 }
 
@@ -621,17 +699,32 @@ static size_t bn_slab_bytes(int C) {
     return (size_t)(256 / tpc) * 2 * C * sizeof(float);
 }
 
-static int bn_blocks(int64_t rows, int C) {
+// workgroups of the two reduction kernels.  Measured on [16,128,128,256] bf16 from HBM (tools/kbench_stream.py cold): the statistics pass (one
+// tensor, eight rows in flight per lane) is fastest with one workgroup per CU (26.8 us; 38.8 at 1024), the backward sums (three tensors, four
+// rows in flight) with four (77.4 us; 102.3 at 256).
+static int bn_blocks(int64_t rows, int C, int cap = 256) {
     const int nchunks = C / 8;
     const int tpc = nchunks < 256 ? nchunks : 256;
     const int rpi = 256 / tpc;
     int64_t blocks = ceil_div64(rows, (int64_t)rpi * 4);
-    if (blocks > 256) blocks = 256;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+constexpr int BN_BWD_REDUCE_MAX_BLOCKS = 1024;
+
+// grid of the element-wise BatchNorm kernels (BnStrip): about eight rows per thread, at most 4096 workgroups
+static int bn_strip_blocks(int64_t rows, int C) {
+    const int nchunks = C / 8;
+    const int tpc = nchunks < 256 ? nchunks : 256;
+    const int rpi = 256 / tpc;
+    int64_t blocks = ceil_div64(rows, (int64_t)rpi * 8);
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
 
-extern "C" size_t iseg_bn_workspace_bytes(int64_t rows, int C) { return (size_t)bn_blocks(rows, C) * 2 * C * sizeof(float); }
+extern "C" size_t iseg_bn_workspace_bytes(int64_t rows, int C) { return (size_t)bn_blocks(rows, C, BN_BWD_REDUCE_MAX_BLOCKS) * 2 * C * sizeof(float); }
 
 extern "C" int iseg_bn_stats(const void* x, int64_t ldx, float* packed, int64_t rows, int C, int dtype, void* ws,
                              size_t ws_bytes, hipStream_t stream) {
@@ -668,8 +761,7 @@ extern "C" int iseg_bn_apply_fwd(const void* x, int64_t ldx, const float* mean, 
                                  hipStream_t stream) {
     ISEG_REQUIRE(x && mean && rstd && gamma && beta && y, "iseg_bn_apply_fwd: null pointer");
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "iseg_bn_apply_fwd: C/ldx/ldy must be multiples of 8");
-    int64_t blocks = ceil_div64(rows * (C / 8), 256);
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = bn_strip_blocks(rows, C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, ldx, mean,
                            rstd, gamma, beta, (bf16_t*)y, ldy, rows, C, relu);
@@ -686,8 +778,7 @@ extern "C" int iseg_bn_apply_fwd_packed(const void* x, int64_t ldx, const float*
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "iseg_bn_apply_fwd_packed: C/ldx/ldy must be multiples of 8");
     ISEG_REQUIRE((((uintptr_t)packed | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)moving_mean | (uintptr_t)moving_var) & 15) == 0,
                  "iseg_bn_apply_fwd_packed: statistics must be 16-byte aligned");
-    int64_t blocks = ceil_div64(rows * (C / 8), 256);
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = bn_strip_blocks(rows, C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_apply_packed_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, ldx, packed, eps,
                            momentum, gamma, beta, mean, rstd, moving_mean, moving_var, (bf16_t*)y, ldy, rows, C, relu);
@@ -702,7 +793,7 @@ extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
                                   void* ws, size_t ws_bytes, hipStream_t stream) {
     ISEG_REQUIRE(dy && x && mean && rstd && sums && (!relu || y), "iseg_bn_bwd_reduce: null pointer");
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && (!relu || ldy % 8 == 0), "iseg_bn_bwd_reduce: alignment");
-    const int blocks = bn_blocks(rows, C);
+    const int blocks = bn_blocks(rows, C, BN_BWD_REDUCE_MAX_BLOCKS);
     const size_t need = (size_t)blocks * 2 * C * sizeof(float);
     if (!ws || ws_bytes < need) {
         iseg_set_error("iseg_bn_bwd_reduce: needs %zu workspace bytes, got %zu", need, ws_bytes);
@@ -738,8 +829,7 @@ extern "C" int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "iseg_bn_bwd_apply: alignment");
     ISEG_REQUIRE((((uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0 && (!(dgamma || dbeta) || ((uintptr_t)sums & 15) == 0),
                  "iseg_bn_bwd_apply_acc: gradient vectors must be 16-byte aligned");
-    int64_t blocks = ceil_div64(rows * (C / 8), 256);
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = bn_strip_blocks(rows, C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy,
                            (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, gamma, sums, inv_n, (bf16_t*)dx, lddx, rows,

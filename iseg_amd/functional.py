@@ -198,6 +198,65 @@ def mlp_gelu(x, W1, b1, W2, b2, residual=None, drop_path_mask=None):
     return _MlpGeluFn.apply(x, W1, b1, W2, b2, residual, drop_path_mask)
 
 
+class _LnMlpResidualFn(Function):
+    """x + drop_path(Dense(gelu(Dense(LayerNorm(x))))) -- the second half of a pre-norm transformer block (backbones/swin.py:233-236) -- on the
+    fused kernels of the ConvNeXt stages (csrc/mlp_fused.hip, csrc/mlp_wgrad.hip: C = 96 / 192, hidden 4C, bf16): LayerNorm rides the row
+    loads, the [M, 4C] hidden tile never leaves the CU in either direction, the skip connection and the drop-path factor ride the epilogue.
+    Replaces LayerNorm + two GEMMs forward and LayerNorm backward + four GEMMs + their split-K sums + the residual fork backward."""
+
+    @staticmethod
+    def forward(ctx, x, ln_gamma, ln_beta, eps, W1, b1, W2, b2, rowscale):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        M = x2.shape[0]
+        rpg = M // rowscale.shape[0] if rowscale is not None else 0
+        fw, bw = nn.mlp_tiled(W1, W2, None)
+        out, mean, rstd = K.convnext_mlp_fwd_ln(x2, ln_gamma.data, ln_beta.data, eps, fw, b1.data, b2.data, None, rowscale, rpg, x2)
+        ctx.params, ctx.rpg = (ln_gamma, ln_beta, W1, b1, W2, b2), rpg
+        ctx.save_for_backward(x2, mean, rstd, bw, rowscale)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mean, rstd, bw, rowscale = ctx.saved_tensors
+        ln_gamma, ln_beta, W1, b1, W2, b2 = ctx.params
+        M, C = x2.shape
+        do2 = _c(dout).reshape(M, C)
+        ln = (mean, rstd, ln_gamma.data, ln_beta.data)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dln = K.convnext_mlp_bwd_data_ln(x2, do2, bw, b1.data, ln, _grad(ln_gamma), _grad(ln_beta), rowscale, ctx.rpg)
+            dx = K.axpby(do2, dln, 1.0, 1.0, out=dln).reshape(dout.shape)      # + the skip connection's share
+        else:      # (the LayerNorm parameter gradients come out of the chain kernel's epilogue)
+            K.convnext_mlp_bwd_data_ln(x2, do2, bw, b1.data, ln, _grad(ln_gamma), _grad(ln_beta), rowscale, ctx.rpg)
+        K.convnext_mlp_wgrad(x2, do2, bw, b1.data, W2.data, b2.data, None, _grad(W1), _grad(b1), _grad(W2), _grad(b2), None, rowscale, ctx.rpg, ln=ln)
+        dist.grads_ready(ln_gamma, ln_beta, W1, b1, W2, b2)
+        return (dx,) + (None,) * 8
+
+
+def ln_mlp_residual_supported(x, params, drop_path_mask=None):
+    """the fused route exists for bf16 rows of 96 / 192 channels with a 4x hidden layer, every parameter trainable (or none needed), and a
+    drop-path group size the kernels' 64-row tiles divide"""
+    ln_gamma, ln_beta, W1, b1, W2, b2 = params
+    C = x.shape[-1]
+    if any(p is None for p in params) or not K.convnext_mlp_supported(C, x.dtype) or C not in (96, 192):
+        return False
+    if tuple(W1.shape) != (C, 4 * C) or tuple(W2.shape) != (4 * C, C):
+        return False
+    if not all(p.requires_grad for p in params) and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        return False      # partly frozen: the weight-gradient kernel books all six parameters
+    rows = x.numel() // C
+    return drop_path_mask is None or (rows % drop_path_mask.shape[0] == 0 and (rows // drop_path_mask.shape[0]) % 64 == 0)
+
+
+def ln_mlp_residual(x, ln_gamma, ln_beta, eps, W1, b1, W2, b2, drop_path_mask=None):
+    """x + drop_path_mask[sample] * dense(gelu(dense(layer_norm(x)))) as ONE tape node (ln_mlp_residual_supported(...) must hold)"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _LnMlpResidualFn.apply(x, ln_gamma, ln_beta, float(eps), W1, b1, W2, b2, drop_path_mask)
+
+
 def dense(x, W, b=None, act=K.ACT_NONE, kshape=None):
     """kshape=(in, out) re-interprets a higher-rank kernel (keras MultiHeadAttention: [C, heads, d] / [heads, d, C]) as [in, out]"""
     _check_act_dtype(x)

@@ -300,6 +300,67 @@ def test_swin_small(cuda, dtype):
         nn.set_compute_dtype(torch.float32)
 
 
+def test_swin_wide_stages_take_the_fused_mlp_node(cuda):
+    """Stages of 96 / 192 channels in bf16: norm2 + MLP + drop path + skip is ONE tape node on the fused ConvNeXt-MLP kernels
+    (F.ln_mlp_residual: LayerNorm on the row loads, hidden tile on the CU, recomputing backward).  A 2-stage model (64x64 input -> 16x16 and
+    8x8 tokens: drop-path groups of 256 / 64 rows) against the fp64 oracle with injected drop-path factors, and against the SAME model on the
+    un-fused route (LayerNorm kernel + GEMM pair), which must agree to bf16 rounding."""
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+    from iseg_amd.backbones.swin import SwinTransformerModel
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    try:
+        shape = (2, 64, 64, 3)
+        swin = SwinTransformerModel(embed_dim=96, depths=[2, 2], num_heads=[3, 6], window_size=7, drop_path_rate=0.2,
+                                    return_endpoints=True, name="swin_wide")
+        _setup(swin, torch.empty(shape, dtype=torch.float32, device="cuda"))
+        g = torch.Generator().manual_seed(3)
+        fa, fb = torch.tensor([1.25, 0.0]), torch.tensor([1.25, 1.25])
+        dp = [[None, (fb.double(), fa.double())], [(fa.double(), fa.double()), (fa.double(), fb.double())]]
+        for li in range(2):
+            for bi in range(2):
+                if dp[li][bi] is not None:
+                    swin.basic_layers[li].blocks[bi].drop_path_masks = tuple(t.float().cuda() for t in dp[li][bi])
+        x = torch.randn(shape, generator=g)
+        seen = []
+        orig = F._LnMlpResidualFn.apply
+        F._LnMlpResidualFn.apply = staticmethod(lambda *a: (seen.append(tuple(a[0].shape)), orig(*a))[1])
+        try:
+            eps = swin(x.cuda(), training=True)
+        finally:
+            del F._LnMlpResidualFn.apply      # back to the inherited classmethod
+        assert seen == [(2, 256, 96)] * 2 + [(2, 64, 192)] * 2, seen      # all four blocks took the fused node
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(swin).items()}
+        ref = OM.swin_forward(w, x.double(), depths=(2, 2), heads=(3, 6), ws=7, dp_factors=dp)
+        for a, b in zip(eps, ref):
+            assert _rel(a, b.detach()) < 4e-2
+        dys = [torch.randn(tuple(r.shape), generator=g).to(torch.bfloat16) for r in ref]
+        torch.autograd.backward(list(eps), [d.cuda() for d in dys])
+        torch.autograd.backward(ref, [d.double() for d in dys])
+        _check_grads(swin, w, 8e-2, l2=True)
+        fused = {p.iseg_name: p.grad.clone() for p in swin.parameters()}
+        # the un-fused route of the same model, same inputs
+        sup = F.ln_mlp_residual_supported
+        F.ln_mlp_residual_supported = lambda *a, **k: False
+        try:
+            for p in swin.parameters():
+                p.grad = None
+            eps2 = swin(x.cuda(), training=True)
+            torch.autograd.backward(list(eps2), [d.cuda() for d in dys])
+        finally:
+            F.ln_mlp_residual_supported = sup
+        for a, b in zip(eps, eps2):
+            assert _rel(a, b.detach().cpu().double()) < 3e-2
+        for p in swin.parameters():
+            ref_g = p.grad.double()
+            err = (fused[p.iseg_name].double() - ref_g).norm().item() / max(ref_g.norm().item(), 1e-12)
+            assert err < 6e-2, (p.iseg_name, err)
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
 def test_swin_absolute_position_embedding(cuda):
     """use_absolute_pos_embed (backbones/swin.py:563-569,606-607): one vector per patch of the build resolution, added to the patch embedding;
     another resolution does not fit (the reference's reshape fails the same way)"""
