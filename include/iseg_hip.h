@@ -136,6 +136,15 @@ size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                        const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
                        int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* LayerNorm followed by a static row permutation with zero padding -- norm1 + tf.pad + tf.roll + window_partition of a Swin block
+ * (backbones/swin.py:246-262) in one pass: y[r,:] = src_index[r] >= 0 ? LN(x[src_index[r],:]) : 0 for r < rows_out; mean / rstd [rows_out]
+ * are kept per OUTPUT row.  Backward over the `rows` SOURCE rows with the inverse table: the gradient row and the statistics of source row
+ * r sit at row dy_index[r] (< 0: no gradient arrives); dx = dx_add + LN^T dy as in iseg_layernorm_bwd (same workspace). */
+int iseg_layernorm_gather_fwd(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean,
+                              float* rstd, int64_t rows_out, int C, float eps, int dtype, iseg_stream_t stream);
+int iseg_layernorm_gather_bwd(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean,
+                              const float* rstd, void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads,
+                              int64_t rows, int C, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Depthwise KxK conv, stride 1, dilation `dil`, explicit top/left padding (TF "same": pad = (K-1)*dil/2):
@@ -429,6 +438,12 @@ int iseg_clip_bwd(const void* x, const void* dy, void* dx, int64_t n, float lo, 
  * backbones/swin.py:46-64,258-288 and PatchMerging's 2x2 space-to-depth (:316-327) as one row permutation each */
 int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int64_t rows_in, int64_t rows_out, int C, int dtype,
                      iseg_stream_t stream);
+/* y[r,:] = residual[r,:] + scale[g] * (idx[r] >= 0 ? x[idx[r],:] : 0), g = (scale_by_source_row ? idx[r] : r) / rows_per_group; residual
+ * and scale optional, C % 8 == 0 -- window_reverse + roll back + crop + drop path + skip connection of a Swin block
+ * (backbones/swin.py:264-279, utils/drops.py:8-22) in one pass, and its gradient towards the window rows (inverse table,
+ * scale_by_source_row = 1) */
+int iseg_gather_rows_fma(const void* x, const int32_t* idx, const float* scale, int64_t rows_per_group, int scale_by_source_row,
+                         const void* residual, void* y, int64_t rows_out, int C, int dtype, iseg_stream_t stream);
 /* backbones/swin.py:134-142: bias[h,i,j] = table[index[i,j], h]; gradient dtable[k,h] (+)= sum_{index[i,j]==k} dbias[h,i,j]
  * (dbias rows have stride ld) */
 /* out[c] (+)= sum_r x[r*ldx + c] for a short, very wide matrix (the [windows, heads*T*ld] score gradients -> bias gradient) */

@@ -63,6 +63,8 @@ SIGNATURES = {
     "iseg_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "iseg_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_layernorm_gather_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "iseg_layernorm_gather_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
     "iseg_dwconv2d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_dwconv2d_bwd_weight_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "iseg_dwconv2d_bwd_weight": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -132,6 +134,7 @@ SIGNATURES = {
     "iseg_clip_fwd": (_i, [_p, _p, _l, _f, _f, _i, _p]),
     "iseg_clip_bwd": (_i, [_p, _p, _p, _l, _f, _f, _i, _p]),
     "iseg_gather_rows": (_i, [_p, _p, _p, _l, _l, _i, _i, _p]),
+    "iseg_gather_rows_fma": (_i, [_p, _p, _p, _l, _i, _p, _p, _l, _i, _i, _p]),
     "iseg_relpos_bias_scatter_grad_window": (_i, [_p, _i, _p, _i, _i, _i, _p]),
     "iseg_colsum_wide_workspace_bytes": (_z, [_l, _l]),
     "iseg_colsum_wide": (_i, [_p, _l, _l, _l, _p, _i, _i, _p, _z, _p]),

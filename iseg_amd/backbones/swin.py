@@ -160,15 +160,27 @@ class SwinTransformerBlock(Layer):
         n, h, w, c = inputs.shape
         ws = self.window_size
         masks = self.drop_path_masks or (None, None)
-        inputs, shortcut = F.fork(inputs, 2)      # residual fork (gradients summed by our own kernel)
-        shortcut = shortcut.reshape(n, h * w, c)
-        x = self.norm1(inputs)
         part, rev, hp, wp = window_index_tables(n, h, w, ws, self.shift_size)
         n_win = n * (hp // ws) * (wp // ws)
-        x_windows = F.permute_rows(x, part, rev, (n_win, ws * ws, c))      # pad + roll + partition
-        attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
-        x = F.permute_rows(attn_windows, rev, part, (n, h * w, c))         # reverse + roll back + crop
-        x = F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0]))
+        if self.norm1.built and c % 8 == 0 and not nn.dry_run():
+            # norm1 + pad + roll + partition in one pass; reverse + roll back + crop + drop path + skip connection in another; the skip
+            # connection's gradient rides the LayerNorm backward (F._LnGatherFn) -- five passes over the token rows less each way
+            mask = None
+            if training and self.drop_path_prob != 0.0:
+                mask = masks[0] if masks[0] is not None else F.drop_path_factors(n, 1.0 - self.drop_path_prob, inputs.device)
+            tokens = inputs.reshape(n, h * w, c)
+            link = F.residual_branch_link()
+            x_windows = F.layer_norm_permute_rows(tokens, self.norm1.gamma, self.norm1.beta, self.norm1.epsilon, part, rev, (n_win, ws * ws, c), link)
+            attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
+            x = F.permute_rows_residual(attn_windows, tokens, rev, part, mask, link)
+        else:
+            inputs, shortcut = F.fork(inputs, 2)      # residual fork (gradients summed by our own kernel)
+            shortcut = shortcut.reshape(n, h * w, c)
+            x = self.norm1(inputs)
+            x_windows = F.permute_rows(x, part, rev, (n_win, ws * ws, c))      # pad + roll + partition
+            attn_windows = self.attention(x_windows, attention_mask=attention_mask if self.shift_size > 0 else None, training=training)
+            x = F.permute_rows(attn_windows, rev, part, (n, h * w, c))         # reverse + roll back + crop
+            x = F.add(shortcut, F.drop_path(x, self.drop_path_prob, training, mask=masks[0]))
         if self.mlp.fusable(training):      # skip + drop_path(mlp(.)) out of the second product's epilogue
             mask = None
             if training and self.drop_path_prob != 0.0:

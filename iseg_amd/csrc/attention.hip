@@ -220,6 +220,30 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
     }
 }
 
+// y[r, :] = res[r, :] + scale[g] * (idx[r] >= 0 ? x[idx[r], :] : 0),  g = (by_src ? idx[r] : r) / rows_per_group   (res, scale optional; C % 8 == 0)
+// -- window reverse + roll back + crop + drop path + skip connection of a Swin block in one pass (backbones/swin.py:264-279: by_src = 0), and
+// its gradient towards the window rows (the inverse table, the factor of the SOURCE row's sample: by_src = 1)
+template <class T>
+__global__ __launch_bounds__(256) void gather_rows_fma_kernel(const T* __restrict__ x, const int32_t* __restrict__ idx, const float* __restrict__ scale,
+                                                              int64_t rows_per_group, int by_src, const T* __restrict__ res, T* __restrict__ y,
+                                                              int64_t rows_out, int C) {
+    const int chunks = C / 8;
+    const int64_t total = rows_out * chunks;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / chunks;
+        const int c = (int)(i % chunks) * 8;
+        const int32_t src = idx[r];
+        float v[8], a[8];
+        load8<T>(x + (int64_t)(src >= 0 ? src : 0) * C + c, v);      // (unconditional load from a clamped address, selected afterwards)
+        if (res) load8<T>(res + r * C + c, a);
+        float f = src >= 0 ? 1.f : 0.f;
+        if (scale && src >= 0) f = scale[(by_src ? (int64_t)src : r) / rows_per_group];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = res ? fmaf(f, v[u], a[u]) : f * v[u];
+        store8<T>(y + r * C + c, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void relpos_gather_kernel(const float* __restrict__ table, const int32_t* __restrict__ index,
                                                             float* __restrict__ bias, int heads, int TT) {
     const int total = heads * TT;
@@ -397,6 +421,20 @@ extern "C" int iseg_gather_rows(const void* x, const int32_t* idx, void* y, int6
                                (float*)y, rows_out, C);
     }
     return iseg_check_launch("iseg_gather_rows");
+}
+
+extern "C" int iseg_gather_rows_fma(const void* x, const int32_t* idx, const float* scale, int64_t rows_per_group, int scale_by_source_row,
+                                    const void* residual, void* y, int64_t rows_out, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && idx && y && rows_out > 0 && C > 0 && C % 8 == 0, "iseg_gather_rows_fma: bad arguments (C = %d must be a multiple of 8)", C);
+    ISEG_REQUIRE(!scale || rows_per_group > 0, "iseg_gather_rows_fma: scale needs rows_per_group > 0");
+    ISEG_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0, "iseg_gather_rows_fma: operands must be 16-byte aligned");
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((gather_rows_fma_kernel<bf16_t>), dim3(ew_blocks(rows_out * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, idx, scale,
+                           rows_per_group, scale_by_source_row, (const bf16_t*)residual, (bf16_t*)y, rows_out, C);
+    else
+        hipLaunchKernelGGL((gather_rows_fma_kernel<float>), dim3(ew_blocks(rows_out * (C / 8))), dim3(256), 0, stream, (const float*)x, idx, scale,
+                           rows_per_group, scale_by_source_row, (const float*)residual, (float*)y, rows_out, C);
+    return iseg_check_launch("iseg_gather_rows_fma");
 }
 
 extern "C" int iseg_relpos_bias_scatter_grad_window(const float* dbias, int ld, float* dtable, int ws, int heads, int accumulate,

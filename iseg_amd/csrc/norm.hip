@@ -29,7 +29,9 @@ template <class T, int CPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int64_t rows, int C, float eps, int lpr) {
+                                                            int64_t rows, int C, float eps, int lpr, const int32_t* __restrict__ src_index) {
+    // src_index (optional): output row r is LayerNorm(x[src_index[r]]), or a row of ZEROS where src_index[r] < 0 -- Swin's norm1 followed by
+    // zero-pad + cyclic roll + window partition (backbones/swin.py:246-262) in one pass; statistics are then kept per OUTPUT row
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int rpw = 64 / lpr;  // rows per wave
     const int sub = lane / lpr, li = lane % lpr;
@@ -50,7 +52,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
         const int64_t row = rbase + sub;
         const bool valid = row < rows;
-        const int64_t rc = valid ? row : rows - 1;
+        int64_t rc = valid ? row : rows - 1;
+        bool pad_row = false;
+        if (src_index) {
+            const int32_t src = src_index[rc];
+            pad_row = src < 0;
+            rc = pad_row ? 0 : src;
+        }
         float v[CPL][8];
         float s = 0.f;
 #pragma unroll
@@ -86,13 +94,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             if (valid && c < nchunks) {
                 float o[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) o[u] = (v[i][u] - mean) * rstd * g[i][u] + bt[i][u];
+                for (int u = 0; u < 8; ++u) o[u] = pad_row ? 0.f : (v[i][u] - mean) * rstd * g[i][u] + bt[i][u];
                 store8<T>(y + row * C + c * 8, o);
             }
         }
         if (valid && li == 0) {
-            if (mean_out) mean_out[row] = mean;
-            if (rstd_out) rstd_out[row] = rstd;
+            if (mean_out) mean_out[row] = pad_row ? 0.f : mean;
+            if (rstd_out) rstd_out[row] = pad_row ? 0.f : rstd;
         }
     }
 }
@@ -109,7 +117,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             const T* __restrict__ dx_add, float* __restrict__ partials,
-                                                            int64_t rows, int C, int lpr) {
+                                                            int64_t rows, int C, int lpr, const int32_t* __restrict__ dy_index) {
+    // dy_index (optional): the gradient row and the saved statistics of source row r sit at row dy_index[r] (< 0: no gradient arrives) -- the
+    // backward of layernorm_fwd_kernel's src_index form with the inverse table
     extern __shared__ __attribute__((aligned(16))) float lds_part[];  // [2][C]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int rpw = 64 / lpr;
@@ -141,14 +151,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             // every load is issued unconditionally from a clamped address and zeroed by a select afterwards: a branch per load makes hipcc
             // wait for each one at the join, which serialises the rows again
             const int64_t rc = valid[q] ? row : rows - 1;
-            mu[q] = mean[rc];
-            rs[q] = valid[q] ? rstd[rc] : 0.f;
+            int64_t rd = rc;
+            bool has_dy = true;
+            if (dy_index) {
+                const int32_t j = dy_index[rc];
+                has_dy = j >= 0;
+                rd = has_dy ? j : 0;
+            }
+            mu[q] = mean[rd];
+            rs[q] = valid[q] && has_dy ? rstd[rd] : 0.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 const int c = li + i * lpr;
-                const bool ok = valid[q] && c < nchunks;
+                const bool ok = valid[q] && has_dy && c < nchunks;
                 const int cc = c < nchunks ? c : nchunks - 1;
-                load8<T>(dy + rc * C + cc * 8, d[q][i]);
+                load8<T>(dy + rd * C + cc * 8, d[q][i]);
                 load8<T>(x + rc * C + cc * 8, xv[q][i]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -595,8 +612,22 @@ static inline int strip_grid(int64_t rows, int rows_per_block_iter, int max_bloc
 
 }  // namespace
 
+static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int64_t rows, int C, float eps, int dtype, hipStream_t stream);
+
 extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                   int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
+    return layernorm_fwd_launch(x, nullptr, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream);
+}
+
+extern "C" int iseg_layernorm_gather_fwd(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean,
+                                         float* rstd, int64_t rows_out, int C, float eps, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(src_index, "iseg_layernorm_gather_fwd: null index table");
+    return layernorm_fwd_launch(x, src_index, gamma, beta, y, mean, rstd, rows_out, C, eps, dtype, stream);
+}
+
+static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
     const int lpr = ln_lanes_per_row(C);
@@ -607,7 +638,7 @@ extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float
     const int cpl = (C / 8 + lpr - 1) / lpr;
 #define LN_FWD(T, CPL)                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
-                       (T*)y, mean, rstd, rows, C, eps, lpr)
+                       (T*)y, mean, rstd, rows, C, eps, lpr, src_index)
 #define LN_FWD_T(T)                  \
     do {                             \
         if (cpl <= 1) LN_FWD(T, 1);      \
@@ -651,9 +682,29 @@ extern "C" size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
     return (size_t)ln_bwd_blocks(rows, C) * 2 * C * sizeof(float);
 }
 
+static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
+                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads,
                                   int64_t rows, int C, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return layernorm_bwd_launch(dy, nullptr, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, accumulate_param_grads, rows, C, dtype, ws, ws_bytes,
+                                stream);
+}
+
+extern "C" int iseg_layernorm_gather_bwd(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean,
+                                         const float* rstd, void* dx, const void* dx_add, float* dgamma, float* dbeta,
+                                         int accumulate_param_grads, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes,
+                                         hipStream_t stream) {
+    ISEG_REQUIRE(dy_index, "iseg_layernorm_gather_bwd: null index table");
+    return layernorm_bwd_launch(dy, dy_index, x, gamma, mean, rstd, dx, dx_add, dgamma, dbeta, accumulate_param_grads, rows, C, dtype, ws, ws_bytes,
+                                stream);
+}
+
+static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
+                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
     ISEG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "iseg_layernorm_bwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_bwd: C=%d must be a positive multiple of 8", C);
     const int lpr = ln_lanes_per_row(C);
@@ -671,7 +722,7 @@ extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* ga
     const int cpl = (C / 8 + lpr - 1) / lpr;
 #define LN_BWD(T, CPL, U)                                                                                                   \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
-                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr)
+                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index)
     // rows in flight per lane group: 4 when a wavefront holds one or two rows per iteration, 2 for four, else 1 (64 / lpr rows already)
 #define LN_BWD_T(T)                                     \
     do {                                                \

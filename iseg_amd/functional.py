@@ -1889,6 +1889,79 @@ def permute_rows(x, idx_fwd, idx_bwd, out_shape):
     return _GatherRowsFn.apply(x, idx_fwd, idx_bwd, tuple(out_shape))
 
 
+class _LnGatherFn(Function):
+    """LayerNorm + static row permutation with zero padding in one pass each way (Swin: norm1 + pad + roll + window partition).  `link`
+    pairs the node with the _GatherResidualFn that closes the same residual branch: that node's backward runs first and leaves the skip
+    connection's gradient in link["dres"], which this node's LayerNorm backward adds on its way out (dx_add) -- the branch's fork costs no pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, idx_fwd, idx_bwd, out_shape, link):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        y, mean, rstd = K.layernorm_gather_fwd(x2, idx_fwd, gamma.data, beta.data, eps)
+        ctx.gamma, ctx.beta, ctx.idx_bwd, ctx.link, ctx.in_shape = gamma, beta, idx_bwd, link, x.shape
+        ctx.save_for_backward(x2, mean, rstd)
+        if link is not None:
+            link["armed"] = bool(ctx.needs_input_grad[0])
+        return y.reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        C = x2.shape[1]
+        dres = ctx.link.pop("dres", None) if ctx.link is not None else None
+        if dres is not None:
+            dres = _c(dres).reshape(-1, C)
+        dx = K.layernorm_gather_bwd(_c(dy).reshape(-1, C), ctx.idx_bwd, x2, ctx.gamma.data, mean, rstd, _grad(ctx.gamma), _grad(ctx.beta), dx_add=dres)
+        dist.grads_ready(ctx.gamma, ctx.beta)
+        return (dx.reshape(ctx.in_shape) if ctx.needs_input_grad[0] else None,) + (None,) * 7
+
+
+class _GatherResidualFn(Function):
+    """residual + rowscale[sample] * rows(y)[idx_fwd] in one pass (Swin: window reverse + roll back + crop + drop path + skip connection)"""
+
+    @staticmethod
+    def forward(ctx, y, residual, idx_fwd, idx_bwd, rowscale, link):
+        C = y.shape[-1]
+        r2 = _c(residual).reshape(-1, C)
+        rpg = r2.shape[0] // rowscale.shape[0] if rowscale is not None else 0
+        ctx.idx_bwd, ctx.rowscale, ctx.rpg, ctx.link, ctx.y_shape = idx_bwd, rowscale, rpg, link, y.shape
+        return K.gather_rows_fma(_c(y).reshape(-1, C), idx_fwd, rowscale, rpg, False, r2).reshape(residual.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        C = dout.shape[-1]
+        d2 = _c(dout).reshape(-1, C)
+        dy = K.gather_rows_fma(d2, ctx.idx_bwd, ctx.rowscale, ctx.rpg, True, None).reshape(ctx.y_shape) if ctx.needs_input_grad[0] else None
+        dres = dout if ctx.needs_input_grad[1] else None
+        if dres is not None and ctx.link is not None and ctx.link.get("armed") and dy is not None:
+            ctx.link["dres"] = dres      # the paired _LnGatherFn adds it inside its LayerNorm backward
+            dres = None
+        return dy, dres, None, None, None, None
+
+
+def residual_branch_link():
+    """the pairing object of layer_norm_permute_rows / permute_rows_residual on one residual branch (see _LnGatherFn)"""
+    return {}
+
+
+def layer_norm_permute_rows(x, gamma, beta, eps, idx_fwd, idx_bwd, out_shape, link=None):
+    """permute_rows(layer_norm(x), idx_fwd, idx_bwd, out_shape) as one tape node; padding rows (idx_fwd < 0) are zero"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(out_shape, x)
+    return _LnGatherFn.apply(x, gamma, beta, float(eps), idx_fwd, idx_bwd, tuple(out_shape), link)
+
+
+def permute_rows_residual(y, residual, idx_fwd, idx_bwd, drop_path_mask=None, link=None):
+    """residual + drop_path_mask[sample] * permute_rows(y, idx_fwd, idx_bwd, residual.shape) as one tape node.  With `link` shared with the
+    layer_norm_permute_rows that opened the branch FROM THE SAME TENSOR `residual`, the skip connection's gradient is delivered through that
+    node (the caller must not consume `residual` anywhere else between the two)."""
+    if nn.dry_run():
+        return _dry(residual.shape, residual)
+    return _GatherResidualFn.apply(y, residual, idx_fwd, idx_bwd, drop_path_mask, link)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # token-axis helpers of backbones/vit.py:277-323: class token, position embedding, token slicing
 # ---------------------------------------------------------------------------------------------------------

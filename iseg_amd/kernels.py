@@ -368,6 +368,40 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dgamma, dbeta, dx_add=None, accu
     return dx
 
 
+def layernorm_gather_fwd(x2d, src_index, gamma, beta, eps):
+    """y[r] = LN(x2d[src_index[r]]) or a zero row where src_index[r] < 0; mean / rstd per OUTPUT row (iseg_layernorm_gather_fwd)"""
+    _require_cuda(x2d, src_index)
+    rows_out, Cc = src_index.numel(), x2d.shape[1]
+    y = torch.empty((rows_out, Cc), dtype=x2d.dtype, device=x2d.device)
+    mean = torch.empty(rows_out, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(rows_out, dtype=torch.float32, device=x2d.device)
+    _hip.call("iseg_layernorm_gather_fwd", ptr(x2d), ptr(src_index), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows_out, Cc, eps,
+              dt(x2d), stream())
+    return y, mean, rstd
+
+
+def layernorm_gather_bwd(dy2d, dy_index, x2d, gamma, mean, rstd, dgamma, dbeta, dx_add=None, accumulate=True):
+    """backward of layernorm_gather_fwd over the source rows: the gradient row / statistics of source row r are row dy_index[r] of dy2d / mean / rstd"""
+    _require_cuda(dy2d, dy_index, x2d)
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    need = _hip.lib().iseg_layernorm_bwd_workspace_bytes(rows, Cc)
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_layernorm_gather_bwd", ptr(dy2d), ptr(dy_index), ptr(x2d), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dx_add), ptr(dgamma),
+              ptr(dbeta), int(accumulate), rows, Cc, dt(x2d), ptr(ws), wsb, stream())
+    return dx
+
+
+def gather_rows_fma(x2d, idx, scale=None, rows_per_group=0, scale_by_source_row=False, residual=None):
+    """y[r] = residual[r] + scale[g] * x2d[idx[r]] (zero where idx[r] < 0), g = (idx[r] if scale_by_source_row else r) // rows_per_group"""
+    _require_cuda(x2d, idx)
+    rows_out, Cc = idx.numel(), x2d.shape[1]
+    y = torch.empty((rows_out, Cc), dtype=x2d.dtype, device=x2d.device)
+    _hip.call("iseg_gather_rows_fma", ptr(x2d), ptr(idx), ptr(scale), int(rows_per_group), int(scale_by_source_row), ptr(residual), ptr(y), rows_out,
+              Cc, dt(x2d), stream())
+    return y
+
+
 def bn_stats(x2d, ldx, rows, Cc, out=None):
     """packed [2C+1] = (sum, sum of squares, count); `out`: a slice of a larger message (several layers, one all-reduce)"""
     packed = out if out is not None else torch.empty(2 * Cc + 1, dtype=torch.float32, device=x2d.device)
