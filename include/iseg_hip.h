@@ -205,6 +205,19 @@ int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
 int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
                           const float* rstd, const float* gamma, const float* sums, float inv_n, void* dx, int64_t lddx, float* dgamma,
                           float* dbeta, int64_t rows, int C, int relu, int dtype, iseg_stream_t stream);
+/* The fused-ReLU backward pair for a forward that did not keep its output: the ReLU mask is re-derived from x,
+ * (x - mean) * rstd * gamma + beta > 0 (the forward's own expression), instead of being read from y. */
+int iseg_bn_bwd_reduce_remask(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                              const float* gamma, const float* beta, float* sums, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes,
+                              iseg_stream_t stream);
+int iseg_bn_bwd_apply_remask(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const float* sums, float inv_n, void* dx, int64_t lddx, float* dgamma,
+                             float* dbeta, int64_t rows, int C, int dtype, iseg_stream_t stream);
+/* One level of the FPN top-down pathway (layers/fpn.py:46-57) in one pass: out = relu((z - mean) * rstd * gamma + beta) + bilinear_up(x),
+ * TF2 half-pixel bilinear (utils/common.py resize_image); z, out [N, Ho, Wo, C], x [N, Hi, Wi, C], C % 8 == 0.  mean / rstd come from
+ * iseg_bn_stats + iseg_bn_finalize; the backward is iseg_resize_bilinear_bwd + the _remask pair above. */
+int iseg_bn_relu_upsample_add(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* x,
+                              void* out, int N, int Hi, int Wi, int Ho, int Wo, int C, int dtype, iseg_stream_t stream);
 int iseg_rsqrt_eps(const float* var, float eps, float* out, int n, iseg_stream_t stream); /* inference: rstd of moving var */
 
 /* ---------------------------------------------------------------------------------------------------------

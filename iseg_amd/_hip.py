@@ -82,6 +82,9 @@ SIGNATURES = {
     "iseg_bn_bwd_reduce": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _l, _i, _i, _i, _p, _z, _p]),
     "iseg_bn_bwd_apply": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _f, _p, _l, _l, _i, _i, _i, _p]),
     "iseg_bn_bwd_apply_acc": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _p, _p, _f, _p, _l, _p, _p, _l, _i, _i, _i, _p]),
+    "iseg_bn_bwd_reduce_remask": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
+    "iseg_bn_bwd_apply_remask": (_i, [_p, _l, _p, _l, _p, _p, _p, _p, _p, _f, _p, _l, _p, _p, _l, _i, _i, _p]),
+    "iseg_bn_relu_upsample_add": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_rsqrt_eps": (_i, [_p, _f, _p, _i, _p]),
     "iseg_cast": (_i, [_p, _i, _p, _i, _l, _p]),
     "iseg_deferred_begin": (_i, [_p, _z, _p, _z, _p]),

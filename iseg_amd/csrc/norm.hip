@@ -462,7 +462,10 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x,
                                                             int64_t ldx, const T* __restrict__ y, int64_t ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ partials, int64_t rows, int C, int relu) {
+                                                            float* __restrict__ partials, int64_t rows, int C, int relu,
+                                                            const float* __restrict__ re_gamma, const float* __restrict__ re_beta) {
+    // re_gamma / re_beta (with relu): the forward output was not kept -- the ReLU mask is re-derived from x, (x - mean) * rstd * gamma + beta > 0
+    // with the forward's own expression (y = NULL)
     extern __shared__ __attribute__((aligned(16))) float lds_s[];      // [rows per iteration][2][C], as in bn_stats_kernel
     const int nchunks = C / 8;
     const int tpc = nchunks < 256 ? nchunks : 256;
@@ -472,9 +475,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     for (int c = tc; c < nchunks; c += tpc) {
         float s[8] = {}, q[8] = {};
         if (active) {
-            float m[8], rs[8];
+            float m[8], rs[8], rg[8], rb[8];
             load8<float>(mean + c * 8, m);
             load8<float>(rstd + c * 8, rs);
+            const bool recompute = relu && re_gamma;
+            if (recompute) {
+                load8<float>(re_gamma + c * 8, rg);
+                load8<float>(re_beta + c * 8, rb);
+            }
             int64_t r = (int64_t)blockIdx.x * rpi + tr;
             const int64_t rstep = (int64_t)gridDim.x * rpi;
             constexpr int UB = 4;      // four rows per trip, all of their loads issued together
@@ -484,7 +492,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 for (int k = 0; k < UB; ++k) {
                     load8<T>(dy + (r + k * rstep) * lddy + c * 8, d[k]);
                     load8<T>(x + (r + k * rstep) * ldx + c * 8, xv[k]);
-                    if (relu) load8<T>(y + (r + k * rstep) * ldy + c * 8, yv[k]);
+                    if (relu && !recompute) load8<T>(y + (r + k * rstep) * ldy + c * 8, yv[k]);
+                }
+                if (recompute) {
+#pragma unroll
+                    for (int k = 0; k < UB; ++k)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) yv[k][u] = (xv[k][u] - m[u]) * rs[u] * rg[u] + rb[u];
                 }
 #pragma unroll
                 for (int k = 0; k < UB; ++k)
@@ -501,7 +515,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 load8<T>(x + r * ldx + c * 8, xv);
                 if (relu) {
                     float yv[8];
-                    load8<T>(y + r * ldy + c * 8, yv);
+                    if (recompute) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) yv[u] = (xv[u] - m[u]) * rs[u] * rg[u] + rb[u];
+                    } else {
+                        load8<T>(y + r * ldy + c * 8, yv);
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
                 }
@@ -535,13 +554,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
                                                            float inv_n, T* __restrict__ dx, int64_t lddx, int64_t rows, int C,
-                                                           int relu, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           int relu, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ re_beta) {
+    // re_beta (with relu): the ReLU mask is re-derived from x as in bn_bwd_reduce_kernel (y = NULL)
     const BnStrip st(C);
     if (!st.active) return;
     const int64_t rstep = (int64_t)gridDim.x * st.rpi;
+    const bool recompute = relu && re_beta;
     for (int cc = st.tc; cc < st.nchunks; cc += st.tpc) {
         const int c = cc * 8;
-        float m[8], rs[8], g[8], s1[8], s2[8];
+        float m[8], rs[8], g[8], s1[8], s2[8], rb[8];
+        if (recompute) load8<float>(re_beta + c, rb);
         load8<float>(mean + c, m);
         load8<float>(rstd + c, rs);
         load8<float>(gamma + c, g);
@@ -570,12 +593,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             for (int k = 0; k < UB; ++k) {
                 load8<T>(dy + (r + k * rstep) * lddy + c, d[k]);
                 load8<T>(x + (r + k * rstep) * ldx + c, xv[k]);
-                if (relu) load8<T>(y + (r + k * rstep) * ldy + c, yv[k]);
+                if (relu && !recompute) load8<T>(y + (r + k * rstep) * ldy + c, yv[k]);
             }
 #pragma unroll
             for (int k = 0; k < UB; ++k) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
+                    if (recompute) yv[k][u] = (xv[k][u] - m[u]) * rs[u] * g[u] + rb[u];
                     const float dv = (relu && !(yv[k][u] > 0.f)) ? 0.f : d[k][u];
                     const float xh = (xv[k][u] - m[u]) * rs[u];
                     d[k][u] = g[u] * rs[u] * (dv - s1[u] * inv_n - xh * s2[u] * inv_n);
@@ -589,7 +613,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             load8<T>(x + r * ldx + c, xv);
             if (relu) {
                 float yv[8];
-                load8<T>(y + r * ldy + c, yv);
+                if (recompute) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) yv[u] = (xv[u] - m[u]) * rs[u] * g[u] + rb[u];
+                } else {
+                    load8<T>(y + r * ldy + c, yv);
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) d[u] = yv[u] > 0.f ? d[u] : 0.f;
             }
@@ -839,11 +868,28 @@ extern "C" int iseg_bn_apply_fwd_packed(const void* x, int64_t ldx, const float*
     return iseg_check_launch("iseg_bn_apply_fwd_packed");
 }
 
+static int bn_bwd_reduce_launch(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                                const float* rstd, const float* re_gamma, const float* re_beta, float* sums, int64_t rows, int C, int relu, int dtype,
+                                void* ws, size_t ws_bytes, hipStream_t stream);
+
 extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
                                   const float* mean, const float* rstd, float* sums, int64_t rows, int C, int relu, int dtype,
                                   void* ws, size_t ws_bytes, hipStream_t stream) {
-    ISEG_REQUIRE(dy && x && mean && rstd && sums && (!relu || y), "iseg_bn_bwd_reduce: null pointer");
-    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && (!relu || ldy % 8 == 0), "iseg_bn_bwd_reduce: alignment");
+    return bn_bwd_reduce_launch(dy, lddy, x, ldx, y, ldy, mean, rstd, nullptr, nullptr, sums, rows, C, relu, dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int iseg_bn_bwd_reduce_remask(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                                         const float* gamma, const float* beta, float* sums, int64_t rows, int C, int dtype, void* ws,
+                                         size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(gamma && beta && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "iseg_bn_bwd_reduce_remask: gamma / beta must be 16-byte aligned");
+    return bn_bwd_reduce_launch(dy, lddy, x, ldx, nullptr, 0, mean, rstd, gamma, beta, sums, rows, C, 1, dtype, ws, ws_bytes, stream);
+}
+
+static int bn_bwd_reduce_launch(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                                const float* rstd, const float* re_gamma, const float* re_beta, float* sums, int64_t rows, int C, int relu, int dtype,
+                                void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && mean && rstd && sums && (!relu || y || re_gamma), "iseg_bn_bwd_reduce: null pointer");
+    ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && (!relu || re_gamma || ldy % 8 == 0), "iseg_bn_bwd_reduce: alignment");
     const int blocks = bn_blocks(rows, C, BN_BWD_REDUCE_MAX_BLOCKS);
     const size_t need = (size_t)blocks * 2 * C * sizeof(float);
     if (!ws || ws_bytes < need) {
@@ -853,10 +899,10 @@ extern "C" int iseg_bn_bwd_reduce(const void* dy, int64_t lddy, const void* x, i
     const size_t lds = bn_slab_bytes(C);
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), lds, stream, (const bf16_t*)dy, lddy,
-                           (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);
+                           (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, (float*)ws, rows, C, relu, re_gamma, re_beta);
     else
         hipLaunchKernelGGL((bn_bwd_reduce_kernel<float>), dim3(blocks), dim3(256), lds, stream, (const float*)dy, lddy,
-                           (const float*)x, ldx, (const float*)y, ldy, mean, rstd, (float*)ws, rows, C, relu);
+                           (const float*)x, ldx, (const float*)y, ldy, mean, rstd, (float*)ws, rows, C, relu, re_gamma, re_beta);
     launch_reduce_rows((const float*)ws, blocks, 2 * C, 0, 1, 2 * C, sums, nullptr, 2 * C, 0, 1.f, 0, stream);
     return iseg_check_launch("iseg_bn_bwd_reduce");
 }
@@ -872,11 +918,28 @@ extern "C" int iseg_bn_bwd_apply(const void* dy, int64_t lddy, const void* x, in
     return iseg_bn_bwd_apply_acc(dy, lddy, x, ldx, y, ldy, mean, rstd, gamma, sums, inv_n, dx, lddx, nullptr, nullptr, rows, C, relu, dtype, stream);
 }
 
+static int bn_bwd_apply_launch(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                               const float* rstd, const float* gamma, const float* re_beta, const float* sums, float inv_n, void* dx, int64_t lddx,
+                               float* dgamma, float* dbeta, int64_t rows, int C, int relu, int dtype, hipStream_t stream);
+
 extern "C" int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy,
                                      const float* mean, const float* rstd, const float* gamma, const float* sums, float inv_n,
                                      void* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, int relu, int dtype,
                                      hipStream_t stream) {
-    ISEG_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && (!relu || y), "iseg_bn_bwd_apply: null pointer");
+    return bn_bwd_apply_launch(dy, lddy, x, ldx, y, ldy, mean, rstd, gamma, nullptr, sums, inv_n, dx, lddx, dgamma, dbeta, rows, C, relu, dtype, stream);
+}
+
+extern "C" int iseg_bn_bwd_apply_remask(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, const float* sums, float inv_n, void* dx, int64_t lddx,
+                                        float* dgamma, float* dbeta, int64_t rows, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(beta && ((uintptr_t)beta & 15) == 0, "iseg_bn_bwd_apply_remask: beta must be 16-byte aligned");
+    return bn_bwd_apply_launch(dy, lddy, x, ldx, nullptr, 0, mean, rstd, gamma, beta, sums, inv_n, dx, lddx, dgamma, dbeta, rows, C, 1, dtype, stream);
+}
+
+static int bn_bwd_apply_launch(const void* dy, int64_t lddy, const void* x, int64_t ldx, const void* y, int64_t ldy, const float* mean,
+                               const float* rstd, const float* gamma, const float* re_beta, const float* sums, float inv_n, void* dx, int64_t lddx,
+                               float* dgamma, float* dbeta, int64_t rows, int C, int relu, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(dy && x && mean && rstd && gamma && sums && dx && (!relu || y || re_beta), "iseg_bn_bwd_apply: null pointer");
     ISEG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "iseg_bn_bwd_apply: alignment");
     ISEG_REQUIRE((((uintptr_t)dgamma | (uintptr_t)dbeta) & 15) == 0 && (!(dgamma || dbeta) || ((uintptr_t)sums & 15) == 0),
                  "iseg_bn_bwd_apply_acc: gradient vectors must be 16-byte aligned");
@@ -884,10 +947,10 @@ extern "C" int iseg_bn_bwd_apply_acc(const void* dy, int64_t lddy, const void* x
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy,
                            (const bf16_t*)x, ldx, (const bf16_t*)y, ldy, mean, rstd, gamma, sums, inv_n, (bf16_t*)dx, lddx, rows,
-                           C, relu, dgamma, dbeta);
+                           C, relu, dgamma, dbeta, re_beta);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)dy, lddy,
                            (const float*)x, ldx, (const float*)y, ldy, mean, rstd, gamma, sums, inv_n, (float*)dx, lddx, rows, C,
-                           relu, dgamma, dbeta);
+                           relu, dgamma, dbeta, re_beta);
     return iseg_check_launch("iseg_bn_bwd_apply");
 }

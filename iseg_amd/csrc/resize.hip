@@ -314,6 +314,47 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_vec_kernel(const TI* 
     }
 }
 
+// out = relu((z - mean) * rstd * gamma + beta) + bilinear_up(x): one level of the FPN top-down pathway (layers/fpn.py:46-57: ConvNormAct's
+// BatchNorm + ReLU, resize_image of the running map, the sum) in one pass -- neither the normalised map nor the up-sampled one is written
+// (3 x 403 MB each way at the stride-4 level of Swin-T + FPN).  z, out [N, Ho, Wo, C]; x [N, Hi, Wi, C]; C % 8 == 0.
+template <class T>
+__global__ __launch_bounds__(256) void bn_relu_upsample_add_kernel(const T* __restrict__ z, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, const T* __restrict__ x, T* __restrict__ out,
+                                                                   int N, int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx) {
+    const int C8 = C / 8;
+    const int64_t total = (int64_t)N * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        int64_t r = i / C8;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const Lerp ly = lerp_of(oy, sy, Hi), lx = lerp_of(ox, sx, Wi);
+        const T* top = x + ((int64_t)n * Hi + ly.lo) * Wi * C + c;
+        const T* bot = x + ((int64_t)n * Hi + ly.hi) * Wi * C + c;
+        float tl[8], tr[8], bl[8], br[8], v[8], m[8], s[8], g[8], b[8];
+        load8<T>(z + i * 8, v);
+        load8<T>(top + (int64_t)lx.lo * C, tl);
+        load8<T>(top + (int64_t)lx.hi * C, tr);
+        load8<T>(bot + (int64_t)lx.lo * C, bl);
+        load8<T>(bot + (int64_t)lx.hi * C, br);
+        load8<float>(mean + c, m);
+        load8<float>(rstd + c, s);
+        load8<float>(gamma + c, g);
+        load8<float>(beta + c, b);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float tp = tl[u] + (tr[u] - tl[u]) * lx.t;
+            const float bt = bl[u] + (br[u] - bl[u]) * lx.t;
+            const float y = fmaxf((v[u] - m[u]) * s[u] * g[u] + b[u], 0.f);
+            v[u] = y + (tp + (bt - tp) * ly.t);
+        }
+        store8<T>(out + i * 8, v);
+    }
+}
+
 template <class TI, class TO>
 __global__ __launch_bounds__(256) void resize_bwd_axis_vec_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t O, int Dn, int J,
                                                                   int64_t Q, float scale, const TO* __restrict__ add) {
@@ -429,6 +470,24 @@ extern "C" int iseg_resize_bilinear_fwd(const void* x, int in_dtype, void* y, in
     }
 #undef RS
     return iseg_check_launch("iseg_resize_bilinear_fwd");
+}
+
+extern "C" int iseg_bn_relu_upsample_add(const void* z, const float* mean, const float* rstd, const float* gamma, const float* beta, const void* x,
+                                         void* out, int N, int Hi, int Wi, int Ho, int Wo, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(z && mean && rstd && gamma && beta && x && out && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0,
+                 "iseg_bn_relu_upsample_add: bad arguments");
+    ISEG_REQUIRE(C > 0 && C % 8 == 0, "iseg_bn_relu_upsample_add: C = %d must be a multiple of 8", C);
+    ISEG_REQUIRE((((uintptr_t)z | (uintptr_t)x | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+                 "iseg_bn_relu_upsample_add: operands must be 16-byte aligned");
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    const unsigned vb = cap_blocks((int64_t)N * Ho * Wo * (C / 8));
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((bn_relu_upsample_add_kernel<bf16_t>), dim3(vb), dim3(256), 0, stream, (const bf16_t*)z, mean, rstd, gamma, beta,
+                           (const bf16_t*)x, (bf16_t*)out, N, Hi, Wi, Ho, Wo, C, sy, sx);
+    else
+        hipLaunchKernelGGL((bn_relu_upsample_add_kernel<float>), dim3(vb), dim3(256), 0, stream, (const float*)z, mean, rstd, gamma, beta,
+                           (const float*)x, (float*)out, N, Hi, Wi, Ho, Wo, C, sy, sx);
+    return iseg_check_launch("iseg_bn_relu_upsample_add");
 }
 
 extern "C" size_t iseg_resize_bilinear_bwd_workspace_bytes(int N, int Hi, int Wi, int Ho, int Wo, int C) {

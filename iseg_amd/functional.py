@@ -580,6 +580,62 @@ class _BatchNormTrainFn(Function):
         return dx.reshape(dy.shape), None, None, None, None, None, None, None, None
 
 
+class _BnReluUpsampleAddFn(Function):
+    """relu(batch_norm(z)) + resize_bilinear(x, z's height and width) -- one level of the FPN top-down pathway (layers/fpn.py:46-57) -- with
+    training-mode (Sync)BN statistics: the normalised map and the up-sampled map are never written, and the backward pass re-derives the
+    ReLU mask from z instead of reading a saved output.  Statistics / parameter-gradient arithmetic is _BatchNormTrainFn's."""
+
+    @staticmethod
+    def forward(ctx, z, x, gamma, beta, moving_mean, moving_var, eps, momentum, sync):
+        N, Ho, Wo, C = z.shape
+        zc, xc = _c(z), _c(x)
+        z2 = zc.reshape(-1, C)
+        rows = z2.shape[0]
+        packed = K.bn_stats(z2, C, rows, C)
+        if sync:
+            dist.all_reduce_sum(packed)
+        mean, rstd = K.bn_finalize(packed, C, eps, momentum, moving_mean, moving_var)
+        out = K.bn_relu_upsample_add(zc, mean, rstd, gamma.data, beta.data, xc)
+        ctx.gamma, ctx.beta, ctx.sync, ctx.x_shape, ctx.x_dtype = gamma, beta, sync, x.shape, x.dtype
+        ctx.save_for_backward(z2, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z2, mean, rstd = ctx.saved_tensors
+        rows, C = z2.shape
+        dc = _c(dout)
+        d2 = dc.reshape(rows, C)
+        dx = K.resize_bilinear_bwd(dc, ctx.x_shape[1], ctx.x_shape[2], ctx.x_dtype) if ctx.needs_input_grad[1] else None
+        dz = None
+        g, b = ctx.gamma.data, ctx.beta.data
+        sums = K.bn_bwd_reduce_remask(d2, C, z2, C, mean, rstd, g, b, rows, C)
+        dbeta = _grad(ctx.beta) if ctx.beta.requires_grad else None
+        dgamma = _grad(ctx.gamma) if ctx.gamma.requires_grad else None
+        if ctx.sync and dist.active():
+            K.accumulate_pair(sums, C, dbeta, dgamma)
+            dist.grads_ready(ctx.gamma, ctx.beta)
+            sums = sums.clone()
+            dist.all_reduce_sum(sums)
+            if ctx.needs_input_grad[0]:
+                dz = K.bn_bwd_apply_remask(d2, C, z2, C, mean, rstd, g, b, sums, 1.0 / (rows * dist.world_size()), torch.empty_like(z2), C, rows, C)
+        else:
+            if ctx.needs_input_grad[0]:
+                dz = K.bn_bwd_apply_remask(d2, C, z2, C, mean, rstd, g, b, sums, 1.0 / rows, torch.empty_like(z2), C, rows, C, dgamma=dgamma, dbeta=dbeta)
+            else:
+                K.accumulate_pair(sums, C, dbeta, dgamma)
+            dist.grads_ready(ctx.gamma, ctx.beta)
+        return (dz.reshape(dout.shape) if dz is not None else None), dx, None, None, None, None, None, None, None
+
+
+def batch_norm_relu_upsample_add(z, x, gamma, beta, moving_mean, moving_var, eps, momentum, sync=True):
+    """relu(batch_norm(z, training=True)) + resize_bilinear(x, z.shape[1:3]) as one tape node; channels % 8 == 0, same dtype"""
+    _check_act_dtype(z)
+    if nn.dry_run():
+        return _dry(z.shape, z)
+    return _BnReluUpsampleAddFn.apply(z, x, gamma, beta, moving_mean, moving_var, float(eps), float(momentum), bool(sync))
+
+
 class _BatchNormGroupFn(Function):
     """Several independent SyncBN layers whose inputs all exist before any of them is normalised (the five ASPP branches,
     layers/aspp.py:57-71): their packed statistics travel in ONE all-reduce forward and ONE backward instead of one per layer --

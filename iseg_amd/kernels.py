@@ -458,6 +458,33 @@ def bn_bwd_apply(dy2d, lddy, x2d, ldx, y2d, ldy, mean, rstd, gamma, sums, inv_n,
     return dx2d
 
 
+def bn_bwd_reduce_remask(dy2d, lddy, x2d, ldx, mean, rstd, gamma, beta, rows, Cc, out=None):
+    """bn_bwd_reduce with fused ReLU whose mask is re-derived from x (the forward kept no output)"""
+    sums = out if out is not None else torch.empty(2 * Cc, dtype=torch.float32, device=x2d.device)
+    need = _hip.lib().iseg_bn_workspace_bytes(rows, Cc)
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_bn_bwd_reduce_remask", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(sums), rows, Cc,
+              dt(x2d), ptr(ws), wsb, stream())
+    return sums
+
+
+def bn_bwd_apply_remask(dy2d, lddy, x2d, ldx, mean, rstd, gamma, beta, sums, inv_n, dx2d, lddx, rows, Cc, dgamma=None, dbeta=None):
+    _hip.call("iseg_bn_bwd_apply_remask", ptr(dy2d), lddy, ptr(x2d), ldx, ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(sums), inv_n,
+              ptr(dx2d), lddx, ptr(dgamma), ptr(dbeta), rows, Cc, dt(x2d), stream())
+    return dx2d
+
+
+def bn_relu_upsample_add(z, mean, rstd, gamma, beta, x):
+    """relu(bn(z)) + bilinear_up(x) in one pass: z [N, Ho, Wo, C], x [N, Hi, Wi, C] (iseg_bn_relu_upsample_add)"""
+    _require_cuda(z, x)
+    N, Ho, Wo, Cc = z.shape
+    _, Hi, Wi, _ = x.shape
+    out = torch.empty_like(z)
+    _hip.call("iseg_bn_relu_upsample_add", ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(x), ptr(out), N, Hi, Wi, Ho, Wo, Cc, dt(z),
+              stream())
+    return out
+
+
 def rsqrt_eps(var, eps):
     out = torch.empty_like(var)
     _hip.call("iseg_rsqrt_eps", ptr(var), eps, ptr(out), var.numel(), stream())

@@ -165,7 +165,17 @@ def test_fpn_layer(cuda, dtype, training):
         _setup(fpn, [torch.empty(s, dtype=dtype, device="cuda") for s in shapes], dtype)
         feats = [rnd(s, 10 + i).to(dtype) for i, s in enumerate(shapes)]
         fg = [f.cuda().requires_grad_(True) for f in feats]
-        outs = fpn(fg, training=training)
+        from iseg_amd import functional as F
+
+        seen = []
+        orig = F._BnReluUpsampleAddFn.apply
+        F._BnReluUpsampleAddFn.apply = staticmethod(lambda *a: (seen.append(tuple(a[0].shape)), orig(*a))[1])
+        try:
+            outs = fpn(fg, training=training)
+        finally:
+            del F._BnReluUpsampleAddFn.apply
+        # training mode: BatchNorm + ReLU + up-sampling + sum of every level is ONE node (csrc/resize.hip bn_relu_upsample_add_kernel)
+        assert seen == ([(2, 4, 4, 64), (2, 8, 8, 64), (2, 16, 16, 64)] if training else []), seen
         w = {k: v.requires_grad_(True) for k, v in OM.export_weights(fpn).items()}
         fr = [f.double().requires_grad_(True) for f in feats]
         outs_r = OM.fpn(w, "fpn", fr, training)
