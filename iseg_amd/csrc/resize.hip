@@ -322,20 +322,21 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_add_kernel(const T* __re
                                                                    const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, const T* __restrict__ x, T* __restrict__ out,
                                                                    int N, int Hi, int Wi, int Ho, int Wo, int C, float sy, float sx) {
-    const int C8 = C / 8;
-    const int64_t total = (int64_t)N * Ho * Wo * C8;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // (the host keeps N * Ho * Wo * C / 8 below 2^31: 32-bit index arithmetic -- three 64-bit divisions per 16 bytes cost more than the loads)
+    const unsigned C8 = C / 8;
+    const unsigned total = (unsigned)N * Ho * Wo * C8;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int c = (int)(i % C8) * 8;
-        int64_t r = i / C8;
-        const int ox = (int)(r % Wo);
-        r /= Wo;
-        const int oy = (int)(r % Ho);
-        const int n = (int)(r / Ho);
+        unsigned r = i / C8;
+        const int ox = (int)(r % (unsigned)Wo);
+        r /= (unsigned)Wo;
+        const int oy = (int)(r % (unsigned)Ho);
+        const int n = (int)(r / (unsigned)Ho);
         const Lerp ly = lerp_of(oy, sy, Hi), lx = lerp_of(ox, sx, Wi);
         const T* top = x + ((int64_t)n * Hi + ly.lo) * Wi * C + c;
         const T* bot = x + ((int64_t)n * Hi + ly.hi) * Wi * C + c;
         float tl[8], tr[8], bl[8], br[8], v[8], m[8], s[8], g[8], b[8];
-        load8<T>(z + i * 8, v);
+        load8<T>(z + (int64_t)i * 8, v);
         load8<T>(top + (int64_t)lx.lo * C, tl);
         load8<T>(top + (int64_t)lx.hi * C, tr);
         load8<T>(bot + (int64_t)lx.lo * C, bl);
@@ -351,7 +352,64 @@ __global__ __launch_bounds__(256) void bn_relu_upsample_add_kernel(const T* __re
             const float y = fmaxf((v[u] - m[u]) * s[u] * g[u] + b[u], 0.f);
             v[u] = y + (tp + (bt - tp) * ly.t);
         }
-        store8<T>(out + i * 8, v);
+        store8<T>(out + (int64_t)i * 8, v);
+    }
+}
+
+// Transposed interpolation of an exact x2 up-sampling (Ho = 2 Hi, Wo = 2 Wi: every FPN level at even sizes) in ONE pass: source pixel
+// (jy, jx) collects the 4 x 4 destinations 2j - 1 .. 2j + 2 of each axis with the weights the two-pass form derives (bwd_weight), all sixteen
+// loads issued unconditionally from clamped addresses (no fp32 intermediate of N Ho Wi C: 167 + 114 us -> one pass at the stride-4 level).
+template <class TI, class TO>
+__global__ __launch_bounds__(256) void resize_bwd_x2_vec_kernel(const TI* __restrict__ dy, TO* __restrict__ dx, int N, int Hi, int Wi, int C,
+                                                                const TO* __restrict__ add) {
+    const unsigned C8 = C / 8;
+    const unsigned total = (unsigned)N * Hi * Wi * C8;
+    const int Ho = 2 * Hi, Wo = 2 * Wi;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int c = (int)(i % C8) * 8;
+        unsigned r = i / C8;
+        const int jx = (int)(r % (unsigned)Wi);
+        r /= (unsigned)Wi;
+        const int jy = (int)(r % (unsigned)Hi);
+        const int n = (int)(r / (unsigned)Hi);
+        float wy[4], wx[4];
+        int yy[4], xx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = 2 * jy - 1 + k, e = 2 * jx - 1 + k;
+            const bool vy = d >= 0 && d < Ho, vx = e >= 0 && e < Wo;
+            yy[k] = vy ? d : 0;
+            xx[k] = vx ? e : 0;
+            wy[k] = vy ? bwd_weight(d, jy, 0.5f, Hi) : 0.f;
+            wx[k] = vx ? bwd_weight(e, jx, 0.5f, Wi) : 0.f;
+        }
+        float v[16][8];
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) load8<TI>(dy + (((int64_t)n * Ho + yy[ky]) * Wo + xx[kx]) * C + c, v[4 * ky + kx]);
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            float row[8];      // the x pass of this destination row first, then the y weight: the two-pass form's order
+#pragma unroll
+            for (int u = 0; u < 8; ++u) row[u] = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) row[u] += wx[kx] * v[4 * ky + kx][u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += wy[ky] * row[u];
+        }
+        if (add) {
+            float a[8];
+            load8<TO>(add + (int64_t)i * 8, a);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += a[u];
+        }
+        store8<TO>(dx + (int64_t)i * 8, acc);
     }
 }
 
@@ -477,6 +535,7 @@ extern "C" int iseg_bn_relu_upsample_add(const void* z, const float* mean, const
     ISEG_REQUIRE(z && mean && rstd && gamma && beta && x && out && N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0,
                  "iseg_bn_relu_upsample_add: bad arguments");
     ISEG_REQUIRE(C > 0 && C % 8 == 0, "iseg_bn_relu_upsample_add: C = %d must be a multiple of 8", C);
+    ISEG_REQUIRE((int64_t)N * Ho * Wo * (C / 8) < (1ll << 31), "iseg_bn_relu_upsample_add: more than 2^31 16-byte chunks");
     ISEG_REQUIRE((((uintptr_t)z | (uintptr_t)x | (uintptr_t)out | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
                  "iseg_bn_relu_upsample_add: operands must be 16-byte aligned");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
@@ -507,6 +566,19 @@ extern "C" int iseg_resize_bilinear_bwd(const void* dy, int dy_dtype, void* dx, 
     }
     float* tmp = (float*)ws;
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    // exact x2 up-sampling with 16-byte channel chunks: one pass, no intermediate
+    static const bool x2_off = [] { const char* e = getenv("ISEG_RESIZE_BWD_X2"); return e && atoi(e) == 0; }();
+    if (!x2_off && Ho == 2 * Hi && Wo == 2 * Wi && C % 8 == 0 && dy_dtype == dx_dtype && (int64_t)N * Hi * Wi * (C / 8) < (1ll << 31) &&
+        (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)dx_add) & 15) == 0) {
+        const unsigned vb = cap_blocks((int64_t)N * Hi * Wi * (C / 8));
+        if (dy_dtype == ISEG_BF16)
+            hipLaunchKernelGGL((resize_bwd_x2_vec_kernel<bf16_t, bf16_t>), dim3(vb), dim3(256), 0, stream, (const bf16_t*)dy, (bf16_t*)dx, N, Hi, Wi, C,
+                               (const bf16_t*)dx_add);
+        else
+            hipLaunchKernelGGL((resize_bwd_x2_vec_kernel<float, float>), dim3(vb), dim3(256), 0, stream, (const float*)dy, (float*)dx, N, Hi, Wi, C,
+                               (const float*)dx_add);
+        return iseg_check_launch("iseg_resize_bilinear_bwd");
+    }
     // X pass: [N*Ho, Wo, C] -> [N*Ho, Wi, C]
     const int64_t t1 = (int64_t)N * Ho * Wi * C;
     const size_t row_bytes = ((size_t)Wo * C + (size_t)3 * Wo) * sizeof(float);   // gradient row + destination lerp table
