@@ -34,6 +34,7 @@ static inline size_t dtype_size(int dtype) { return dtype == ISEG_BF16 ? 2 : 4; 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;      // one dword of a bf16 row: operand of v_dot2_f32_bf16
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }

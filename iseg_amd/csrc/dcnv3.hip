@@ -354,6 +354,13 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
 // Values are clamped to |v| < 2^23 by the fixed-point conversion (resolution 9.1e-13).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int DCN_TS = 16, DCN_WS = 24;
+// LDS image of a window: pixel (ly, lx), channel c at accumulator index ly * RP + lx * PP + c with PP = CG + 1 and RP = WS * PP + 1 (odd
+// pitches: the lanes of one LDS atomic -- a fixed channel, 16 x 4 neighbouring output pixels whose footprints step along ly for consecutive
+// lanes and along lx for consecutive rows -- spread over the banks, and the channel is an IMMEDIATE offset of the instruction.  The rotated
+// slot (c + ly + lx) mod CG of the first form cost three VALU instructions of address arithmetic per atomic: 1 700 of a wavefront's 7 700.)
+template <int CG> struct DcnWinLds {
+    static constexpr int PP = CG + 1, RP = DCN_WS * PP + 1, CELLS = DCN_WS * RP;
+};
 
 struct DcnWin {
     int tiles_y, tiles_x;      // output tiles
@@ -380,15 +387,15 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
     constexpr bool FIX32 = sizeof(T) == 2;
     using Acc = typename std::conditional<FIX32, int, unsigned long long>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned long long win_raw[];
-    // [WS*WS][CG]; channel c of window pixel (ly, lx) sits in slot (c + ly + lx) mod CG: the lanes of one ds_add (a fixed channel, 16 x 4
-    // neighbouring output pixels, whose footprints step along ly for consecutive lanes and along lx for consecutive rows) then spread over all
-    // banks.  Rotating by the linear pixel index ly * 24 + lx instead put 16 consecutive lanes on two banks (24 * 16 words = 0 mod 32).
+    // window image: DcnWinLds (padded pitches).
     // (Kept unrolled over the points at 161 registers / three workgroups per CU: capped at 128 for a fourth it spills 54-66 registers and
     // runs 1.5x slower, rolled or not.)
+    using WL = DcnWinLds<CG>;
     Acc* const win_acc = reinterpret_cast<Acc*>(win_raw);
+    T* const stage = reinterpret_cast<T*>(win_acc + WL::CELLS);      // [256 pixels][P mask gradients | 2 P offset gradients], behind the window
     __shared__ float wave_max[4];
     constexpr int WPIX = DCN_WS * DCN_WS;
-    for (int i = threadIdx.x; i < WPIX * CG; i += 256) win_acc[i] = (Acc)0;
+    for (int i = threadIdx.x; i < WL::CELLS; i += 256) win_acc[i] = (Acc)0;
     int b = blockIdx.x;
     const int gi = b % g.G;
     b /= g.G;
@@ -402,10 +409,15 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
     const int P = g.kh * g.kw;
     const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
     float d[CG];
+    constexpr int RAWD = CG * (int)sizeof(T) / 16;
+    uint4 draw[RAWD];      // the same row as stored (bf16 pairs: operands of v_dot2_f32_bf16)
+#pragma unroll
+    for (int r = 0; r < RAWD; ++r) draw[r] = make_uint4(0u, 0u, 0u, 0u);
     if (live) {
 #pragma unroll
-        for (int c0 = 0; c0 < CG; c0 += 8) ldv<T, 8>(dy + (pix * g.G + gi) * CG + c0, d + c0);
+        for (int r = 0; r < RAWD; ++r) draw[r] = reinterpret_cast<const uint4*>(dy + (pix * g.G + gi) * CG)[r];
     }
+    dcn_unpack_row<T, CG>(draw, d);
     bool spilled = false;
     // every sampling point's offsets and mask up front (one round trip instead of one per point; P <= DCN_PMAX is a condition of this path)
     float offs[DCN_PMAX][2], mk[DCN_PMAX];
@@ -465,11 +477,27 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
         if (p >= P || !live) continue;      // (P is uniform; dead lanes belong to partial edge tiles)
         const Tap tp = ntp;
         int64_t srcs[4];
-        float v[4][CG];
+        float dots[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             srcs[k] = nsrc[k];
-            dcn_unpack_row<T, CG>(nxt[k], v[k]);
+            // <dy, x corner> over the group's channels: bf16 pairs straight into v_dot2_f32_bf16 (exact products, fp32 sums) -- no unpack
+            float dot = 0.f;
+            if constexpr (FIX32) {
+#pragma unroll
+                for (int r = 0; r < RAW; ++r) {
+                    dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, draw[r].x), __builtin_bit_cast(bf16x2_t, nxt[k][r].x), dot, false);
+                    dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, draw[r].y), __builtin_bit_cast(bf16x2_t, nxt[k][r].y), dot, false);
+                    dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, draw[r].z), __builtin_bit_cast(bf16x2_t, nxt[k][r].z), dot, false);
+                    dot = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, draw[r].w), __builtin_bit_cast(bf16x2_t, nxt[k][r].w), dot, false);
+                }
+            } else {
+                float v[CG];
+                dcn_unpack_row<T, CG>(nxt[k], v);
+#pragma unroll
+                for (int c = 0; c < CG; ++c) dot = fmaf(d[c], v[c], dot);
+            }
+            dots[k] = dot;
         }
         if (p + 1 < P) request(p + 1);
         const float m = mk[p];
@@ -482,25 +510,22 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (srcs[k] < 0) continue;
-            float dot = 0.f;
-#pragma unroll
-            for (int c = 0; c < CG; ++c) dot = fmaf(d[c], v[k][c], dot);
+            const float dot = dots[k];
             gm = fmaf(wgt[k], dot, gm);
             gpx = fmaf(wpx[k], dot, gpx);
             gpy = fmaf(wpy[k], dot, gpy);
             const int lx = xs[k] - wx0, ly = ys[k] - wy0;
             if ((unsigned)lx < (unsigned)DCN_WS && (unsigned)ly < (unsigned)DCN_WS) {
-                const int wp = ly * DCN_WS + lx, rot = ly + lx;      // (channel slot: see the note on the window layout above)
-                Acc* dst = win_acc + wp * CG;
+                Acc* dst = win_acc + ly * WL::RP + lx * WL::PP;      // (+ c: an immediate of the ds_add)
                 if constexpr (FIX32) {
                     const float c32 = m * wgt[k] * scale;
 #pragma unroll
                     for (int c = 0; c < CG; ++c)      // round to nearest through the 1.5 * 2^23 binade: |addend| < 2^16 by the scale
-                        atomicAdd(dst + ((c + rot) & (CG - 1)), __float_as_int(fmaf(d[c], c32, 12582912.f)) - 0x4B400000);
+                        atomicAdd(dst + c, __float_as_int(fmaf(d[c], c32, 12582912.f)) - 0x4B400000);
                 } else {
                     const float coef = m * wgt[k] * DCN_FIX;
 #pragma unroll
-                    for (int c = 0; c < CG; ++c) atomicAdd(dst + ((c + rot) & (CG - 1)), dcn_to_fixed(d[c] * coef));
+                    for (int c = 0; c < CG; ++c) atomicAdd(dst + c, dcn_to_fixed(d[c] * coef));
                 }
             } else {
                 spilled = true;
@@ -510,17 +535,39 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
                 for (int c = 0; c < CG; ++c) atomicAdd(dst + c, dcn_to_fixed(d[c] * coef));
             }
         }
-        dmask[(pix * g.G + gi) * P + p] = from_f32<T>(gm);
-        doffset[((pix * g.G + gi) * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
-        doffset[((pix * g.G + gi) * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
+        // staged in LDS and written after the loop: a lane's own stores (one element of a pixel's run per point, pixels 2 G P bytes apart)
+        // were 64 partial cache lines per instruction -- 194 of the kernel's 540 us at 8 x 128 x 128 x 112, 3.5x its algorithmic write traffic
+        T* const st = stage + threadIdx.x * (3 * DCN_PMAX);
+        st[p] = from_f32<T>(gm);
+        st[DCN_PMAX + 2 * p] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
+        st[DCN_PMAX + 2 * p + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
     }
     if (spilled) atomicOr(side_used, 1);
     __syncthreads();
+    // the staged mask / offset gradients: consecutive lanes write consecutive elements of a pixel's run (P mask values, 2 P offset values)
+    for (int e = threadIdx.x; e < 256 * P; e += 256) {
+        const int pl = e / P, p = e - pl * P;
+        const int hh = ty * DCN_TS + (pl >> 4), ww = tx * DCN_TS + (pl & 15);
+        if (hh < g.Ho && ww < g.Wo) {
+            const int64_t run = ((((int64_t)n * g.Ho + hh) * g.Wo + ww) * g.G + gi) * P + p;
+            const T* sp = stage + pl * (3 * DCN_PMAX);
+            dmask[run] = sp[p];
+            if constexpr (sizeof(T) == 2) {      // the (x, y) pair of a point as one dword
+                const unsigned pair = (unsigned)__builtin_bit_cast(unsigned short, sp[DCN_PMAX + 2 * p]) |
+                                      ((unsigned)__builtin_bit_cast(unsigned short, sp[DCN_PMAX + 2 * p + 1]) << 16);
+                reinterpret_cast<unsigned*>(doffset)[run] = pair;
+            } else {
+                doffset[run * 2] = sp[DCN_PMAX + 2 * p];
+                doffset[run * 2 + 1] = sp[DCN_PMAX + 2 * p + 1];
+            }
+        }
+    }
     float* out = windows + (int64_t)blockIdx.x * WPIX * CG;
     for (int i = threadIdx.x; i < WPIX * CG; i += 256) {
-        const int wp = i / CG, c = i % CG, rot = wp / DCN_WS + wp % DCN_WS;
-        if constexpr (FIX32) out[i] = (float)win_acc[wp * CG + ((c + rot) & (CG - 1))] * inv_scale;
-        else out[i] = (float)((double)(long long)win_acc[wp * CG + ((c + rot) & (CG - 1))] * DCN_UNFIX);
+        const int wp = i / CG, c = i % CG;
+        const int cell = (wp / DCN_WS) * WL::RP + (wp % DCN_WS) * WL::PP + c;
+        if constexpr (FIX32) out[i] = (float)win_acc[cell] * inv_scale;
+        else out[i] = (float)((double)(long long)win_acc[cell] * DCN_UNFIX);
     }
 }
 
@@ -530,26 +577,28 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
                                                                const int* __restrict__ side_used, float* __restrict__ dx, DcnGeom g,
                                                                DcnWin wn) {
     constexpr int WPIX = DCN_WS * DCN_WS, Q = CG / 4;
-    const int64_t total = (int64_t)g.N * g.H * g.W * g.G * Q;
+    // (the host keeps N H W G Q and the bracket products below 2^31: 32-bit index arithmetic -- the 64-bit divisions of the first form were
+    // most of this kernel's 600 VALU instructions per wavefront)
+    const unsigned total = (unsigned)g.N * g.H * g.W * g.G * Q;
     const bool use_side = *side_used != 0;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int qc = (int)(i % Q);
-        int64_t t = i / Q;
-        const int gi = (int)(t % g.G);
-        t /= g.G;
-        const int ux = (int)(t % g.W);
-        t /= g.W;
-        const int uy = (int)(t % g.H);
-        const int n = (int)(t / g.H);
+    const int kx = DCN_TS * g.stride * (g.Win - 2), ky = DCN_TS * g.stride * (g.Hin - 2);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const int qc = (int)(i % (unsigned)Q);
+        unsigned t = i / (unsigned)Q;
+        const int gi = (int)(t % (unsigned)g.G);
+        t /= (unsigned)g.G;
+        const int ux = (int)(t % (unsigned)g.W);
+        t /= (unsigned)g.W;
+        const int uy = (int)(t % (unsigned)g.H);
+        const int n = (int)(t / (unsigned)g.H);
         const int px = ux + g.pad, py = uy + g.pad;
         // tiles whose window may hold (py, px): x0(ty) = floor(ty * kx / Hin) + c0x - rx grows with the tile ROW index; bracket the solutions
         // of x0(ty) <= px < x0(ty) + WS with one tile of slack and test exactly below
-        const int64_t kx = (int64_t)DCN_TS * g.stride * (g.Win - 2), ky = (int64_t)DCN_TS * g.stride * (g.Hin - 2);
-        const int64_t ax = px - wn.c0x + wn.rx, ay = py - wn.c0y + wn.ry;
-        const int ty_hi = (int)min((int64_t)wn.tiles_y - 1, kx > 0 ? ((ax + 1) * g.Hin) / kx + 1 : (int64_t)wn.tiles_y - 1);
-        const int ty_lo = (int)max((int64_t)0, kx > 0 ? ((ax - DCN_WS) * g.Hin) / kx - 1 : (int64_t)0);
-        const int tx_hi = (int)min((int64_t)wn.tiles_x - 1, ky > 0 ? ((ay + 1) * g.Win) / ky + 1 : (int64_t)wn.tiles_x - 1);
-        const int tx_lo = (int)max((int64_t)0, ky > 0 ? ((ay - DCN_WS) * g.Win) / ky - 1 : (int64_t)0);
+        const int ax = px - wn.c0x + wn.rx, ay = py - wn.c0y + wn.ry;
+        const int ty_hi = min(wn.tiles_y - 1, kx > 0 ? ((ax + 1) * g.Hin) / kx + 1 : wn.tiles_y - 1);
+        const int ty_lo = max(0, kx > 0 ? ((ax - DCN_WS) * g.Hin) / kx - 1 : 0);
+        const int tx_hi = min(wn.tiles_x - 1, ky > 0 ? ((ay + 1) * g.Win) / ky + 1 : wn.tiles_x - 1);
+        const int tx_lo = max(0, ky > 0 ? ((ay - DCN_WS) * g.Win) / ky - 1 : 0);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int ty = ty_lo; ty <= ty_hi; ++ty) {
             const int lx = px - dcn_win_x0(g, wn, ty);
@@ -708,6 +757,10 @@ static bool dcn_window(const DcnGeom& g, DcnWin* wn) {
     if (g.Cg != 8 && g.Cg != 16) return false;
     if (g.kh * g.kw > DCN_PMAX) return false;
     if (g.Win <= 2 || g.Hin <= 2) return false;
+    // 32-bit index arithmetic of the gather kernel: element count and bracket products
+    if ((int64_t)g.N * g.H * g.W * g.G * g.Cg >= (1ll << 31) || (int64_t)(g.Win + DCN_WS + 64) * g.Hin >= (1ll << 30) ||
+        (int64_t)(g.Hin + DCN_WS + 64) * g.Win >= (1ll << 30) || (int64_t)DCN_TS * g.stride * (g.Win + g.Hin) >= (1ll << 30))
+        return false;
     wn->tiles_y = (g.Ho + DCN_TS - 1) / DCN_TS;
     wn->tiles_x = (g.Wo + DCN_TS - 1) / DCN_TS;
     const double half = (double)((g.dil * (g.kh - 1)) / 2), halfw = (double)((g.dil * (g.kw - 1)) / 2);
@@ -807,12 +860,14 @@ extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mas
         const int64_t n16 = (int64_t)(need - side_off) / 16;      // side buffer + flag
         hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)side, n16);
         const unsigned blocks = (unsigned)((int64_t)N * wn.tiles_y * wn.tiles_x * G);
-        const size_t lds = (size_t)DCN_WS * DCN_WS * Cg * (dtype == ISEG_BF16 ? sizeof(int) : sizeof(unsigned long long));
+        const size_t cells = Cg == 16 ? DcnWinLds<16>::CELLS : DcnWinLds<8>::CELLS;
+        const size_t stage_bytes = (size_t)256 * 3 * DCN_PMAX * (dtype == ISEG_BF16 ? 2 : 4);      // staged mask / offset gradients
+        const size_t lds = cells * (dtype == ISEG_BF16 ? sizeof(int) : sizeof(unsigned long long)) + stage_bytes;
 #define DCN_WIN(T, CG)                                                                                                                      \
     do {                                                                                                                                    \
         static const bool raised = [] {                                                                                                     \
             return hipFuncSetAttribute(reinterpret_cast<const void*>(&dcnv3_bwd_win_kernel<T, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       DCN_WS * DCN_WS * CG * 8) == hipSuccess;                                                             \
+                                       DcnWinLds<CG>::CELLS * 8 + 256 * 3 * DCN_PMAX * 4) == hipSuccess;                                    \
         }();                                                                                                                                \
         (void)raised;                                                                                                                       \
         hipLaunchKernelGGL((dcnv3_bwd_win_kernel<T, CG>), dim3(blocks), dim3(256), lds, stream, (const T*)x, (const T*)offset, (const T*)mask, \
