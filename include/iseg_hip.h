@@ -136,6 +136,16 @@ size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
                        const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
                        int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* Tail of a post-norm residual branch in one pass each way (backbones/intern_image/intern_image.py:226-236: x = residual + drop_path(gamma *
+ * norm(f(x))), utils/drops.py:8-22): y = residual + rowscale[row / rows_per_group] * colscale[c] * LN(x); colscale [C], rowscale, residual
+ * optional.  Backward: dx = LN^T(rowscale colscale dy); dgamma, dbeta and dcolscale (NULL: not wanted) are ACCUMULATED -- the three come from
+ * the same two column sums.  Workspace of the backward: iseg_layernorm_bwd_workspace_bytes(rows, C) + 2 C floats. */
+int iseg_layernorm_post_fwd(const void* x, const float* gamma, const float* beta, const float* colscale, const float* rowscale,
+                            int64_t rows_per_group, const void* residual, void* y, float* mean, float* rstd, int64_t rows, int C, float eps,
+                            int dtype, iseg_stream_t stream);
+int iseg_layernorm_post_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* colscale, const float* rowscale,
+                            int64_t rows_per_group, const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+                            float* dcolscale, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* LayerNorm followed by a static row permutation with zero padding -- norm1 + tf.pad + tf.roll + window_partition of a Swin block
  * (backbones/swin.py:246-262) in one pass: y[r,:] = src_index[r] >= 0 ? LN(x[src_index[r],:]) : 0 for r < rows_out; mean / rstd [rows_out]
  * are kept per OUTPUT row.  Backward over the `rows` SOURCE rows with the inverse table: the gradient row and the statistics of source row

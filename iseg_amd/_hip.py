@@ -63,6 +63,8 @@ SIGNATURES = {
     "iseg_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_layernorm_bwd_workspace_bytes": (_z, [_l, _i]),
     "iseg_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
+    "iseg_layernorm_post_fwd": (_i, [_p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "iseg_layernorm_post_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _z, _p]),
     "iseg_layernorm_gather_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_layernorm_gather_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
     "iseg_dwconv2d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

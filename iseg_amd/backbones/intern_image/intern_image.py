@@ -93,6 +93,13 @@ class InternImageLayer(Layer):
             self.res_post_norm2 = LayerNormalization(epsilon=LN_EPS, name=f"{self.name}/res_post_norm2")
         self.built = True
 
+    def _post_fusable(self):
+        from ... import nn
+
+        ps = [self.norm1.gamma, self.norm1.beta, self.norm2.gamma, self.norm2.beta]
+        return (not nn.dry_run() and self.norm1.built and self.norm2.built and all(p is not None and p.requires_grad for p in ps)
+                and ps[0].shape[0] % 8 == 0)
+
     def _scale(self, x, gamma):
         return x if gamma is None else F.scale_channels(x, gamma)
 
@@ -100,6 +107,17 @@ class InternImageLayer(Layer):
         masks = self.drop_path_masks or (None, None)
         dp = lambda t, i: F.drop_path(t, self.drop_path_rate, bool(training), mask=masks[i])  # noqa: E731
         x, residual = F.fork(inputs, 2)      # residual forks: gradients summed by our own kernel
+        if self.use_post_norm and self._post_fusable():
+            # LayerNorm + layer scale + drop path + skip connection of each half in one pass forward and one backward (F.layer_norm_post)
+            def factors(i):
+                if not training or self.drop_path_rate == 0.0:
+                    return None
+                return masks[i] if masks[i] is not None else F.drop_path_factors(inputs.shape[0], 1.0 - self.drop_path_rate, inputs.device)
+
+            n1, n2 = self.norm1, self.norm2
+            x = F.layer_norm_post(self.dcn(x, training=training), n1.gamma, n1.beta, n1.epsilon, self.gamma1, factors(0), residual)
+            x, residual = F.fork(x, 2)
+            return F.layer_norm_post(self.mlp(x, training=training), n2.gamma, n2.beta, n2.epsilon, self.gamma2, factors(1), residual)
         if self.use_post_norm:
             x = dp(self._scale(self.norm1(self.dcn(x, training=training)), self.gamma1), 0)
             x, residual = F.fork(F.add(residual, x), 2)

@@ -14,6 +14,15 @@ namespace {
 
 constexpr int LN_MAX_CHUNKS = 8;  // 8-element chunks per lane kept in registers
 
+// Optional tail of a post-norm residual branch (backbones/intern_image/intern_image.py:226-236: x = residual + drop_path(gamma_ls * norm(f(x)))):
+// y = residual + rowscale[row / rows_per_group] * colscale[c] * LayerNorm(x).  All-NULL = plain LayerNorm.
+struct LnPost {
+    const float* colscale;      // layer scale, [C] (NULL: 1)
+    const float* rowscale;      // drop-path factor per group of rows_per_group rows (NULL: 1)
+    int64_t rows_per_group;
+    const void* residual;       // [rows, C] in the activation dtype (NULL: none)
+};
+
 // lanes per row: smallest power of two >= number of 8-element chunks, capped at 64
 static inline int ln_lanes_per_row(int C) {
     const int chunks = (C + 7) / 8;
@@ -29,7 +38,8 @@ template <class T, int CPL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int64_t rows, int C, float eps, int lpr, const int32_t* __restrict__ src_index) {
+                                                            int64_t rows, int C, float eps, int lpr, const int32_t* __restrict__ src_index,
+                                                            LnPost post) {
     // src_index (optional): output row r is LayerNorm(x[src_index[r]]), or a row of ZEROS where src_index[r] < 0 -- Swin's norm1 followed by
     // zero-pad + cyclic roll + window partition (backbones/swin.py:246-262) in one pass; statistics are then kept per OUTPUT row
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -48,7 +58,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int cc = c < nchunks ? c : nchunks - 1;
         load8<float>(gamma + cc * 8, g[i]);
         load8<float>(beta + cc * 8, bt[i]);
+        if (post.colscale) {      // the layer scale folds into the affine pair: cs * (xhat g + b) = xhat (cs g) + cs b
+            float cs[8];
+            load8<float>(post.colscale + cc * 8, cs);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[i][u] *= cs[u], bt[i][u] *= cs[u];
+        }
     }
+    const T* const res = static_cast<const T*>(post.residual);
     for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
         const int64_t row = rbase + sub;
         const bool valid = row < rows;
@@ -88,6 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         }
         q = group_sum(q, lpr);
         const float rstd = rsqrtf(q / (float)C + eps);
+        const float rsf = post.rowscale && valid ? post.rowscale[row / post.rows_per_group] : 1.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = li + i * lpr;
@@ -95,6 +113,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                 float o[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) o[u] = pad_row ? 0.f : (v[i][u] - mean) * rstd * g[i][u] + bt[i][u];
+                if (post.rowscale) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] *= rsf;
+                }
+                if (res) {
+                    float a[8];
+                    load8<T>(res + row * C + c * 8, a);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) o[u] += a[u];
+                }
                 store8<T>(y + row * C + c * 8, o);
             }
         }
@@ -117,7 +145,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             const T* __restrict__ dx_add, float* __restrict__ partials,
-                                                            int64_t rows, int C, int lpr, const int32_t* __restrict__ dy_index) {
+                                                            int64_t rows, int C, int lpr, const int32_t* __restrict__ dy_index, LnPost post) {
+    // post (a post-norm residual branch, see LnPost): the arriving gradient is taken as rowscale * dy and the affine scale as colscale * gamma;
+    // the column sums written to `partials` are then A = sum rowscale dy xhat and B = sum rowscale dy, from which the host-side finish derives
+    // dgamma = colscale A, dbeta = colscale B and dcolscale = gamma A + beta B
     // dy_index (optional): the gradient row and the saved statistics of source row r sit at row dy_index[r] (< 0: no gradient arrives) -- the
     // backward of layernorm_fwd_kernel's src_index form with the inverse table
     extern __shared__ __attribute__((aligned(16))) float lds_part[];  // [2][C]
@@ -134,7 +165,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         const int c = li + i * lpr;
 #pragma unroll
         for (int u = 0; u < 8; ++u) dg[i][u] = db[i][u] = gam[i][u] = 0.f;
-        if (c < nchunks) load8<float>(gamma + c * 8, gam[i]);
+        if (c < nchunks) {
+            load8<float>(gamma + c * 8, gam[i]);
+            if (post.colscale) {
+                float cs[8];
+                load8<float>(post.colscale + c * 8, cs);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gam[i][u] *= cs[u];
+            }
+        }
     }
 
     // U rows per lane group are in flight together: with wide rows (one row per wavefront and iteration) the loop is otherwise one dependent
@@ -160,6 +199,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
             mu[q] = mean[rd];
             rs[q] = valid[q] && has_dy ? rstd[rd] : 0.f;
+            const float rsf = post.rowscale ? post.rowscale[rd / post.rows_per_group] : 1.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 const int c = li + i * lpr;
@@ -169,7 +209,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 load8<T>(x + rc * C + cc * 8, xv[q][i]);
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    d[q][i][u] = ok ? d[q][i][u] : 0.f;
+                    d[q][i][u] = ok ? d[q][i][u] * rsf : 0.f;
                     xv[q][i][u] = ok ? xv[q][i][u] : mu[q];
                 }
             }
@@ -244,6 +284,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < 2 * C; i += 256) out[i] = lds_part[i];
 }
 
+
+// parameter gradients of a post-norm residual branch from the two column sums of layernorm_bwd_kernel (see LnPost): sums = [A | B]
+__global__ void ln_post_finish_kernel(const float* __restrict__ sums, const float* __restrict__ colscale, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                      float* __restrict__ dcolscale, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float A = sums[c], B = sums[C + c], cs = colscale ? colscale[c] : 1.f;
+    dgamma[c] += cs * A;
+    dbeta[c] += cs * B;
+    if (dcolscale) dcolscale[c] += gamma[c] * A + beta[c] * B;
+}
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm
@@ -642,11 +694,19 @@ static inline int strip_grid(int64_t rows, int rows_per_block_iter, int max_bloc
 }  // namespace
 
 static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                int64_t rows, int C, float eps, int dtype, hipStream_t stream);
+                                int64_t rows, int C, float eps, int dtype, hipStream_t stream, const LnPost& post = LnPost{});
 
 extern "C" int iseg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                   int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
     return layernorm_fwd_launch(x, nullptr, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream);
+}
+
+extern "C" int iseg_layernorm_post_fwd(const void* x, const float* gamma, const float* beta, const float* colscale, const float* rowscale,
+                                       int64_t rows_per_group, const void* residual, void* y, float* mean, float* rstd, int64_t rows, int C,
+                                       float eps, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(!rowscale || rows_per_group > 0, "iseg_layernorm_post_fwd: rowscale needs rows_per_group > 0");
+    ISEG_REQUIRE((((uintptr_t)colscale | (uintptr_t)residual) & 15) == 0, "iseg_layernorm_post_fwd: colscale / residual must be 16-byte aligned");
+    return layernorm_fwd_launch(x, nullptr, gamma, beta, y, mean, rstd, rows, C, eps, dtype, stream, LnPost{colscale, rowscale, rows_per_group, residual});
 }
 
 extern "C" int iseg_layernorm_gather_fwd(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean,
@@ -656,7 +716,7 @@ extern "C" int iseg_layernorm_gather_fwd(const void* x, const int32_t* src_index
 }
 
 static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                                int64_t rows, int C, float eps, int dtype, hipStream_t stream) {
+                                int64_t rows, int C, float eps, int dtype, hipStream_t stream, const LnPost& post) {
     ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
     const int lpr = ln_lanes_per_row(C);
@@ -667,7 +727,7 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
     const int cpl = (C / 8 + lpr - 1) / lpr;
 #define LN_FWD(T, CPL)                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
-                       (T*)y, mean, rstd, rows, C, eps, lpr, src_index)
+                       (T*)y, mean, rstd, rows, C, eps, lpr, src_index, post)
 #define LN_FWD_T(T)                  \
     do {                             \
         if (cpl <= 1) LN_FWD(T, 1);      \
@@ -713,7 +773,20 @@ extern "C" size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
 
 static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
-                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream);
+                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream, const LnPost& post = LnPost{}, const float* beta = nullptr,
+                                float* dcolscale = nullptr);
+
+// backward of iseg_layernorm_post_fwd: dx = LN^T (rowscale colscale dy); dgamma, dbeta and dcolscale (NULL: not wanted) are ACCUMULATED.
+// Workspace: iseg_layernorm_bwd_workspace_bytes(rows, C) + 2 C floats.
+extern "C" int iseg_layernorm_post_bwd(const void* dy, const void* x, const float* gamma, const float* beta, const float* colscale,
+                                       const float* rowscale, int64_t rows_per_group, const float* mean, const float* rstd, void* dx,
+                                       float* dgamma, float* dbeta, float* dcolscale, int64_t rows, int C, int dtype, void* ws, size_t ws_bytes,
+                                       hipStream_t stream) {
+    ISEG_REQUIRE(beta && (!rowscale || rows_per_group > 0) && (!dcolscale || colscale), "iseg_layernorm_post_bwd: bad arguments");
+    ISEG_REQUIRE(((uintptr_t)colscale & 15) == 0, "iseg_layernorm_post_bwd: colscale must be 16-byte aligned");
+    return layernorm_bwd_launch(dy, nullptr, x, gamma, mean, rstd, dx, nullptr, dgamma, dbeta, 1, rows, C, dtype, ws, ws_bytes, stream,
+                                LnPost{colscale, rowscale, rows_per_group, nullptr}, beta, dcolscale);
+}
 
 extern "C" int iseg_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                                   void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads,
@@ -733,25 +806,26 @@ extern "C" int iseg_layernorm_gather_bwd(const void* dy, const int32_t* dy_index
 
 static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const void* x, const float* gamma, const float* mean, const float* rstd,
                                 void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
-                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+                                int dtype, void* ws, size_t ws_bytes, hipStream_t stream, const LnPost& post, const float* beta, float* dcolscale) {
     ISEG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "iseg_layernorm_bwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_bwd: C=%d must be a positive multiple of 8", C);
     const int lpr = ln_lanes_per_row(C);
     ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_bwd: C=%d too wide", C);
     const int blocks = ln_bwd_blocks(rows, C);
-    const size_t need = (size_t)blocks * 2 * C * sizeof(float);
+    const bool posted = post.colscale || post.rowscale;      // the column sums need the finish kernel: summed here, not by the deferred queue
+    const size_t need = (size_t)blocks * 2 * C * sizeof(float) + (posted ? (size_t)2 * C * sizeof(float) : 0);
     if (!ws || ws_bytes < need) {
         iseg_set_error("iseg_layernorm_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
     float* partials = (float*)ws;
-    float* const arena = iseg_deferred_partials(need, dgamma, dbeta, accumulate_param_grads, stream);      // (see common.h: deferred reductions)
+    float* const arena = posted ? nullptr : iseg_deferred_partials(need, dgamma, dbeta, accumulate_param_grads, stream);      // (see common.h: deferred reductions)
     if (arena) partials = arena;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const int cpl = (C / 8 + lpr - 1) / lpr;
 #define LN_BWD(T, CPL, U)                                                                                                   \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
-                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index)
+                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index, post)
     // rows in flight per lane group: 4 when a wavefront holds one or two rows per iteration, 2 for four, else 1 (64 / lpr rows already)
 #define LN_BWD_T(T)                                     \
     do {                                                \
@@ -767,7 +841,12 @@ static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const v
     else LN_BWD_T(float);
 #undef LN_BWD_T
 #undef LN_BWD
-    if (arena) iseg_deferred_push(partials, blocks, 2 * C, 2 * C, dgamma, dbeta, C, 1.f, stream);
+    if (posted) {
+        float* sums = partials + (size_t)blocks * 2 * C;
+        launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, sums, nullptr, 2 * C, 0, 1.f, 0, stream);
+        hipLaunchKernelGGL(ln_post_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums, post.colscale, gamma, beta, dgamma, dbeta,
+                           dcolscale, C);
+    } else if (arena) iseg_deferred_push(partials, blocks, 2 * C, 2 * C, dgamma, dbeta, C, 1.f, stream);
     else launch_reduce_rows(partials, blocks, 2 * C, 0, 1, 2 * C, dgamma, dbeta, C, 0, 1.f, accumulate_param_grads, stream);
     return iseg_check_launch("iseg_layernorm_bwd");
 }

@@ -532,6 +532,43 @@ class _LayerNormFn(Function):
         return dx.reshape(dy.shape), None, None, None
 
 
+class _LayerNormPostFn(Function):
+    """residual + drop_path_mask[sample] * colscale * layer_norm(x): the tail of a post-norm residual branch (InternImage, post_norm = True) as one
+    pass each way -- LayerNorm, layer scale, drop path and the skip connection forward; backward one LayerNorm-backward pass whose two column
+    sums also give the layer-scale gradient (csrc/norm.hip LnPost)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, colscale, rowscale, residual):
+        C = x.shape[-1]
+        x2 = _c(x).reshape(-1, C)
+        rpg = x2.shape[0] // rowscale.shape[0] if rowscale is not None else 0
+        r2 = _c(residual).reshape(-1, C) if residual is not None else None
+        y, mean, rstd = K.layernorm_post_fwd(x2, gamma.data, beta.data, eps, colscale.data if colscale is not None else None, rowscale, rpg, r2)
+        ctx.params, ctx.rpg = (gamma, beta, colscale), rpg
+        ctx.save_for_backward(x2, mean, rstd, rowscale)
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, rowscale = ctx.saved_tensors
+        gamma, beta, colscale = ctx.params
+        C = x2.shape[1]
+        want_cs = colscale is not None and colscale.requires_grad
+        dx = K.layernorm_post_bwd(_c(dy).reshape(-1, C), x2, gamma.data, beta.data, mean, rstd, _grad(gamma), _grad(beta),
+                                  colscale=colscale.data if colscale is not None else None, dcolscale=_grad(colscale) if want_cs else None,
+                                  rowscale=rowscale, rows_per_group=ctx.rpg)
+        dist.grads_ready(gamma, beta, colscale) if colscale is not None else dist.grads_ready(gamma, beta)
+        return (dx.reshape(dy.shape) if ctx.needs_input_grad[0] else None), None, None, None, None, None, (dy if ctx.needs_input_grad[6] else None)
+
+
+def layer_norm_post(x, gamma, beta, eps, colscale=None, drop_path_mask=None, residual=None):
+    """residual + drop_path_mask[sample] * colscale * layer_norm(x, gamma, beta, eps) as one tape node (channels % 8 == 0; gamma and beta trainable)"""
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _LayerNormPostFn.apply(x, gamma, beta, float(eps), colscale, drop_path_mask, residual)
+
+
 def layer_norm(x, gamma, beta, eps):
     _check_act_dtype(x)
     if nn.dry_run():

@@ -368,6 +368,30 @@ def layernorm_bwd(dy2d, x2d, gamma, mean, rstd, dgamma, dbeta, dx_add=None, accu
     return dx
 
 
+def layernorm_post_fwd(x2d, gamma, beta, eps, colscale=None, rowscale=None, rows_per_group=0, residual=None):
+    """residual + rowscale[row // rows_per_group] * colscale * LN(x2d) in one pass (iseg_layernorm_post_fwd); returns (y, mean, rstd)"""
+    _require_cuda(x2d)
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    _hip.call("iseg_layernorm_post_fwd", ptr(x2d), ptr(gamma), ptr(beta), ptr(colscale), ptr(rowscale), int(rows_per_group), ptr(residual), ptr(y),
+              ptr(mean), ptr(rstd), rows, Cc, eps, dt(x2d), stream())
+    return y, mean, rstd
+
+
+def layernorm_post_bwd(dy2d, x2d, gamma, beta, mean, rstd, dgamma, dbeta, colscale=None, dcolscale=None, rowscale=None, rows_per_group=0):
+    """backward of layernorm_post_fwd: returns dx; dgamma / dbeta / dcolscale are accumulated"""
+    _require_cuda(dy2d, x2d)
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    need = _hip.lib().iseg_layernorm_bwd_workspace_bytes(rows, Cc) + 2 * Cc * 4
+    ws, wsb = workspace(need, x2d.device)
+    _hip.call("iseg_layernorm_post_bwd", ptr(dy2d), ptr(x2d), ptr(gamma), ptr(beta), ptr(colscale), ptr(rowscale), int(rows_per_group), ptr(mean),
+              ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dcolscale), rows, Cc, dt(x2d), ptr(ws), wsb, stream())
+    return dx
+
+
 def layernorm_gather_fwd(x2d, src_index, gamma, beta, eps):
     """y[r] = LN(x2d[src_index[r]]) or a zero row where src_index[r] < 0; mean / rstd per OUTPUT row (iseg_layernorm_gather_fwd)"""
     _require_cuda(x2d, src_index)
