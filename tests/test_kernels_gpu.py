@@ -191,6 +191,131 @@ def test_layernorm_fwd_bwd(cuda, dtype, rows, C):
 
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,groups", [(1003, 96, 1), (4 * 130, 112, 4), (300, 384, 3), (64, 768, 2), (7, 8, 1)])
+@pytest.mark.parametrize("use_cs,use_rs,use_res", [(True, True, True), (False, False, False), (True, False, True)])
+def test_layernorm_post_norm_tail(cuda, dtype, rows, C, groups, use_cs, use_rs, use_res):
+    """iseg_layernorm_post_fwd / _bwd: residual + rowscale[group] * colscale * LN(x) (backbones/intern_image/intern_image.py:226-236 with
+    utils/drops.py:8-22) against fp64 autograd -- the three parameter gradients come from the same two column sums"""
+    k = K()
+    x, xr = q(rnd((rows, C), 1) * 2 + 0.3, dtype)
+    g = (rnd((C,), 2) * 0.3 + 1).float()
+    b = (rnd((C,), 3) * 0.2).float()
+    cs = (rnd((C,), 6) * 0.4 + 1).float()
+    rs = torch.tensor([0.0, 1.25, 1.25, 2.5][:groups] if groups > 1 else [1.25], dtype=torch.float32)
+    res, resr = q(rnd((rows, C), 7), dtype)
+    rpg = rows // groups
+    y, mean, rstd = k.layernorm_post_fwd(x, g.cuda(), b.cuda(), 1e-6, colscale=cs.cuda() if use_cs else None, rowscale=rs.cuda() if use_rs else None,
+                                         rows_per_group=rpg if use_rs else 0, residual=res if use_res else None)
+    xx = xr.clone().requires_grad_(True)
+    gg, bb, cc = g.double().requires_grad_(True), b.double().requires_grad_(True), cs.double().requires_grad_(True)
+    yo = O.layer_norm(xx, gg, bb, 1e-6)
+    if use_cs:
+        yo = yo * cc
+    if use_rs:
+        yo = yo * rs.double()[torch.arange(rows) // rpg][:, None]
+    if use_res:
+        yo = yo + resr
+    close(y, yo, dtype, "ln post fwd")
+    dy, dyr = q(rnd((rows, C), 4), dtype)
+    yo.backward(dyr)
+    dgam, dbet, dcs = torch.full((C,), 0.5, device="cuda"), torch.full((C,), -0.25, device="cuda"), torch.full((C,), 2.0, device="cuda")
+    dx = k.layernorm_post_bwd(dy, x, g.cuda(), b.cuda(), mean, rstd, dgam, dbet, colscale=cs.cuda() if use_cs else None,
+                              dcolscale=dcs if use_cs else None, rowscale=rs.cuda() if use_rs else None, rows_per_group=rpg if use_rs else 0)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    close(dx, xx.grad, dtype, "ln post dx", f32_tol=1e-4, bf16_tol=2e-2)
+    close(dgam - 0.5, gg.grad, torch.float32, "ln post dgamma (accumulated)", f32_tol=tol)
+    close(dbet + 0.25, bb.grad, torch.float32, "ln post dbeta (accumulated)", f32_tol=tol)
+    if use_cs:
+        close(dcs - 2.0, cc.grad, torch.float32, "ln post dcolscale (accumulated)", f32_tol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C,pad_every", [(900, 96, 7), (257, 192, 3), (64, 32, 0)])
+def test_layernorm_with_row_tables_and_gather_fma(cuda, dtype, rows, C, pad_every):
+    """iseg_layernorm_gather_fwd / _bwd and iseg_gather_rows_fma: norm1 + pad / roll / window partition, window reverse + drop path + skip
+    (backbones/swin.py:246-279) with arbitrary permutation tables: padding rows (-1) are zero, the inverse table routes the gradient back"""
+    k = K()
+    gen = torch.Generator().manual_seed(11)
+    perm = torch.randperm(rows, generator=gen)
+    fwd = []                                  # output row -> source row, with padding rows sprinkled in
+    for i, src in enumerate(perm.tolist()):
+        if pad_every and i % pad_every == 0:
+            fwd.append(-1)
+        fwd.append(src)
+    fwd = torch.tensor(fwd, dtype=torch.int32)
+    inv = torch.empty(rows, dtype=torch.int32)
+    inv[fwd[fwd >= 0].long()] = torch.nonzero(fwd >= 0).flatten().int()
+    x, xr = q(rnd((rows, C), 1) * 2 + 0.3, dtype)
+    g = (rnd((C,), 2) * 0.3 + 1).float()
+    b = (rnd((C,), 3) * 0.2).float()
+    y, mean, rstd = k.layernorm_gather_fwd(x, fwd.cuda(), g.cuda(), b.cuda(), 1e-5)
+    xx = xr.clone().requires_grad_(True)
+    gg, bb = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ln = O.layer_norm(xx, gg, bb, 1e-5)
+    yo = torch.where((fwd >= 0)[:, None], ln[fwd.clamp(min=0).long()], torch.zeros((), dtype=torch.float64))
+    close(y, yo, dtype, "ln gather fwd")
+    assert (y[(fwd < 0).cuda()] == 0).all()
+    dy, dyr = q(rnd(tuple(yo.shape), 4), dtype)
+    add, addr = q(rnd((rows, C), 5), dtype)
+    yo.backward(dyr)
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = k.layernorm_gather_bwd(dy, inv.cuda(), x, g.cuda(), mean, rstd, dgam, dbet, dx_add=add)
+    close(dx, xx.grad + addr, dtype, "ln gather dx", f32_tol=1e-4, bf16_tol=2e-2)
+    close(dgam, gg.grad, torch.float32, "ln gather dgamma", f32_tol=2e-4 if dtype == torch.float32 else 2e-2)
+    close(dbet, bb.grad, torch.float32, "ln gather dbeta", f32_tol=2e-4)
+    # window reverse + drop path + skip: out[m] = res[m] + f[m // rpg] * w[inv[m]]; gradient to the window rows by the forward table, factor of the source row
+    groups = 3 if rows % 3 == 0 else 1
+    rpg = rows // groups
+    f = torch.tensor([1.25, 0.0, 2.0][:groups], dtype=torch.float32)
+    w, wr = q(rnd(tuple(yo.shape), 8), dtype)
+    res, resr = q(rnd((rows, C), 9), dtype)
+    out = k.gather_rows_fma(w, inv.cuda(), f.cuda(), rpg, False, res)
+    fo = f.double()[torch.arange(rows) // rpg][:, None]
+    close(out, resr + fo * wr[inv.long()], dtype, "gather fma fwd")
+    d, dr = q(rnd((rows, C), 10), dtype)
+    dw = k.gather_rows_fma(d, fwd.cuda(), f.cuda(), rpg, True, None)
+    want = torch.where((fwd >= 0)[:, None], (fo * dr)[fwd.clamp(min=0).long()], torch.zeros((), dtype=torch.float64))
+    close(dw, want, dtype, "gather fma bwd")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,Hc,Wc", [((2, 16, 16, 64), 8, 8), ((1, 24, 32, 96), 12, 16), ((2, 10, 14, 32), 4, 5), ((1, 9, 9, 8), 9, 9)])
+def test_bn_relu_upsample_add_and_remask_backward(cuda, dtype, shape, Hc, Wc):
+    """iseg_bn_relu_upsample_add + iseg_bn_bwd_{reduce,apply}_remask + the one-pass x2 bilinear backward: one level of the FPN top-down pathway
+    (layers/fpn.py:46-57) against fp64 autograd through batch_norm_train / relu / resize_bilinear"""
+    k = K()
+    N, H, W, C = shape
+    rows = N * H * W
+    z, zr = q(rnd(shape, 1) * 1.5 + 0.2, dtype)
+    xc, xcr = q(rnd((N, Hc, Wc, C), 2), dtype)
+    g = (rnd((C,), 3) * 0.3 + 1).float()
+    b = (rnd((C,), 4) * 0.2).float()
+    packed = k.bn_stats(z.reshape(rows, C), C, rows, C)
+    mean, rstd = k.bn_finalize(packed, C, 1e-3, 0.9, None, None)
+    out = k.bn_relu_upsample_add(z, mean, rstd, g.cuda(), b.cuda(), xc)
+    zz, xx = zr.clone().requires_grad_(True), xcr.clone().requires_grad_(True)
+    gg, bb = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    bn, _, _ = O.batch_norm_train(zz, gg, bb, 1e-3)
+    # the device's own pre-activation decides the mask (ties at zero cannot differ between the two sides)
+    pre = (z.reshape(rows, C).double().cpu() - mean.cpu().double()) * rstd.cpu().double() * g.double() + b.double()
+    mask = (pre.float() > 0).reshape(shape)
+    yo = bn * mask + O.resize_bilinear(xx, (H, W))
+    close(out, yo, dtype, "bn relu upsample add", f32_tol=1e-4, bf16_tol=2e-2)
+    dy, dyr = q(rnd(shape, 5), dtype)
+    yo.backward(dyr)
+    d2, z2 = dy.reshape(rows, C), z.reshape(rows, C)
+    sums = k.bn_bwd_reduce_remask(d2, C, z2, C, mean, rstd, g.cuda(), b.cuda(), rows, C)
+    tol = 3e-4 if dtype == torch.float32 else 3e-2
+    close(sums[:C], bb.grad, torch.float32, "remask dbeta", f32_tol=tol)
+    close(sums[C:], gg.grad, torch.float32, "remask dgamma", f32_tol=tol)
+    dz = k.bn_bwd_apply_remask(d2, C, z2, C, mean, rstd, g.cuda(), b.cuda(), sums, 1.0 / rows, torch.empty_like(z2), C, rows, C)
+    close(dz.reshape(shape), zz.grad, dtype, "remask dz", f32_tol=3e-4, bf16_tol=3e-2)
+    dxc = k.resize_bilinear_bwd(dy, Hc, Wc, dtype)      # exact x2 shapes take the one-pass kernel, the others the two-pass form
+    close(dxc, xx.grad, dtype, "resize bwd", f32_tol=1e-4, bf16_tol=2e-2)
+
+
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape,Kk,dil", [((2, 13, 17, 96), 7, 1), ((1, 40, 70, 32), 7, 1), ((1, 16, 16, 768), 7, 2), ((2, 9, 9, 192), 7, 1), ((1, 20, 11, 64), 3, 1),
                                          ((1, 8, 8, 112), 3, 2), ((1, 33, 5, 384), 5, 1), ((3, 64, 64, 64), 7, 1), ((1, 73, 100, 32), 7, 1), ((2, 16, 16, 96), 7, 1),
                                          ((1, 7, 5, 32), 7, 1), ((5, 32, 32, 160), 7, 1)])
