@@ -346,7 +346,7 @@ def test_dwconv_fwd_bwd(cuda, dtype, shape, Kk, dil):
 
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,C,relu", [(4096, 256, True), (16, 256, True), (1000, 48, False), (333, 2048, True)])
+@pytest.mark.parametrize("rows,C,relu", [(4096, 256, True), (16, 256, True), (1000, 48, False), (333, 2048, True), (20000, 64, True), (1024, 2048, False)])
 def test_batchnorm_train(cuda, dtype, rows, C, relu):
     k = K()
     x, xr = q(rnd((rows, C), 1) * 1.5 + 0.2, dtype)
