@@ -92,7 +92,31 @@ def cold(N, H, W, C, R=10):
     line("bn_bwd_apply relu (3r+w)", timeit(rot(lambda x, d, y: K.bn_bwd_apply(d, C, x, C, y, C, mean, rstd, gamma, sums, 1.0 / rows, dx, C, rows, C, True))), 4 * B)
 
 
+def fpn(N=16, H=128, W=128, C=768):
+    """one FPN level at the Swin-T + FPN stride-4 shape: the fused kernel against its parts"""
+    dev = "cuda"
+    z = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+    xc = torch.randn(N, H // 2, W // 2, C, device=dev).to(torch.bfloat16)
+    dy = torch.randn(N, H, W, C, device=dev).to(torch.bfloat16)
+    B = z.numel() * 2
+    rows = N * H * W
+    g, b = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    packed = K.bn_stats(z.reshape(rows, C), C, rows, C)
+    mean, rstd = K.bn_finalize(packed, C, 1e-3, 0.9, None, None)
+    print(f"[{N},{H},{W},{C}] bf16: {B / 1e6:.0f} MB per tensor")
+    line("bn_relu_upsample_add (r + r/4 + w)", timeit(lambda: K.bn_relu_upsample_add(z, mean, rstd, g, b, xc)), 2 * B + B // 4)
+    line("resize_bilinear_bwd x2 (r + w/4)", timeit(lambda: K.resize_bilinear_bwd(dy, H // 2, W // 2, torch.bfloat16)), B + B // 4)
+    z2, d2 = z.reshape(rows, C), dy.reshape(rows, C)
+    sums = K.bn_bwd_reduce_remask(d2, C, z2, C, mean, rstd, g, b, rows, C)
+    line("bn_bwd_reduce_remask (2r)", timeit(lambda: K.bn_bwd_reduce_remask(d2, C, z2, C, mean, rstd, g, b, rows, C, out=sums)), 2 * B)
+    dz = torch.empty_like(z2)
+    line("bn_bwd_apply_remask (2r + w)", timeit(lambda: K.bn_bwd_apply_remask(d2, C, z2, C, mean, rstd, g, b, sums, 1.0 / rows, dz, C, rows, C)), 3 * B)
+    line("bn_stats (r)", timeit(lambda: K.bn_stats(z2, C, rows, C, out=packed)), B)
+
+
 def main():
+    if sys.argv[1:2] == ["fpn"]:
+        return fpn(*[int(v) for v in sys.argv[2:]])
     if sys.argv[1:2] == ["cold"]:
         a = [int(v) for v in sys.argv[2:]] or [16, 128, 128, 256]
         return cold(*a)
