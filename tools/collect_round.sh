@@ -16,11 +16,11 @@ echo "graph configs done"
 : > "$out/configs_kernels.md"
 for c in cfg1 cfg3 cfg4 cfg5; do
   (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$R/$out/prof_$c" -- python3 "$R/tools/bench_configs.py" $c --steps 5 --warmup 2 > "$R/$out/prof_$c.log" 2>&1)
-  python3 tools/prof_config.py "$out/prof_$c" $c 7 14 >> "$out/configs_kernels.md"
+  python3 tools/prof_config.py "$out/prof_$c" $c 7 20 >> "$out/configs_kernels.md"
   rm -rf "$out/prof_$c" "$out/prof_$c.log"
   echo "$c profiled"
 done
 python3 tools/dp_overhead.py 30 > "$out/dp_overhead.txt" 2>&1 || true
 echo "dp overhead done"
-{ python3 tools/kbench_mlp_bwd.py; python3 tools/kbench_conv_strided.py; python3 tools/kbench_dcn.py; } > "$out/kernels.txt" 2>&1 || true
+{ python3 tools/kbench_mlp_bwd.py; python3 tools/kbench_conv_strided.py; python3 tools/kbench_dcn.py; python3 tools/kbench_stream.py fpn; python3 tools/kbench_stream.py cold; } > "$out/kernels.txt" 2>&1 || true
 echo "kernel loops done"
