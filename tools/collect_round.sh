@@ -9,9 +9,14 @@ out=$1
 export TMPDIR=/tmp
 R=$(pwd)
 mkdir -p "$out"
-python3 tools/bench_configs.py cfg1 cfg3 cfg4 cfg4_infer cfg5 v2 2>/dev/null | grep ms_per_step > "$out/configs.jsonl"
+: > "$out/configs.jsonl"
+for c in cfg1 cfg3 cfg4 cfg4_infer cfg5 v2; do      # one process per configuration: the last of six in one process ran 15 % slow
+  python3 tools/bench_configs.py $c --steps 20 --warmup 5 2>/dev/null | grep ms_per_step >> "$out/configs.jsonl"
+done
 echo "eager configs done"
-python3 tools/bench_configs.py cfg1 cfg3 cfg4 cfg5 v2 --graph-step 2>/dev/null | grep ms_per_step >> "$out/configs.jsonl"
+for c in cfg1 cfg3 cfg4 cfg5 v2; do
+  python3 tools/bench_configs.py $c --graph-step --steps 20 --warmup 5 2>/dev/null | grep ms_per_step >> "$out/configs.jsonl"
+done
 echo "graph configs done"
 : > "$out/configs_kernels.md"
 for c in cfg1 cfg3 cfg4 cfg5; do
