@@ -34,7 +34,7 @@ static inline int ln_lanes_per_row(int C) {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: `LPR` lanes cooperate on one row, 64/LPR rows per wave, values stay in registers
 // ------------------------------------------------------------------------------------------------
-template <class T, int CPL>
+template <class T, int CPL, bool POST = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int cc = c < nchunks ? c : nchunks - 1;
         load8<float>(gamma + cc * 8, g[i]);
         load8<float>(beta + cc * 8, bt[i]);
-        if (post.colscale) {      // the layer scale folds into the affine pair: cs * (xhat g + b) = xhat (cs g) + cs b
+        if (POST && post.colscale) {      // the layer scale folds into the affine pair: cs * (xhat g + b) = xhat (cs g) + cs b
             float cs[8];
             load8<float>(post.colscale + cc * 8, cs);
 #pragma unroll
             for (int u = 0; u < 8; ++u) g[i][u] *= cs[u], bt[i][u] *= cs[u];
         }
     }
-    const T* const res = static_cast<const T*>(post.residual);
+    const T* const res = POST ? static_cast<const T*>(post.residual) : nullptr;      // (POST = false: the plain kernel carries none of the tail)
     for (int64_t rbase = wave_global * rpw; rbase < rows; rbase += nwaves * rpw) {
         const int64_t row = rbase + sub;
         const bool valid = row < rows;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         }
         q = group_sum(q, lpr);
         const float rstd = rsqrtf(q / (float)C + eps);
-        const float rsf = post.rowscale && valid ? post.rowscale[row / post.rows_per_group] : 1.f;
+        const float rsf = POST && post.rowscale && valid ? post.rowscale[row / post.rows_per_group] : 1.f;
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = li + i * lpr;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                 float o[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) o[u] = pad_row ? 0.f : (v[i][u] - mean) * rstd * g[i][u] + bt[i][u];
-                if (post.rowscale) {
+                if (POST && post.rowscale) {
 #pragma unroll
                     for (int u = 0; u < 8; ++u) o[u] *= rsf;
                 }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // Each lane always owns the same channel chunks, so the parameter-gradient partials live in registers for
 // the whole row strip and are combined once per block through LDS.
 // ------------------------------------------------------------------------------------------------
-template <class T, int CPL, int U>
+template <class T, int CPL, int U, bool POST = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int u = 0; u < 8; ++u) dg[i][u] = db[i][u] = gam[i][u] = 0.f;
         if (c < nchunks) {
             load8<float>(gamma + c * 8, gam[i]);
-            if (post.colscale) {
+            if (POST && post.colscale) {
                 float cs[8];
                 load8<float>(post.colscale + c * 8, cs);
 #pragma unroll
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
             mu[q] = mean[rd];
             rs[q] = valid[q] && has_dy ? rstd[rd] : 0.f;
-            const float rsf = post.rowscale ? post.rowscale[rd / post.rows_per_group] : 1.f;
+            const float rsf = POST && post.rowscale ? post.rowscale[rd / post.rows_per_group] : 1.f;
 #pragma unroll
             for (int i = 0; i < CPL; ++i) {
                 const int c = li + i * lpr;
@@ -725,9 +725,16 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
     int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4);
     if (blocks > 256 * 8) blocks = 256 * 8;
     const int cpl = (C / 8 + lpr - 1) / lpr;
-#define LN_FWD(T, CPL)                                                                                                      \
-    hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
-                       (T*)y, mean, rstd, rows, C, eps, lpr, src_index, post)
+    const bool posted = post.colscale || post.rowscale || post.residual;
+#define LN_FWD(T, CPL)                                                                                                                    \
+    do {                                                                                                                                  \
+        if (posted)                                                                                                                       \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL, true>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
+                               (T*)y, mean, rstd, rows, C, eps, lpr, src_index, post);                                                    \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((layernorm_fwd_kernel<T, CPL, false>), dim3((unsigned)blocks), dim3(256), 0, stream, (const T*)x, gamma, beta, \
+                               (T*)y, mean, rstd, rows, C, eps, lpr, src_index, post);                                                    \
+    } while (0)
 #define LN_FWD_T(T)                  \
     do {                             \
         if (cpl <= 1) LN_FWD(T, 1);      \
@@ -823,9 +830,15 @@ static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const v
     if (arena) partials = arena;
     const size_t lds = 2 * (size_t)C * sizeof(float);
     const int cpl = (C / 8 + lpr - 1) / lpr;
-#define LN_BWD(T, CPL, U)                                                                                                   \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
-                       mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index, post)
+#define LN_BWD(T, CPL, U)                                                                                                                  \
+    do {                                                                                                                                   \
+        if (posted)                                                                                                                        \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U, true>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
+                               mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index, post);                              \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T, CPL, U, false>), dim3(blocks), dim3(256), lds, stream, (const T*)dy, (const T*)x, gamma, \
+                               mean, rstd, (T*)dx, (const T*)dx_add, partials, rows, C, lpr, dy_index, post);                              \
+    } while (0)
     // rows in flight per lane group: 4 when a wavefront holds one or two rows per iteration, 2 for four, else 1 (64 / lpr rows already)
 #define LN_BWD_T(T)                                     \
     do {                                                \
