@@ -13,16 +13,21 @@ OPTIMIZER = ["adamw"]
 CLIPNORM = [None]
 
 
+FACTORY = ["convnext_tiny_aspp"]
+
+
 def _trainer(seed=3):
-    from iseg_amd import nn
+    from iseg_amd import heads, nn
     from iseg_amd.core_env import common_env_setup
     from iseg_amd.core_optimizer import get_optimizer
     from iseg_amd.core_train import CoreTrain
-    from iseg_amd.heads import convnext_tiny_aspp
     from iseg_amd.modelhelper import model_common_setup
 
     strategy = common_env_setup(use_one_device_strategy=True, mixed_precision=True, random_seed=seed)
-    model = convnext_tiny_aspp(build_input_size=(64, 64), drop_path_rate=0.2, dropout_rate=0.1)
+    if FACTORY[0] == "convnext_tiny_aspp":
+        model = heads.convnext_tiny_aspp(build_input_size=(64, 64), drop_path_rate=0.2, dropout_rate=0.1)
+    else:
+        model = getattr(heads, FACTORY[0])(build_input_size=(64, 64))
     helper = model_common_setup(model, restore_checkpoint=False)
     helper.set_optimizer(get_optimizer(strategy, initial_lr=1e-3 if OPTIMIZER[0] == "adamw" else 2e-2, end_lr=0.0, epoch_steps=20, train_epoch=1,
                                        warmup_steps=3, warmup_lr=1e-5, optimizer=OPTIMIZER[0], adamw_weight_decay=0.05, clipnorm=CLIPNORM[0]))
@@ -160,3 +165,22 @@ def test_graphed_step_with_per_variable_norm_clipping(cuda):
     assert le == lg, (le, lg)
     assert torch.equal(we, wg) and torch.equal(cme, cmg)
     assert le != plain, "the clip changed nothing: too loose to exercise the norm reduction"
+
+
+@pytest.mark.parametrize("factory", ["swin_tiny_fpn", "intern_image_base_aspp"])
+def test_other_compositions_replay_bit_exact(cuda, factory):
+    """Swin-T + FPN (row-table LayerNorm paired with the residual gather through a link object, the MLP halves on the fused ConvNeXt-MLP node,
+    FPN levels as one node with training-mode BatchNorm) and InternImage-B + ASPP (post-norm tails, DCNv3 fixed-point windows): four replayed
+    steps == four eager steps, bit for bit -- the Python-side pairing of the new nodes exists only while the step is captured"""
+    FACTORY[0] = factory
+    try:
+        batches = _batches()
+        le, we, ite, cme, _, w0e = _run(False, 4, batches)
+        lg, wg, itg, cmg, step, w0g = _run(True, 4, batches)
+    finally:
+        FACTORY[0] = "convnext_tiny_aspp"
+    assert torch.equal(w0e, w0g), "the two trainers did not start from the same weights"
+    assert any(e.get("graph") is not None for e in step.entries.values()), "the step was never captured"
+    assert le == lg, (le, lg)
+    assert torch.equal(we, wg), float((we - wg).abs().max())
+    assert cme is not None and torch.equal(cme, cmg)
