@@ -198,6 +198,64 @@ def mlp_gelu(x, W1, b1, W2, b2, residual=None, drop_path_mask=None):
     return _MlpGeluFn.apply(x, W1, b1, W2, b2, residual, drop_path_mask)
 
 
+class _DenseGroupFn(Function):
+    """Several Dense layers of ONE input whose outputs are wanted side by side -- keras MultiHeadAttention's query / key / value projections
+    (backbones/vit.py:142-147: three kernels [C, heads, d]) feeding the packed attention kernels: every product writes its column block of
+    the [M, sum N] result directly (no concat copy), and the backward pass reads the gradient's column blocks in place (strided operands: no
+    slice copies) and accumulates the three data gradients in the GEMM epilogue (no adds)."""
+
+    @staticmethod
+    def forward(ctx, x, n, *wb):
+        Ws, bs = wb[:n], wb[n:2 * n]
+        Kd = x.shape[-1]
+        x2 = _c(x).reshape(-1, Kd)
+        Ns = [W.numel() // Kd for W in Ws]
+        out = torch.empty((x2.shape[0], sum(Ns)), dtype=x2.dtype, device=x2.device)
+        off = 0
+        for W, b, N in zip(Ws, bs, Ns):
+            view = out[:, off:off + N]
+            bias = b.data.reshape(-1) if b is not None else None
+            Wt = _kcontig_kernel(W, x2, Kd, N)
+            if Wt is not None:
+                K.dense_fwd_t(x2, Wt, bias, out=view)
+            else:
+                K.dense_fwd(x2, nn.w(W).reshape(Kd, N), bias, out=view)
+            off += N
+        ctx.Ws, ctx.bs, ctx.Ns, ctx.Kd = Ws, bs, Ns, Kd
+        ctx.save_for_backward(x2)
+        return out.reshape(*x.shape[:-1], sum(Ns))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        Kd = ctx.Kd
+        d2 = _c(dy).reshape(x2.shape[0], sum(ctx.Ns))
+        dx, off = None, 0
+        for W, b, N in zip(ctx.Ws, ctx.bs, ctx.Ns):
+            dv = d2[:, off:off + N]      # a strided view: the GEMMs take the row stride
+            want_b = b is not None and b.requires_grad
+            if W.requires_grad:
+                K.dense_wgrad(x2, dv, _grad(W).reshape(Kd, N), bias_grad=(_grad(b).reshape(-1) if want_b else None))
+            elif want_b:
+                K.colsum(dv, dv.stride(0), 0, 1, dv.shape[0], N, _grad(b).reshape(-1), accumulate=True)
+            if ctx.needs_input_grad[0]:
+                Wn = nn.w(W).reshape(Kd, N)
+                dx = K.dense_dgrad(dv, Wn) if dx is None else K.dense_dgrad(dv, Wn, out=dx, residual=dx)      # + the earlier blocks, in the epilogue
+            off += N
+        dist.grads_ready(*ctx.Ws, *[b for b in ctx.bs if b is not None])
+        return (dx.reshape(*dy.shape[:-1], Kd) if dx is not None else None, None) + (None,) * (2 * len(ctx.Ws))
+
+
+def dense_group(x, kernels, biases):
+    """[dense(x, W_i, b_i) for i] concatenated along the last axis as one tape node; a kernel of rank > 2 is read as [in, rest] (keras
+    MultiHeadAttention: [C, heads, d]); biases: a list of the same length (entries may be None)"""
+    _check_act_dtype(x)
+    Kd = x.shape[-1]
+    if nn.dry_run():
+        return _dry((*x.shape[:-1], sum(W.numel() // Kd for W in kernels)), x)
+    return _DenseGroupFn.apply(x, len(kernels), *kernels, *biases)
+
+
 class _LnMlpResidualFn(Function):
     """x + drop_path(Dense(gelu(Dense(LayerNorm(x))))) -- the second half of a pre-norm transformer block (backbones/swin.py:233-236) -- on the
     fused kernels of the ConvNeXt stages (csrc/mlp_fused.hip, csrc/mlp_wgrad.hip: C = 96 / 192, hidden 4C, bf16): LayerNorm rides the row

@@ -34,9 +34,7 @@ class MultiHeadAttention(Layer):
             raise NotImplementedError("MultiHeadAttention: self-attention only (query is value is key)")
         b, t, c = query.shape
         h, dk, dv = self.num_heads, self.key_dim, self.value_dim
-        q = F.dense(query, self.query_kernel, self.query_bias, kshape=(c, h * dk))
-        k = F.dense(query, self.key_kernel, self.key_bias, kshape=(c, h * dk))
-        v = F.dense(query, self.value_kernel, self.value_bias, kshape=(c, h * dv))
-        qkv = F.concat([q, k, v])
+        # the three projections as one node: column blocks of qkv written / read in place, data gradients accumulated in the GEMM epilogue
+        qkv = F.dense_group(query, [self.query_kernel, self.key_kernel, self.value_kernel], [self.query_bias, self.key_bias, self.value_bias])
         x = F.attention_packed(qkv, h, h * dk, h * dv, float(dk) ** -0.5, dropout_rate=self.dropout, training=bool(training))
         return F.dense(x, self.output_kernel, self.output_bias, kshape=(h * dv, c))
