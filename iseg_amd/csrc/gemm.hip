@@ -15,7 +15,7 @@
 #include "common.h"
 #include "iseg_hip.h"
 
-#include "gemm_dma.h"
+#include "gemm_dma_tn.h"
 
 using namespace iseg_mm;
 
@@ -31,6 +31,13 @@ int long_k_tile() {
 int dma_mode() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_DMA");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+int dma_tn_mode() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_DMA_TN");
         return e ? atoi(e) : 1;
     }();
     return v;
@@ -127,6 +134,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int nsplit
 // choose the split so that a skinny-output contraction (wgrad: M,N small, K = pixels) still fills 256 CUs
 int choose_split(const iseg_gemm_args* g, int tile) {
     if (g->split_k > 0) return g->split_k;
+    // weight-gradient orientation on the LDS-DMA pipeline (gemm_dma_tn.h): 256-row tiles, one workgroup per CU
+    if (const int form = iseg_mm::dma_tn_form(g)) {
+        const int s = iseg_mm::dma_tn_split(g, form);
+        if (s > 1) return s;
+    }
     const int64_t tiles = ceil_div64(g->M + (g->colsum_out ? 1 : 0), tile) * ceil_div64(g->N, tile);
     if (tiles >= 256 || g->K < 2048 || g->batch > 1 || g->b_group_rows > 0) return 1;
     // the LDS-DMA pipeline keeps several K-tiles in flight per workgroup: half-filled grids are better left unsplit
@@ -162,6 +174,7 @@ extern "C" int iseg_gemm_variant(const iseg_gemm_args* g) {
     if (!g || g->in_dtype != ISEG_BF16) return 0;
     const int nsplit = iseg_gemm_splits(g);
     const int64_t kps = nsplit > 1 ? ceil_div64(ceil_div64(g->K, nsplit), 128) * 128 : g->K;
+    if (nsplit > 1 && iseg_mm::dma_tn_form(g)) return iseg_mm::dma_tn_form(g);      // 7 / 8: the weight-gradient LDS-DMA kernel
     if (!iseg_mm::dma_mode() || !iseg_mm::dma_eligible(g, kps)) return 0;
     return iseg_mm::dma_form(g, (int)ceil_div64(g->K, kps));
 }

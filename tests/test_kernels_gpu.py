@@ -119,6 +119,55 @@ def test_gemm_wgrad_splitk(cuda, dtype, M, N, Kd, split):
     close(out, want, torch.float32 if dtype == torch.float32 else dtype, "wgrad", f32_tol=5e-5, bf16_tol=2e-4)
 
 
+@pytest.mark.parametrize("rows,C,N,form", [(16384, 1536, 384, 7), (16384, 384, 1536, 8), (4096, 3072, 768, 7), (4096, 768, 3072, 7),
+                                           (2048, 136, 200, 7), (6144, 392, 128, 7), (2176, 128, 520, 8)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_wgrad_lds_dma_pipeline(cuda, rows, C, N, form, bias):
+    """weight gradients in the ConvNeXt stage-2 / stage-3 shapes (and ragged ones: M, N not multiples of the tile) take the LDS-DMA kernel of
+    csrc/gemm_dma_tn.h (256 x 128 / 128 x 256 tiles, split over the reduction, ones-row by one more MFMA per fragment): dW and db against the oracle,
+    the slab form (dense_wgrad_slabs) against the summed form, and two runs bit-identical (use_deterministic, core_env.py:39-48)"""
+    import ctypes as Ct
+
+    from iseg_amd import _hip
+
+    k = K()
+    x, xr = q(rnd((rows, C), 11), torch.bfloat16)
+    dy, dyr = q(rnd((rows, N), 12), torch.bfloat16)
+    g = _hip.GemmArgs()
+    g.A, g.lda, g.a_kcontig = x.data_ptr(), x.stride(0), 0
+    g.B, g.ldb, g.b_kcontig = dy.data_ptr(), dy.stride(0), 0
+    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.batch, g.batch_inner = C, N, rows, 1, 0, 1, 1
+    dummy = torch.zeros(1, device="cuda")
+    g.D, g.ldd = dummy.data_ptr(), N
+    if bias:
+        g.colsum_out = dummy.data_ptr()
+    assert int(_hip.lib().iseg_gemm_variant(Ct.byref(g))) == form, "the problem did not plan onto the LDS-DMA weight-gradient kernel"
+    dW = torch.full((C, N), 0.25, device="cuda")
+    db = torch.full((N,), -1.0, device="cuda")
+    if bias:
+        assert k.wgrad_can_fuse_bias(x) or C % 128 == 0
+        k.gemm(x, dy, dW, C, N, rows, lda=x.stride(0), ldb=dy.stride(0), ldd=N, a_kcontig=0, b_kcontig=0, accumulate=True, colsum_out=db,
+               colsum_accumulate=True)
+    else:
+        k.gemm(x, dy, dW, C, N, rows, lda=x.stride(0), ldb=dy.stride(0), ldd=N, a_kcontig=0, b_kcontig=0, accumulate=True)
+    want = xr.T @ dyr
+    close(dW, want + 0.25, torch.float32, "dW", f32_tol=2e-5)
+    if bias:
+        close(db, dyr.sum(0) - 1.0, torch.float32, "db", f32_tol=2e-5)
+    dW2 = torch.full((C, N), 0.25, device="cuda")
+    db2 = torch.full((N,), -1.0, device="cuda")
+    k.gemm(x, dy, dW2, C, N, rows, lda=x.stride(0), ldb=dy.stride(0), ldd=N, a_kcontig=0, b_kcontig=0, accumulate=True,
+           colsum_out=db2 if bias else None, colsum_accumulate=True)
+    assert torch.equal(dW, dW2) and (not bias or torch.equal(db, db2)), "two runs of the split weight gradient differ"
+    if bias and N % 4 == 0 and k.wgrad_can_fuse_bias(x):
+        got = k.dense_wgrad_slabs(x, dy)
+        assert got is not None
+        slabs, n = got
+        total = slabs.view(-1, C + 1, N)[:n].double().sum(0).cpu()
+        close(total[:C], want, torch.float32, "slab sum", f32_tol=2e-5)
+        close(total[C], dyr.sum(0), torch.float32, "ones-row of the slabs", f32_tol=2e-5)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,C", [(520, 96), (300, 192), (130, 384)])
 def test_gemm_a_operand_gelu_transform(cuda, dtype, M, C):
