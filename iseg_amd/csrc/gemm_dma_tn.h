@@ -108,7 +108,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
         for (int i = 0; i < FM; ++i) aa[i] = sbase + a_off[i];
 #pragma unroll
         for (int j = 0; j < FN; ++j) ab[j] = sbase + b_off[j];
+        // (ISEG_TN_ABL_*: ablation builds of tools/micro/tn_bench.hip -- results are wrong, timings tell what the loop is made of)
+#ifdef ISEG_TN_ABL_NOREAD
+#define ISEG_TR_READ(dst, addr, OFF) asm volatile("" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#else
 #define ISEG_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
+#endif
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             ISEG_TR_READ(ra[0][i][0], aa[i], 0);
@@ -146,10 +151,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
             for (int i = 0; i < FM; ++i) af[i] = join(ra[ks][i][0], ra[ks][i][1]);
 #pragma unroll
             for (int j = 0; j < FN; ++j) bfr[j] = join(rb[ks][j][0], rb[ks][j][1]);
+#ifdef ISEG_TN_ABL_NOMFMA
+            acc[0][0][0] += __builtin_bit_cast(float, ra[ks][0][0].x ^ rb[ks][0][0].x);
+#else
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#endif
             if (ones) {
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], one8, acc1[j], 0, 0, 0);
@@ -173,13 +182,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
     int stage = 0, fill = (NS - 1) % NS;
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt;
+#ifndef ISEG_TN_ABL_NOWAIT
         if (ahead >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
         else if (NS > 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifndef ISEG_TN_ABL_NODMA
         if (kt + NS - 1 < nk) issue(fill);
+#endif
         compute(stage);
         stage = stage + 1 == NS ? 0 : stage + 1;
         fill = fill + 1 == NS ? 0 : fill + 1;
