@@ -23,13 +23,25 @@ struct LnPost {
     const void* residual;       // [rows, C] in the activation dtype (NULL: none)
 };
 
-// lanes per row: smallest power of two >= number of 8-element chunks, capped at 64
-static inline int ln_lanes_per_row(int C) {
+// lanes per row: smallest power of two >= number of 8-element chunks, capped at 64.  `thirds` (the forward kernel at the narrow ConvNeXt / Swin
+// widths 96 and 192: 12 / 24 chunks): 4 / 8 lanes with three chunks each instead of 16 / 32 lanes with a quarter of them idle -- measured
+// (tools/kbench_ln.py, 16 images) forward 22.0 -> 17.6 us at 128 x 128 x 96 and 13.4 -> 11.0 at 64 x 64 x 192, equal at 384 / 768; the backward kernel
+// LOSES with it at every width (39 -> 59, 26 -> 32, 19.5 -> 22.9, 16.5 -> 19.3 us: 144 more registers of rows in flight) and keeps the old split.
+static inline int ln_lanes_per_row(int C, bool thirds = false) {
     const int chunks = (C + 7) / 8;
+    static const int cpl3 = [] {
+        const char* e = getenv("ISEG_LN_CPL3");
+        return e ? atoi(e) : 1;
+    }();
+    if (thirds && cpl3 && chunks % 3 == 0 && chunks <= 24) {
+        const int t = chunks / 3;
+        if (t >= 1 && (t & (t - 1)) == 0) return t;
+    }
     int l = 1;
     while (l < chunks && l < 64) l <<= 1;
     return l;
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward: `LPR` lanes cooperate on one row, 64/LPR rows per wave, values stay in registers
@@ -719,7 +731,7 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
                                 int64_t rows, int C, float eps, int dtype, hipStream_t stream, const LnPost& post) {
     ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
-    const int lpr = ln_lanes_per_row(C);
+    const int lpr = ln_lanes_per_row(C, true);
     ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_fwd: C=%d too wide (max %d)", C, 64 * 8 * LN_MAX_CHUNKS);
     const int rpw = 64 / lpr;
     int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4);
@@ -739,6 +751,7 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
     do {                             \
         if (cpl <= 1) LN_FWD(T, 1);      \
         else if (cpl <= 2) LN_FWD(T, 2); \
+        else if (cpl <= 3) LN_FWD(T, 3); \
         else if (cpl <= 4) LN_FWD(T, 4); \
         else LN_FWD(T, 8);               \
     } while (0)

@@ -65,6 +65,13 @@ def main():
             else:
                 def step():
                     return trainer.train_step(x, y)
+        elif args.graph_step:
+            from iseg_amd.graphs import graphed_inference
+
+            ginf = graphed_inference(model, (512, 512))      # the whole sliding-window call replayed from one HIP graph per input shape
+
+            def step():
+                return ginf(x)
         else:
             def step():
                 with torch.no_grad():
@@ -79,9 +86,9 @@ def main():
         dt = (time.perf_counter() - t0) / args.steps
         rec = {"config": name, "workload": desc, "batch": batch, "dtype": "bf16", "ms_per_step": round(dt * 1e3, 3),
                "images_per_sec": round(batch / dt, 2), "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2)}
+        rec["step"] = "hip graph replay" if args.graph_step else "eager"
         if training:
             rec["loss"] = round(float(out[0]), 4)
-            rec["step"] = "hip graph replay" if args.graph_step else "eager"
         print(json.dumps(rec), flush=True)
         del model, helper
         torch.cuda.empty_cache()

@@ -14,7 +14,7 @@ for c in cfg1 cfg3 cfg4 cfg4_infer cfg5 v2; do      # one process per configurat
   python3 tools/bench_configs.py $c --steps 20 --warmup 5 2>/dev/null | grep ms_per_step >> "$out/configs.jsonl"
 done
 echo "eager configs done"
-for c in cfg1 cfg3 cfg4 cfg5 v2; do
+for c in cfg1 cfg3 cfg4 cfg4_infer cfg5 v2; do
   python3 tools/bench_configs.py $c --graph-step --steps 20 --warmup 5 2>/dev/null | grep ms_per_step >> "$out/configs.jsonl"
 done
 echo "graph configs done"
