@@ -223,6 +223,16 @@ def mhsa_layer(w, prefix, x, heads):
     return O.mhsa_core(q, k, v, heads)
 
 
+def axial_attention_layer(w, prefix, x, heads, shared_qk=False):
+    """layers/multihead_axial_attention.py:149-172"""
+    def conv1x1(name, t):
+        return O.conv2d(t, w[f"{prefix}/{name}/kernel"], w.get(f"{prefix}/{name}/bias"), 1, 1, "valid")
+
+    q = conv1x1("query_conv", x)
+    k = q if shared_qk else conv1x1("key_conv", x)
+    return O.axial_attention_core(q, k, conv1x1("value_conv", x), heads)
+
+
 # ------------------------------------------------------------------------------------------------------
 # backbones/vit.py:19-63,66-113,163-183,277-323
 # ------------------------------------------------------------------------------------------------------

@@ -458,6 +458,29 @@ def mhsa_core(q, k, v, heads, apply_scale=True, eps=1e-7, attention_mask=None, r
     return (out, a) if return_attention_map else out
 
 
+def axial_attention_core(q, k, v, heads, apply_scale=True, eps=1e-7):
+    """layers/multihead_axial_attention.py:84-146 on finite inputs: per head a column map softmax(q k^T / sqrt(d)) over H ([N, heads, W, H, H], :95-99)
+    and a row map over W ([N, heads, H, W, W], :101-105), both clipped to [eps, 1 - eps] (:125-126); the value is mixed along H, then along W
+    (:130-135); heads end up channel-minor (:137-139: [N, H, W, C / heads, heads] flattened)"""
+    N, H, W, Cq = q.shape
+    Cv = v.shape[-1]
+    dq, dv = Cq // heads, Cv // heads
+    qh = q.reshape(N, H, W, heads, dq)
+    kh = k.reshape(N, H, W, heads, dq)
+    v_map = qh.permute(0, 3, 2, 1, 4) @ kh.permute(0, 3, 2, 4, 1)      # [N, heads, W, H, H]
+    u_map = qh.permute(0, 3, 1, 2, 4) @ kh.permute(0, 3, 1, 4, 2)      # [N, heads, H, W, W]
+    if apply_scale:
+        v_map = v_map / math.sqrt(dq)
+        u_map = u_map / math.sqrt(dq)
+    v_map = torch.clamp(torch.softmax(v_map, dim=-1), eps, 1.0 - eps)
+    u_map = torch.clamp(torch.softmax(u_map, dim=-1), eps, 1.0 - eps)
+    x = v.reshape(N, H, W, heads, dv).permute(0, 3, 2, 1, 4)             # [N, heads, W, H, C]
+    x = v_map @ x
+    x = x.permute(0, 1, 3, 2, 4)                                         # [N, heads, H, W, C]
+    x = u_map @ x
+    return x.permute(0, 2, 3, 4, 1).reshape(N, H, W, dv * heads)
+
+
 # ------------------------------------------------------------------------------------------------------
 # layers/dcn_v3/op.py:16-109 + utils.py:14-209, transcribed op for op (tensor form), quirks included:
 # ref is stacked [y, x] while grid / offset / the sampler use [x, y]; weights come from the clipped corners.

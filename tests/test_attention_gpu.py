@@ -187,6 +187,36 @@ def test_mhsa_layer(cuda, dtype):
         nn.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,heads,shared_qk", [((2, 6, 5, 64), 4, False), ((1, 9, 12, 32), 2, True), ((2, 7, 7, 48), 1, False)])
+def test_axial_attention_layer(cuda, dtype, shape, heads, shared_qk):
+    """MultiHeadAxialAttentionLayer (layers/multihead_axial_attention.py:15-172): output, input gradient and every parameter gradient against
+    the oracle's line-by-line restatement (column map, row map, clip, H-then-W mixing, channel-minor head interleave)"""
+    from iseg_amd import nn
+    from iseg_amd.layers.multihead_axial_attention import MultiHeadAxialAttentionLayer
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        layer = MultiHeadAxialAttentionLayer(num_heads=heads, shared_qk=shared_qk, name="axial")
+        _setup(layer, torch.empty(shape, dtype=dtype, device="cuda"))
+        x = rnd(shape, 1).to(dtype)
+        xg = x.cuda().requires_grad_(True)
+        y = layer(xg, training=True)
+        assert tuple(y.shape) == shape
+        w = {k_: v.requires_grad_(True) for k_, v in OM.export_weights(layer).items()}
+        xr = x.double().requires_grad_(True)
+        yr = OM.axial_attention_layer(w, "axial", xr, heads, shared_qk=shared_qk)
+        assert _rel(y, yr.detach()) < (2e-5 if dtype == torch.float32 else 3e-2)
+        dy = rnd(shape, 2).to(dtype)
+        y.backward(dy.cuda())
+        yr.backward(dy.double())
+        assert _rel(xg.grad, xr.grad) < (2e-4 if dtype == torch.float32 else 5e-2)
+        _check_grads(layer, w, 3e-4 if dtype == torch.float32 else 6e-2, l2=dtype != torch.float32, skip=("key_conv/bias",))
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
 def test_mhsa_attention_mask_and_attention_map(cuda):
     """compute_attention(attention_mask=...) (layers/multihead_self_attention.py:108-151, safed_softmax's additive mask) and
     return_attention_map: the [N, heads, HW, HW] probabilities that multiply V; call() ignores its attention_mask argument like the
