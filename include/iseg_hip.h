@@ -119,7 +119,11 @@ int iseg_gemm_splits(const iseg_gemm_args* args_h);
 int iseg_gemm_slabs(const iseg_gemm_args* args_h);
 /* which main loop iseg_gemm runs for this problem (profiling labels): 0 = register-staged gemm_bf16_kernel / fp32 kernel,
    1..4 = LDS-DMA pipeline gemm_bf16_dma_kernel with tile 128x64 / 256x128 / 128x128 (2 stages) / 128x128 (3 stages),
-   5 = 256x128 persistent (one workgroup per CU walks several tiles), 6 = 256x192 (2 stages) */
+   5 = 256x128 persistent (one workgroup per CU walks several tiles), 6 = 256x192 (2 stages),
+   7 / 8 = the weight-gradient orientation (a_kcontig = b_kcontig = 0, split over K: Dense / 1x1-conv kernel gradients,
+   layers' `kernel` of backbones/convnext.py:51-55, backbones/swin.py:17-43) on the LDS-DMA pipeline gemm_bf16_dma_tn_kernel with
+   256x128 / 128x256 tiles (M, N >= 128 and multiples of 8, K a multiple of 128 and >= 2048, aligned operands; ISEG_GEMM_DMA_TN=0 pins the
+   register-staged kernel) */
 int iseg_gemm_variant(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
 int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
