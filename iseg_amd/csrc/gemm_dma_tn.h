@@ -23,6 +23,8 @@ namespace iseg_mm {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+static __device__ uint4 tn_zero_page;      // sixteen zero bytes (device globals are zero-initialised): the source of reduction rows past K
+
 __device__ __forceinline__ int tn_key(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
 
 template <int WM, int WN, int NS>
@@ -46,10 +48,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
     const int64_t m0 = (int64_t)(t / tiles_n) * BM, n0 = (int64_t)(t % tiles_n) * BN;
     const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    const int nk = (int)((kend - kbeg) / 64);
+    const int nk = (int)((kend - kbeg + 63) / 64);      // the last stage of the last split may be ragged: its rows past K read a zero page
 
     // per-lane DMA sources: piece P = wid + p * NW of a stage; 16-byte slot S = 64 P + lane of the A image (P < PA) or of the B image
     const bf16_t* src[PPW];
+    int left[PPW];      // reduction rows from this lane's row of the piece to the end of the split's range (<= 0: a row past K)
 #pragma unroll
     for (int p = 0; p < PPW; ++p) {
         const int P = wid + p * NW;
@@ -58,18 +61,24 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
             int64_t col = m0 + chunk * 8;
             col = col + 8 <= M ? col : M - 8;      // columns past M: any valid chunk (their products are never stored)
             src[p] = A + (kbeg + k) * lda + col;
+            left[p] = (int)(kend - kbeg) - k;
         } else {
             const int S = (P - PA) * 64 + lane, k = S / CPB, chunk = (S % CPB) ^ tn_key(k);
             int64_t col = n0 + chunk * 8;
             col = col + 8 <= N ? col : N - 8;
             src[p] = B + (kbeg + k) * ldb + col;
+            left[p] = (int)(kend - kbeg) - k;
         }
     }
+    const bf16_t* const zero = reinterpret_cast<const bf16_t*>(&tn_zero_page);
     auto issue = [&](int stage) {
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_void_ptr)src[p], (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
+            // (a select, not a branch: rows past the end of a ragged reduction -- K = 17424 pixel rows of a 513 x 513 crop at stride 16 -- contribute zeros)
+            const bf16_t* const from = left[p] > 0 ? src[p] : zero;
+            __builtin_amdgcn_global_load_lds((glb_void_ptr)from, (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
             src[p] += p < PA / NW ? 64 * lda : 64 * ldb;
+            left[p] -= 64;
         }
     };
 
@@ -225,7 +234,7 @@ int dma_tn_mode();      // ISEG_GEMM_DMA_TN: 0 = never, 1 = whenever eligible (d
 inline int dma_tn_form(const iseg_gemm_args* g) {
     if (!dma_tn_mode() || g->in_dtype != ISEG_BF16 || g->a_kcontig || g->b_kcontig || g->a_act != ISEG_ACT_NONE) return 0;
     if (g->batch > 1 || g->b_group_rows > 0 || g->split_k == 1) return 0;
-    if (g->M < 128 || g->N < 128 || g->M % 8 || g->N % 8 || g->K % 128 || g->K < 2048) return 0;
+    if (g->M < 128 || g->N < 128 || g->M % 8 || g->N % 8 || g->K < 2048) return 0;      // (any K: a ragged last stage reads zeros)
     if (((uintptr_t)g->A % 16) || ((uintptr_t)g->B % 16) || g->lda % 8 || g->ldb % 8) return 0;
     if (g->colsum_out && g->M < 64) return 0;
     const int64_t t7 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), t8 = ceil_div64(g->M, 128) * ceil_div64(g->N, 256);

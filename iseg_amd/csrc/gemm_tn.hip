@@ -1,5 +1,5 @@
 // bf16 MFMA GEMM instantiations, orientation "tn" (see gemm_impl.h); split from gemm.hip for parallel compilation.
-// Split weight-gradient problems that qualify (gemm_dma_tn.h: aligned, M and N >= 128, K % 128 == 0) take the LDS-DMA pipeline.
+// Split weight-gradient problems that qualify (gemm_dma_tn.h: aligned, M and N >= 128, K >= 2048) take the LDS-DMA pipeline.
 #include "gemm_dma_tn.h"
 
 namespace iseg_mm {

@@ -731,7 +731,9 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
                                 int64_t rows, int C, float eps, int dtype, hipStream_t stream, const LnPost& post) {
     ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
     ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
-    const int lpr = ln_lanes_per_row(C, true);
+    // (bf16 storage only: in fp32 storage the other lane split changes the order of the row sums in the last bit, and the fp32 path is held to
+    // bit-exact argmax masks against the oracle at 512 x 512 -- test_cfg2_at_the_benchmark_shape flipped one near-tie with it)
+    const int lpr = ln_lanes_per_row(C, dtype == ISEG_BF16);
     ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_fwd: C=%d too wide (max %d)", C, 64 * 8 * LN_MAX_CHUNKS);
     const int rpw = 64 / lpr;
     int64_t blocks = ceil_div64(rows, (int64_t)rpw * 4);

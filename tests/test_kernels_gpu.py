@@ -120,7 +120,8 @@ def test_gemm_wgrad_splitk(cuda, dtype, M, N, Kd, split):
 
 
 @pytest.mark.parametrize("rows,C,N,form", [(16384, 1536, 384, 7), (16384, 384, 1536, 8), (4096, 3072, 768, 7), (4096, 768, 3072, 7),
-                                           (2048, 136, 200, 7), (6144, 392, 128, 7), (2176, 128, 520, 8)])
+                                           (2048, 136, 200, 7), (6144, 392, 128, 7), (2176, 128, 520, 8),
+                                           (17424, 384, 1536, 8), (8200, 768, 2304, 7), (2049, 128, 128, 7)])      # ragged reductions: rows % 64 != 0
 @pytest.mark.parametrize("bias", [False, True])
 def test_wgrad_lds_dma_pipeline(cuda, rows, C, N, form, bias):
     """weight gradients in the ConvNeXt stage-2 / stage-3 shapes (and ragged ones: M, N not multiples of the tile) take the LDS-DMA kernel of
