@@ -234,9 +234,16 @@ int dma_tn_mode();      // ISEG_GEMM_DMA_TN: 0 = never, 1 = whenever eligible (d
 inline int dma_tn_form(const iseg_gemm_args* g) {
     if (!dma_tn_mode() || g->in_dtype != ISEG_BF16 || g->a_kcontig || g->b_kcontig || g->a_act != ISEG_ACT_NONE) return 0;
     if (g->batch > 1 || g->b_group_rows > 0 || g->split_k == 1) return 0;
-    if (g->M < 128 || g->N < 128 || g->M % 8 || g->N % 8 || g->K < 2048) return 0;      // (any K: a ragged last stage reads zeros)
+    static const int min_mn = [] {      // ISEG_GEMM_DMA_TN_MIN: narrowest M / N the kernel takes (columns past M / N are clamped duplicates)
+        const char* e = getenv("ISEG_GEMM_DMA_TN_MIN");
+        const int v = e ? atoi(e) : 64;
+        return v < 64 ? 64 : v;      // (the ones-row lives in the first 64 rows' wavefronts)
+    }();
+    if (g->M < min_mn || g->N < min_mn || g->M % 8 || g->N % 8 || g->K < 2048) return 0;      // (any K: a ragged last stage reads zeros)
+    // a side below 128 pays for clamped duplicate columns: measured (tools/kbench_wgrad_tn.py, KBENCH_NARROW=1, register kernel -> this one, us)
+    // 96 x 384 55.0 -> 47.4, 384 x 96 58.0 -> 45.9, 112 x 336 29.9 -> 26.0, 112 x 448 32.9 -> 27.9, but 96 x 288 46.4 -> 51.7 and 96 x 96 23.7 -> 24.4
+    if ((g->M < 128 || g->N < 128) && (g->M > g->N ? g->M : g->N) < 320) return 0;
     if (((uintptr_t)g->A % 16) || ((uintptr_t)g->B % 16) || g->lda % 8 || g->ldb % 8) return 0;
-    if (g->colsum_out && g->M < 64) return 0;
     const int64_t t7 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128), t8 = ceil_div64(g->M, 128) * ceil_div64(g->N, 256);
     return t8 < t7 ? 8 : 7;
 }
