@@ -122,7 +122,7 @@ int iseg_gemm_slabs(const iseg_gemm_args* args_h);
    5 = 256x128 persistent (one workgroup per CU walks several tiles), 6 = 256x192 (2 stages),
    7 / 8 = the weight-gradient orientation (a_kcontig = b_kcontig = 0, split over K: Dense / 1x1-conv kernel gradients,
    layers' `kernel` of backbones/convnext.py:51-55, backbones/swin.py:17-43) on the LDS-DMA pipeline gemm_bf16_dma_tn_kernel with
-   256x128 / 128x256 tiles (M, N >= 128 and multiples of 8, any K >= 2048, aligned operands; ISEG_GEMM_DMA_TN=0 pins the
+   256x128 / 128x256 tiles (M, N multiples of 8 and >= 128 -- or one of them 64..127 when the other is >= 320 --, any K >= 2048, aligned operands; ISEG_GEMM_DMA_TN=0 pins the
    register-staged kernel) */
 int iseg_gemm_variant(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
