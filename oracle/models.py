@@ -223,6 +223,69 @@ def mhsa_layer(w, prefix, x, heads):
     return O.mhsa_core(q, k, v, heads)
 
 
+def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_filters=256, num_repeats=5, use_sum_for_combination=True,
+                   training=False, eps=1e-3):
+    """layers/nasfpn.py:196-232 (input pyramid), :248-271 (resample), :304-311 (global attention), :313-383 (one cell), line by line.
+    inputs: {level: [N, H, W, C]}; block_specs: [(level, combine_fn, (offset0, offset1), is_output)]"""
+    def bn(prefix, y):
+        g, b = w[f"{prefix}/gamma"], w[f"{prefix}/beta"]
+        if training:
+            return O.batch_norm_train(y, g, b, eps)[0]
+        return O.batch_norm_infer(y, g, b, w[f"{prefix}/moving_mean"], w[f"{prefix}/moving_variance"], eps)
+
+    def resample(x, input_level, target_level):
+        if input_level < target_level:
+            stride = 2 ** (target_level - input_level)
+            return O.max_pool_same(x, stride, stride)
+        if input_level > target_level:
+            s = 2 ** (input_level - target_level)
+            return x.repeat_interleave(s, dim=1).repeat_interleave(s, dim=2)      # nearest_upsampling (:48-84)
+        return x
+
+    def global_attention(feat0, feat1):
+        m = torch.sigmoid(feat0.amax(dim=(1, 2), keepdim=True))
+        return feat0 + feat1 * m
+
+    feats = []
+    for level in range(min_level, max_level + 1):
+        if level in inputs:
+            x = inputs[level]
+            if x.shape[-1] != num_filters:
+                p = f"{name}/resample_l{level}"
+                x = bn(f"{p}/bn", O.conv2d(x, w[f"{p}/separable_conv2d/kernel"], w[f"{p}/separable_conv2d/bias"], 1, 1, "same"))
+            feats.append(x)
+        else:
+            feats.append(O.max_pool_same(feats[-1], 2, 2))
+    n_levels = max_level - min_level + 1
+    out = None
+    for r in range(num_repeats):
+        feats = list(feats)
+        levels = list(range(min_level, max_level + 1))
+        used = [0] * len(feats)
+        for i, (new_level, combine_fn, (i0, i1), is_output) in enumerate(block_specs):
+            node0, l0, node1, l1 = feats[i0], levels[i0], feats[i1], levels[i1]
+            used[i0] += 1
+            used[i1] += 1
+            node0, node1 = resample(node0, l0, new_level), resample(node1, l1, new_level)
+            if use_sum_for_combination or combine_fn == "sum":
+                new_node = node0 + node1
+            else:
+                new_node = global_attention(node0, node1) if l0 >= l1 else global_attention(node1, node0)
+            if is_output:
+                for j in range(len(feats)):
+                    if used[j] == 0 and levels[j] == new_level:
+                        used[j] += 1
+                        new_node = new_node + feats[j]
+            p = f"{name}/cell_{r}/sub_policy{i}/op_after_combine{n_levels + i}"
+            new_node = bn(f"{p}/bn", O.conv2d(torch.relu(new_node), w[f"{p}/conv/kernel"], w[f"{p}/conv/bias"], 1, 1, "same"))
+            feats.append(new_node)
+            levels.append(new_level)
+            used.append(0)
+        out = {levels[i]: feats[i] for i in range(len(feats) - n_levels, len(feats))}
+        feats = [out[level] for level in range(min_level, max_level + 1)]
+    return out
+
+
 def axial_attention_layer(w, prefix, x, heads, shared_qk=False):
     """layers/multihead_axial_attention.py:149-172"""
     def conv1x1(name, t):
