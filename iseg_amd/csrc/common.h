@@ -251,9 +251,13 @@ __device__ __forceinline__ void gelu_fast_both(float x, float& y, float& dy) {
 #define ISEG_GELU_SIG_A0 1.5950157270240881f
 #define ISEG_GELU_SIG_A1 0.07401132728640801f
 #define ISEG_GELU_SIG_A2 (-0.0007030389408329068f)
-#ifdef ISEG_GELU_SIG2
-// A/B build only (ISEG_BUILD_DEFINES=ISEG_GELU_SIG2): the two-coefficient fit -- no clamp (its polynomial is monotone), one FMA less per value and
-// per derivative; |gelu error| <= 2.7e-4, |gelu' error| <= 8.7e-4 (ten times the three-coefficient fit's).  Measured: DESIGN 5.2, round 4.
+// gelu(x) AND gelu'(x) of the bf16 kernels that need both (weight-gradient recompute, the forward GEMM epilogue that saves the derivative): the
+// two-coefficient sigmoid fit -- no clamp (its polynomial is monotone), 9 full-rate VALU + v_exp_f32 + v_rcp_f32 for the pair;
+// |gelu error| <= 2.7e-4, |gelu' error| <= 8.7e-4 (bf16 half-ulp at 1: 2e-3; the reference evaluates GELU in bf16 arithmetic under
+// mixed_bfloat16, utils/common.py:32-64 + backbones/convnext.py:53, i.e. with ~4e-3 per operation).  Round 5: measured 39 issue cycles per
+// pair against 48 for the three-coefficient fit and 45 for two polynomials (tools/micro/valu_rates.hip, profiles/r05_micro.txt).
+// ISEG_GELU_SIG3 (A/B build define) restores the three-coefficient fit (2.6e-5 / 1.1e-4).
+#ifndef ISEG_GELU_SIG3
 __device__ __forceinline__ float gelu_sig(float x) {
     constexpr float L = -1.4426950408889634f;
     const float p = fmaf(0.06940208738399849f * L, x * x, 1.600313485784997f * L);
@@ -286,6 +290,60 @@ __device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
     const float dp = fmaf(fmaf(5.f * ISEG_GELU_SIG_A2, x2, 3.f * ISEG_GELU_SIG_A1), x2, ISEG_GELU_SIG_A0);
     y = x * s;
     dy = fmaf(y * dp, 1.0f - s, s);
+}
+#endif
+
+// Transcendental-free GELU / GELU' for the bf16 kernels that need ONE of the two (round 5; fits: tools/fit_gelu_poly.py).  Every instruction is
+// on the vector pipe's full-rate path (v_fma_f32 / v_mul_f32 / v_add_f32: 2.3-2.7 cycles per wave-instruction at two wavefronts per SIMD; v_exp /
+// v_rcp cost 8.3, v_min / v_med3 / every v_pk_*_f16 4.4 -- packed f16 buys nothing over this form, profiles/r05_micro.txt):
+//     s = clamp01(x / (2 c) + 1/2)      ONE v_fma_f32 with the clamp output modifier
+//     w = s - 1/2                       = clamp(x, -c, c) / (2 c)
+//     Phi(x)   ~ 1/2 + w q(w^2),  q(1/4) = 1  (c = 3.75, degree 6):  |gelu error| <= 8.9e-5 max(1, |x|), exactly x / exactly 0 beyond the clamp
+//     gelu'(x) ~ 1/2 + w r(w^2),  r(1/4) = 1  (c = 4,    degree 7):  |gelu' error| <= 5.2e-4
+// (Phi - 1/2 and gelu' - 1/2 are odd, so q and r are polynomials in w^2.)  gelu: 11 instructions = 26 cycles against 41 for the sigmoid form;
+// gelu' alone: 12 against the 48 of gelu_sig_both.
+// clamp01(a * b + 1/2) as ONE v_fma_f32 ... clamp.  With a literal multiplier hipcc emits v_fmamk_f32 (VOP2: no output modifier) + v_max_f32 ...
+// clamp (half rate); with the multiplier in a scalar register it must use the VOP3 form and folds the clamp into it.  The constant therefore
+// goes through an opaque s_mov.  (NOT inline assembly for the FMA itself: the hazard recogniser does not look inside an asm statement, and an asm
+// v_fma that reads an MFMA accumulator is issued without the wait states the matrix pipe needs -- the first version of this read stale values.)
+__device__ __forceinline__ float iseg_opaque_scalar(float v) {
+    float k;
+    asm("s_mov_b32 %0, %1" : "=s"(k) : "s"(v));
+    return k;
+}
+__device__ __forceinline__ float iseg_fma_half_clamp01(float a, float b) {
+    return __builtin_amdgcn_fmed3f(fmaf(a, iseg_opaque_scalar(b), 0.5f), 0.f, 1.f);
+}
+#ifndef ISEG_GELU_NOPOLY
+__device__ __forceinline__ float gelu_poly(float x) {
+    const float w = iseg_fma_half_clamp01(x, 1.f / 7.5f) - 0.5f;
+    const float t = w * w;
+    float q = fmaf(6617.0283203125f, t, -7851.36572265625f);
+    q = fmaf(q, t, 3995.16552734375f);
+    q = fmaf(q, t, -1156.386962890625f);
+    q = fmaf(q, t, 214.41412353515625f);
+    q = fmaf(q, t, -27.49638557434082f);
+    q = fmaf(q, t, 2.987506628036499f);
+    return x * fmaf(w, q, 0.5f);
+}
+__device__ __forceinline__ float gelu_poly_grad(float x) {
+    const float w = iseg_fma_half_clamp01(x, 0.125f) - 0.5f;
+    const float t = w * w;
+    float r = fmaf(-375307.59375f, t, 481274.125f);
+    r = fmaf(r, t, -262435.875f);
+    r = fmaf(r, t, 79767.0f);
+    r = fmaf(r, t, -14897.58984375f);
+    r = fmaf(r, t, 1771.6455078125f);
+    r = fmaf(r, t, -132.86141967773438f);
+    r = fmaf(r, t, 6.365922927856445f);
+    return fmaf(w, r, 0.5f);
+}
+#else      // A/B build define: the sigmoid forms everywhere (round 4's arithmetic)
+__device__ __forceinline__ float gelu_poly(float x) { return gelu_sig(x); }
+__device__ __forceinline__ float gelu_poly_grad(float x) {
+    float y, d;
+    gelu_sig_both(x, y, d);
+    return d;
 }
 #endif
 

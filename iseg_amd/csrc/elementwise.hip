@@ -344,7 +344,7 @@ __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64
         float v[8];
         load8<T>(x + i * 8, v);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = act == ISEG_ACT_RELU ? fmaxf(v[u], 0.f) : (sizeof(T) == 2 ? gelu_fast(v[u]) : gelu_erf(v[u]));
+        for (int u = 0; u < 8; ++u) v[u] = act == ISEG_ACT_RELU ? fmaxf(v[u], 0.f) : (sizeof(T) == 2 ? gelu_poly(v[u]) : gelu_erf(v[u]));
         store8<T>(y + i * 8, v);
     }
     for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -364,7 +364,7 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a
 #pragma unroll
         // bf16 storage: the 1.5e-7 approximation of common.h (as in the GEMM epilogues); fp32 parity path: libm erf
         for (int u = 0; u < 8; ++u)
-            d[u] = act == ISEG_ACT_RELU ? (a[u] > 0.f ? d[u] : 0.f) : d[u] * (sizeof(T) == 2 ? gelu_fast_grad(a[u]) : gelu_erf_grad(a[u]));
+            d[u] = act == ISEG_ACT_RELU ? (a[u] > 0.f ? d[u] : 0.f) : d[u] * (sizeof(T) == 2 ? gelu_poly_grad(a[u]) : gelu_erf_grad(a[u]));
         store8<T>(dx + i * 8, d);
     }
     for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {

@@ -89,7 +89,7 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
             store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_sig(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_poly(v[i]) : gelu_erf(v[i]);
         }
     } else if (e.act == ISEG_ACT_MUL_AUX) {
         float a[8];
@@ -100,7 +100,7 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
         float a[8];
         load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_fast_grad(a[i]) : gelu_erf_grad(a[i]);
+        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_poly_grad(a[i]) : gelu_erf_grad(a[i]);
     } else if (e.act == ISEG_ACT_RELU_GRAD) {
         float a[8];
         load8<TO>(reinterpret_cast<const TO*>(e.aux) + m * e.ldaux + n, a);
@@ -191,14 +191,14 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
             store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, d);
         } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_sig(v[i]) : gelu_erf(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = FAST ? gelu_poly(v[i]) : gelu_erf(v[i]);
         }
     } else if (e.act == ISEG_ACT_MUL_AUX) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= pf.aux.get(i);
     } else if (e.act == ISEG_ACT_GELU_GRAD) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_fast_grad(pf.aux.get(i)) : gelu_erf_grad(pf.aux.get(i));
+        for (int i = 0; i < 8; ++i) v[i] *= FAST ? gelu_poly_grad(pf.aux.get(i)) : gelu_erf_grad(pf.aux.get(i));
     } else if (e.act == ISEG_ACT_RELU_GRAD) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = pf.aux.get(i) > 0.f ? v[i] : 0.f;
@@ -320,7 +320,7 @@ template <int ROWS, bool KC, int NTHREADS, int BK> struct Stager {
 #pragma unroll
         for (int i = 0; i < PER_THREAD; ++i)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) regs[i][u] = (bf16_t)gelu_fast((float)regs[i][u]);
+            for (int u = 0; u < 8; ++u) regs[i][u] = (bf16_t)gelu_poly((float)regs[i][u]);
     }
     __device__ __forceinline__ void store(bf16_t* lds, int tid) const {
 #pragma unroll

@@ -84,7 +84,7 @@ template <class G, int WAVES> struct RingFeeder {
 #define MLP_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 template <int C, int SUB, int WAVES, int NSTAGES>
-__global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const void* __restrict__ FW,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(C == 96 ? 4 : (C == 192 ? 2 : 1)))) void convnext_mlp_fwd_kernel(const bf16_t* __restrict__ Y, const void* __restrict__ FW,
                                                                const float* __restrict__ b1, const float* __restrict__ b2,
                                                                const float* __restrict__ gamma, const float* __restrict__ rowscale,
                                                                int64_t rows_per_group, const bf16_t* __restrict__ R, bf16_t* __restrict__ O,
@@ -104,8 +104,16 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
         int64_t row = m0 + r;
         row = row < M ? row : M - 1;
         const bf16_t* yp = Y + row * C + 8 * h;
+#ifdef ISEG_ABL_MLP_NOIO      // ablation (tools/kbench_mlp.py under ISEG_BUILD_DEFINES): no row loads, no residual loads, no stores
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) yf[kk][u] = (bf16_t)(0.01f * (float)((lane + kk + u) & 15));
+        (void)yp;
+#else
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) yf[kk] = *reinterpret_cast<const bf16x8*>(yp + 16 * kk);
+#endif
         // Y is the LayerNorm INPUT (ln.gamma != NULL): a row lives in the two lanes r and r + 32, so the statistics are an in-lane sum and one
         // lane-half exchange; y2 never exists in HBM (round 3).  The row's mean / rstd are saved for the backward kernels.
         if (ln.gamma) mlp_layernorm_rows<KK>(yf, ln, m0 + r < M ? m0 + r : -1, h, C);
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
     // the fragments go through a rolling window of FD registers sets, FD pieces ahead of the MFMA that uses them.  Left to itself hipcc
     // sinks every ds_read_b128 next to its MFMA and waits for it (lgkmcnt(0) per MFMA: ~3x the MFMA time with one wavefront per SIMD);
     // the sched_barrier after each MFMA pins the order written here.
-    constexpr int NF = SUB * (KK + 2 * CB), FD = 4;
+    constexpr int NF = SUB * (KK + 2 * CB), FD = C == 96 ? 3 : 4;      // (C = 96 runs two workgroups per CU: 128 registers, three fragments in flight is what fits)
     auto compute = [&](int stage, int kt) {
         const char* fb = smem + stage * STAGE + fo;
         bf16x8 win[FD];
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
             }
             bf16x8 gf[2];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) gf[j >> 3][j & 7] = (bf16_t)gelu_sig(hacc[j]);
+            for (int j = 0; j < 16; ++j) gf[j >> 3][j & 7] = (bf16_t)gelu_poly(hacc[j]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb)
@@ -220,8 +228,13 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
         if (m < M) {
             const int c0 = 32 * cb + 16 * eh;
             float res[16], bb[16], gg[16];
+#ifdef ISEG_ABL_MLP_NOIO
+#pragma unroll
+            for (int u = 0; u < 16; ++u) res[u] = 0.f;
+#else
             load8<bf16_t>(R + m * C + c0, res);
             load8<bf16_t>(R + m * C + c0 + 8, res + 8);
+#endif
             load8<float>(b2 + c0, bb);      // (16-byte vector loads: one dword load per element was 96 extra loads per lane at C = 96)
             load8<float>(b2 + c0 + 8, bb + 8);
             if (gamma) {
@@ -234,8 +247,13 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_fwd_kernel(const bf16
                 if (gamma) t *= gg[u];
                 v[u] = fmaf(t, rs, res[u]);
             }
-            store8<bf16_t>(O + m * C + c0, v);
-            store8<bf16_t>(O + m * C + c0 + 8, v + 8);
+#ifdef ISEG_ABL_MLP_NOIO
+            if (v[0] == 12345.678f)
+#endif
+            {
+                store8<bf16_t>(O + m * C + c0, v);
+                store8<bf16_t>(O + m * C + c0 + 8, v + 8);
+            }
         }
     }
 }
@@ -382,7 +400,8 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 float gd;
-                gelu_sig_both(hacc[j], gv[j], gd);
+                if constexpr (STORE) gelu_sig_both(hacc[j], gv[j], gd);
+                else gd = gelu_poly_grad(hacc[j]);      // the chain alone needs the derivative only: 12 full-rate instructions, no transcendental
                 dv[j] = dacc[j] * gd;
             }
             bf16x8 hf[2];

@@ -20,7 +20,12 @@ def main():
     text = open(out).read().split("\n")
     bad = 0
     kernel, in_loop, after_issue = None, False, False
+    in_asm = False      # between ;;#ASMSTART and ;;#ASMEND: a wait written in the source (the counted ring waits and the tail's vmcnt(0)), not the compiler's
     for ln in text:
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
         m = re.match(r"^(_ZN\S*convnext_mlp_(fwd|bwd)_kernel\S*):", ln)
         if m:
             kernel, in_loop, after_issue = m.group(1), False, False
@@ -38,7 +43,7 @@ def main():
             after_issue = True
         if in_loop and after_issue and "v_mfma" in ln:
             after_issue = False
-        if in_loop and after_issue and re.search(r"s_waitcnt vmcnt\(0\)", ln):
+        if in_loop and after_issue and not in_asm and re.search(r"s_waitcnt vmcnt\(0\)", ln):
             print(f"{kernel}: vmcnt(0) between the DMA issue and the first MFMA of a ring stage")
             bad += 1
     print("mlp_fused ISA:", "OK" if not bad else f"{bad} ring drain(s)")

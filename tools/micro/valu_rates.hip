@@ -30,6 +30,51 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
                     const float p = fmaf(fmaf(0.001f, x2, -0.1f), x2, -2.3f);
                     const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * p));
                     v = x * s + a;
+                } else if (MODE == 10) asm volatile("v_pk_fma_f16 %0, %1, %0, %2" : "+v"(v) : "v"(a), "v"(b));
+                else if (MODE == 11) asm volatile("v_pk_mul_f16 %0, %1, %0" : "+v"(v) : "v"(a));
+                else if (MODE == 12) asm volatile("v_pk_add_f16 %0, %1, %0" : "+v"(v) : "v"(a));
+                else if (MODE == 13) asm volatile("v_pk_min_f16 %0, %1, %0" : "+v"(v) : "v"(a));
+                else if (MODE == 14) asm volatile("v_pk_max_f16 %0, %1, %0" : "+v"(v) : "v"(a));
+                else if (MODE == 15) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(v) : "v"(a));
+                else if (MODE == 16) asm volatile("v_fma_mix_f32 %0, %1, %0, %2 op_sel_hi:[1,0,0]" : "+v"(v) : "v"(a), "v"(b));
+                else if (MODE == 17) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(v));
+                else if (MODE == 18) asm volatile("v_exp_f16 %0, %0" : "+v"(v));
+                else if (MODE == 19) asm volatile("v_rcp_f16 %0, %0" : "+v"(v));
+                else if (MODE == 20) asm volatile("v_fma_f16 %0, %1, %0, %2" : "+v"(v) : "v"(a), "v"(b));
+                else if (MODE == 21) asm volatile("v_fma_mixlo_f16 %0, %1, %0, %2 op_sel_hi:[0,0,0]" : "+v"(v) : "v"(a), "v"(b));
+                else if (MODE == 22) asm volatile("v_pk_fma_f16 %0, %1, %0, %2 clamp" : "+v"(v) : "v"(a), "v"(b));
+                else if (MODE == 23) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(*reinterpret_cast<double*>(&acc[i & ~1])) : "v"(*reinterpret_cast<double*>(&acc[(i & ~1) ^ 2])));
+                else if (MODE == 24) {      // packed-f16 gelu of TWO elements (slot = 2 evaluations): pkrtz + clamp(2) + t^2 + 4 fma + fma + mul
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 x = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(v, v + a));
+                    const h2 lim = {(_Float16)4.f, (_Float16)4.f};
+                    h2 t = __builtin_elementwise_min(__builtin_elementwise_max(x, -lim), lim);
+                    const h2 t2 = t * t;
+                    h2 q = (h2){(_Float16)1e-4f, (_Float16)1e-4f} * t2 + (h2){(_Float16)-3e-3f, (_Float16)-3e-3f};
+                    q = q * t2 + (h2){(_Float16)2e-2f, (_Float16)2e-2f};
+                    q = q * t2 + (h2){(_Float16)-6e-2f, (_Float16)-6e-2f};
+                    q = q * t2 + (h2){(_Float16)0.39f, (_Float16)0.39f};
+                    const h2 phi = t * q + (h2){(_Float16)0.5f, (_Float16)0.5f};
+                    const h2 g = x * phi;
+                    v = __builtin_bit_cast(float, g);
+                } else if (MODE == 25) {      // packed-f16 gelu' of TWO elements times an fp32 factor each (v_fma_mix_f32), packed to bf16
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 x = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(v, v + a));
+                    const h2 lim = {(_Float16)4.f, (_Float16)4.f};
+                    h2 t = __builtin_elementwise_min(__builtin_elementwise_max(x, -lim), lim);
+                    const h2 t2 = t * t;
+                    h2 q = (h2){(_Float16)1e-4f, (_Float16)1e-4f} * t2 + (h2){(_Float16)-3e-3f, (_Float16)-3e-3f};
+                    q = q * t2 + (h2){(_Float16)2e-2f, (_Float16)2e-2f};
+                    q = q * t2 + (h2){(_Float16)-6e-2f, (_Float16)-6e-2f};
+                    q = q * t2 + (h2){(_Float16)-0.2f, (_Float16)-0.2f};
+                    q = q * t2 + (h2){(_Float16)0.79f, (_Float16)0.79f};
+                    const h2 d = t * q + (h2){(_Float16)0.5f, (_Float16)0.5f};
+                    const float d0 = (float)d[0] * a, d1 = (float)d[1] * b;
+                    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                    b2 o;
+                    o[0] = (__bf16)d0;
+                    o[1] = (__bf16)d1;
+                    v = __builtin_bit_cast(float, o);
                 } else if (MODE == 9) {      // clamped odd polynomial, degree 6 in x^2: 1 med3 + 1 mul + 6 fma + 1 fma + 1 mul
                     const float x = v;
                     const float xc = __builtin_amdgcn_fmed3f(x, -b, b);
@@ -84,6 +129,22 @@ int main() {
         run<6, 16>("v_cvt_pk_bf16_f32", w);
         run<8, 16>("gelu sigmoid form (whole)", w);
         run<9, 16>("gelu clamped polynomial (whole)", w);
+        run<10, 16>("v_pk_fma_f16 (2 elements)", w);
+        run<22, 16>("v_pk_fma_f16 clamp", w);
+        run<11, 16>("v_pk_mul_f16", w);
+        run<12, 16>("v_pk_add_f16", w);
+        run<13, 16>("v_pk_min_f16", w);
+        run<14, 16>("v_pk_max_f16", w);
+        run<15, 16>("v_cvt_pkrtz_f16_f32", w);
+        run<16, 16>("v_fma_mix_f32 (f16 x f32 + f32)", w);
+        run<21, 16>("v_fma_mixlo_f16", w);
+        run<17, 16>("v_cvt_f32_f16", w);
+        run<18, 16>("v_exp_f16", w);
+        run<19, 16>("v_rcp_f16", w);
+        run<20, 16>("v_fma_f16", w);
+        run<23, 16>("v_pk_mul_f32", w);
+        run<24, 16>("gelu packed f16 poly (slot = 2 values)", w);
+        run<25, 16>("gelu' packed f16 x f32 -> bf16 (slot = 2)", w);
     }
     return 0;
 }
