@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--graph-step", action="store_true", help="(default on one GPU since round 4; kept for old command lines)")
     ap.add_argument("--eager-step", action="store_true", help="enqueue every launch of the timed steps from the host instead of replaying the step from one HIP graph")
     ap.add_argument("--roofline-steps", type=int, default=3, help="eager steps in front of the timed region whose dominant-GEMM launches carry HIP event pairs")
+    ap.add_argument("--probe-native", action="store_true",
+                    help="(internal) the probe job of choose_exchange(): two eager + two replayed steps with the stream-ordered RCCL exchange")
     ap.add_argument("--check-launch", action="store_true",
                     help="rendezvous + one all-reduce only (gloo when there is no GPU): tests the --gpus N self-launch path on CPU")
     return ap.parse_args()
@@ -156,6 +158,8 @@ def check_launch(args):
         time.sleep(3600)
     if os.environ.get("ISEG_BENCH_TEST_FAIL") == str(os.environ.get("RANK", "0")):
         sys.exit(7)
+    # (the launch check probes only when a test scripts the probe's outcome: its other cases are about the launcher itself)
+    exchange = choose_exchange(args) if (use_gpu or os.environ.get("ISEG_BENCH_TEST_PROBE")) else "not probed"
     dist.init(backend=None if use_gpu else "gloo")
     n = joined_ranks(torch.device("cuda", dist.local_rank()) if use_gpu else torch.device("cpu"))
     if n != args.gpus:
@@ -163,9 +167,107 @@ def check_launch(args):
         sys.exit(3)
     dist.barrier()
     if dist.rank() == 0:
-        print(json.dumps({"metric": "launch_check", "n_gpus": n, "backend": torch.distributed.get_backend() if n > 1 else "none"}))
+        print(json.dumps({"metric": "launch_check", "n_gpus": n, "backend": torch.distributed.get_backend() if n > 1 else "none",
+                          "exchange": exchange}))
     if dist.is_initialized():
         torch.distributed.destroy_process_group()
+
+
+PROBE_MARK = "ISEG_PROBE_NATIVE_OK"
+
+
+def choose_exchange(args):
+    """Data-parallel runs (N > 1): which exchange does the measured job use?  The fast one -- SyncBN messages and gradient buckets enqueued on
+    explicit HIP streams through the C ABI's own RCCL communicator (ISEG_DIST_NATIVE=1), which makes the whole step one HIP graph -- has never met
+    two ranks on hardware, and a mismatch inside a replayed graph hangs without a watchdog.  So every rank, BEFORE it touches the GPU, starts a
+    fresh child (same RANK / WORLD_SIZE, its own rendezvous port) that runs the probe job: two eager and two replayed steps with that exchange,
+    then a c10d all-reduce(MIN) of the ranks' success flags, then the marker line.  The marker -- a value every rank computed from the same
+    all-reduce -- decides, not the child's exit code, so all ranks take the same branch: marker seen -> native + graph replay; anything else
+    (crash, timeout: the child is killed by pid after ISEG_BENCH_PROBE_TIMEOUT_S, default 240 s) -> c10d work objects + eager step.
+    An explicit ISEG_DIST_NATIVE in the environment is the user's decision and skips the probe."""
+    import subprocess
+
+    if args.gpus <= 1:
+        return "none (one rank)"
+    if os.environ.get("ISEG_DIST_NATIVE") is not None:
+        return "stream-ordered RCCL through the C ABI (ISEG_DIST_NATIVE set by the caller)" if os.environ["ISEG_DIST_NATIVE"] not in ("0", "") \
+            else "c10d work objects (ISEG_DIST_NATIVE=0 set by the caller)"
+    limit = float(os.environ.get("ISEG_BENCH_PROBE_TIMEOUT_S", "240"))
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+    env = dict(os.environ, ISEG_DIST_NATIVE="1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--probe-native", "--batch", str(args.batch), "--size", str(args.size)]
+    if args.check_launch:
+        cmd.append("--check-launch")
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    except OSError as e:
+        print(f"bench.py: probe could not start ({e})", file=sys.stderr)
+        return "c10d work objects (probe could not start)"
+    import signal
+
+    def _term(signum, frame):      # the launcher's watchdog terminates this rank: take the probe child along (by pid)
+        child.kill()
+        sys.exit(143)
+
+    prev = signal.signal(signal.SIGTERM, _term)
+    try:
+        out, _ = child.communicate(timeout=limit)
+        why = f"exit code {child.returncode}"
+    except subprocess.TimeoutExpired:
+        child.kill()      # (the child this rank started, by pid)
+        out, _ = child.communicate()
+        why = f"no result after {limit:.0f} s"
+    signal.signal(signal.SIGTERM, prev)
+    text = out.decode("utf-8", "replace") if out else ""
+    if PROBE_MARK in text:
+        os.environ["ISEG_DIST_NATIVE"] = "1"
+        return "stream-ordered RCCL through the C ABI (probe passed on every rank)"
+    print(f"bench.py: rank {os.environ.get('RANK', '?')}: native-exchange probe did not pass ({why}); falling back to c10d + eager step\n"
+          f"---- probe output (tail) ----\n{text[-1200:]}", file=sys.stderr)
+    os.environ["ISEG_DIST_NATIVE"] = "0"
+    return f"c10d work objects (native-exchange probe did not pass: {why})"
+
+
+def probe_native(args):
+    """the probe job (child of choose_exchange): see there.  On a box without GPUs (--check-launch, tests/test_bench_launch.py) the training
+    steps are skipped and ISEG_BENCH_TEST_PROBE = ok | fail | hang scripts the outcome of rank 1."""
+    from iseg_amd import dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    ok = 1.0
+    if args.check_launch:
+        mode = os.environ.get("ISEG_BENCH_TEST_PROBE", "ok")
+        if rank == 1 and mode == "fail":
+            os._exit(5)
+        if rank == 1 and mode == "hang":
+            time.sleep(3600)
+        dist.init(backend="gloo")
+        flag = torch.tensor([ok], dtype=torch.float32)
+    else:
+        from iseg_amd.data import synthetic_batch
+        from iseg_amd.graphs import GraphedTrainStep
+
+        try:
+            strategy, model, trainer = build_trainer(args)
+            x, y = synthetic_batch(args.batch, args.size, args.size, seed=100 + rank)
+            x, y = x.cuda(), y.cuda()
+            losses = [float(trainer.train_step(x, y)[0]) for _ in range(2)]
+            step = GraphedTrainStep(trainer, warmup=0)
+            if not step._eligible(x):
+                raise RuntimeError("the data-parallel step is not capturable with this exchange")
+            losses += [float(step(x, y)[0]) for _ in range(3)]
+            torch.cuda.synchronize()
+            if not all(v == v and abs(v) < 1e4 for v in losses):
+                raise RuntimeError(f"losses {losses}")
+        except Exception as e:      # noqa: BLE001 -- any failure means: do not use this exchange
+            print(f"probe rank {rank}: {type(e).__name__}: {e}", flush=True)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device="cuda")
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    if float(flag.item()) == 1.0:
+        print(PROBE_MARK, flush=True)
+    sys.stdout.flush()
+    os._exit(0)      # no teardown: the decision has been printed, a communicator that hangs on exit must not undo it
 
 
 def build_trainer(args):
@@ -336,40 +438,66 @@ def step_fractions(args, ips_per_gpu, sec_per_step):
 
 
 def cpu_baseline(args):
-    """The CPU oracle (oracle/, a port: the TensorFlow reference cannot run here) doing the same train step -- forward, mean
-    ignore-label CE, backward -- in fp32 on the host cores, on a bounded sample: batch 1 at the benchmark resolution."""
+    """The CPU oracle (oracle/, a port: the TensorFlow reference cannot run here) on the host cores, on bounded samples:
+      value / sample   the flagship's train step -- forward, mean ignore-label CE, backward -- in fp32, one image at the benchmark resolution;
+      cfg1_train       BASELINE configs[0], the reference's own CPU-runnable case: ResNet-50 + ASPP, 256 x 256, batch 2, the same train step;
+      cfg2_fp32_forward_ms   the fp32 forward of the flagship on the two-image parity batch (what the logits / argmax parity tests compare with)."""
     from oracle import models as OM
     from iseg_amd.data import synthetic_batch
-    from iseg_amd.heads import convnext_tiny_aspp
+    from iseg_amd.heads import convnext_tiny_aspp, resnet50_aspp
     from iseg_amd import nn
 
     import contextlib
 
-    prev = nn.device()
-    nn.set_device("cpu")
-    try:
-        with contextlib.redirect_stdout(sys.stderr):      # (build-time chatter: stdout carries the JSON line only)
-            m = convnext_tiny_aspp(num_class=21, build_input_size=(args.size, args.size))
-    finally:
-        nn.set_device(prev if prev.type != "cpu" else None)
-    w = OM.export_weights(m, dtype=torch.float32)
-    x, y = synthetic_batch(1, args.size, args.size, seed=0)
+    def build(factory, **kw):
+        prev = nn.device()
+        nn.set_device("cpu")
+        try:
+            with contextlib.redirect_stdout(sys.stderr):      # (build-time chatter: stdout carries the JSON line only)
+                return factory(num_class=21, **kw)
+        finally:
+            nn.set_device(prev if prev.type != "cpu" else None)
+
+    def grad_weights(w):
+        return {k: (v.clone().requires_grad_(True) if not k.endswith(("moving_mean", "moving_variance")) else v) for k, v in w.items()}
+
+    def timed(fn, budget_s, max_n):
+        fn()
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < budget_s and n < max_n:
+            fn()
+            n += 1
+        return (time.time() - t0) / n, n
+
     cores = torch.get_num_threads()
+    w = OM.export_weights(build(convnext_tiny_aspp, build_input_size=(args.size, args.size)), dtype=torch.float32)
+    x, y = synthetic_batch(1, args.size, args.size, seed=0)
 
     def step():
-        wr = {k: (v.clone().requires_grad_(True) if not k.endswith(("moving_mean", "moving_variance")) else v) for k, v in w.items()}
-        out = OM.convnext_aspp_forward(wr, x, training=True)
-        OM.mean_ce_loss(out["logits"], y).backward()
+        OM.mean_ce_loss(OM.convnext_aspp_forward(grad_weights(w), x, training=True)["logits"], y).backward()
 
-    step()
-    t0 = time.time()
-    n = 0
-    while time.time() - t0 < 12.0 and n < 8:
-        step()
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train steps (fwd+bwd, fp32, torch-CPU oracle) of ConvNeXt-T+ASPP on 1 image {args.size}x{args.size}"}
+    dt, n = timed(step, 10.0, 8)
+    out = {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": f"{n} train steps (fwd+bwd, fp32, torch-CPU oracle) of ConvNeXt-T+ASPP on 1 image {args.size}x{args.size}"}
+    x2, _ = synthetic_batch(2, args.size, args.size, seed=31)
+
+    def fwd():
+        with torch.no_grad():
+            OM.convnext_aspp_forward(w, x2, training=False)
+
+    dtf, nf = timed(fwd, 5.0, 6)
+    out["cfg2_fp32_forward_ms"] = {"value": round(dtf * 1e3, 1), "sample": f"{nf} forward passes (fp32, torch-CPU oracle) of the flagship on the 2-image parity batch {args.size}x{args.size}"}
+    w1 = OM.export_weights(build(resnet50_aspp, build_input_size=(256, 256)), dtype=torch.float32)
+    x1, y1 = synthetic_batch(2, 256, 256, seed=4)
+
+    def step1():
+        OM.mean_ce_loss(OM.resnet_aspp_forward(grad_weights(w1), x1, training=True)["logits"], y1).backward()
+
+    dt1, n1 = timed(step1, 6.0, 12)
+    out["cfg1_train"] = {"value": round(2.0 / dt1, 3), "unit": "images/s",
+                         "sample": f"{n1} train steps (fwd+bwd, fp32, torch-CPU oracle) of BASELINE configs[0]: ResNet-50+ASPP, 256x256, batch 2"}
+    return out
 
 
 def main():
@@ -380,8 +508,11 @@ def main():
     if env_world not in (0, args.gpus) or (args.gpus == 1 and env_world > 1):
         print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}", file=sys.stderr)
         sys.exit(2)
+    if args.probe_native:
+        return probe_native(args)
     if args.check_launch:
         return check_launch(args)
+    exchange = choose_exchange(args)      # (N > 1: before this process touches the GPU; sets ISEG_DIST_NATIVE for the measured job)
     from iseg_amd import dist
     from iseg_amd.data import synthetic_batch
 
@@ -475,6 +606,7 @@ def main():
         "images_per_sec_per_gpu": round(ips / world, 2),
         "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
         "final_loss": round(loss_val, 5),
+        "exchange": exchange,
         "step_mode": ("hip-graph replay of the whole step (one graph launch per step)" if replay and any(e.get("graph") is not None for e in getattr(step_fn, "entries", {}).values())
                       else "eager (every kernel enqueued from the host)"),
     }

@@ -46,6 +46,8 @@ typedef struct ihipStream_t* iseg_stream_t; /* == hipStream_t */
 #define ISEG_ACT_GELU_GRAD 3 /* v *= gelu'(aux)  : backward of ISEG_ACT_GELU, aux = saved pre-activation */
 #define ISEG_ACT_RELU_GRAD 4 /* v  = aux > 0 ? v : 0 */
 #define ISEG_ACT_MUL_AUX 5   /* v *= aux : backward of ISEG_ACT_GELU when the forward saved gelu'(pre) (pre_deriv = 1) */
+#define ISEG_ACT_SIGMOID 6   /* tf.nn.sigmoid (layers/nasfpn.py:304-311 global-attention gate); iseg_act_fwd / iseg_act_bwd only */
+#define ISEG_ACT_SWISH 7     /* tf.nn.silu / keras "swish": x sigmoid(x) (backbones/eva/swiglu.py:13, layers/nasfpn.py:289); iseg_act_fwd / _bwd only */
 
 int iseg_version(void);
 /* copies the calling thread's last error message (NUL-terminated) into buf_h; returns its length */
@@ -92,7 +94,7 @@ typedef struct iseg_gemm_args {
     int split_k;
     int a_act; /* ISEG_ACT_NONE or ISEG_ACT_GELU: A := gelu(A) applied while the operand is staged (the GELU output of
                   backbones/convnext.py:53 is never materialised; pwconv2 and its weight gradient re-derive it) */
-    float* colsum_out; /* [N] or NULL.  wgrad orientation only (a_kcontig=0,b_kcontig=0, bf16, M % 128 != 0): also returns
+    float* colsum_out; /* [N] or NULL.  wgrad orientation only (a_kcontig=0,b_kcontig=0, bf16, M % 8 == 0): also returns
                           sum_k B(k,:) -- the Dense bias gradient -- from a virtual ones-row of A, i.e. without another pass
                           over the [pixels, N] gradient tensor */
     int colsum_accumulate;
@@ -295,7 +297,7 @@ int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, const u
 /* P masks of n samples each in one launch (s [P, n], keep_probs [P] on the device): the drop_path call sites of one training step */
 int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, const uint64_t* seed_offset, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
-/* keras.activations.relu / gelu where no GEMM epilogue is available; bwd: dx = dy*act'(aux) */
+/* keras.activations.relu / gelu / sigmoid / swish where no GEMM epilogue is available; bwd: dx = dy*act'(aux), aux = pre-activation */
 int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, iseg_stream_t stream);
 int iseg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, iseg_stream_t stream);
 /* tf.concat(axis=-1) as slice writes: dst[r][0:cols] = src[r][0:cols] (layers/aspp.py:69) */

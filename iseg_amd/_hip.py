@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libiseg_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX, ACT_SIGMOID, ACT_SWISH = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class HipLibraryMissing(RuntimeError):

@@ -162,7 +162,7 @@ class SwinTransformerBlock(Layer):
         masks = self.drop_path_masks or (None, None)
         part, rev, hp, wp = window_index_tables(n, h, w, ws, self.shift_size)
         n_win = n * (hp // ws) * (wp // ws)
-        if self.norm1.built and c % 8 == 0 and not nn.dry_run():
+        if self.norm1.built and c % 8 == 0 and not nn.dry_run() and self.norm1.gamma.requires_grad and self.norm1.beta.requires_grad:
             # norm1 + pad + roll + partition in one pass; reverse + roll back + crop + drop path + skip connection in another; the skip
             # connection's gradient rides the LayerNorm backward (F._LnGatherFn) -- five passes over the token rows less each way
             mask = None

@@ -298,7 +298,7 @@ __device__ __forceinline__ void gelu_sig_both(float x, float& y, float& dy) {
 // v_rcp cost 8.3, v_min / v_med3 / every v_pk_*_f16 4.4 -- packed f16 buys nothing over this form, profiles/r05_micro.txt):
 //     s = clamp01(x / (2 c) + 1/2)      ONE v_fma_f32 with the clamp output modifier
 //     w = s - 1/2                       = clamp(x, -c, c) / (2 c)
-//     Phi(x)   ~ 1/2 + w q(w^2),  q(1/4) = 1  (c = 3.75, degree 6):  |gelu error| <= 8.9e-5 max(1, |x|), exactly x / exactly 0 beyond the clamp
+//     Phi(x)   ~ 1/2 + w q(w^2),  q(1/4) = 1  (c = 3.75, degree 6):  |gelu error| <= 8.9e-5 max(1, |x|); x (1 - 1e-6) / 1e-6 x beyond the clamp
 //     gelu'(x) ~ 1/2 + w r(w^2),  r(1/4) = 1  (c = 4,    degree 7):  |gelu' error| <= 5.2e-4
 // (Phi - 1/2 and gelu' - 1/2 are odd, so q and r are polynomials in w^2.)  gelu: 11 instructions = 26 cycles against 41 for the sigmoid form;
 // gelu' alone: 12 against the 48 of gelu_sig_both.

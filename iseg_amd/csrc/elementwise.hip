@@ -336,7 +336,33 @@ __global__ void rsqrt_eps_kernel(const float* __restrict__ var, float eps, float
     if (i < n) out[i] = rsqrtf(var[i] + eps);
 }
 
-// standalone activations (keras.activations.relu / gelu) for layers whose activation cannot ride a GEMM epilogue
+// standalone activations (keras.activations.relu / gelu / sigmoid / swish) for layers whose activation cannot ride a GEMM epilogue.
+// FAST (bf16 storage): the transcendental-free GELU forms of common.h; fp32 storage: libm erf.  sigmoid / swish (tf.nn.sigmoid, tf.nn.silu:
+// layers/nasfpn.py:304-311, backbones/eva/swiglu.py:13) are evaluated with expf in both.
+template <bool FAST> __device__ __forceinline__ float act_value(float v, int act) {
+    switch (act) {
+        case ISEG_ACT_RELU: return fmaxf(v, 0.f);
+        case ISEG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case ISEG_ACT_SWISH: return v / (1.f + expf(-v));
+        default: return FAST ? gelu_poly(v) : gelu_erf(v);
+    }
+}
+// d act / d pre-activation at the pre-activation a
+template <bool FAST> __device__ __forceinline__ float act_deriv(float a, int act) {
+    switch (act) {
+        case ISEG_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+        case ISEG_ACT_SIGMOID: {
+            const float s = 1.f / (1.f + expf(-a));
+            return s * (1.f - s);
+        }
+        case ISEG_ACT_SWISH: {
+            const float s = 1.f / (1.f + expf(-a));
+            return s * (1.f + a * (1.f - s));
+        }
+        default: return FAST ? gelu_poly_grad(a) : gelu_erf_grad(a);
+    }
+}
+
 template <class T>
 __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, int act) {
     const int64_t nv = n / 8;
@@ -344,16 +370,14 @@ __global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64
         float v[8];
         load8<T>(x + i * 8, v);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = act == ISEG_ACT_RELU ? fmaxf(v[u], 0.f) : (sizeof(T) == 2 ? gelu_poly(v[u]) : gelu_erf(v[u]));
+        for (int u = 0; u < 8; ++u) v[u] = act_value<sizeof(T) == 2>(v[u], act);
         store8<T>(y + i * 8, v);
     }
-    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = to_f32(x[i]);
-        y[i] = from_f32<T>(act == ISEG_ACT_RELU ? fmaxf(v, 0.f) : gelu_erf(v));
-    }
+    for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = from_f32<T>(act_value<false>(to_f32(x[i]), act));
 }
 
-// dx = dy * act'(aux): aux = pre-activation (gelu) or pre-/post-activation (relu)
+// dx = dy * act'(aux): aux = the pre-activation (for relu the post-activation serves as well)
 template <class T>
 __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux, T* __restrict__ dx, int64_t n, int act) {
     const int64_t nv = n / 8;
@@ -362,14 +386,12 @@ __global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ a
         load8<T>(dy + i * 8, d);
         load8<T>(aux + i * 8, a);
 #pragma unroll
-        // bf16 storage: the 1.5e-7 approximation of common.h (as in the GEMM epilogues); fp32 parity path: libm erf
-        for (int u = 0; u < 8; ++u)
-            d[u] = act == ISEG_ACT_RELU ? (a[u] > 0.f ? d[u] : 0.f) : d[u] * (sizeof(T) == 2 ? gelu_poly_grad(a[u]) : gelu_erf_grad(a[u]));
+        for (int u = 0; u < 8; ++u) d[u] = act == ISEG_ACT_RELU ? (a[u] > 0.f ? d[u] : 0.f) : d[u] * act_deriv<sizeof(T) == 2>(a[u], act);
         store8<T>(dx + i * 8, d);
     }
     for (int64_t i = nv * 8 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float d = to_f32(dy[i]), a = to_f32(aux[i]);
-        dx[i] = from_f32<T>(act == ISEG_ACT_RELU ? (a > 0.f ? d : 0.f) : d * gelu_erf_grad(a));
+        dx[i] = from_f32<T>(act == ISEG_ACT_RELU ? (a > 0.f ? d : 0.f) : d * act_deriv<false>(a, act));
     }
 }
 
@@ -854,7 +876,7 @@ extern "C" int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const
 }
 
 extern "C" int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, hipStream_t stream) {
-    ISEG_REQUIRE(x && y && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU), "iseg_act_fwd: bad arguments");
+    ISEG_REQUIRE(x && y && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU || act == ISEG_ACT_SIGMOID || act == ISEG_ACT_SWISH), "iseg_act_fwd: bad arguments (act = %d)", act);
     if (n == 0) return ISEG_OK;
     const unsigned blocks = cap_blocks(ceil_div64(n, 8));
     if (dtype == ISEG_BF16)
@@ -865,7 +887,7 @@ extern "C" int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtyp
 }
 
 extern "C" int iseg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, hipStream_t stream) {
-    ISEG_REQUIRE(dy && aux && dx && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU), "iseg_act_bwd: bad arguments");
+    ISEG_REQUIRE(dy && aux && dx && (act == ISEG_ACT_RELU || act == ISEG_ACT_GELU || act == ISEG_ACT_SIGMOID || act == ISEG_ACT_SWISH), "iseg_act_bwd: bad arguments (act = %d)", act);
     if (n == 0) return ISEG_OK;
     const unsigned blocks = cap_blocks(ceil_div64(n, 8));
     if (dtype == ISEG_BF16)

@@ -229,10 +229,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
 }
 
 int dma_tn_mode();      // ISEG_GEMM_DMA_TN: 0 = never, 1 = whenever eligible (default)
+bool dma_tn_lds_ok();   // gemm_tn.hip: the 144-KiB dynamic-LDS limit of both tile forms was raised (once per process); false -> the register kernel keeps these problems
 
 // 0 = not eligible; 7 = 256 x 128 tiles, 8 = 128 x 256 tiles (the codes iseg_gemm_variant reports)
 inline int dma_tn_form(const iseg_gemm_args* g) {
     if (!dma_tn_mode() || g->in_dtype != ISEG_BF16 || g->a_kcontig || g->b_kcontig || g->a_act != ISEG_ACT_NONE) return 0;
+    if (!dma_tn_lds_ok()) return 0;
     if (g->batch > 1 || g->b_group_rows > 0 || g->split_k == 1) return 0;
     static const int min_mn = [] {      // ISEG_GEMM_DMA_TN_MIN: narrowest M / N the kernel takes (columns past M / N are clamped duplicates)
         const char* e = getenv("ISEG_GEMM_DMA_TN_MIN");
@@ -263,12 +265,7 @@ void launch_dma_tn(const iseg_gemm_args* g, int nsplit, int64_t k_per_split, flo
     constexpr int NS = 3, BM = WM * 64, BN = WN * 64;
     const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
     const int ntiles = tiles_m * tiles_n;
-    constexpr int lds = NS * 64 * (BM + BN) * 2;
-    static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_kernel<WM, WN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   lds) == hipSuccess;
-    }();
-    (void)raised;
+    constexpr int lds = NS * 64 * (BM + BN) * 2;      // (the limit was raised by dma_tn_lds_ok(), which dma_tn_form() requires)
     hipLaunchKernelGGL((gemm_bf16_dma_tn_kernel<WM, WN, NS>), dim3(ntiles, nsplit, 1), dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
                        (const bf16_t*)g->B, g->ldb, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, g->colsum_out ? 1 : 0);
 }

@@ -3,6 +3,17 @@
 #include "gemm_dma_tn.h"
 
 namespace iseg_mm {
+bool dma_tn_lds_ok() {
+    static const bool ok = [] {
+        constexpr int lds = 3 * 64 * (256 + 128) * 2;      // three 64-row stages of a 256 x 128 / 128 x 256 tile pair
+        const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        if (!(a && b)) (void)hipGetLastError();      // not an error of the call that asked: the register-staged kernel takes these problems
+        return a && b;
+    }();
+    return ok;
+}
+
 void gemm_bf16_tn(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     if (slabs && nsplit > 1 && kps % 64 == 0) {
         const int form = dma_tn_form(g);

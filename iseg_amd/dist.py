@@ -69,7 +69,7 @@ def init(backend=None):
 # 128-byte RCCL id to the other ranks) and the default exchange; "emulate" runs the same scheduling with a blocking c10d primitive (gloo on the
 # CPU: tests/test_dist_gloo.py).  Reference: distribution/distribution_utils.py:75-95,158-169 (MirroredStrategy's NCCL all-reduce).
 # ---------------------------------------------------------------------------------------------------------
-_NATIVE = {"comm": None, "side": None, "join": None}
+_NATIVE = {"comm": None, "comm_side": None, "side": None, "join": None}
 
 
 def native_mode():
@@ -80,9 +80,13 @@ def native_mode():
     return "emulate" if v == "emulate" else ""
 
 
-def _native_comm():
-    """the C-ABI communicator of this process, created on first use: rank 0 draws the id, c10d broadcasts it"""
-    if _NATIVE["comm"] is None:
+def _native_comm(which="comm"):
+    """the C-ABI communicators of this process, created on first use: rank 0 draws the id, c10d broadcasts it.  Two of them: "comm" carries the
+    SyncBN messages on the compute stream, "comm_side" the gradient buckets on the side stream -- operations on ONE RCCL communicator are
+    serialised in host-issue order whatever streams they are enqueued on, so a bucket sum sharing the SyncBN communicator would sit in front of the
+    backward pass's next SyncBN message instead of overlapping it.  Every rank creates both in the same order (first use is the first forward
+    SyncBN message / the first bucket of the first step, identical on all ranks)."""
+    if _NATIVE[which] is None:
         import ctypes as C
 
         from . import _hip
@@ -100,11 +104,11 @@ def _native_comm():
             uid = u.cpu()
         comm = C.c_void_p()
         _hip.check(L.iseg_comm_init(C.byref(comm), world_size(), rank(), bytes(uid.numpy().tobytes())), "iseg_comm_init")
-        _NATIVE["comm"] = comm
-    return _NATIVE["comm"]
+        _NATIVE[which] = comm
+    return _NATIVE[which]
 
 
-def _stream_all_reduce(t, raw_stream):
+def _stream_all_reduce(t, raw_stream, which="comm"):
     """in-place sum over the ranks, enqueued on `raw_stream` (a hipStream_t handle); returns at once"""
     mode = native_mode()
     if mode == "rccl":
@@ -115,9 +119,12 @@ def _stream_all_reduce(t, raw_stream):
             raise ValueError("stream-ordered all-reduce needs a contiguous tensor (a slice of the flat buffers is)")
         code = K.F32 if t.dtype == torch.float32 else K.BF16 if t.dtype == torch.bfloat16 else None
         if code is None or not t.is_cuda:      # integer counts (confusion matrices) and host tensors: not for the C ABI's device entry; take the c10d call
+            if t.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"stream-ordered all-reduce of a {t.dtype} tensor under graph capture: only float32 / bfloat16 go through the C ABI's "
+                                   "communicator, and a c10d work object cannot be captured")
             td.all_reduce(t, op=td.ReduceOp.SUM)
             return
-        _hip.check(_hip.lib().iseg_allreduce_sum(_native_comm(), K.ptr(t), t.numel(), code, raw_stream), "iseg_allreduce_sum")
+        _hip.check(_hip.lib().iseg_allreduce_sum(_native_comm(which), K.ptr(t), t.numel(), code, raw_stream), "iseg_allreduce_sum")
     else:
         td.all_reduce(t, op=td.ReduceOp.SUM)
 
@@ -216,7 +223,7 @@ class GradReducer:
         fork = torch.cuda.Event()
         fork.record()                      # on the current (compute / capture) stream
         side.wait_event(fork)
-        _stream_all_reduce(t, side.cuda_stream)
+        _stream_all_reduce(t, side.cuda_stream, "comm_side")
         self.side_used = True
 
     def ready(self, *params):

@@ -878,6 +878,20 @@ def gelu(x):
     return _ActFn.apply(x, K.ACT_GELU)
 
 
+def sigmoid(x):
+    """tf.nn.sigmoid (layers/nasfpn.py:304-311) through the C-ABI activation kernel"""
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ActFn.apply(x, K.ACT_SIGMOID)
+
+
+def swish(x):
+    """tf.nn.silu / keras.activations.swish: x * sigmoid(x) (backbones/eva/swiglu.py:13, layers/nasfpn.py:289)"""
+    if nn.dry_run():
+        return _dry(x.shape, x)
+    return _ActFn.apply(x, K.ACT_SWISH)
+
+
 class _Relu6Fn(Function):
     @staticmethod
     def forward(ctx, x):
@@ -2053,7 +2067,9 @@ class _LnGatherFn(Function):
         ctx.gamma, ctx.beta, ctx.idx_bwd, ctx.link, ctx.in_shape = gamma, beta, idx_bwd, link, x.shape
         ctx.save_for_backward(x2, mean, rstd)
         if link is not None:
+            link.pop("dres", None)      # nothing of an earlier step (a backward pass that stopped between the two nodes) survives into this one
             link["armed"] = bool(ctx.needs_input_grad[0])
+            link["x"] = (x.data_ptr(), tuple(x.shape))      # the skip connection handed over through the link must be THIS tensor
         return y.reshape(out_shape)
 
     @staticmethod
@@ -2077,6 +2093,9 @@ class _GatherResidualFn(Function):
         r2 = _c(residual).reshape(-1, C)
         rpg = r2.shape[0] // rowscale.shape[0] if rowscale is not None else 0
         ctx.idx_bwd, ctx.rowscale, ctx.rpg, ctx.link, ctx.y_shape = idx_bwd, rowscale, rpg, link, y.shape
+        if link is not None and link.get("armed") and link.get("x") != (residual.data_ptr(), tuple(residual.shape)):
+            raise ValueError("permute_rows_residual: `link` pairs this node with a layer_norm_permute_rows of ANOTHER tensor -- the skip connection's "
+                             "gradient would be added to the wrong LayerNorm input")
         return K.gather_rows_fma(_c(y).reshape(-1, C), idx_fwd, rowscale, rpg, False, r2).reshape(residual.shape)
 
     @staticmethod

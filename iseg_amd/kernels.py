@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _hip
-from ._hip import F32, BF16, ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX, GemmArgs  # noqa: F401
+from ._hip import F32, BF16, ACT_NONE, ACT_RELU, ACT_GELU, ACT_GELU_GRAD, ACT_RELU_GRAD, ACT_MUL_AUX, ACT_SIGMOID, ACT_SWISH, GemmArgs  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 

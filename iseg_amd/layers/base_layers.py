@@ -22,6 +22,10 @@ def get_activation(act):
         return F.relu
     if act == "gelu":
         return F.gelu
+    if act in ("swish", "silu"):
+        return F.swish
+    if act == "sigmoid":
+        return F.sigmoid
     raise ValueError(f"activation {act!r} not supported")
 
 
@@ -119,6 +123,41 @@ class DepthwiseConv2D(Layer):
         if d[0] != d[1]:
             raise NotImplementedError("DepthwiseConv2D: anisotropic dilation")
         return F.depthwise_conv2d(inputs, self.depthwise_kernel, self.bias, d[0], strides=st[0])
+
+
+class SeparableConv2D(Layer):
+    """keras.layers.SeparableConv2D (depth_multiplier 1): depthwise k x k without bias, then a 1 x 1 convolution with the bias.  Weights in Keras'
+    names and layouts: depthwise_kernel [kh, kw, Cin, 1], pointwise_kernel [1, 1, Cin, filters], bias [filters]."""
+
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", dilation_rate=(1, 1), activation=None, use_bias=True,
+                 depthwise_initializer="glorot_uniform", pointwise_initializer="glorot_uniform", bias_initializer="zeros", name=None,
+                 trainable=True, **kw):
+        super().__init__(name=name, trainable=trainable)
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.padding = padding.lower()
+        self.dilation_rate = _pair(dilation_rate)
+        self.activation = get_activation(activation)
+        self.use_bias = use_bias
+        self.depthwise_initializer, self.pointwise_initializer, self.bias_initializer = depthwise_initializer, pointwise_initializer, bias_initializer
+        self.depthwise_kernel = self.pointwise_kernel = self.bias = None
+
+    def build(self, input_shape):
+        c = int(input_shape[-1])
+        self.depthwise_kernel = self.add_weight("depthwise_kernel", (*self.kernel_size, c, 1), self.depthwise_initializer)
+        self.pointwise_kernel = self.add_weight("pointwise_kernel", (1, 1, c, self.filters), self.pointwise_initializer)
+        if self.use_bias:
+            self.bias = self.add_weight("bias", (self.filters,), self.bias_initializer)
+        self.built = True
+
+    def call(self, inputs, training=None):
+        st, d = _pair(self.strides), _pair(self.dilation_rate)
+        if st[0] != st[1] or d[0] != d[1] or self.padding != "same" or self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] % 2 == 0:
+            raise NotImplementedError("SeparableConv2D: odd square kernels, isotropic strides / dilation and padding='same' only")
+        y = F.depthwise_conv2d(inputs, self.depthwise_kernel, None, d[0], strides=st[0])
+        y = F.conv2d(y, self.pointwise_kernel, self.bias, (1, 1), (1, 1), "same", 1)
+        return y if self.activation is None else self.activation(y)
 
 
 class LayerNormalization(Layer):

@@ -13,16 +13,18 @@ Everything is composed from this package's kernels: the implicit-GEMM convolutio
   * the maximum over H x W is a chain of max-pools with windows of at most 15 x 15 cells (padding="same" pads with -inf, so ragged sizes
     work): each link takes the pooling kernels' two-pass gradient (one winner byte per window).  A tie sends the gradient to the first
     maximal cell (TF's MaxPoolGrad rule) where `reduce_max` would split it between the tied cells -- conv + BatchNorm outputs do not tie;
-  * the sigmoid runs on the [N, C] maxima (a few thousand numbers) as a torch expression;
+  * the sigmoid of the [N, C] maxima is the C ABI's activation kernel (`iseg_act_fwd` / `iseg_act_bwd`, ISEG_ACT_SIGMOID) in fp32;
   * the per-sample channel gate is `iseg_scale_cols` per sample, its gradient `iseg_mul_colsum` per sample.
-The separable-convolution variant (`use_separable_conv=True`) and activations other than relu are not built and raise."""
+Both convolution variants are built: plain `Conv2D` and `use_separable_conv=True` (keras SeparableConv2D = depthwise k x k + pointwise 1 x 1, :176-181,
+283-302), with any activation `keras.activations.get` of this package knows (relu, gelu, swish / silu, sigmoid; :194).  Initialisers follow
+:283-302 (VarianceScaling(2, fan_out, untruncated normal), zero biases); weight regularisers are not modelled by this package and raise."""
 import torch
 
 from .. import functional as F
 from .. import kernels as K
 from .. import nn as _nn
 from ..nn import Layer
-from .base_layers import BatchNormalization, Conv2D
+from .base_layers import BatchNormalization, Conv2D, SeparableConv2D, get_activation
 
 # (block_level, combine_fn, (input_offset0, input_offset1), is_output) -- nasfpn.py:37-45
 NASFPN_BLOCK_SPECS = [
@@ -90,19 +92,22 @@ def global_max(x):
 
 
 class _SigmoidGateFn(torch.autograd.Function):
-    """m = sigmoid(x) for the [N, 1, 1, C] maxima -> fp32 [N, C]"""
+    """m = sigmoid(x) for the [N, 1, 1, C] maxima -> fp32 [N, C] (C-ABI kernels: cast, iseg_act_fwd / iseg_act_bwd with ISEG_ACT_SIGMOID)"""
 
     @staticmethod
     def forward(ctx, x):
-        m = torch.sigmoid(x.reshape(x.shape[0], x.shape[-1]).float())
-        ctx.save_for_backward(m)
+        pre = x.reshape(x.shape[0], x.shape[-1]).contiguous()
+        pre = pre if pre.dtype == torch.float32 else K.cast(pre, torch.float32)
+        ctx.save_for_backward(pre)
         ctx.shape, ctx.dtype = x.shape, x.dtype
-        return m
+        return K.act_fwd(pre, K.ACT_SIGMOID)
 
     @staticmethod
     def backward(ctx, dm):
-        (m,) = ctx.saved_tensors
-        return (dm * m * (1.0 - m)).to(ctx.dtype).reshape(ctx.shape)
+        (pre,) = ctx.saved_tensors
+        dx = K.act_bwd(dm.contiguous(), pre, K.ACT_SIGMOID)
+        dx = dx if ctx.dtype == torch.float32 else K.cast(dx, ctx.dtype)
+        return dx.reshape(ctx.shape)
 
 
 class _ChannelGateFn(torch.autograd.Function):
@@ -147,10 +152,10 @@ class NASFPN(Layer):
                  use_separable_conv=False, activation="relu", use_sync_bn=False, norm_momentum=0.99, norm_epsilon=0.001,
                  kernel_initializer="VarianceScaling", kernel_regularizer=None, bias_regularizer=None, name="nasfpn", trainable=True, **kwargs):
         super().__init__(name=name, trainable=trainable)
-        if use_separable_conv:
-            raise NotImplementedError("NASFPN(use_separable_conv=True) is not built (the reference's default is the plain convolution)")
-        if activation != "relu":
-            raise NotImplementedError(f"NASFPN(activation={activation!r}): relu is built")
+        if kernel_regularizer is not None or bias_regularizer is not None:
+            raise NotImplementedError("NASFPN: kernel_regularizer / bias_regularizer are not modelled by this package (no layer of it adds a weight penalty)")
+        self.use_separable_conv = bool(use_separable_conv)
+        self.activation = get_activation(activation) or (lambda t: t)
         if min(str(k) for k in input_specs.keys()) > str(min_level):
             raise ValueError("Backbone min level should be less or equal to FPN min level")      # (nasfpn.py:237-239)
         self.input_specs = {str(k): tuple(v) for k, v in input_specs.items()}
@@ -161,13 +166,21 @@ class NASFPN(Layer):
         self.norm_kwargs = dict(momentum=norm_momentum, epsilon=norm_epsilon, synchronized=bool(use_sync_bn))
         self._build_layers()
 
+    def _conv(self, filters, kernel_size, name):
+        """(:176-181, :283-302) the convolution class and its initialisers: VarianceScaling(scale 2, fan_out, untruncated normal), zero biases"""
+        if self.use_separable_conv:
+            return SeparableConv2D(filters, kernel_size, padding="same", depthwise_initializer="he_normal_fan_out",
+                                   pointwise_initializer="he_normal_fan_out", bias_initializer="zeros", trainable=self.trainable, name=name)
+        return Conv2D(filters, kernel_size, padding="same", kernel_initializer="he_normal_fan_out", bias_initializer="zeros",
+                      trainable=self.trainable, name=name)
+
     def _build_layers(self):
         nf = self.num_filters
         self.resample = torch.nn.ModuleDict()
         for level in range(self.min_level, self.max_level + 1):
             spec = self.input_specs.get(str(level))
             if spec is not None and int(spec[-1]) != nf:      # (:254-262) only where the channel count differs
-                conv = Conv2D(nf, 1, padding="same", trainable=self.trainable, name=f"{self.name}/resample_l{level}/separable_conv2d")
+                conv = self._conv(nf, 1, f"{self.name}/resample_l{level}/separable_conv2d")
                 bn = BatchNormalization(name=f"{self.name}/resample_l{level}/bn", trainable=self.trainable, **self.norm_kwargs)
                 conv.build((None, None, None, int(spec[-1])))
                 bn.build((None, None, None, nf))
@@ -179,7 +192,7 @@ class NASFPN(Layer):
             cell = torch.nn.ModuleList()
             for i in range(len(self.block_specs)):
                 prefix = f"{self.name}/cell_{r}/sub_policy{i}/op_after_combine{n_levels + i}"
-                conv = Conv2D(nf, (3, 3), padding="same", trainable=self.trainable, name=f"{prefix}/conv")
+                conv = self._conv(nf, (3, 3), f"{prefix}/conv")
                 bn = BatchNormalization(name=f"{prefix}/bn", trainable=self.trainable, **self.norm_kwargs)
                 conv.build((None, None, None, nf))
                 bn.build((None, None, None, nf))
@@ -229,7 +242,7 @@ class NASFPN(Layer):
                         used[j] += 1
                         new_node = F.add(new_node, feats[j])
             conv, bn = cell[i]
-            new_node = bn(conv(F.relu(new_node), training=training), training=training)
+            new_node = bn(conv(self.activation(new_node), training=training), training=training)
             feats.append(new_node)
             levels.append(new_level)
             used.append(0)

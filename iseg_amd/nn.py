@@ -87,6 +87,9 @@ def init_tensor(initializer, shape, name):
     if initializer == "he_normal":
         fi, _ = _fans(shape)
         return torch.randn(shape, generator=_gen(name)) * math.sqrt(2.0 / fi)
+    if initializer == "he_normal_fan_out":      # keras VarianceScaling(scale=2, mode="fan_out", distribution="untruncated_normal") (layers/nasfpn.py:283-302)
+        _, fo = _fans(shape)
+        return torch.randn(shape, generator=_gen(name)) * math.sqrt(2.0 / fo)
     if isinstance(initializer, tuple) and initializer[0] == "uniform":      # keras RandomUniform(-v, v)
         return (torch.rand(shape, generator=_gen(name)) * 2 - 1) * float(initializer[1])
     if isinstance(initializer, tuple) and initializer[0] == "truncated_normal":

@@ -224,9 +224,18 @@ def mhsa_layer(w, prefix, x, heads):
 
 
 def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_filters=256, num_repeats=5, use_sum_for_combination=True,
-                   training=False, eps=1e-3):
+                   training=False, eps=1e-3, use_separable_conv=False, activation="relu"):
     """layers/nasfpn.py:196-232 (input pyramid), :248-271 (resample), :304-311 (global attention), :313-383 (one cell), line by line.
-    inputs: {level: [N, H, W, C]}; block_specs: [(level, combine_fn, (offset0, offset1), is_output)]"""
+    inputs: {level: [N, H, W, C]}; block_specs: [(level, combine_fn, (offset0, offset1), is_output)].  use_separable_conv (:176-181): every
+    convolution is keras SeparableConv2D = depthwise k x k (no bias) then pointwise 1 x 1 + bias; activation (:194): keras.activations.get."""
+    act = {"relu": torch.relu, "swish": lambda t: t * torch.sigmoid(t), "silu": lambda t: t * torch.sigmoid(t), "gelu": O.gelu}[activation]
+
+    def conv(prefix, t):
+        if use_separable_conv:
+            t = O.depthwise_conv2d(t, w[f"{prefix}/depthwise_kernel"], None, 1, 1, "same")
+            return O.conv2d(t, w[f"{prefix}/pointwise_kernel"], w[f"{prefix}/bias"], 1, 1, "same")
+        return O.conv2d(t, w[f"{prefix}/kernel"], w[f"{prefix}/bias"], 1, 1, "same")
+
     def bn(prefix, y):
         g, b = w[f"{prefix}/gamma"], w[f"{prefix}/beta"]
         if training:
@@ -252,7 +261,7 @@ def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_f
             x = inputs[level]
             if x.shape[-1] != num_filters:
                 p = f"{name}/resample_l{level}"
-                x = bn(f"{p}/bn", O.conv2d(x, w[f"{p}/separable_conv2d/kernel"], w[f"{p}/separable_conv2d/bias"], 1, 1, "same"))
+                x = bn(f"{p}/bn", conv(f"{p}/separable_conv2d", x))
             feats.append(x)
         else:
             feats.append(O.max_pool_same(feats[-1], 2, 2))
@@ -277,7 +286,7 @@ def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_f
                         used[j] += 1
                         new_node = new_node + feats[j]
             p = f"{name}/cell_{r}/sub_policy{i}/op_after_combine{n_levels + i}"
-            new_node = bn(f"{p}/bn", O.conv2d(torch.relu(new_node), w[f"{p}/conv/kernel"], w[f"{p}/conv/bias"], 1, 1, "same"))
+            new_node = bn(f"{p}/bn", conv(f"{p}/conv", act(new_node)))
             feats.append(new_node)
             levels.append(new_level)
             used.append(0)

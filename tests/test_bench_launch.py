@@ -64,3 +64,40 @@ def test_launcher_parent_counts_gpus_without_touching_them():
     assert out.stdout.strip().splitlines()[-1] == "3", out.stderr[-500:]
     out = subprocess.run([sys.executable, "-c", code], env=_env(HIP_VISIBLE_DEVICES=""), capture_output=True, text=True, timeout=120)
     assert out.stdout.strip().splitlines()[-1] == "0"
+
+
+def _probe_run(mode, tmp_path, timeout_s="20"):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TEST_PROBE=mode, ISEG_BENCH_PROBE_TIMEOUT_S=timeout_s, ISEG_BENCH_TIMEOUT_S="200",
+                                ISEG_BENCH_LOG_DIR=str(tmp_path)), capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]), r
+
+
+def test_exchange_probe_passes_on_every_rank_selects_the_stream_ordered_exchange(tmp_path):
+    """bench.py --gpus N (round-4 verdict, item 5): every rank starts a fresh probe child before it touches the GPU; the children's common
+    all-reduce(MIN) of success flags prints the marker on every rank -> the measured job runs the stream-ordered RCCL exchange (+ graph replay)"""
+    out, _ = _probe_run("ok", tmp_path)
+    assert out["n_gpus"] == 2 and out["exchange"].startswith("stream-ordered RCCL"), out
+
+
+def test_exchange_probe_failure_on_one_rank_falls_back_on_every_rank(tmp_path):
+    """rank 1's probe child dies before the agreement: rank 0's child never gets its all-reduce partner, is killed by pid at the probe's own
+    timeout, and BOTH ranks take the c10d + eager branch (a mixed choice would hang the measured job); the job itself still completes"""
+    out, r = _probe_run("fail", tmp_path)
+    assert out["n_gpus"] == 2 and out["exchange"].startswith("c10d work objects"), out
+    logs = "".join(open(os.path.join(tmp_path, f)).read() for f in sorted(os.listdir(tmp_path)))
+    assert logs.count("native-exchange probe did not pass") == 2, logs[-1500:]
+
+
+def test_exchange_probe_hang_is_cut_off_by_its_timeout(tmp_path):
+    out, _ = _probe_run("hang", tmp_path, timeout_s="15")
+    assert out["exchange"].startswith("c10d work objects") and "no result after 15 s" in out["exchange"], out
+
+
+def test_an_explicit_exchange_choice_skips_the_probe():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TEST_PROBE="hang", ISEG_DIST_NATIVE="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "set by the caller" in out["exchange"]

@@ -708,3 +708,31 @@ def test_strided_depthwise_conv_matches_oracle(cuda, dtype, shape, k, s, dil):
         assert torch.equal(wp.grad, first)
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+def test_gelu_approximations_on_a_dense_grid(cuda):
+    """The transcendental-free GELU / GELU' of the bf16 kernels (csrc/common.h gelu_poly / gelu_poly_grad, round 5) through the C-ABI
+    activation kernels on EVERY bf16 value in [-8, 8], against the exact-erf oracle (keras.activations.gelu, backbones/convnext.py:53):
+    approximation error <= 1e-3 / 2e-3 (the round-4 verdict's gate) on top of the bf16 output rounding (2^-8 relative).  fp32 storage
+    keeps erff and is checked at 2e-6."""
+    k = K()
+    bits = torch.arange(0, 1 << 16, dtype=torch.int32)
+    allbf = bits.to(torch.int16).view(torch.bfloat16)
+    x = allbf[torch.isfinite(allbf.float()) & (allbf.float().abs() <= 8)]
+    xd = x.double()
+    want = O.gelu(xd)
+    xg = xd.clone().requires_grad_(True)
+    (dwant,) = torch.autograd.grad(O.gelu(xg).sum(), xg)
+    y = k.act_fwd(x.cuda(), k.ACT_GELU).cpu().double()
+    assert ((y - want).abs() <= 1e-3 + 2.0 ** -8 * want.abs()).all(), (y - want).abs().max().item()
+    ones = torch.ones_like(x)
+    d = k.act_bwd(ones.cuda(), x.cuda(), k.ACT_GELU).cpu().double()
+    assert ((d - dwant).abs() <= 2e-3 + 2.0 ** -8 * dwant.abs()).all(), (d - dwant).abs().max().item()
+    # the tails: gelu(x) -> x, gelu'(x) -> 1 on the right, both -> 0 on the left, for every finite bf16 beyond the grid
+    far = allbf[torch.isfinite(allbf.float()) & (allbf.float().abs() > 8) & (allbf.float().abs() < 1e18)]
+    yf = k.act_fwd(far.cuda(), k.ACT_GELU).cpu().double()
+    fd = far.double()
+    assert ((yf - torch.where(fd > 0, fd, torch.zeros_like(fd))).abs() <= 2.0 ** -8 * fd.abs()).all()
+    x32 = x.float()
+    y32 = k.act_fwd(x32.cuda(), k.ACT_GELU).cpu().double()
+    assert (y32 - want).abs().max().item() < 2e-6

@@ -273,3 +273,66 @@ def test_photometric_restatement_known_answers():
     assert np.allclose(O.adjust_saturation(np.array([[[-3.0, -1.0, -2.0]]]), 1.1), [[[-1.0, -1.0, -1.0]]])      # tf: S = 0 when max <= 0
     full = O.photometric_sequence(x, brightness_delta=40.0, contrast=1.25, saturation=1.2, hue=0.05, distortions=True)
     assert full.min() >= 0.0 and full.max() <= 256.0
+
+
+# ---- round 5: the GELU approximations of the bf16 kernels (csrc/common.h), emulated in float32 with the kernels' operation order -------------
+# Accuracy gate of the round-4 verdict: |gelu error| <= 1e-3 and |gelu' error| <= 2e-3 on [-8, 8] against the exact-erf form
+# (keras.activations.gelu, backbones/convnext.py:53).  fp32 storage keeps erff; these forms serve bf16 storage only (half-ulp at 1: 2e-3).
+_GELU_Q = [2.987506628036499, -27.49638557434082, 214.41412353515625, -1156.386962890625, 3995.16552734375, -7851.36572265625, 6617.0283203125]
+_GELU_R = [6.365922927856445, -132.86141967773438, 1771.6455078125, -14897.58984375, 79767.0, -262435.875, 481274.125, -375307.59375]
+
+
+def _f32_fma(a, b, c):
+    import numpy as np
+
+    return (a.astype(np.float64) * b.astype(np.float64) + np.asarray(c, dtype=np.float64)).astype(np.float32)
+
+
+def _poly_half(x, inv2c, coef):
+    """1/2 + w q(w^2), w = clamp01(x / (2 c) + 1/2) - 1/2: gelu_poly / gelu_poly_grad of csrc/common.h"""
+    import numpy as np
+
+    f = np.float32
+    s = np.clip(_f32_fma(x, np.full_like(x, f(inv2c)), 0.5), 0, 1).astype(f)
+    w = (s - f(0.5)).astype(f)
+    t = (w * w).astype(f)
+    q = np.full_like(x, f(coef[-1]))
+    for c in coef[-2::-1]:
+        q = _f32_fma(q, t, f(c))
+    return _f32_fma(w, q, 0.5)
+
+
+def test_gelu_polynomial_forms_meet_the_bf16_accuracy_gate():
+    import numpy as np
+    from scipy.special import erf
+
+    x = np.linspace(-8, 8, 320001).astype(np.float32)
+    xd = x.astype(np.float64)
+    Phi = 0.5 * (1 + erf(xd / np.sqrt(2)))
+    dg = Phi + xd * np.exp(-xd * xd / 2) / np.sqrt(2 * np.pi)
+    g = (x * _poly_half(x, 1 / 7.5, _GELU_Q)).astype(np.float64)
+    d = _poly_half(x, 0.125, _GELU_R).astype(np.float64)
+    assert np.abs(g - xd * Phi).max() < 4e-4          # measured 3.3e-4 (8.9e-5 max(1, |x|))
+    assert np.abs(d - dg).max() < 6e-4                # measured 5.2e-4
+    # beyond the clamp the forms are constant: Phi = 1 / 0 and gelu' = 1 / 0 up to float32 rounding of the coefficient sum (q(1/4) = 1)
+    big = np.array([4.0, 7.5, 100.0, 3e4], dtype=np.float32)
+    assert np.abs(_poly_half(big, 1 / 7.5, _GELU_Q) - 1).max() < 2e-6
+    assert np.abs(_poly_half(-big, 1 / 7.5, _GELU_Q)).max() < 2e-6
+    assert np.abs(_poly_half(big, 0.125, _GELU_R) - 1).max() < 2e-5
+    assert np.abs(_poly_half(-big, 0.125, _GELU_R)).max() < 2e-5
+
+
+def test_gelu_two_coefficient_sigmoid_pair_meets_the_gate():
+    """gelu_sig_both (the weight-gradient recompute and the forward epilogue that saves gelu'): x sigmoid(x (a0 + a1 x^2)) and its derivative"""
+    import numpy as np
+    from scipy.special import erf
+
+    x = np.linspace(-8, 8, 320001)
+    Phi = 0.5 * (1 + erf(x / np.sqrt(2)))
+    dg = Phi + x * np.exp(-x * x / 2) / np.sqrt(2 * np.pi)
+    a0, a1 = 1.600313485784997, 0.06940208738399849
+    s = 1 / (1 + np.exp(-x * (a0 + a1 * x * x)))
+    y = x * s
+    dy = s + y * (1 - s) * (a0 + 3 * a1 * x * x)
+    assert np.abs(y - x * Phi).max() < 1e-3           # 2.7e-4
+    assert np.abs(dy - dg).max() < 2e-3               # 8.7e-4
