@@ -171,6 +171,12 @@ int iseg_layernorm_gather_bwd(const void* dy, const int32_t* dy_index, const voi
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C,
                       int K, int dil, int pad_t, int pad_l, int flip, int dtype, iseg_stream_t stream);
+/* The 7 x 7 / bf16 / C % 32 == 0 case of iseg_dwconv2d_fwd on the matrix cores (csrc/dwconv_mfma.hip: banded products with
+ * v_mfma_f32_4x4x4_16b_bf16, block = channel) -- the route iseg_dwconv2d_fwd takes by itself for large planes (ISEG_DW_MFMA), exported so that
+ * tests and benchmarks can name it.  Same arguments and semantics (backbones/convnext.py:23-27,47-50); weights are rounded to bf16 as the
+ * reference's mixed_bfloat16 policy does.  ISEG_ERR_UNSUPPORTED when the shape is not eligible. */
+int iseg_dwconv2d7_mfma(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int pad_t,
+                        int pad_l, int flip, iseg_stream_t stream);
 size_t iseg_dwconv2d_bwd_weight_workspace_bytes(int N, int H, int W, int C, int K);
 int iseg_dwconv2d_bwd_weight(const void* x, const void* dy, float* dw, float* db, int accumulate, int N, int H, int W, int C,
                              int K, int dil, int pad_t, int pad_l, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);

@@ -1148,6 +1148,9 @@ void launch_bw_cv(const void* x, const void* dy, float* ws, int N, int H, int W,
 
 }  // namespace
 
+bool iseg_dwconv7_mfma_launch(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W, int C, int K, int dil,
+                              int pad_t, int pad_l, int flip, hipStream_t s);      // dwconv_mfma.hip
+
 extern "C" int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bias, const void* add, void* y, int N, int H, int W,
                                  int C, int K, int dil, int pad_t, int pad_l, int flip, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(x && w && y, "iseg_dwconv2d_fwd: null pointer");
@@ -1159,6 +1162,9 @@ extern "C" int iseg_dwconv2d_fwd(const void* x, const float* w, const float* bia
     (K == 7   ? launch_fwd_cv<T, 7>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
      : K == 5 ? launch_fwd_cv<T, 5>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream)          \
               : launch_fwd_cv<T, 3>(x, w, bias, add, y, N, H, W, C, dil, pad_t, pad_l, flip, stream))
+    // 7 x 7, bf16, C % 32 == 0: the banded products on the matrix cores (dwconv_mfma.hip, round 5; ISEG_DW_MFMA=0 keeps the VALU kernels)
+    if (dtype == ISEG_BF16 && iseg_dwconv7_mfma_launch(x, w, bias, add, y, N, H, W, C, K, dil, pad_t, pad_l, flip, stream))
+        return iseg_check_launch("iseg_dwconv2d (mfma)");
     if (dtype == ISEG_BF16 && launch_fwd_dma(x, w, bias, add, y, N, H, W, C, K, dil, pad_t, pad_l, flip, stream))
         return iseg_check_launch("iseg_dwconv2d");
     return dtype == ISEG_BF16 ? DW_FWD(bf16_t) : DW_FWD(float);

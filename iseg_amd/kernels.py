@@ -528,6 +528,15 @@ def dwconv2d(x, w, bias, K, dil, pad_t, pad_l, *, flip=False, add=None):
     return y
 
 
+def dwconv2d7_mfma(x, w, bias, pad_t=3, pad_l=3, *, flip=False, add=None):
+    """the 7 x 7 depthwise convolution on the matrix cores (csrc/dwconv_mfma.hip), named explicitly; dwconv2d takes this route by itself for large planes"""
+    _require_cuda(x)
+    N, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    _hip.call("iseg_dwconv2d7_mfma", ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), N, H, W, Cc, pad_t, pad_l, int(flip), stream())
+    return y
+
+
 def dwconv2d_bwd_weight(x, dy, dw, db, K, dil, pad_t, pad_l, accumulate=True):
     N, H, W, Cc = x.shape
     need = _hip.lib().iseg_dwconv2d_bwd_weight_workspace_bytes(N, H, W, Cc, K)

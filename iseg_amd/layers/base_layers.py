@@ -155,7 +155,10 @@ class SeparableConv2D(Layer):
         st, d = _pair(self.strides), _pair(self.dilation_rate)
         if st[0] != st[1] or d[0] != d[1] or self.padding != "same" or self.kernel_size[0] != self.kernel_size[1] or self.kernel_size[0] % 2 == 0:
             raise NotImplementedError("SeparableConv2D: odd square kernels, isotropic strides / dilation and padding='same' only")
-        y = F.depthwise_conv2d(inputs, self.depthwise_kernel, None, d[0], strides=st[0])
+        if self.kernel_size == (1, 1) and st == (1, 1):
+            y = F.scale_channels(inputs, self.depthwise_kernel)      # a 1 x 1 depthwise kernel is one factor per channel ([1, 1, C, 1] = C numbers)
+        else:
+            y = F.depthwise_conv2d(inputs, self.depthwise_kernel, None, d[0], strides=st[0])
         y = F.conv2d(y, self.pointwise_kernel, self.bias, (1, 1), (1, 1), "same", 1)
         return y if self.activation is None else self.activation(y)
 

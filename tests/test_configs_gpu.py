@@ -72,7 +72,7 @@ def test_full_architectures_train_in_bf16(cuda, factory, size):
     assert tuple(logits.shape) == (2, size, size, 21) and torch.isfinite(logits).all()
 
 
-def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3):
+def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3, tie_margin=0.0):
     """fp32 storage: logits < logit_tol abs and the argmax mask bit-exact against the oracle's whole-model forward, the mean ignore-label
     loss within 1e-4, and selected weight gradients of that loss against fp64 autograd through the oracle"""
     from iseg_amd import functional as F
@@ -85,7 +85,13 @@ def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3):
     assert logits.dtype == torch.float32 and tuple(logits.shape) == tuple(ref.shape)
     err = (logits.cpu().double() - ref).abs().max().item()
     assert err < logit_tol, err
-    assert torch.equal(logits.argmax(-1).cpu(), O.argmax_first(ref))
+    differ = logits.argmax(-1).cpu() != O.argmax_first(ref)
+    if bool(differ.any()):
+        # tie_margin > 0 (half a million pixels per image: the x32 bilinear upsampling leaves pixels whose two best classes agree to fp32 rounding): a pixel may
+        # differ only where the ORACLE's own decision is such a tie -- its two largest logits closer than tie_margin
+        top2 = ref.topk(2, dim=-1).values
+        margin = (top2[..., 0] - top2[..., 1])[differ]
+        assert margin.max().item() < tie_margin, (int(differ.sum()), margin.max().item())
     loss_fn = catecrossentropy_ignore_label_loss(num_class=21, ignore_label=255, batch_size=x.shape[0])
     got = float(loss_fn(y.cuda(), logits).mean())
     want = OM.mean_ce_loss(ref, y).item()
@@ -337,8 +343,8 @@ def test_cfg2_benchmark_shape_fp32_gradients_against_the_oracle(cuda):
     model = _flagship((512, 512))
     x, y = synthetic_batch(2, 512, 512, seed=33)
     _whole_model_parity(model, lambda w, t: OM.convnext_aspp_forward(w, t, training=False), x, y,
-                        ["downsample_layers/0/0/kernel", "stages/0/1/dwconv/kernel", "stages/1/2/gamma", "stages/2/4/pwconv1/kernel",
-                         "downsample_layers/3/1/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"])
+                        ["downsample_layers/0/0/kernel", "stages/0/1/dwconv/depthwise_kernel", "stages/1/2/gamma", "stages/2/4/pwconv1/kernel",
+                         "downsample_layers/3/1/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"], tie_margin=1e-5)
 
 
 def test_cfg2_benchmark_shape_bf16_gradients(cuda):

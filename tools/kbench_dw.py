@@ -19,12 +19,14 @@ for (S, C) in [(128, 96), (64, 192), (32, 384), (16, 768)]:
     wd = torch.randn(49, C, device="cuda") / 7; bd = torch.randn(C, device="cuda")
     dwg = torch.zeros(49, C, device="cuda"); dbg = torch.zeros(C, device="cuda")
     f = timeit(lambda: K.dwconv2d(x, wd, bd, 7, 1, 3, 3))
+    g = timeit(lambda: K.dwconv2d(x, wd, None, 7, 1, 3, 3, flip=True, add=x))
     b = timeit(lambda: K.dwconv2d_bwd_weight(x, x, dwg, dbg, 7, 1, 3, 3))
-    out.append(f"S{S}C{C} fwd {f:6.1f} bww {b:6.1f}")
+    out.append(f"S{S}C{C} fwd {f:6.1f} bwd-data {g:6.1f} bww {b:6.1f}")
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
+subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ISEG_DW_MFMA="1", TAG="mfma (dwconv_mfma.hip)"))
 for dma in ("1", "0"):
-    env = dict(os.environ, ISEG_DW_BW_DMA=dma, ISEG_DW_FWD_DMA=dma, TAG=f"dma={dma}")
+    env = dict(os.environ, ISEG_DW_MFMA="0", ISEG_DW_BW_DMA=dma, ISEG_DW_FWD_DMA=dma, TAG=f"valu dma={dma}")
     subprocess.run([sys.executable, "-c", code], env=env)
 for slots in sys.argv[1:]:      # extra arguments: resident-workgroup targets of the DMA-tiled weight gradient (ISEG_DW_BW_DMA_SLOTS)
     env = dict(os.environ, ISEG_DW_BW_DMA_SLOTS=slots, TAG=f"dma=1 bw slots={slots}")
