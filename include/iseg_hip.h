@@ -303,6 +303,19 @@ int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, const u
 /* P masks of n samples each in one launch (s [P, n], keep_probs [P] on the device): the drop_path call sites of one training step */
 int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, const uint64_t* seed_offset, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
+/* EVA-02 (backbones/eva/*).
+ * iseg_qkv_rope: packed attention rows qkv [rows = B * tokens][3 C] = [q | k | v] -> out (out == qkv: in place): q += q_bias, v += v_bias (the fused projection's
+ *   bias [q_bias | 0 | v_bias], attention.py:100-112; either may be NULL), then the rotary embedding on q and k of the tokens t >= prefix
+ *   (apply_rot_embed_cat, rotar_embedding_cat.py:117-135; the class token keeps its values, attention.py:136-146).  emb fp32 [tokens - prefix][2 head_dim]
+ *   = [sin | cos] (RotaryEmbeddingCat.get_embed), NULL = no rotation.  inverse = 1 applies the transposed rotation (the backward pass; pass NULL biases).
+ * iseg_glu_fwd / _bwd: out = act(gate) * x on strided [rows, cols] operands (SwiGLU: two Dense outputs, swiglu.py:88-92; GluMlp: the two column halves
+ *   of one Dense output, glumlp.py:96-103); act = ISEG_ACT_GELU | ISEG_ACT_SWISH | ISEG_ACT_SIGMOID; bwd: dgate = dout x act'(gate), dx = dout act(gate). */
+int iseg_qkv_rope(const void* qkv, void* out, const float* q_bias, const float* v_bias, const float* emb, int64_t rows, int tokens, int prefix, int C, int head_dim,
+                  int inverse, int dtype, iseg_stream_t stream);
+int iseg_glu_fwd(const void* gate, int64_t ld_gate, const void* x, int64_t ld_x, void* out, int64_t ld_out, int64_t rows, int cols, int act, int dtype,
+                 iseg_stream_t stream);
+int iseg_glu_bwd(const void* dout, int64_t ld_dout, const void* gate, int64_t ld_gate, const void* x, int64_t ld_x, void* dgate, int64_t ld_dgate,
+                 void* dx, int64_t ld_dx, int64_t rows, int cols, int act, int dtype, iseg_stream_t stream);
 /* keras.activations.relu / gelu / sigmoid / swish where no GEMM epilogue is available; bwd: dx = dy*act'(aux), aux = pre-activation */
 int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, iseg_stream_t stream);
 int iseg_act_bwd(const void* dy, const void* aux, void* dx, int64_t n, int act, int dtype, iseg_stream_t stream);

@@ -35,6 +35,11 @@ def _builtin_backbones():
     from .intern_image import intern_image_small, intern_image_tiny
     from .vit import ViT16B, ViT16L
 
+    from .eva import EVA02_large_patch14_224, EVA02_large_patch16_224, EVA02_large_patch16_512_COCO, EVA02_large_patch16_512_MV, \
+        EVA02_tiny_patch_14_336
+
+    d.update({ss.EVA02_LARGE: EVA02_large_patch16_224, ss.EVA02_LARGE_P14: EVA02_large_patch14_224, ss.EVA02_TINY: EVA02_tiny_patch_14_336,
+              ss.EVA02_LARGE_COCO: EVA02_large_patch16_512_COCO, ss.EVA02_LARGE_MV: EVA02_large_patch16_512_MV})      # (feature_extractor.py:121-125)
     d.update({ss.SWIN_TINY_224: swin_tiny_224, ss.SWIN_BASE_384: swin_base_384, ss.SWIN_LARGE_384: swin_large_384,
               ss.VIT_B: ViT16B, ss.VIT_L: ViT16L, ss.INTERN_IMAGE_TINY: intern_image_tiny,
               ss.INTERN_IMAGE_SMALL: intern_image_small})

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libiseg_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_nn.hip", "gemm_nt.hip", "gemm_tn.hip", "norm.hip", "dwconv.hip", "dwconv_mfma.hip", "dwconv_strided.hip", "elementwise.hip", "resize.hip", "loss.hip", "optim.hip", "misc.hip", "attention.hip", "dcnv3.hip", "winattn.hip", "flashattn.hip", "mlp_fused.hip", "mlp_wgrad.hip", "conv_igemm.hip", "augment.hip", "grn.hip", "comm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_nn.hip", "gemm_nt.hip", "gemm_tn.hip", "norm.hip", "dwconv.hip", "dwconv_mfma.hip", "dwconv_strided.hip", "elementwise.hip", "resize.hip", "loss.hip", "optim.hip", "misc.hip", "attention.hip", "dcnv3.hip", "winattn.hip", "flashattn.hip", "mlp_fused.hip", "mlp_wgrad.hip", "conv_igemm.hip", "augment.hip", "grn.hip", "eva.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
          "-Wno-unused-result"] + [f"-D{d}" for d in os.environ.get("ISEG_BUILD_DEFINES", "").split() if d]
 

@@ -2032,6 +2032,96 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
                               rate, next_seed() if rate > 0 else 0, int(bias_window))
 
 
+class _QkvRopeFn(Function):
+    """packed attention rows [B, T, 3C]: q += q_bias, v += v_bias, rotary embedding on q and k of the tokens >= prefix -- one pass
+    (csrc/eva.hip; backbones/eva/attention.py:100-112,136-146).  Backward: the transposed rotation in place on the gradient, bias gradients as
+    strided column sums of its q / v blocks."""
+
+    @staticmethod
+    def forward(ctx, qkv, q_bias, v_bias, emb, prefix, heads):
+        B, T, C3 = qkv.shape
+        C = C3 // 3
+        ctx.q_bias, ctx.v_bias, ctx.emb, ctx.geom = q_bias, v_bias, emb, (T, int(prefix), C, C // heads)
+        src = _c(qkv)
+        out = torch.empty_like(src)
+        K.qkv_rope(src, None if q_bias is None else q_bias.data, None if v_bias is None else v_bias.data, emb, T, int(prefix), C, C // heads, out=out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        T, prefix, C, hd = ctx.geom
+        d = _c(d)
+        g = torch.empty_like(d)
+        K.qkv_rope(d, None, None, ctx.emb, T, prefix, C, hd, inverse=True, out=g)
+        d2 = g.reshape(-1, 3 * C)
+        for b, off in ((ctx.q_bias, 0), (ctx.v_bias, 2 * C)):
+            if b is not None and b.requires_grad:
+                K.colsum(d2[:, off:off + C], d2.stride(0), 0, 1, d2.shape[0], C, _grad(b).reshape(-1), accumulate=True)
+        dist.grads_ready(*[b for b in (ctx.q_bias, ctx.v_bias) if b is not None])
+        return g, None, None, None, None, None
+
+
+def qkv_rope(qkv, q_bias, v_bias, emb, prefix, heads):
+    """EVA attention's bias + rotary step on packed [B, T, 3C] rows (emb fp32 [T - prefix, 2 head_dim] or None)"""
+    if nn.dry_run():
+        return qkv
+    if q_bias is None and v_bias is None and emb is None:
+        return qkv
+    return _QkvRopeFn.apply(qkv, q_bias, v_bias, emb, prefix, heads)
+
+
+class _GluFn(Function):
+    """act(gate) * x (backbones/eva/swiglu.py:88-92, glumlp.py:96-103); `packed` [.., 2H] = [x | gate] (gate_last) or [gate | x]"""
+
+    @staticmethod
+    def forward(ctx, gate, x, act, packed_order):
+        if packed_order:      # gate is the packed tensor, x unused
+            H = gate.shape[-1] // 2
+            p2 = _c(gate).reshape(-1, 2 * H)
+            g2, x2 = (p2[:, H:], p2[:, :H]) if packed_order == 1 else (p2[:, :H], p2[:, H:])
+            out_shape = (*gate.shape[:-1], H)
+        else:
+            H = gate.shape[-1]
+            g2, x2 = _c(gate).reshape(-1, H), _c(x).reshape(-1, H)
+            out_shape = gate.shape
+        ctx.act, ctx.packed_order, ctx.in_shape = act, packed_order, gate.shape
+        ctx.save_for_backward(g2, x2)
+        return K.glu_fwd(g2, x2, act).reshape(out_shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g2, x2 = ctx.saved_tensors
+        H = g2.shape[1]
+        d2 = _c(dout).reshape(-1, H)
+        if ctx.packed_order:
+            dp = torch.empty((g2.shape[0], 2 * H), dtype=g2.dtype, device=g2.device)
+            dg, dx = (dp[:, H:], dp[:, :H]) if ctx.packed_order == 1 else (dp[:, :H], dp[:, H:])
+            K.glu_bwd(d2, g2, x2, dg, dx, ctx.act)
+            return dp.reshape(ctx.in_shape), None, None, None
+        dg, dx = torch.empty_like(g2), torch.empty_like(x2)
+        K.glu_bwd(d2, g2, x2, dg, dx, ctx.act)
+        return dg.reshape(ctx.in_shape), dx.reshape(ctx.in_shape), None, None
+
+
+_GLU_ACTS = {"gelu": K.ACT_GELU, "swish": K.ACT_SWISH, "silu": K.ACT_SWISH, "sigmoid": K.ACT_SIGMOID}
+
+
+def glu(gate, x, activation):
+    """activation(gate) * x, both [..., H]"""
+    _check_act_dtype(gate)
+    if nn.dry_run():
+        return _dry(gate.shape, gate)
+    return _GluFn.apply(gate, x, _GLU_ACTS[activation], 0)
+
+
+def glu_packed(packed, activation, gate_last=True):
+    """x1, x2 = split(packed, 2, axis=-1); x1 * activation(x2) if gate_last else activation(x1) * x2   (glumlp.py:96-103)"""
+    _check_act_dtype(packed)
+    if nn.dry_run():
+        return _dry((*packed.shape[:-1], packed.shape[-1] // 2), packed)
+    return _GluFn.apply(packed, None, _GLU_ACTS[activation], 1 if gate_last else 2)
+
+
 class _GatherRowsFn(Function):
     @staticmethod
     def forward(ctx, x, idx_fwd, idx_bwd, out_shape):

@@ -758,6 +758,29 @@ def act_bwd(dy, aux, act):
     return dx
 
 
+def qkv_rope(qkv, q_bias, v_bias, emb, tokens, prefix, C, head_dim, inverse=False, out=None):
+    """packed attention rows [B * tokens, 3 C] (csrc/eva.hip): q / v bias, rotary embedding on q and k of the tokens >= prefix; out=None: in place"""
+    _require_cuda(qkv)
+    out = qkv if out is None else out
+    _hip.call("iseg_qkv_rope", ptr(qkv), ptr(out), ptr(q_bias), ptr(v_bias), ptr(emb), qkv.numel() // (3 * C), tokens, prefix, C, head_dim, int(inverse),
+              dt(qkv), stream())
+    return out
+
+
+def glu_fwd(gate, x, act):
+    """act(gate) * x; gate / x: [rows, cols] views with unit column stride (row strides free)"""
+    rows, cols = gate.shape
+    out = torch.empty((rows, cols), dtype=gate.dtype, device=gate.device)
+    _hip.call("iseg_glu_fwd", ptr(gate), gate.stride(0), ptr(x), x.stride(0), ptr(out), cols, rows, cols, act, dt(gate), stream())
+    return out
+
+
+def glu_bwd(dout, gate, x, dgate, dx, act):
+    rows, cols = gate.shape
+    _hip.call("iseg_glu_bwd", ptr(dout), dout.stride(0), ptr(gate), gate.stride(0), ptr(x), x.stride(0), ptr(dgate), dgate.stride(0), ptr(dx),
+              dx.stride(0), rows, cols, act, dt(gate), stream())
+
+
 def copy2d(src, ld_src, dst, ld_dst, rows, cols):
     _hip.call("iseg_copy2d", ptr(src), ld_src, ptr(dst), ld_dst, rows, cols, dt(src), stream())
     return dst

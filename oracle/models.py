@@ -337,6 +337,112 @@ def vit_forward(w, x, name, num_layer, pretrain_size, patch=16, dp_factors=None)
 
 
 # ------------------------------------------------------------------------------------------------------
+# backbones/eva/*: rotary table (rotar_embedding_cat.py:35-47,50-112,137-171), rot / apply_rot_embed_cat (:117-135), EvaAttention
+# (attention.py:96-178), SwiGLU (swiglu.py:88-100), GluMlp (glumlp.py:96-112), Mlp (mlp.py), EvaBlock (block.py:140-183), Eva (eva.py:226-312)
+# ------------------------------------------------------------------------------------------------------
+def eva_rope_table(h, w, head_dim, temperature=10000.0):
+    """RotaryEmbeddingCat(filters = head_dim, in_pixels=False, feat_shape=None, ref_feat_shape=None)([h, w]): float32 like the reference's tf ops,
+    returned as float64 (sin [h w, head_dim], cos [h w, head_dim]).  numpy on purpose: the product builds its table with torch."""
+    import numpy as np
+
+    nb = head_dim // 4
+    bands = (1.0 / (np.float32(temperature) ** (np.arange(nb, dtype=np.float32) / np.float32(nb)))).astype(np.float32)      # freq_bands(step=1)
+    ty, tx = np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32)
+    grid = np.stack(np.meshgrid(ty, tx, indexing="ij"), axis=-1)[..., None]      # [H, W, 2, 1]
+    pos = (grid * bands).astype(np.float32)                                        # [H, W, 2, nb]
+    sin = np.repeat(np.sin(pos).astype(np.float32).reshape(h * w, -1), 2, axis=-1)      # tf.repeat(repeats=[2], axis=-1)
+    cos = np.repeat(np.cos(pos).astype(np.float32).reshape(h * w, -1), 2, axis=-1)
+    return torch.from_numpy(sin).double(), torch.from_numpy(cos).double()
+
+
+def eva_rot(x):
+    return torch.stack([-x[..., 1::2], x[..., ::2]], dim=-1).reshape(x.shape)
+
+
+def eva_attention(w, p, x, heads, fused, rope, prefix, use_norm):
+    B, T, C = x.shape
+    hd = C // heads
+    if fused:
+        qkv = O.dense(x, w[f"{p}/qkv/kernel"]) + torch.cat([w[f"{p}/q_bias"], torch.zeros_like(w[f"{p}/q_bias"]), w[f"{p}/v_bias"]])
+        qkv = qkv.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+    else:
+        q = O.dense(x, w[f"{p}/q_proj/kernel"], w.get(f"{p}/q_proj/bias")).reshape(B, T, heads, hd).permute(0, 2, 1, 3)
+        k = O.dense(x, w[f"{p}/k_proj/kernel"]).reshape(B, T, heads, hd).permute(0, 2, 1, 3)
+        v = O.dense(x, w[f"{p}/v_proj/kernel"], w.get(f"{p}/v_proj/bias")).reshape(B, T, heads, hd).permute(0, 2, 1, 3)
+    if rope is not None:
+        sin, cos = rope
+        q = torch.cat([q[:, :, :prefix], q[:, :, prefix:] * cos + eva_rot(q[:, :, prefix:]) * sin], dim=2)
+        k = torch.cat([k[:, :, :prefix], k[:, :, prefix:] * cos + eva_rot(k[:, :, prefix:]) * sin], dim=2)
+    a = torch.softmax((q * hd ** -0.5) @ k.transpose(-1, -2), dim=-1)
+    y = (a @ v).permute(0, 2, 1, 3).reshape(B, T, C)
+    if use_norm:
+        y = O.layer_norm(y, w[f"{p}/norm/gamma"], w[f"{p}/norm/beta"], 1e-6)
+    return O.dense(y, w[f"{p}/proj/kernel"], w[f"{p}/proj/bias"])
+
+
+def _eva_act(name):
+    return {"gelu": O.gelu, "swish": lambda t: t * torch.sigmoid(t), "silu": lambda t: t * torch.sigmoid(t), "sigmoid": torch.sigmoid}[name]
+
+
+def eva_mlp(w, p, x, kind, activation="gelu"):
+    """kind: "swiglu" (SwiGLU with LayerNorm, gate activation = the block's activation), "glu" (GluMlp, swish gate on the second half, no norm),
+    "mlp" / "mlp_norm" (Mlp without / with LayerNorm)"""
+    if kind == "swiglu":
+        y = _eva_act(activation)(O.dense(x, w[f"{p}/fc1_g/kernel"], w[f"{p}/fc1_g/bias"])) * O.dense(x, w[f"{p}/fc1_x/kernel"], w[f"{p}/fc1_x/bias"])
+        y = O.layer_norm(y, w[f"{p}/norm/gamma"], w[f"{p}/norm/beta"], 1e-6)
+    elif kind == "glu":
+        y = O.dense(x, w[f"{p}/fc1/kernel"], w[f"{p}/fc1/bias"])
+        h = y.shape[-1] // 2
+        y = y[..., :h] * _eva_act("swish")(y[..., h:])
+    else:
+        y = _eva_act(activation)(O.dense(x, w[f"{p}/fc1/kernel"], w[f"{p}/fc1/bias"]))
+        if kind == "mlp_norm":
+            y = O.layer_norm(y, w[f"{p}/norm/gamma"], w[f"{p}/norm/beta"], 1e-6)
+    return O.dense(y, w[f"{p}/fc2/kernel"], w[f"{p}/fc2/bias"])
+
+
+def eva_block(w, p, x, heads, fused, rope, prefix, mlp_kind, scale_attention_inner=False, post_norm=False, activation="gelu", dp=None):
+    residual = x
+    y = x if post_norm else O.layer_norm(x, w[f"{p}/norm1/gamma"], w[f"{p}/norm1/beta"], 1e-6)
+    y = eva_attention(w, f"{p}/attn", y, heads, fused, rope, prefix, scale_attention_inner)
+    if post_norm:
+        y = O.layer_norm(y, w[f"{p}/norm1/gamma"], w[f"{p}/norm1/beta"], 1e-6)
+    if f"{p}/gamma_1" in w:
+        y = y * w[f"{p}/gamma_1"]
+    if dp is not None:
+        y = y * dp.reshape(-1, 1, 1)
+    x = residual = y + residual
+    y = x if post_norm else O.layer_norm(x, w[f"{p}/norm2/gamma"], w[f"{p}/norm2/beta"], 1e-6)
+    y = eva_mlp(w, f"{p}/mlp", y, mlp_kind, activation)
+    if post_norm:
+        y = O.layer_norm(y, w[f"{p}/norm2/gamma"], w[f"{p}/norm2/beta"], 1e-6)
+    if f"{p}/gamma_2" in w:
+        y = y * w[f"{p}/gamma_2"]
+    return y + residual      # (block.py:180-181: no drop path on the second branch)
+
+
+def eva_forward(w, x, name, depth, heads, patch, fused, mlp_kind, grid_size, scale_attention_inner=False, post_norm=False, activation="gelu",
+                dp_factors=None):
+    """Eva.call with return_endpoints=True: [class_token, patch_embedding, block outputs ...]; grid_size = the token grid the position embedding
+    was built for (it is resampled bilinearly to this call's grid)"""
+    x = O.conv2d(x, w[f"{name}/patch_embed/projection/kernel"], w[f"{name}/patch_embed/projection/bias"], patch, 1, "valid")
+    patch_embedding = x
+    N, H, W, C = x.shape
+    sin, cos = eva_rope_table(H, W, C // heads)
+    x = torch.cat([w[f"{name}/class_token"].expand(N, 1, C), x.reshape(N, H * W, C)], dim=1)
+    pos = w[f"{name}/pos_embed"]
+    grid = O.resize_bilinear(pos[:, 1:].reshape(1, grid_size[0], grid_size[1], C), (H, W)).reshape(1, H * W, C)
+    x = x + torch.cat([pos[:, :1], grid], dim=1)
+    ends = []
+    for i in range(depth):
+        x = eva_block(w, f"{name}/blocks/{i}", x, heads, fused, (sin, cos), 1, mlp_kind, scale_attention_inner, post_norm, activation,
+                      None if dp_factors is None else dp_factors[i])
+        ends.append(x[:, 1:].reshape(N, H, W, C))
+    return [x[:, :1], patch_embedding] + ends
+
+
+# ------------------------------------------------------------------------------------------------------
 # backbones/swin.py: window_partition/reverse :46-64, WindowAttention :117-167, block :237-294, PatchMerging :309-337,
 # mask :391-433, PatchEmbed :479-501, model :601-622
 # ------------------------------------------------------------------------------------------------------

@@ -336,3 +336,23 @@ def test_gelu_two_coefficient_sigmoid_pair_meets_the_gate():
     dy = s + y * (1 - s) * (a0 + 3 * a1 * x * x)
     assert np.abs(y - x * Phi).max() < 1e-3           # 2.7e-4
     assert np.abs(dy - dg).max() < 2e-3               # 8.7e-4
+
+
+def test_eva_rotary_table_known_values_and_the_products_table():
+    """RotaryEmbeddingCat(in_pixels=False) (backbones/eva/rotar_embedding_cat.py:35-47,137-171): angle of token (y, x), band i = coordinate /
+    10000^(i / nb) with nb = head_dim / 4; layout [y-bands | x-bands], every entry twice; the product's torch table agrees with the oracle's numpy one"""
+    from iseg_amd.backbones.eva.rotar_embedding_cat import RotaryEmbeddingCat
+    from oracle import models as OM
+
+    sin, cos = OM.eva_rope_table(3, 4, 16)      # nb = 4
+    assert tuple(sin.shape) == (12, 16)
+    assert sin[0].abs().max().item() == 0 and (cos[0] - 1).abs().max().item() == 0           # token (0, 0)
+    t = 1 * 4 + 2                                                                               # token (y = 1, x = 2)
+    want_y = [math.sin(1 / 10000 ** (i / 4)) for i in range(4)]
+    want_x = [math.sin(2 / 10000 ** (i / 4)) for i in range(4)]
+    assert sin[t, 0:8:2].tolist() == pytest.approx(want_y, abs=1e-6) and sin[t, 1:8:2].tolist() == pytest.approx(want_y, abs=1e-6)
+    assert sin[t, 8:16:2].tolist() == pytest.approx(want_x, abs=1e-6)
+    table = RotaryEmbeddingCat(filters=16, in_pixels=False).get_embed_host([3, 4])
+    assert (table.double() - torch.cat([sin, cos], dim=-1)).abs().max().item() < 2e-6
+    x = torch.arange(8, dtype=torch.float64).reshape(1, 8)
+    assert OM.eva_rot(x).tolist() == [[-1.0, 0.0, -3.0, 2.0, -5.0, 4.0, -7.0, 6.0]]              # rot (:117-125)
