@@ -303,6 +303,14 @@ int iseg_drop_path_mask(float* s, int n, float keep_prob, uint64_t seed, const u
 /* P masks of n samples each in one launch (s [P, n], keep_probs [P] on the device): the drop_path call sites of one training step */
 int iseg_drop_path_masks(float* s, const float* keep_probs, int P, int n, uint64_t seed, const uint64_t* seed_offset, iseg_stream_t stream);
 int iseg_fill_f32(float* p, float value, int64_t n, iseg_stream_t stream);
+/* DCNv2's sampling half (layers/dcn_v2.py:114-229; FaPN's FeatureAlignment, layers/fapn.py:44-80): offset [N,H,W,27] = the offset convolution's output
+ * (9 x (dy, dx), then 9 mask logits); col [N,H,W,9,C] = sigmoid(logit_p) * bilinear sample of x (zero-padded by 1) at (h + ky + dy_p, w + kx + dx_p), with the
+ * reference's clipping of the position and both corners to [0, H+1] x [0, W+1] and weights from the clipped values.  The layer's output is then the GEMM
+ * col [N H W, 9 C] x kernel [9 C, filters] (:230-240).  bwd: dx fp32 (64-bit fixed-point accumulation: deterministic), doffset [N,H,W,27] in storage type. */
+int iseg_dcnv2_sample_fwd(const void* x, const void* offset, void* col, int N, int H, int W, int C, int dtype, iseg_stream_t stream);
+size_t iseg_dcnv2_sample_bwd_workspace_bytes(int N, int H, int W, int C);
+int iseg_dcnv2_sample_bwd(const void* x, const void* offset, const void* dcol, float* dx_f32, void* doffset, int N, int H, int W, int C, int dtype,
+                          void* ws, size_t ws_bytes, iseg_stream_t stream);
 /* EVA-02 (backbones/eva/*).
  * iseg_qkv_rope: packed attention rows qkv [rows = B * tokens][3 C] = [q | k | v] -> out (out == qkv: in place): q += q_bias, v += v_bias (the fused projection's
  *   bias [q_bias | 0 | v_bias], attention.py:100-112; either may be NULL), then the rotary embedding on q and k of the tokens t >= prefix

@@ -68,6 +68,9 @@ SIGNATURES = {
     "iseg_layernorm_gather_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "iseg_layernorm_gather_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _i, _p, _z, _p]),
     "iseg_dwconv2d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "iseg_dcnv2_sample_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "iseg_dcnv2_sample_bwd_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "iseg_dcnv2_sample_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "iseg_qkv_rope": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _i, _p]),
     "iseg_glu_fwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
     "iseg_glu_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),

@@ -1070,3 +1070,175 @@ extern "C" int iseg_scale_cols(const void* x, const float* colscale, void* y, in
                            C);
     return iseg_check_launch("iseg_scale_cols");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// DCNv2 (layers/dcn_v2.py:16-281 of the reference, the deformable convolution of FaPN's FeatureAlignment, layers/fapn.py:44-80): the sampling half.
+//   off [N, H, W, 27] = the offset convolution's output: 9 x (dy, dx) then 9 mask logits (:114-137, deformable_groups = 1)
+//   col [N, H, W, 9, C]: col[.., p, :] = sigmoid(logit_p) * bilinear(x zero-padded by 1, (h + ky + dy_p, w + kx + dx_p))     p = 3 ky + kx
+// with the reference's arithmetic: the sampling position, its floor and floor + 1 are all clipped to [0, H + 1] x [0, W + 1] (padded coordinates), and
+// the four weights come from the CLIPPED values (:150-189); the convolution itself is then one GEMM col [N H W, 9 C] x kernel [9 C, filters]
+// (:230-240).  Coordinates and weights in fp32 whatever the storage type (as DCNv3 here).  Backward: d offset / d logit per (pixel, point) by a lane-group
+// sum over the channels; dx by 64-bit fixed-point atomics (order-free, bit-reproducible) into a zeroed accumulator, converted by dcn_unfix_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Dcn2Tap {
+    int y0, y1, x0, x1;                      // clipped corners, UNPADDED coordinates (-1 and H / W are the zero border)
+    float d0y, d0x, d1y, d1x;                // gy - y0, gx - x0, y1 - gy, x1 - gx   (clipped values)
+    float m, in_y, in_x;                     // sigmoid(logit); 1 where the unclipped position lies inside the clip range (tf.clip_by_value's gradient)
+};
+
+template <class T>
+__device__ __forceinline__ Dcn2Tap dcn2_tap(const T* __restrict__ off, int h, int w, int p, int H, int W) {
+    const float oy = to_f32(off[2 * p]), ox = to_f32(off[2 * p + 1]);
+    const float gy_u = (float)(h + p / 3) + oy, gx_u = (float)(w + p % 3) + ox;      // (h + ph) + (ky - ph) + dy, padded coordinates
+    const float hy = (float)(H + 1), hx = (float)(W + 1);
+    Dcn2Tap t;
+    t.in_y = gy_u >= 0.f && gy_u <= hy ? 1.f : 0.f;
+    t.in_x = gx_u >= 0.f && gx_u <= hx ? 1.f : 0.f;
+    const float fy = floorf(gy_u), fx = floorf(gx_u);
+    const float y1 = fminf(fmaxf(fy + 1.f, 0.f), hy), x1 = fminf(fmaxf(fx + 1.f, 0.f), hx);
+    const float y0 = fminf(fmaxf(fy, 0.f), hy), x0 = fminf(fmaxf(fx, 0.f), hx);
+    const float gy = fminf(fmaxf(gy_u, 0.f), hy), gx = fminf(fmaxf(gx_u, 0.f), hx);
+    t.d0y = gy - y0;
+    t.d0x = gx - x0;
+    t.d1y = y1 - gy;
+    t.d1x = x1 - gx;
+    t.y0 = (int)y0 - 1;
+    t.y1 = (int)y1 - 1;
+    t.x0 = (int)x0 - 1;
+    t.x1 = (int)x1 - 1;
+    t.m = 1.f / (1.f + expf(-to_f32(off[18 + p])));
+    return t;
+}
+
+// one thread = (pixel, point, 8 channels)
+template <class T>
+__global__ __launch_bounds__(256) void dcnv2_sample_fwd_kernel(const T* __restrict__ x, const T* __restrict__ off, T* __restrict__ col, int N, int H, int W,
+                                                               int C) {
+    const int cv = C / 8;
+    const int64_t total = (int64_t)N * H * W * 9 * cv;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % cv) * 8;
+        int64_t t = i / cv;
+        const int p = (int)(t % 9);
+        const int64_t pix = t / 9;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H);
+        const int64_t n = pix / ((int64_t)W * H);
+        const Dcn2Tap tp = dcn2_tap(off + pix * 27, h, w, p, H, W);
+        // corners in the reference's order (:167-173): (y1, x1), (y1, x0), (y0, x1), (y0, x0) with weights d0y d0x, d0y d1x, d1y d0x, d1y d1x
+        const int ys[4] = {tp.y1, tp.y1, tp.y0, tp.y0}, xs[4] = {tp.x1, tp.x0, tp.x1, tp.x0};
+        const float ws4[4] = {tp.d0y * tp.d0x, tp.d0y * tp.d1x, tp.d1y * tp.d0x, tp.d1y * tp.d1x};
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((unsigned)ys[k] < (unsigned)H && (unsigned)xs[k] < (unsigned)W) {
+                float v[8];
+                load8<T>(x + ((n * H + ys[k]) * W + xs[k]) * C + c, v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = fmaf(ws4[k], v[u], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] *= tp.m;
+        store8<T>(col + (pix * 9 + p) * C + c, acc);
+    }
+}
+
+// LC lanes per (pixel, point): each walks its 8-channel chunks; d offset / d logit meet by a lane-group sum
+template <class T, int LC>
+__global__ __launch_bounds__(256) void dcnv2_sample_bwd_kernel(const T* __restrict__ x, const T* __restrict__ off, const T* __restrict__ dcol,
+                                                               unsigned long long* __restrict__ dx, T* __restrict__ doff, int N, int H, int W, int C) {
+    const int64_t total = (int64_t)N * H * W * 9 * LC;
+    const int cv = C / 8;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < (total + 255) / 256 * 256; i += (int64_t)gridDim.x * 256) {
+        const bool live = i < total;
+        const int64_t ii = live ? i : total - 1;
+        const int lc = (int)(ii % LC);
+        const int64_t t = ii / LC;
+        const int p = (int)(t % 9);
+        const int64_t pix = t / 9;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H);
+        const int64_t n = pix / ((int64_t)W * H);
+        const Dcn2Tap tp = dcn2_tap(off + pix * 27, h, w, p, H, W);
+        const int ys[4] = {tp.y1, tp.y1, tp.y0, tp.y0}, xs[4] = {tp.x1, tp.x0, tp.x1, tp.x0};
+        const float ws4[4] = {tp.d0y * tp.d0x, tp.d0y * tp.d1x, tp.d1y * tp.d0x, tp.d1y * tp.d1x};
+        // d bilinear / d gy = d0x (v11 - v01) + d1x (v10 - v00);  d / d gx = d0y (v11 - v10) + d1y (v01 - v00)
+        const float wy[4] = {tp.d0x, tp.d1x, -tp.d0x, -tp.d1x}, wx[4] = {tp.d0y, -tp.d0y, tp.d1y, -tp.d1y};
+        float g_m = 0.f, g_y = 0.f, g_x = 0.f;
+        for (int cc = lc; cc < cv && live; cc += LC) {
+            const int c = cc * 8;
+            float d[8];
+            load8<T>(dcol + (pix * 9 + p) * C + c, d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((unsigned)ys[k] < (unsigned)H && (unsigned)xs[k] < (unsigned)W) {
+                    const int64_t src = ((n * H + ys[k]) * W + xs[k]) * C + c;
+                    float v[8];
+                    load8<T>(x + src, v);
+                    float dot = 0.f;
+                    const float coef = tp.m * ws4[k] * DCN_FIX;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        dot = fmaf(d[u], v[u], dot);
+                        atomicAdd(dx + src + u, dcn_to_fixed(d[u] * coef));
+                    }
+                    g_m = fmaf(ws4[k], dot, g_m);
+                    g_y = fmaf(wy[k], dot, g_y);
+                    g_x = fmaf(wx[k], dot, g_x);
+                }
+            }
+        }
+        g_m = group_sum(g_m, LC);
+        g_y = group_sum(g_y, LC);
+        g_x = group_sum(g_x, LC);
+        if (live && lc == 0) {
+            T* o = doff + pix * 27;
+            o[2 * p] = from_f32<T>(g_y * tp.m * tp.in_y);
+            o[2 * p + 1] = from_f32<T>(g_x * tp.m * tp.in_x);
+            o[18 + p] = from_f32<T>(g_m * tp.m * (1.f - tp.m));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int iseg_dcnv2_sample_fwd(const void* x, const void* offset, void* col, int N, int H, int W, int C, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(x && offset && col && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "iseg_dcnv2_sample_fwd: bad arguments (C = %d must be a multiple of 8)", C);
+    ISEG_REQUIRE((int64_t)N * H * W * 9 * C < (1ll << 40), "iseg_dcnv2_sample_fwd: tensor too large");
+    const int64_t lanes = (int64_t)N * H * W * 9 * (C / 8);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((dcnv2_sample_fwd_kernel<bf16_t>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)offset, (bf16_t*)col,
+                           N, H, W, C);
+    else
+        hipLaunchKernelGGL((dcnv2_sample_fwd_kernel<float>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const float*)x, (const float*)offset, (float*)col, N,
+                           H, W, C);
+    return iseg_check_launch("iseg_dcnv2_sample_fwd");
+}
+
+extern "C" size_t iseg_dcnv2_sample_bwd_workspace_bytes(int N, int H, int W, int C) {
+    return ((size_t)N * H * W * C * sizeof(unsigned long long) + 15) / 16 * 16;
+}
+
+extern "C" int iseg_dcnv2_sample_bwd(const void* x, const void* offset, const void* dcol, float* dx_f32, void* doffset, int N, int H, int W, int C,
+                                     int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    ISEG_REQUIRE(x && offset && dcol && dx_f32 && doffset && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "iseg_dcnv2_sample_bwd: bad arguments");
+    const size_t need = iseg_dcnv2_sample_bwd_workspace_bytes(N, H, W, C);
+    if (!ws || ws_bytes < need) {
+        iseg_set_error("iseg_dcnv2_sample_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const int64_t nel = (int64_t)N * H * W * C, n16 = (int64_t)(need / 16);
+    unsigned long long* acc = (unsigned long long*)ws;
+    hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)ws, n16);
+    constexpr int LC = 8;
+    const int64_t lanes = (int64_t)N * H * W * 9 * LC;
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL((dcnv2_sample_bwd_kernel<bf16_t, LC>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)offset,
+                           (const bf16_t*)dcol, acc, (bf16_t*)doffset, N, H, W, C);
+    else
+        hipLaunchKernelGGL((dcnv2_sample_bwd_kernel<float, LC>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const float*)x, (const float*)offset,
+                           (const float*)dcol, acc, (float*)doffset, N, H, W, C);
+    hipLaunchKernelGGL(dcn_unfix_kernel, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel);
+    return iseg_check_launch("iseg_dcnv2_sample_bwd");
+}

@@ -2032,6 +2032,30 @@ def attention_packed(qkv, heads, Cq, Cv, scale, *, bias_table=None, bias_index=N
                               rate, next_seed() if rate > 0 else 0, int(bias_window))
 
 
+class _Dcnv2SampleFn(Function):
+    """DCNv2's modulated deformable sampling (layers/dcn_v2.py:114-229): x [N,H,W,C], offset [N,H,W,27] -> [N,H,W,9 C]"""
+
+    @staticmethod
+    def forward(ctx, x, offset):
+        xc, oc = _c(x), _c(offset)
+        ctx.save_for_backward(xc, oc)
+        N, H, W, C = xc.shape
+        return K.dcnv2_sample_fwd(xc, oc).reshape(N, H, W, 9 * C)
+
+    @staticmethod
+    def backward(ctx, dcol):
+        xc, oc = ctx.saved_tensors
+        dx, doff = K.dcnv2_sample_bwd(xc, oc, _c(dcol))
+        return (dx if xc.dtype == torch.float32 else K.cast(dx, xc.dtype)), doff
+
+
+def dcnv2_sample(x, offset):
+    _check_act_dtype(x)
+    if nn.dry_run():
+        return _dry((*x.shape[:3], 9 * x.shape[3]), x)
+    return _Dcnv2SampleFn.apply(x, offset)
+
+
 class _QkvRopeFn(Function):
     """packed attention rows [B, T, 3C]: q += q_bias, v += v_bias, rotary embedding on q and k of the tokens >= prefix -- one pass
     (csrc/eva.hip; backbones/eva/attention.py:100-112,136-146).  Backward: the transposed rotation in place on the gradient, bias gradients as

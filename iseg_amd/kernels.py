@@ -758,6 +758,24 @@ def act_bwd(dy, aux, act):
     return dx
 
 
+def dcnv2_sample_fwd(x, offset):
+    """x [N,H,W,C], offset [N,H,W,27] -> col [N,H,W,9,C] (csrc/dcnv3.hip dcnv2_sample_*; layers/dcn_v2.py:114-229)"""
+    _require_cuda(x, offset)
+    N, H, W, Cc = x.shape
+    col = torch.empty((N, H, W, 9, Cc), dtype=x.dtype, device=x.device)
+    _hip.call("iseg_dcnv2_sample_fwd", ptr(x), ptr(offset), ptr(col), N, H, W, Cc, dt(x), stream())
+    return col
+
+
+def dcnv2_sample_bwd(x, offset, dcol):
+    N, H, W, Cc = x.shape
+    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
+    doff = torch.empty_like(offset)
+    ws, wsb = workspace(_hip.lib().iseg_dcnv2_sample_bwd_workspace_bytes(N, H, W, Cc), x.device)
+    _hip.call("iseg_dcnv2_sample_bwd", ptr(x), ptr(offset), ptr(dcol), ptr(dx), ptr(doff), N, H, W, Cc, dt(x), ptr(ws), wsb, stream())
+    return dx, doff
+
+
 def qkv_rope(qkv, q_bias, v_bias, emb, tokens, prefix, C, head_dim, inverse=False, out=None):
     """packed attention rows [B * tokens, 3 C] (csrc/eva.hip): q / v bias, rotary embedding on q and k of the tokens >= prefix; out=None: in place"""
     _require_cuda(qkv)

@@ -295,6 +295,33 @@ def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_f
     return out
 
 
+def se_module(w, p, x, bias=True, activation=torch.relu):
+    """layers/se.py:33-47"""
+    g = x.mean(dim=(1, 2), keepdim=True)
+    g = activation(O.conv2d(g, w[f"{p}/down_conv/kernel"], w.get(f"{p}/down_conv/bias") if bias else None, 1, 1, "valid"))
+    g = torch.sigmoid(O.conv2d(g, w[f"{p}/expand_conv/kernel"], w.get(f"{p}/expand_conv/bias") if bias else None, 1, 1, "valid"))
+    return g * x
+
+
+def fapn_forward(w, name, feats):
+    """layers/fapn.py:13-140: FeatureAlignedPyramidNet(warp_coarse_feature=False) on feats (fine -> coarse); returns all levels fine -> coarse"""
+    x = feats[-1]
+    out = [x]
+    for i in range(len(feats) - 2, -1, -1):
+        p = f"{name}/skip_conv_filters{i}"
+        large = feats[i]
+        up = O.resize_bilinear(x, (large.shape[1], large.shape[2]))
+        arm = se_module(w, f"{p}/lateral_conv", large, bias=False) + large                  # FeatureSelectionModule :31-41
+        arm = O.conv2d(arm, w[f"{p}/lateral_conv/conv/kernel"], None, 1, 1, "valid")
+        offset = O.conv2d(torch.cat([arm, up * 2], dim=-1), w[f"{p}/offset_conv/kernel"], None, 1, 1, "valid")
+        d = f"{p}/depack_l2"
+        align = torch.relu(O.dcnv2(up, offset, w[f"{d}/kernel"], w[f"{d}/bias"], w[f"{d}/offset_kernel"], w[f"{d}/offset_bias"]))
+        x = align + arm
+        out.append(x)
+    out.reverse()
+    return out
+
+
 def axial_attention_layer(w, prefix, x, heads, shared_qk=False):
     """layers/multihead_axial_attention.py:149-172"""
     def conv1x1(name, t):

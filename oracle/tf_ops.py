@@ -589,3 +589,38 @@ def photometric_sequence(x, brightness_delta=0.0, contrast=1.0, saturation=1.0, 
             x = adjust_saturation(x, saturation)
         x = np.clip(adjust_hue(x, hue), 0.0, 256.0)       # (RandomHueAugment clips too: the same clip twice)
     return x
+
+
+def dcnv2(x, offset_in, kernel, bias, offset_kernel, offset_bias, dilation=1):
+    """layers/dcn_v2.py:110-262 (_forward) op for op: offset convolution, (dy, dx) + sigmoid mask per kernel point, the position and its two integer
+    corners clipped to the zero-padded image [0, H + 1] x [0, W + 1], the four bilinear weights from the CLIPPED values in the order
+    (y1, x1), (y1, x0), (y0, x1), (y0, x0), gather, modulate, and one product with the [kh kw C, filters] kernel."""
+    kh, kw = kernel.shape[0], kernel.shape[1]
+    ks, ph, pw = kh * kw, (kh - 1) // 2, (kw - 1) // 2
+    off = conv2d(offset_in, offset_kernel, offset_bias, 1, dilation, "same")                 # :114-121
+    B, H, W, C = x.shape
+    oyox = off[..., :2 * ks].reshape(B, H, W, ks, 2)
+    mask = torch.sigmoid(off[..., 2 * ks:])                                                  # :135-137
+    ys, xs = torch.arange(H, dtype=x.dtype), torch.arange(W, dtype=x.dtype)
+    grid = torch.stack(torch.meshgrid(ys, xs, indexing="ij"), dim=-1).reshape(1, H, W, 1, 2)      # (y, x)
+    patch = torch.stack(torch.meshgrid(torch.arange(-ph, ph + 1, dtype=x.dtype), torch.arange(-pw, pw + 1, dtype=x.dtype), indexing="ij"),
+                        dim=-1).reshape(ks, 2)                                               # :98-103: row-major (ky, kx)
+    g = grid + torch.tensor([ph, pw], dtype=x.dtype) + patch + oyox                          # :139-147
+    hi = torch.tensor([H + 1, W + 1], dtype=x.dtype)
+    lo = torch.zeros(2, dtype=x.dtype)
+    f = torch.floor(g)
+    i1 = torch.minimum(torch.maximum(f + 1, lo), hi)                                         # :150-156
+    i0 = torch.minimum(torch.maximum(f, lo), hi)                                             # :160
+    gc = torch.minimum(torch.maximum(g, lo), hi)                                             # :164
+    d0, d1 = gc - i0, i1 - gc                                                                # :182-183
+    wts = torch.stack([d0[..., 0] * d0[..., 1], d0[..., 0] * d1[..., 1], d1[..., 0] * d0[..., 1], d1[..., 0] * d1[..., 1]], dim=-1)      # :185-199
+    xp = torch.nn.functional.pad(x, (0, 0, pw, pw, ph, ph))                                  # :201
+    corners = [(i1[..., 0], i1[..., 1]), (i1[..., 0], i0[..., 1]), (i0[..., 0], i1[..., 1]), (i0[..., 0], i0[..., 1])]      # :167-173
+    bidx = torch.arange(B).reshape(B, 1, 1, 1).expand(B, H, W, ks)
+    col = torch.zeros((B, H, W, ks, C), dtype=x.dtype)
+    for k, (cy, cx) in enumerate(corners):
+        col = col + wts[..., k:k + 1] * xp[bidx, cy.long(), cx.long()]
+    col = col * mask.unsqueeze(-1)
+    out = col.reshape(B, H * W, ks * C) @ kernel.reshape(ks * C, -1)                         # :230-240
+    out = out.reshape(B, H, W, -1)
+    return out if bias is None else out + bias

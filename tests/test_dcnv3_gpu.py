@@ -170,3 +170,99 @@ def test_dcnv3_general_backward_is_bit_identical_and_right(cuda, dtype, shape, G
     close(outs[0][2], mr.grad, dtype, "dcnv3 dmask", f32_tol=2e-5, bf16_tol=2e-2)
     for o in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
+
+
+# ---- DCNv2 / FaPN (layers/dcn_v2.py, layers/fapn.py; round 5) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,W,C,Fo,custom", [(2, 9, 7, 16, 24, True), (1, 12, 12, 32, 32, False), (2, 5, 6, 8, 16, True)])
+def test_dcnv2_layer_forward_and_gradients(cuda, dtype, N, H, W, C, Fo, custom):
+    """DCNv2 (modulated deformable sampling kernels + offset convolution + one GEMM) against the op-for-op restatement of layers/dcn_v2.py:110-262:
+    offsets large enough to leave the image (the clipped-corner weights and the zero border take part), output, input / offset-input gradients and
+    every parameter gradient.  bf16: offsets land on cell borders where the offset gradient is discontinuous -- direction / size band only."""
+    from iseg_amd import nn
+    from iseg_amd.layers.dcn_v2 import DCNv2
+    from iseg_amd.param_store import ParamStore
+    from oracle import models as OM
+    from oracle import tf_ops as O
+    from tests.util_models import randomize_parameters
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn((N, H, W, C), generator=g).to(dtype)
+        o = (torch.randn((N, H, W, C), generator=g) * 1.5).to(dtype)
+        layer = DCNv2(Fo, (3, 3), use_custom_offset=custom, activation="relu", name="dcn")
+        ins = [torch.empty((N, H, W, C), dtype=dtype, device="cuda")] * 2 if custom else torch.empty((N, H, W, C), dtype=dtype, device="cuda")
+        with nn.dry_run_scope():
+            layer(ins)
+        layer._iseg_store = ParamStore(list(layer.parameters()))
+        randomize_parameters(layer, 5)
+        xg, og = x.cuda().requires_grad_(True), o.cuda().requires_grad_(True)
+        y = layer([xg, og]) if custom else layer(xg)
+        w = {k: v.requires_grad_(True) for k, v in OM.export_weights(layer).items()}
+        xr, orr = x.double().requires_grad_(True), o.double().requires_grad_(True)
+        yr = torch.relu(O.dcnv2(xr, orr if custom else xr, w["dcn/kernel"], w["dcn/bias"], w["dcn/offset_kernel"], w["dcn/offset_bias"]))
+        f32 = dtype == torch.float32
+        scale = yr.abs().max().item()
+        assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < (2e-5 if f32 else 4e-2) * scale
+        dy = torch.randn(tuple(yr.shape), generator=g).to(dtype)
+        y.backward(dy.cuda())
+        yr.backward(dy.double())
+
+        def rel(a, b):
+            return (a.detach().cpu().double() - b).norm().item() / max(b.norm().item(), 1e-12)
+
+        tol = 2e-4 if f32 else 0.25
+        assert rel(xg.grad, xr.grad) < tol
+        if custom:
+            assert rel(og.grad, orr.grad) < tol
+        for p in layer.parameters():
+            assert rel(p.grad, w[p.iseg_name].grad) < tol, p.iseg_name
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fapn_decoder_matches_oracle(cuda, dtype):
+    """FeatureAlignedPyramidNet (layers/fapn.py:83-140) on three pyramid levels: squeeze-and-excitation gate + projection of the skip, bilinear
+    up-sampling of the coarser level, offsets from both, DCNv2 alignment, relu, sum -- every level and (fp32) every gradient"""
+    from iseg_amd import nn
+    from iseg_amd.layers.fapn import FeatureAlignedPyramidNet
+    from iseg_amd.param_store import ParamStore
+    from oracle import models as OM
+    from tests.util_models import randomize_parameters
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        shapes = [(2, 16, 20, 24), (2, 8, 10, 40), (2, 4, 5, 32)]      # the coarsest level already has skip_conv_filters channels
+        fapn = FeatureAlignedPyramidNet(skip_conv_filters=32, name="fapn")
+        with nn.dry_run_scope():
+            fapn([torch.empty(s, dtype=dtype, device="cuda") for s in shapes])
+        fapn._iseg_store = ParamStore(list(fapn.parameters()))
+        randomize_parameters(fapn, 9)
+        g = torch.Generator().manual_seed(1)
+        xs = [torch.randn(s, generator=g).to(dtype) for s in shapes]
+        xg = [t.cuda().requires_grad_(True) for t in xs]
+        outs = fapn(xg, training=False)
+        w = {k: v.requires_grad_(True) for k, v in OM.export_weights(fapn).items()}
+        xr = [t.double().requires_grad_(True) for t in xs]
+        ref = OM.fapn_forward(w, "fapn", xr)
+        assert len(outs) == len(ref) == 3 and tuple(outs[0].shape) == (2, 16, 20, 32)
+        f32 = dtype == torch.float32
+        for a, b in zip(outs, ref):
+            assert (a.detach().cpu().double() - b.detach()).abs().max().item() < (5e-5 if f32 else 6e-2) * b.abs().max().item()
+        dy = torch.randn(tuple(ref[0].shape), generator=g).to(dtype)
+        outs[0].backward(dy.cuda())
+        ref[0].backward(dy.double())
+        if f32:
+            for a, b in zip(xg, xr):
+                assert (a.grad.cpu().double() - b.grad).norm().item() < 5e-4 * b.grad.norm().item()
+            for p in fapn.parameters():
+                r = w[p.iseg_name].grad
+                assert (p.grad.cpu().double() - r).norm().item() < 1e-3 * max(r.norm().item(), 1e-9), p.iseg_name
+        else:
+            assert all(torch.isfinite(a.grad.float()).all() for a in xg)
+    finally:
+        nn.set_compute_dtype(torch.float32)

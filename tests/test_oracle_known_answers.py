@@ -356,3 +356,21 @@ def test_eva_rotary_table_known_values_and_the_products_table():
     assert (table.double() - torch.cat([sin, cos], dim=-1)).abs().max().item() < 2e-6
     x = torch.arange(8, dtype=torch.float64).reshape(1, 8)
     assert OM.eva_rot(x).tolist() == [[-1.0, 0.0, -3.0, 2.0, -5.0, 4.0, -7.0, 6.0]]              # rot (:117-125)
+
+
+def test_dcnv2_restatement_reduces_to_half_a_convolution_at_zero_offsets():
+    """layers/dcn_v2.py: offset_kernel / offset_bias are zero-initialised (:80-94), so a fresh DCNv2 samples the undeformed 3 x 3 patch with mask
+    sigmoid(0) = 1/2 -- exactly half of Conv2D(padding="same") with the same kernel; an offset of (+1, 0) on every point reads one row further down"""
+    from oracle import tf_ops as OO
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 6, 7, 4), generator=g, dtype=torch.float64)
+    k = torch.randn((3, 3, 4, 5), generator=g, dtype=torch.float64)
+    b = torch.randn((5,), generator=g, dtype=torch.float64)
+    zk, zb = torch.zeros((3, 3, 4, 27), dtype=torch.float64), torch.zeros(27, dtype=torch.float64)
+    assert torch.allclose(OO.dcnv2(x, x, k, b, zk, zb), 0.5 * OO.conv2d(x, k, None, 1, 1, "same") + b, atol=1e-12)
+    ob = zb.clone()
+    ob[0:18:2] = 1.0      # dy = +1 for all nine points
+    # tap (ky, kx) of output row h then reads x[h + ky] (zero past the last row): a "valid" convolution of x padded by 0 / 2 rows and 1 / 1 columns
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 0, 2))
+    assert torch.allclose(OO.dcnv2(x, x, k, None, zk, ob), 0.5 * OO.conv2d(xp, k, None, 1, 1, "valid"), atol=1e-12)
