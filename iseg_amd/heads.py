@@ -58,6 +58,22 @@ class FPNHead(Layer):
         return self.end_conv(levels[0], training=training)
 
 
+class FaPNHead(Layer):
+    """FeatureAlignedPyramidNet (layers/fapn.py:83-140) in the place of FPN: the coarsest endpoint must already carry `top_filters` channels
+    (warp_coarse_feature=False), every finer level is aligned to it through DCNv2 -> finest level -> ConvNormAct(256, 1x1)."""
+
+    def __init__(self, top_filters, filters=256, name="fapn_head"):
+        super().__init__(name=name)
+        from .layers.fapn import FeatureAlignedPyramidNet
+
+        self.fapn = FeatureAlignedPyramidNet(skip_conv_filters=top_filters, name=f"{self.name}/fapn")
+        self.end_conv = ConvNormAct(filters, (1, 1), name=f"{self.name}/end_conv")
+
+    def call(self, inputs, training=None):
+        levels = self.fapn(list(inputs)[1:], training=training)
+        return self.end_conv(levels[0], training=training)
+
+
 class SimpleDecoderHead(Layer):
     """BASELINE config 4: ViT returns one endpoint; SimpleDecoder(48, 256)((e, ConvNormAct(256, 1x1)(e)))."""
 
@@ -74,6 +90,14 @@ class SimpleDecoderHead(Layer):
         return self.decoder((low, self.high_conv(high, training=training)), training=training)
 
 
+class LastEndpointDecoderHead(SimpleDecoderHead):
+    """SimpleDecoderHead on the LAST endpoint of a plain-ViT style backbone that returns one endpoint per block (EVA: [class token, patch embedding,
+    block 0, ...], backbones/eva/eva.py:297-310)"""
+
+    def call(self, inputs, training=None):
+        return super().call([list(inputs)[-1]], training=training)
+
+
 def _managed(backbone_name, head, num_class, output_stride, build_input_size, backbone_custom_fn=None):
     model = SegManaged(backbone_name=backbone_name, backbone_custom_fn=backbone_custom_fn, output_stride=output_stride,
                        num_class=num_class, build_input_size=build_input_size, name="seg")
@@ -86,6 +110,16 @@ def resnet50_aspp(num_class=21, output_stride=32, build_input_size=(256, 256), d
     """BASELINE config 1: ResNet-50 (slim/beta) + ASPP"""
     return _managed("resnet50", ASPPHead(256, output_stride=output_stride, dropout_rate=dropout_rate), num_class, output_stride,
                     build_input_size)
+
+
+def swin_tiny_fapn(num_class=21, build_input_size=(512, 512)):
+    """Swin-T + the FaPN decoder (layers/fapn.py)"""
+    return _managed("swin_tiny_224", FaPNHead(top_filters=768), num_class, 32, build_input_size)
+
+
+def eva02_tiny_simple_decoder(num_class=21, build_input_size=(448, 448)):
+    """EVA02-tiny (backbones/eva/eva.py:441-467, patch 14) + SimpleDecoder on its last endpoint"""
+    return _managed("eva02_tiny", LastEndpointDecoderHead(), num_class, 14, build_input_size)
 
 
 def swin_tiny_fpn(num_class=21, build_input_size=(512, 512)):

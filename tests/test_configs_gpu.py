@@ -49,7 +49,7 @@ def test_cfg1_resnet50_aspp_fp32_logits_argmax_and_loss(cuda):
 
 
 @pytest.mark.parametrize("factory,size", [("resnet50_aspp", 128), ("swin_tiny_fpn", 96), ("vit_base_simple_decoder", 96),
-                                          ("intern_image_base_aspp", 96)])
+                                          ("intern_image_base_aspp", 96), ("swin_tiny_fapn", 96), ("eva02_tiny_simple_decoder", 112)])
 def test_full_architectures_train_in_bf16(cuda, factory, size):
     from iseg_amd import heads, nn
     from iseg_amd.core_optimizer import get_optimizer
