@@ -35,6 +35,9 @@ def _builtin_backbones():
     from .intern_image import intern_image_small, intern_image_tiny
     from .vit import ViT16B, ViT16L
 
+    from .moat.moat import moat0, moat1, moat2, moat3, moat4
+
+    d.update({ss.MOAT0: moat0, ss.MOAT1: moat1, ss.MOAT2: moat2, ss.MOAT3: moat3, ss.MOAT4: moat4})      # (feature_extractor.py:106-110)
     from .eva import EVA02_large_patch14_224, EVA02_large_patch16_224, EVA02_large_patch16_512_COCO, EVA02_large_patch16_512_MV, \
         EVA02_tiny_patch_14_336
 
@@ -51,6 +54,8 @@ def get_backbone(name=ss.RESNET50, custom_backbone_fn=None, output_stride=32, re
                  efficientnet_use_top=True, moat_use_pos_encoding=False):
     name = name.lower()
     general_kwargs = {"return_endpoints": return_endpoints}
+    if ss.MOAT in name:      # :73-76
+        general_kwargs.update({"use_pos_emb": moat_use_pos_encoding})
     if ss.RESNET in name:      # :58-66
         general_kwargs.update({"use_bias": False, "replace_7x7_conv": True, "slim_behaviour": resnet_slim,
                                "custom_block": custom_resblock})

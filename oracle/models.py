@@ -295,6 +295,64 @@ def nasfpn_forward(w, inputs, name, block_specs, min_level=3, max_level=7, num_f
     return out
 
 
+# ------------------------------------------------------------------------------------------------------
+# backbones/moat/*: stem (moat.py:113-137), MBConvBlock / MOATBlock (moat_blocks.py:216-245, 466-508), Attention without relative position embedding
+# (attention.py:318-339), MOAT.call (moat.py:227-242)
+# ------------------------------------------------------------------------------------------------------
+def _moat_mbconv(w, p, x, stride, with_se, training, new_stats, bn_eps=1e-3):
+    shortcut = O.avg_pool_same(x, 2, stride) if stride > 1 else x
+    if f"{p}/shortcut_conv/kernel" in w:
+        shortcut = O.conv2d(shortcut, w[f"{p}/shortcut_conv/kernel"], w[f"{p}/shortcut_conv/bias"], 1, 1, "same")
+    y = _bn(w, f"{p}/pre_norm", x, training, bn_eps, new_stats=new_stats)
+    y = O.conv2d(y, w[f"{p}/expand_conv/kernel"], None, 1, 1, "same")
+    y = O.gelu(_bn(w, f"{p}/expand_norm", y, training, bn_eps, new_stats=new_stats))
+    y = O.depthwise_conv2d(y, w[f"{p}/depthwise_conv/depthwise_kernel"], None, stride, 1, "same")
+    y = O.gelu(_bn(w, f"{p}/depthwise_norm", y, training, bn_eps, new_stats=new_stats))
+    if with_se:
+        g = y.mean(dim=(1, 2), keepdim=True)
+        g = O.conv2d(g, w[f"{p}/se/reduce_conv2d/kernel"], w[f"{p}/se/reduce_conv2d/bias"], 1, 1, "same")
+        g = O.conv2d(g * torch.sigmoid(g), w[f"{p}/se/expand_conv2d/kernel"], w[f"{p}/se/expand_conv2d/bias"], 1, 1, "same")
+        y = torch.sigmoid(g) * y
+    return O.conv2d(y, w[f"{p}/shrink_conv/kernel"], w[f"{p}/shrink_conv/bias"], 1, 1, "same"), shortcut
+
+
+def _moat_attention(w, p, x, head_size):
+    B, H, W, C = x.shape
+    t = x.reshape(B, H * W, C)
+    q = torch.einsum("btc,cnk->btnk", t, w[f"{p}/q/weight"]) + w[f"{p}/q/bias"]
+    k = torch.einsum("btc,cnk->btnk", t, w[f"{p}/k/weight"]) + w[f"{p}/k/bias"]
+    v = torch.einsum("btc,cnk->btnk", t, w[f"{p}/v/weight"]) + w[f"{p}/v/bias"]
+    a = torch.softmax(torch.einsum("bsnk,btnk->bnst", q * head_size ** -0.5, k), dim=-1)
+    o = torch.einsum("bnst,btnk->bsnk", a, v)
+    return (torch.einsum("bsnk,nkc->bsc", o, w[f"{p}/o/weight"]) + w[f"{p}/o/bias"]).reshape(B, H, W, -1)
+
+
+def moat_forward(w, x, name, block_types, num_blocks, stage_stride=(2, 2, 2, 2), head_size=32, stem=2, training=False, dp_factors=None,
+                 new_stats=None, ln_eps=1e-5):
+    """MOAT.call with return_endpoints=True: [stem, stage 0 .. 3]; dp_factors[block name] = per-sample factors (one vector for an MBConv block, a
+    pair for a MOAT block) or absent"""
+    dp_factors = dp_factors or {}
+    for i in range(stem):
+        x = O.conv2d(x, w[f"{name}/stem/conv_{i}/kernel"], w[f"{name}/stem/conv_{i}/bias"], 2 if i == 0 else 1, 1, "same")
+        if i < stem - 1:
+            x = O.gelu(_bn(w, f"{name}/stem/norm_{i}", x, training, 1e-3, new_stats=new_stats))
+    ends = [x]
+    for s, kind in enumerate(block_types):
+        for b in range(num_blocks[s]):
+            p = f"{name}/block_{s:0>2d}_{b:0>2d}"
+            stride = stage_stride[s] if b == 0 else 1
+            y, shortcut = _moat_mbconv(w, p, x, stride, kind == "mbconv", training, new_stats)
+            f = dp_factors.get(p)
+            if kind == "mbconv":
+                x = shortcut + (y if f is None else y * f.reshape(-1, 1, 1, 1))
+            else:
+                x = shortcut + (y if f is None else y * f[0].reshape(-1, 1, 1, 1))
+                a = _moat_attention(w, f"{p}/attention", O.layer_norm(x, w[f"{p}/attention_norm/gamma"], w[f"{p}/attention_norm/beta"], ln_eps), head_size)
+                x = x + (a if f is None else a * f[1].reshape(-1, 1, 1, 1))
+        ends.append(x)
+    return ends
+
+
 def se_module(w, p, x, bias=True, activation=torch.relu):
     """layers/se.py:33-47"""
     g = x.mean(dim=(1, 2), keepdim=True)

@@ -1,0 +1,73 @@
+"""MOAT (backbones/moat/* of the reference): a reduced member of the family -- stem, MBConv stages with squeeze-and-excitation, MOAT stages (MBConv
+without SE + global self-attention over the stage's tokens), strided depthwise convolutions, average-pooled shortcuts, drop path with injected
+factors -- against the oracle's restatement, forward (every endpoint) and every gradient; plus the registry names."""
+import pytest
+import torch
+
+from oracle import models as OM
+from tests.test_attention_gpu import _check_grads, _rel, _setup
+from tests.test_kernels_gpu import DTYPES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("training", [False, True])
+def test_moat_reduced_family_member(cuda, dtype, training):
+    from iseg_amd import nn
+    from iseg_amd.backbones.moat.moat import MOAT
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        kinds, blocks = ["mbconv", "mbconv", "moat", "moat"], [1, 2, 2, 1]
+        moat = MOAT(stem_size=[16, 16], block_type_list=kinds, num_blocks=blocks, hidden_size=[16, 32, 64, 96], head_size=32,
+                    position_embedding_size=None, survival_prob=0.8, return_endpoints=True, name="moat")
+        shape = (2, 96, 128, 3)
+        _setup(moat, torch.empty(shape, dtype=torch.float32, device="cuda"))
+        f1, f2 = torch.tensor([1.25, 0.0]), torch.tensor([0.0, 1.25])
+        dp = {}
+        if training:
+            moat._blocks[1][1].drop_path_mask = f1.cuda()
+            moat._blocks[2][0].drop_path_masks = (f2.cuda(), f1.cuda())
+            dp = {"moat/block_01_01": f1.double(), "moat/block_02_00": (f2.double(), f1.double())}
+            for st in moat._blocks:      # every other stochastic depth draw: off (survival 1 keeps the arithmetic, the RNG stream cannot match TF's)
+                for blk in st:
+                    if getattr(blk, "drop_path_mask", 0) is None and not hasattr(blk, "drop_path_masks"):
+                        blk.survival_prob = None
+                    if hasattr(blk, "drop_path_masks") and blk.drop_path_masks is None:
+                        blk.survival_prob = None
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(shape, generator=g)
+        ends = moat(x.cuda(), training=training)
+        w = {k_: (v.requires_grad_(True) if not k_.endswith(("moving_mean", "moving_variance")) else v) for k_, v in OM.export_weights(moat).items()}
+        ref = OM.moat_forward(w, x.double(), "moat", kinds, blocks, training=training, dp_factors=dp)
+        assert [tuple(e.shape) for e in ends] == [tuple(r.shape) for r in ref] == [(2, 48, 64, 16), (2, 24, 32, 16), (2, 12, 16, 32), (2, 6, 8, 64),
+                                                                                     (2, 3, 4, 96)]
+        tol = 2e-4 if dtype == torch.float32 else 6e-2
+        for i, (a, b) in enumerate(zip(ends, ref)):
+            assert _rel(a, b.detach()) < tol, f"endpoint {i}"
+        dy = torch.randn(tuple(ref[-1].shape), generator=g)
+        ends[-1].backward(dy.cuda().to(dtype))
+        ref[-1].backward(dy.to(dtype).double())
+        # batch statistics over 2 x 3 x 4 positions at the last stage: an fp32 forward differs from fp64 by 1e-6, BatchNorm's backward amplifies it
+        # (with batch statistics a constant added in front of a BatchNorm-normalised branch has an analytically ZERO gradient -- the stem's first bias,
+        # every pre_norm beta (a per-channel constant through the bias-free expand convolution into expand_norm): only rounding noise is left to compare)
+        skip = ("pre_norm/beta", "stem/conv_0/bias") if training else ()
+        _check_grads(moat, w, (2e-3 if training else 5e-4) if dtype == torch.float32 else 0.15, l2=True, skip=skip)
+    finally:
+        nn.set_compute_dtype(torch.float32)
+
+
+def test_moat_names_are_registered_and_position_embedding_is_reported(cuda):
+    from iseg_amd import nn
+    from iseg_amd import static_strings as ss
+    from iseg_amd.backbones.feature_extractor import get_backbone
+
+    nn.set_device("cuda:0")
+    b = get_backbone(ss.MOAT0, return_endpoints=True, image_shape=(1, 128, 128, 3))      # (moat_use_pos_encoding=False: the reference's default)
+    with nn.dry_run_scope():
+        ends = b(torch.empty((1, 128, 128, 3), device="cuda"))
+    assert [tuple(e.shape) for e in ends] == [(1, 64, 64, 64), (1, 32, 32, 96), (1, 16, 16, 192), (1, 8, 8, 384), (1, 4, 4, 768)]
+    with pytest.raises(NotImplementedError, match="use_pos_emb"):
+        get_backbone(ss.MOAT0, return_endpoints=True, image_shape=(1, 128, 128, 3), moat_use_pos_encoding=True)
