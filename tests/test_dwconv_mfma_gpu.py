@@ -74,7 +74,7 @@ def test_dwconv7_mfma_rejects_other_shapes_and_the_automatic_route_agrees(cuda):
     with pytest.raises(_hip.HipCallError):
         K.dwconv2d7_mfma(torch.zeros(1, 8, 8, 24, dtype=bf, device="cuda"), torch.zeros(49, 24, device="cuda"), None)      # C % 32 != 0
     # a plane large enough for iseg_dwconv2d_fwd to pick the matrix-core route by itself (>= 2048 units): identical bits to the named entry
-    x = _rnd((4, 128, 128, 64), 9).to(bf).cuda()
+    x = _rnd((16, 128, 128, 64), 9).to(bf).cuda()      # 16 x 64 tiles x 2 slabs = 2 048 units
     w = (_rnd((49, 64), 10) / 7).float().cuda()
     b = _rnd((64,), 11, 0.3).float().cuda()
     assert torch.equal(K.dwconv2d(x, w, b, 7, 1, 3, 3).view(torch.int16), K.dwconv2d7_mfma(x, w, b).view(torch.int16))
