@@ -310,6 +310,8 @@ def _gemm_group_model(key):
     ea = 2 if adt == torch.bfloat16 else 4
     ed = 2 if ddt == torch.bfloat16 else 4
     nbytes = (M * K + K * N) * ea + M * N * ed * (1 + int(has_pre)) + M * N * ed * (int(has_res) + int(has_aux))
+    if len(key) > 13 and key[13] == 9:      # the weight-gradient PAIR launch: two products of these sizes (Z [4C, C] and dW1 [C, 4C]) over K rows
+        return 4.0 * M * N * K, 2 * nbytes
     return 2.0 * M * N * K, nbytes
 
 
@@ -322,6 +324,9 @@ def _kernel_label(key):
               (0, 0): "wgrad x[K,M]^T @ dy[K,N]"}[(akc, bkc)]
     epi = {0: "", 1: "relu", 2: "gelu", 3: "gelu'(aux)", 4: "relu'(aux)", 5: "x aux"}.get(int(act), f"act{act}")
     epi = " + ".join(t for t in (epi, "second output" if has_pre else "", "residual" if has_res else "") if t)
+    if variant == 9:
+        return (f"iseg_mm::gemm_bf16_dma_tn_pair_kernel (both weight gradients of an un-fused ConvNeXt block in one launch: Z = gelu(h)^T dout [{M} x {N}] and "
+                f"dW1 = y2^T dH [{N} x {M}] over {K} pixel rows, split-K slabs)")
     name = "iseg_mm::gemm_bf16_kernel" if not variant else \
         "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages",
                                               5: "256x128,3 stages,persistent", 6: "256x192,2 stages"}[variant]

@@ -130,6 +130,13 @@ int iseg_gemm_variant(const iseg_gemm_args* args_h);
 size_t iseg_gemm_workspace_bytes(const iseg_gemm_args* args_h);
 int iseg_gemm(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
 int iseg_gemm_reduce(const iseg_gemm_args* args_h, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* Two weight-gradient problems over the SAME reduction rows in one launch (the pair of an un-fused ConvNeXt block's backward pass,
+ * backbones/convnext.py:51-54: Z = gelu(h)^T dout and dW1 = y2^T dH).  iseg_gemm_tn_pair_splits: the common split count, 0 = run them one by one.
+ * The caller sets split_k to it in both blocks; iseg_gemm_tn_pair writes both problems' slabs (as defer_reduce = 1 does) and each problem is
+ * finished by iseg_gemm_reduce or by a consumer of its slabs (iseg_layerscale_grads_slabs). */
+int iseg_gemm_tn_pair_splits(const iseg_gemm_args* g0, const iseg_gemm_args* g1);
+int iseg_gemm_tn_pair(const iseg_gemm_args* g0, void* ws0, size_t ws0_bytes, const iseg_gemm_args* g1, void* ws1, size_t ws1_bytes,
+                      iseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis: keras.layers.LayerNormalization(axis=-1, epsilon)

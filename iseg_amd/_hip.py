@@ -55,6 +55,8 @@ SIGNATURES = {
     "iseg_version": (_i, []),
     "iseg_last_error": (_z, [C.c_char_p, _z]),
     "iseg_gemm_splits": (_i, [C.POINTER(GemmArgs)]),
+    "iseg_gemm_tn_pair_splits": (_i, [C.POINTER(GemmArgs), C.POINTER(GemmArgs)]),
+    "iseg_gemm_tn_pair": (_i, [C.POINTER(GemmArgs), _p, _z, C.POINTER(GemmArgs), _p, _z, _p]),
     "iseg_gemm_slabs": (_i, [C.POINTER(GemmArgs)]),
     "iseg_gemm_variant": (_i, [C.POINTER(GemmArgs)]),
     "iseg_gemm_workspace_bytes": (_z, [C.POINTER(GemmArgs)]),

@@ -277,6 +277,37 @@ int gemm_reduce(const iseg_gemm_args* g, const Epi& epi, float* slabs, int eff_s
     return iseg_check_launch("iseg_gemm");
 }
 
+// Two weight-gradient problems over the same reduction rows as ONE launch (gemm_dma_tn.h, gemm_bf16_dma_tn_pair_kernel).
+//   splits = iseg_gemm_tn_pair_splits(g0, g1)    0: do not pair (run them one by one)
+//   the caller sets split_k = splits in both argument blocks, sizes their workspaces with iseg_gemm_workspace_bytes, calls iseg_gemm_tn_pair (which
+//   only writes the slabs, like defer_reduce = 1) and finishes each problem with iseg_gemm_reduce or a consumer of the slabs.
+extern "C" int iseg_gemm_tn_pair_splits(const iseg_gemm_args* g0, const iseg_gemm_args* g1) {
+    if (!g0 || !g1) return 0;
+    iseg_gemm_args a = *g0, b = *g1;
+    a.split_k = b.split_k = 0;
+    static const int off = [] { const char* e = getenv("ISEG_GEMM_TN_PAIR"); return e && atoi(e) == 0; }();
+    return off ? 0 : iseg_mm::gemm_bf16_tn_pair_split(&a, &b);
+}
+
+extern "C" int iseg_gemm_tn_pair(const iseg_gemm_args* g0, void* ws0, size_t ws0_bytes, const iseg_gemm_args* g1, void* ws1, size_t ws1_bytes,
+                                 hipStream_t stream) {
+    ISEG_REQUIRE(g0 && g1 && g0->A && g0->B && g1->A && g1->B, "iseg_gemm_tn_pair: null operand");
+    const int s = iseg_gemm_tn_pair_splits(g0, g1);
+    ISEG_REQUIRE(s > 1 && g0->split_k == s && g1->split_k == s, "iseg_gemm_tn_pair: the problems do not pair (splits %d, split_k %d / %d)", s, g0->split_k,
+                 g1->split_k);
+    ISEG_REQUIRE(!g0->bias && !g1->bias && g0->act == ISEG_ACT_NONE && g1->act == ISEG_ACT_NONE && g0->out_dtype == ISEG_F32 && g1->out_dtype == ISEG_F32,
+                 "iseg_gemm_tn_pair: plain fp32 weight gradients only");
+    const size_t need0 = iseg_gemm_workspace_bytes(g0), need1 = iseg_gemm_workspace_bytes(g1);
+    if (!ws0 || ws0_bytes < need0 || !ws1 || ws1_bytes < need1) {
+        iseg_set_error("iseg_gemm_tn_pair: needs %zu + %zu workspace bytes, got %zu + %zu", need0, need1, ws0_bytes, ws1_bytes);
+        return ISEG_ERR_WORKSPACE;
+    }
+    const int64_t kps = ceil_div64(ceil_div64(g0->K, s), 128) * 128;
+    const int eff = (int)ceil_div64(g0->K, kps);
+    iseg_mm::gemm_bf16_tn_pair(g0, (float*)ws0, g1, (float*)ws1, eff, kps, stream);
+    return iseg_check_launch("iseg_gemm_tn_pair");
+}
+
 // second half of a deferred split-K GEMM (args.defer_reduce = 1): slab-order sum + epilogue.  No-op when the problem is not split.
 extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hipStream_t stream) {
     ISEG_REQUIRE(g && g->D, "iseg_gemm_reduce: null argument");

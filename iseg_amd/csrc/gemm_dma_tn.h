@@ -27,10 +27,10 @@ static __device__ uint4 tn_zero_page;      // sixteen zero bytes (device globals
 
 __device__ __forceinline__ int tn_key(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
 
+// one (tile t, reduction split ksplit) of a problem; the kernels below only decide which problem and which tile a workgroup takes
 template <int WM, int WN, int NS>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
-                                                                        int64_t ldb, int64_t M, int64_t N, int64_t K, int tiles_n, int ntiles,
-                                                                        int64_t k_per_split, float* __restrict__ slabs, int ones_row) {
+__device__ __forceinline__ void tn_tile(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B, int64_t ldb, int64_t M, int64_t N,
+                                        int64_t K, int tiles_n, int t, int ksplit, int64_t k_per_split, float* __restrict__ slabs, int ones_row) {
     constexpr int NW = WM * WN, FM = 4, FN = 4;      // (the waits in `compute` name FM = FN = 4 fragment pairs)
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int ROWA = BM * 2, ROWB = BN * 2;                 // bytes of one k-row of the A / B image
@@ -43,8 +43,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WN, wn = wid % WN;
-    int t, ksplit;
-    tile_and_split(ntiles, t, ksplit);
     const int64_t m0 = (int64_t)(t / tiles_n) * BM, n0 = (int64_t)(t % tiles_n) * BN;
     const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
@@ -228,6 +226,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf1
     }
 }
 
+template <int WM, int WN, int NS>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_tn_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+                                                                        int64_t ldb, int64_t M, int64_t N, int64_t K, int tiles_n, int ntiles,
+                                                                        int64_t k_per_split, float* __restrict__ slabs, int ones_row) {
+    int t, ksplit;
+    tile_and_split(ntiles, t, ksplit);
+    tn_tile<WM, WN, NS>(A, lda, B, ldb, M, N, K, tiles_n, t, ksplit, k_per_split, slabs, ones_row);
+}
+
+// TWO weight-gradient problems over the SAME reduction rows in one launch (round 5): the pair of an un-fused ConvNeXt block, Z = g^T dout
+// [4C, C] and dW1 = y2^T dH [C, 4C] (backbones/convnext.py:51-54 backward).  Launched one after the other each fills the chip with
+// 18 tiles x 13 splits; together 36 tiles x 7 splits do -- half the slab bytes written and summed again, one ring fill and one slab-store
+// tail instead of two.  A workgroup takes a tile of problem 0 or 1 (its own tile form: 256 x 128 or 128 x 256 per problem).
+struct TnProblem {
+    const bf16_t* A;
+    int64_t lda;
+    const bf16_t* B;
+    int64_t ldb;
+    int64_t M, N;
+    float* slabs;
+    int tiles_n, ntiles, form, ones_row;      // form 7 = 256 x 128 tiles, 8 = 128 x 256
+};
+
+template <int NS>
+__global__ __launch_bounds__(512) void gemm_bf16_dma_tn_pair_kernel(TnProblem p0, TnProblem p1, int64_t K, int64_t k_per_split) {
+    int t, ksplit;
+    tile_and_split(p0.ntiles + p1.ntiles, t, ksplit);
+    const bool second = t >= p0.ntiles;      // workgroup-uniform
+    const TnProblem& p = second ? p1 : p0;
+    if (second) t -= p0.ntiles;
+    if (p.form == 7) tn_tile<4, 2, NS>(p.A, p.lda, p.B, p.ldb, p.M, p.N, K, p.tiles_n, t, ksplit, k_per_split, p.slabs, p.ones_row);
+    else tn_tile<2, 4, NS>(p.A, p.lda, p.B, p.ldb, p.M, p.N, K, p.tiles_n, t, ksplit, k_per_split, p.slabs, p.ones_row);
+}
+
 int dma_tn_mode();      // ISEG_GEMM_DMA_TN: 0 = never, 1 = whenever eligible (default)
 bool dma_tn_lds_ok();   // gemm_tn.hip: the 144-KiB dynamic-LDS limit of both tile forms was raised (once per process); false -> the register kernel keeps these problems
 
@@ -268,6 +300,42 @@ void launch_dma_tn(const iseg_gemm_args* g, int nsplit, int64_t k_per_split, flo
     constexpr int lds = NS * 64 * (BM + BN) * 2;      // (the limit was raised by dma_tn_lds_ok(), which dma_tn_form() requires)
     hipLaunchKernelGGL((gemm_bf16_dma_tn_kernel<WM, WN, NS>), dim3(ntiles, nsplit, 1), dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
                        (const bf16_t*)g->B, g->ldb, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, g->colsum_out ? 1 : 0);
+}
+
+// reduction splits of a PAIR launch: one resident round of workgroups over both problems' tiles, at least 512 reduction rows each; 0 = do not pair
+inline int dma_tn_pair_split(const iseg_gemm_args* g0, const iseg_gemm_args* g1) {
+    const int f0 = dma_tn_form(g0), f1 = dma_tn_form(g1);
+    if (!f0 || !f1 || g0->K != g1->K) return 0;
+    auto tiles = [](const iseg_gemm_args* g, int form) {
+        return form == 8 ? ceil_div64(g->M, 128) * ceil_div64(g->N, 256) : ceil_div64(g->M, 256) * ceil_div64(g->N, 128);
+    };
+    const int64_t t = tiles(g0, f0) + tiles(g1, f1);
+    int64_t want = dma_cus() / t;
+    const int64_t maxs = g0->K / 512;
+    if (want > maxs) want = maxs;
+    return (int)(want < 2 ? 0 : want);
+}
+
+inline void launch_dma_tn_pair(const iseg_gemm_args* g0, float* slabs0, const iseg_gemm_args* g1, float* slabs1, int nsplit, int64_t k_per_split,
+                               hipStream_t s) {
+    auto prob = [](const iseg_gemm_args* g, float* slabs) {
+        TnProblem p;
+        p.form = dma_tn_form(g);
+        p.A = (const bf16_t*)g->A;
+        p.lda = g->lda;
+        p.B = (const bf16_t*)g->B;
+        p.ldb = g->ldb;
+        p.M = g->M;
+        p.N = g->N;
+        p.slabs = slabs;
+        p.tiles_n = (int)ceil_div64(g->N, p.form == 8 ? 256 : 128);
+        p.ntiles = (int)ceil_div64(g->M, p.form == 8 ? 128 : 256) * p.tiles_n;
+        p.ones_row = g->colsum_out ? 1 : 0;
+        return p;
+    };
+    const TnProblem p0 = prob(g0, slabs0), p1 = prob(g1, slabs1);
+    constexpr int lds = 3 * 64 * (256 + 128) * 2;
+    hipLaunchKernelGGL((gemm_bf16_dma_tn_pair_kernel<3>), dim3(p0.ntiles + p1.ntiles, nsplit, 1), dim3(512), lds, s, p0, p1, g0->K, k_per_split);
 }
 
 }  // namespace iseg_mm

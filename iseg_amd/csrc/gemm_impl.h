@@ -591,5 +591,7 @@ void dispatch_bk(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kp
 void gemm_bf16_nn(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s);
 void gemm_bf16_nt(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s);
 void gemm_bf16_tn(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s);
+int gemm_bf16_tn_pair_split(const iseg_gemm_args* g0, const iseg_gemm_args* g1);
+void gemm_bf16_tn_pair(const iseg_gemm_args* g0, float* slabs0, const iseg_gemm_args* g1, float* slabs1, int nsplit, int64_t kps, hipStream_t s);
 
 }  // namespace iseg_mm

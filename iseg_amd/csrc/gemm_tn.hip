@@ -8,10 +8,16 @@ bool dma_tn_lds_ok() {
         constexpr int lds = 3 * 64 * (256 + 128) * 2;      // three 64-row stages of a 256 x 128 / 128 x 256 tile pair
         const bool a = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_kernel<4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         const bool b = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_kernel<2, 4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
-        if (!(a && b)) (void)hipGetLastError();      // not an error of the call that asked: the register-staged kernel takes these problems
-        return a && b;
+        const bool c = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_tn_pair_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        if (!(a && b && c)) (void)hipGetLastError();      // not an error of the call that asked: the register-staged kernel takes these problems
+        return a && b && c;
     }();
     return ok;
+}
+
+int gemm_bf16_tn_pair_split(const iseg_gemm_args* g0, const iseg_gemm_args* g1) { return dma_tn_pair_split(g0, g1); }
+void gemm_bf16_tn_pair(const iseg_gemm_args* g0, float* slabs0, const iseg_gemm_args* g1, float* slabs1, int nsplit, int64_t kps, hipStream_t s) {
+    launch_dma_tn_pair(g0, slabs0, g1, slabs1, nsplit, kps, s);
 }
 
 void gemm_bf16_tn(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {

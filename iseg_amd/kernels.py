@@ -256,6 +256,52 @@ def dense_wgrad_slabs(x2d, dy2d):
     return slabs, int(eff)
 
 
+def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True):
+    """The two weight-gradient products of an un-fused ConvNeXt block as ONE launch (csrc/gemm_dma_tn.h, round 5): Z = g^T dbr [4C, C] with its
+    ones-row, stopped at its slabs for layerscale_grads_slabs, and dW1 (+)= x^T dh [C, 4C] (+ db1 from its ones-row), summed by iseg_gemm_reduce.
+    Returns (slabs of Z, slab count) or None when the problems do not pair (the caller then runs them one by one)."""
+    rows, K4 = g2d.shape
+    Cc = dbr2d.shape[1]
+    if not (wgrad_can_fuse_bias(g2d) and wgrad_can_fuse_bias(x2d)) or Cc % 4 != 0:
+        return None
+    _require_cuda(g2d, dbr2d, x2d, dh2d, dW1)
+    dummy = torch.empty(1, dtype=torch.float32, device=g2d.device)
+
+    def args(a, b, out, ldd, bias, acc):
+        g = GemmArgs()
+        g.A, g.lda, g.a_kcontig = ptr(a), a.stride(0), 0
+        g.B, g.ldb, g.b_kcontig = ptr(b), b.stride(0), 0
+        g.D, g.ldd = ptr(out), ldd
+        g.M, g.N, g.K = a.shape[1], b.shape[1], rows
+        g.in_dtype, g.out_dtype = dt(a), 0
+        g.alpha, g.accumulate = 1.0, int(acc)
+        g.colsum_out, g.colsum_accumulate = ptr(bias), int(acc)
+        g.batch, g.batch_inner = 1, 1
+        g.defer_reduce = 1
+        return g
+
+    g0 = args(g2d, dbr2d, dummy, Cc, dummy, False)
+    g1 = args(x2d, dh2d, dW1, dW1.stride(0), db1, accumulate)
+    L = _hip.lib()
+    s = int(L.iseg_gemm_tn_pair_splits(C.byref(g0), C.byref(g1)))
+    if s <= 1:
+        return None
+    g0.split_k = g1.split_k = s
+    need0, need1 = L.iseg_gemm_workspace_bytes(C.byref(g0)), L.iseg_gemm_workspace_bytes(C.byref(g1))
+    eff = int(L.iseg_gemm_slabs(C.byref(g0)))
+    slabs0 = torch.empty(need0 // 4, dtype=torch.float32, device=g2d.device)      # (its own buffer: the consumer's partials use the workspace)
+    ws1, wsb1 = workspace(need1, g2d.device)
+    timer = KERNEL_TIMER[0]
+    if timer is not None:
+        # (variant 9 = the pair launch: bench.py models it as two products [4C, C] and [C, 4C] over `rows`)
+        timer.begin(("gemm", 0, 0, int(K4), int(Cc), int(rows), 0, False, False, False, g2d.dtype, torch.float32, True, 9))
+    _hip.check(L.iseg_gemm_tn_pair(C.byref(g0), ptr(slabs0), need0, C.byref(g1), ptr(ws1), wsb1, stream()), "iseg_gemm_tn_pair")
+    if timer is not None:
+        timer.end()
+    _hip.check(L.iseg_gemm_reduce(C.byref(g1), ptr(ws1), wsb1, stream()), "iseg_gemm_reduce")
+    return slabs0, eff
+
+
 # ---------------------------------------------------------------------------------------------------------
 # norms
 # ---------------------------------------------------------------------------------------------------------
