@@ -338,6 +338,11 @@ def _dma_symbol(key):
     _, akc, bkc, M, N, K, act, has_pre, has_res, has_aux = key[:10]
     variant = key[13] if len(key) > 13 else 0
     shapes = {2: (4, 2, 3, 4), 6: (4, 2, 2, 6), 4: (2, 2, 3, 4)}      # variant -> (WM, WN, NS, FN) of gemm_dma.h dispatch_dma
+    if variant == 9:      # the weight-gradient pair launch: (tiles of both problems) x (splits of one resident round over 256 CUs) x 512 threads
+        tiles = 2 * -(-M // 256) * -(-N // 128)
+        want = max(1, min(256 // tiles, K // 512))
+        kps = -(-(-(-K // want)) // 128) * 128
+        return "gemm_bf16_dma_tn_pair_kernel", tiles * -(-K // kps) * 512
     if variant not in shapes:
         return None, None
     wm, wn, ns, fn = shapes[variant]

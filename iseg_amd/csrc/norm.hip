@@ -764,6 +764,14 @@ static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const f
     return iseg_check_launch("iseg_layernorm_fwd");
 }
 
+static int ln_bwd_u8() {      // experiment (round 5): eight rows in flight per wavefront instead of four where a wavefront holds one or two rows per iteration
+    static const int v = [] {
+        const char* e = getenv("ISEG_LN_BWD_U8");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
 static int ln_bwd_blocks(int64_t rows, int C) {
     const int lpr = ln_lanes_per_row(C);
     const int rpw = 64 / lpr;
@@ -858,7 +866,8 @@ static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const v
 #define LN_BWD_T(T)                                     \
     do {                                                \
         if (cpl <= 1) {                                 \
-            if (lpr >= 32) LN_BWD(T, 1, 4);             \
+            if (lpr >= 32 && ln_bwd_u8()) LN_BWD(T, 1, 8); \
+            else if (lpr >= 32) LN_BWD(T, 1, 4);        \
             else if (lpr >= 16) LN_BWD(T, 1, 2);        \
             else LN_BWD(T, 1, 1);                       \
         } else if (cpl <= 2) LN_BWD(T, 2, 4);           \
