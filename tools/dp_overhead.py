@@ -79,16 +79,16 @@ def main():
             ta = time.perf_counter() - t0
             print(f"{name:52s} {ta / steps * 1e3:6.2f} ms/step  (host enqueue {th / steps * 1e3:5.2f})  collectives enqueued by the host {count[0] / steps:.0f} per step", flush=True)
 
-        def counted(t, raw):
+        def counted(t, raw, *which):
             count[0] += 1
-            return real(t, raw)
+            return real(t, raw, *which)
 
         dist._stream_all_reduce = counted
         run("stream-ordered exchange, eager", trainer.train_step)
         g = GraphedTrainStep(trainer, warmup=0)
         assert g._eligible(x)
         run("stream-ordered exchange, ONE HIP graph per step", g)
-        dist._stream_all_reduce = lambda t, raw: None
+        dist._stream_all_reduce = lambda t, raw, *which: None
         run("collectives stubbed (plumbing only), eager", trainer.train_step)
         g2 = GraphedTrainStep(trainer, warmup=0)
         run("collectives stubbed, ONE HIP graph per step", g2)

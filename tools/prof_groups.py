@@ -10,10 +10,10 @@ import sys
 FAMILIES = [
     ("fused ConvNeXt MLP (fwd / bwd chain / prep)", r"convnext_mlp"),
     ("GEMM (register-staged)", r"gemm_bf16_kernel|gemm_f32_kernel"),
-    ("GEMM (LDS-DMA)", r"gemm_bf16_dma_kernel|gemm_bf16_dma_tn_kernel"),
+    ("GEMM (LDS-DMA)", r"gemm_bf16_dma_kernel|gemm_bf16_dma_tn_kernel|gemm_bf16_dma_tn_pair_kernel"),
     ("implicit-GEMM conv", r"igemm"),
     ("split-K / partial reductions", r"splitk_reduce|reduce_rows"),
-    ("depthwise conv fwd / bwd-data", r"dwconv_fwd"),
+    ("depthwise conv fwd / bwd-data", r"dwconv_fwd|dwconv7_mfma"),
     ("depthwise conv weight grad", r"dwconv_bwd_weight"),
     ("LayerNorm", r"layernorm"),
     ("BatchNorm", r"bn_"),
