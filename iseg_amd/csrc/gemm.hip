@@ -20,6 +20,34 @@
 using namespace iseg_mm;
 
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <string>
+namespace {
+// ISEG_GEMM_LOG=1: census of the problems iseg_gemm was asked for (orientation, shape, split, LDS-DMA form, epilogue), printed to stderr at
+// exit with the call count of each -- how a configuration's contractions map onto the kernels (tools/prof_config.py shows the time per kernel)
+struct GemmCensus {
+    std::mutex mu;
+    std::map<std::string, long> seen;
+    ~GemmCensus() {
+        for (const auto& kv : seen) fprintf(stderr, "[iseg_gemm] %6ld x %s\n", kv.second, kv.first.c_str());
+    }
+};
+bool gemm_log_on() {
+    static const bool v = [] { const char* e = getenv("ISEG_GEMM_LOG"); return e && atoi(e) != 0; }();
+    return v;
+}
+void gemm_log(const iseg_gemm_args* g, int nsplit) {
+    static GemmCensus census;
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s %s->%s M=%lld N=%lld K=%lld batch=%d split=%d form=%d act=%d a_act=%d%s%s%s%s%s", g->a_kcontig ? (g->b_kcontig ? "NT" : "NN") : (g->b_kcontig ? "TT" : "TN"),
+             g->in_dtype == ISEG_BF16 ? "bf16" : "f32", g->out_dtype == ISEG_BF16 ? "bf16" : "f32", (long long)g->M, (long long)g->N, (long long)g->K,
+             g->batch > 1 ? g->batch : 1, nsplit, iseg_gemm_variant(g), g->act, g->a_act, g->bias ? " bias" : "", g->residual ? " residual" : "",
+             g->aux ? " aux" : "", g->pre_out ? " pre_out" : "", g->colsum_out ? " colsum" : "");
+    std::lock_guard<std::mutex> lock(census.mu);
+    ++census.seen[buf];
+}
+}  // namespace
 namespace iseg_mm {
 int long_k_tile() {
     static const int v = [] {
@@ -32,6 +60,14 @@ int dma_mode() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_DMA");
         return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+int dma_min_k() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_DMA_MIN_K");
+        const int k = e ? atoi(e) : 64;
+        return k < 64 ? 64 : k;
     }();
     return v;
 }
@@ -222,6 +258,7 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
     }
     const int64_t slab_rows = g->M + (g->colsum_out ? 1 : 0);
     const int nsplit = iseg_gemm_splits(g);
+    if (gemm_log_on()) gemm_log(g, nsplit);
     float* slabs = nullptr;
     int64_t kps = g->K;
     if (nsplit > 1) {

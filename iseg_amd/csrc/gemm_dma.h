@@ -71,6 +71,11 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
     return e;
 }
 
+// sixteen zero bytes in device memory: what a lane past the K tail asks the DMA for
+static __device__ __attribute__((aligned(16))) unsigned int dma_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+int dma_min_k();      // ISEG_GEMM_DMA_MIN_K (default 64): shortest reduction the pipeline takes
+
 inline int epi_kind(const Epi& e, const float* slabs) {
     if (slabs || e.alpha != 1.f || e.accumulate) return EK_ANY;
     if (e.act == ISEG_ACT_GELU && e.pre_out && e.pre_deriv && e.bias && !e.residual && !e.aux && !e.colscale && !e.rowscale) return EK_GELU_DERIV;
@@ -116,11 +121,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     int64_t m0 = (int64_t)(t / tiles_n) * BM, n0 = (int64_t)(t % tiles_n) * BN;
     const int64_t kbeg = (int64_t)ksplit * k_per_split;
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
-    const int nk = (int)((kend - kbeg) / 64);
+    // K tail: a last K-step of fewer than eight 16-B chunks.  The lanes whose source chunk lies beyond it request a 16-B run of zeros instead
+    // (the stage slot must hold zeros for BOTH operands: whatever lies behind the row's end times zero is not zero when it decodes as inf / NaN)
+    const int nk = (int)((kend - kbeg + 63) / 64);
+    const int tail_chunks = (int)(((kend - kbeg) & 63) >> 3);      // 0: the last K-step is whole
 
     // per-lane DMA sources: piece p of this wavefront covers stage rows 8*(wid + p*NW) .. +7 (A rows first, then B rows);
     // lane l fills LDS slot (row l>>3, chunk l&7) with source chunk (l&7) ^ (l>>3)
     const bf16_t* src[PPW];
+    bool beyond[PPW];      // this lane's source chunk of piece p is past the K tail
     auto point = [&](int64_t pm0, int64_t pn0) {
         const int rsub = lane >> 3;
 #pragma unroll
@@ -129,19 +138,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
             if (r < BM) {
                 int64_t row = pm0 + r;
                 row = row < M ? row : M - 1;
-                src[p] = A + row * lda + kbeg + ((lane & 7) ^ (r & 7)) * 8;
+                const int ch = (lane & 7) ^ (r & 7);
+                src[p] = A + row * lda + kbeg + ch * 8;
+                beyond[p] = ch >= tail_chunks;
             } else {
                 const int rb = r - BM;
                 int64_t row = pn0 + rb;
                 row = row < N ? row : N - 1;
                 // (B per row group: a tile never straddles two groups, b_group_rows % 256 == 0 is checked on the host)
                 const bf16_t* Bg = epi.b_group_rows > 0 ? B + (pm0 / epi.b_group_rows) * epi.b_group_stride : B;
-                src[p] = Bg + row * ldb + kbeg + ((lane & 7) ^ b_key(rb)) * 8;
+                const int ch = (lane & 7) ^ b_key(rb);
+                src[p] = Bg + row * ldb + kbeg + ch * 8;
+                beyond[p] = ch >= tail_chunks;
             }
         }
     };
     point(m0, n0);
-    auto issue = [&](int stage) {
+    // kstep: the K-step the stage is filled with (only the last one can be a tail)
+    auto issue = [&](int stage, int kstep) {
+        if (tail_chunks != 0 && kstep == nk - 1) {
+#pragma unroll
+            for (int p = 0; p < PPW; ++p) {
+                const bf16_t* s = beyond[p] ? reinterpret_cast<const bf16_t*>(dma_zero_chunk) : src[p];
+                __builtin_amdgcn_global_load_lds((glb_void_ptr)s, (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
+                src[p] += 64;
+            }
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
             __builtin_amdgcn_global_load_lds((glb_void_ptr)src[p], (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
@@ -182,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     if (PERSIST) {      // (NS >= 3) prologue of the first tile; every later tile's prologue is issued in front of the previous epilogue
 #pragma unroll
         for (int p = 0; p < NS - 1; ++p)
-            if (p < nk) issue(p);
+            if (p < nk) issue(p, p);
     }
     for (int vt = blockIdx.x;;) {
 #pragma unroll
@@ -190,11 +213,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (NS == 2) {
-        issue(0);
+        issue(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
             if (kt + 1 < nk) {
-                issue(stage ^ 1);
+                issue(stage ^ 1, kt + 1);
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");      // tile kt landed; tile kt+1 stays in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
         if (!PERSIST) {
 #pragma unroll
             for (int p = 0; p < NS - 1; ++p)
-                if (p < nk) issue(p);
+                if (p < nk) issue(p, p);
         }
         int stage = 0, fill = (NS - 1) % NS;
         for (int kt = 0; kt < nk; ++kt) {
@@ -223,7 +246,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + NS - 1 < nk) issue(fill);
+            if (kt + NS - 1 < nk) issue(fill, kt + NS - 1);
             compute(stage);
             stage = stage + 1 == NS ? 0 : stage + 1;
             fill = fill + 1 == NS ? 0 : fill + 1;
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
             point(m0, n0);
 #pragma unroll
             for (int p = 0; p < NS - 1; ++p)
-                if (p < nk) issue(p);
+                if (p < nk) issue(p, p);
         }
     }
     // ---- epilogue from registers: per 16-row block, two 8-column vectors per lane (N % 8 == 0 and aligned operands are
@@ -280,7 +303,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
 // eligibility of a problem for the DMA pipeline (checked on the host)
 inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
     if (!g->a_kcontig || !g->b_kcontig || g->a_act != ISEG_ACT_NONE || g->colsum_out) return false;
-    if (g->K % 64 != 0 || kps % 64 != 0 || g->K < 128 || g->N % 8 != 0 || g->N < 64 || g->M < 64) return false;
+    // K: whole 16-B chunks per row (a last K-step of fewer than eight is zero-filled, see the kernel); a split cuts at multiples of 64
+    if (g->K % 8 != 0 || (kps != g->K && kps % 64 != 0) || g->K < dma_min_k() || g->N % 8 != 0 || g->N < 64 || g->M < 64) return false;
     if (((uintptr_t)g->A % 16) || ((uintptr_t)g->B % 16) || g->lda % 8 || g->ldb % 8) return false;
     if (((uintptr_t)g->D % 16) || g->ldd % 8) return false;
     if (g->residual && (((uintptr_t)g->residual % 16) || g->ldr % 8)) return false;

@@ -651,6 +651,49 @@ def test_gemm_dma_pipeline_matches_oracle_and_register_staged_kernel(cuda, M, N,
     close(o32, 0.5 * (ar @ br.T) + 0.25, torch.float32, "fp32 accumulate", f32_tol=2e-5)
 
 
+@pytest.mark.parametrize("M,N,Kd,split", [(300, 64, 72, 0),          # 64 + one chunk
+                                         (1000, 136, 96, 0),       # Swin-T / ConvNeXt-T stage-0 width
+                                         (7000, 384, 112, 0),      # InternImage-B stage-0 width
+                                         (131072, 112, 112, 0),    # ... at its real row count (256 x 128 tiles)
+                                         (16384, 512, 200, 0),
+                                         (25000, 264, 328, 0),
+                                         (640, 128, 2040, 4)])     # the tail inside the last split
+def test_gemm_dma_pipeline_k_tail(cuda, M, N, Kd, split):
+    """csrc/gemm_dma.h with K % 64 != 0 (round 5): the last K-step's missing 16-B chunks are requested from a run of zeros.  The problems plan
+    onto the LDS-DMA kernel; results against the fp64 oracle; the operands sit in larger buffers filled with NaN around them, so a chunk read past
+    a row's end would show"""
+    import ctypes as Ct
+
+    from iseg_amd import _hip
+
+    k = K()
+    dt = torch.bfloat16
+    _, ar = q(rnd((M, Kd), 1), dt)
+    _, br = q(rnd((N, Kd), 2, Kd ** -0.5), dt)
+    lda = ldb = Kd + 64      # rows padded with NaN: eight more chunks behind every row
+    abuf = torch.full((M, lda), float("nan"), dtype=dt, device="cuda")
+    bbuf = torch.full((N, ldb), float("nan"), dtype=dt, device="cuda")
+    abuf[:, :Kd] = ar.to(dt).cuda()
+    bbuf[:, :Kd] = br.to(dt).cuda()
+    g = _hip.GemmArgs()
+    g.A, g.lda, g.a_kcontig = abuf.data_ptr(), lda, 1
+    g.B, g.ldb, g.b_kcontig = bbuf.data_ptr(), ldb, 1
+    g.M, g.N, g.K, g.in_dtype, g.out_dtype, g.batch, g.batch_inner, g.split_k = M, N, Kd, 1, 1, 1, 1, split
+    out = torch.empty((M, N), dtype=dt, device="cuda")
+    g.D, g.ldd = out.data_ptr(), N
+    assert int(_hip.lib().iseg_gemm_variant(Ct.byref(g))) in (1, 2, 3, 4, 6), "the problem did not plan onto the LDS-DMA kernel"
+    k.gemm(abuf, bbuf, out, M, N, Kd, lda=lda, ldb=ldb, ldd=N, a_kcontig=1, b_kcontig=1, split_k=split)
+    close(out, ar @ br.T, dt, "plain")
+    bias = rnd((N,), 3).float()
+    aux, auxr = q(rnd((M, N), 6), dt)
+    k.gemm(abuf, bbuf, out, M, N, Kd, lda=lda, ldb=ldb, ldd=N, a_kcontig=1, b_kcontig=1, bias=bias.cuda(), act=k.ACT_GELU, split_k=split)
+    close(out, O.gelu(ar @ br.T + bias.double()), dt, "bias+gelu")
+    k.gemm(abuf, bbuf, out, M, N, Kd, lda=lda, ldb=ldb, ldd=N, a_kcontig=1, b_kcontig=1, act=k.ACT_GELU_GRAD, aux=aux, ldaux=N, split_k=split)
+    hh = auxr.clone().requires_grad_(True)
+    O.gelu(hh).backward(ar @ br.T)
+    close(out, hh.grad, dt, "gelu'")
+
+
 def test_gemm_dma_pipeline_strided_batch(cuda):
     k = K()
     dt = torch.bfloat16
