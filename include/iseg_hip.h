@@ -535,6 +535,21 @@ size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int Cg, int kh
 int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset, void* dmask,
                    int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype,
                    void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* The same two entry points with the offsets and the mask (and their gradients) as column ranges of ONE [pixels][ld] matrix -- the output of the
+ * layer's offset and mask projections (layers/dcn_v3/dcn_v3.py:116-123, two Dense layers on the same input) run as a single product:
+ * ld_off / ld_mask = elements between the runs of consecutive output pixels (0 = dense: 2 G P / G P; ld_off even).
+ * iseg_dcn_mask_softmax_fwd / _bwd: the softmax over each (pixel, group)'s P mask logits (dcn_v3.py:121-123) in place on columns
+ * [col0, col0 + G P) of such a matrix; the backward also clears the columns behind col0 + G P of the gradient matrix (padding up to the
+ * product's width), P <= 9.  iseg_split_cols_accumulate: dst0 [rows][n0] += src[:, :n0], dst1 [rows][n1] += src[:, n0:n0+n1] (fp32) -- the
+ * joint weight / bias gradient handed back to the two layers. */
+int iseg_dcnv3_fwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, void* y, int N, int H, int W, int G,
+                      int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype, iseg_stream_t stream);
+int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, float* dx_f32,
+                      void* doffset, void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
+                      float offset_scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+int iseg_dcn_mask_softmax_fwd(void* om, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, iseg_stream_t stream);
+int iseg_dcn_mask_softmax_bwd(const void* om, void* dom, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, iseg_stream_t stream);
+int iseg_split_cols_accumulate(const float* src, int64_t rows, int64_t ld, float* dst0, int n0, float* dst1, int n1, iseg_stream_t stream);
 /* Centre-feature scale of the DCNv3 layer (layers/dcn_v3/dcn_v3.py:138-146; intern_image_huge): out = x (1 - s) + x_proj s with
  * s [pixels, G] (the un-squashed output of center_feature_scale_proj) broadcast over the Cg channels of its group; backward: dx, dx_proj and
  * ds [pixels, G] = sum_c dout (x_proj - x).  Cg in {8, 16}. */

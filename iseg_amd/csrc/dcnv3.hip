@@ -27,6 +27,9 @@ namespace {
 struct DcnGeom {
     int N, H, W, G, Cg, kh, kw, stride, dil, pad, Hin, Win, Ho, Wo;
     float s;
+    // elements between the offset / mask runs of consecutive output pixels (and of their gradients): 2 G P and G P when the two tensors are dense,
+    // the row pitch of the joint projection buffer when both live in one [pixels][ld] matrix (iseg_dcnv3_fwd_ld / _bwd_ld)
+    int ld_off, ld_mask;
 };
 
 struct Tap {
@@ -110,12 +113,14 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_pipe_kernel(const T* __restrict
         const int h = (int)(t % g.Ho);
         const int n = (int)(t / g.Ho);
         float offs[DCN_PMAX][2], mk[DCN_PMAX];
+        const T* const op = offset + (i / g.G) * g.ld_off + gi * P * 2;
+        const T* const mp = mask + (i / g.G) * g.ld_mask + gi * P;
 #pragma unroll
         for (int p = 0; p < DCN_PMAX; ++p) {
-            const int64_t e = i * P + (p < P ? p : P - 1);
-            offs[p][0] = to_f32(offset[e * 2]);
-            offs[p][1] = to_f32(offset[e * 2 + 1]);
-            mk[p] = to_f32(mask[e]);
+            const int pp = p < P ? p : P - 1;
+            offs[p][0] = to_f32(op[pp * 2]);
+            offs[p][1] = to_f32(op[pp * 2 + 1]);
+            mk[p] = to_f32(mp[pp]);
         }
         uint4 nxt[4][RAW];
         Tap ntp{};
@@ -180,8 +185,8 @@ __global__ __launch_bounds__(256) void dcnv3_fwd_kernel(const T* __restrict__ x,
         const int h = (int)(t % g.Ho);
         const int n = (int)(t / g.Ho);
         const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
-        const T* op = offset + (pix * g.G + gi) * P * 2;
-        const T* mp = mask + (pix * g.G + gi) * P;
+        const T* op = offset + pix * g.ld_off + gi * P * 2;
+        const T* mp = mask + pix * g.ld_mask + gi * P;
         T* yp = y + (pix * g.G + gi) * g.Cg;
         for (int c0 = 0; c0 < g.Cg; c0 += CV) {
             float acc[CV];
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
         const int h = (int)(t % g.Ho);
         const int n = (int)(t / g.Ho);
         const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
-        const T* op = offset + (pix * g.G + gi) * P * 2;
-        const T* mp = mask + (pix * g.G + gi) * P;
+        const T* op = offset + pix * g.ld_off + gi * P * 2;
+        const T* mp = mask + pix * g.ld_mask + gi * P;
         const T* dyp = dy + (pix * g.G + gi) * g.Cg;
         for (int p = 0; p < P; ++p) {
             const Tap tp = dcn_tap(g, h, w, p, to_f32(op[2 * p]), to_f32(op[2 * p + 1]));
@@ -274,10 +279,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
                 gpx = fmaf(wpx[k], dot, gpx);
                 gpy = fmaf(wpy[k], dot, gpy);
             }
-            dmask[(pix * g.G + gi) * P + p] = from_f32<T>(gm);
+            dmask[pix * g.ld_mask + gi * P + p] = from_f32<T>(gm);
             // px = e0 * (Win - 2), e0 = ... + off0 * s / Win
-            doffset[((pix * g.G + gi) * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
-            doffset[((pix * g.G + gi) * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
+            doffset[pix * g.ld_off + (gi * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
+            doffset[pix * g.ld_off + (gi * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
         }
     }
 }
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
         const int h = (int)(t % g.Ho);
         const int n = (int)(t / g.Ho);
         const int64_t pix = ((int64_t)n * g.Ho + h) * g.Wo + w;
-        const T* op = offset + (pix * g.G + gi) * P * 2;
-        const T* mp = mask + (pix * g.G + gi) * P;
+        const T* op = offset + pix * g.ld_off + gi * P * 2;
+        const T* mp = mask + pix * g.ld_mask + gi * P;
         const float d = to_f32(dy[(pix * g.G + gi) * g.Cg + c]);
         for (int p = 0; p < P; ++p) {
             const Tap tp = dcn_tap(g, h, w, p, to_f32(op[2 * p]), to_f32(op[2 * p + 1]));
@@ -331,9 +336,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
             gpx = group_sum(gpx, LC);
             gpy = group_sum(gpy, LC);
             if (c == 0) {
-                dmask[(pix * g.G + gi) * P + p] = from_f32<T>(gm);
-                doffset[((pix * g.G + gi) * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
-                doffset[((pix * g.G + gi) * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
+                dmask[pix * g.ld_mask + gi * P + p] = from_f32<T>(gm);
+                doffset[pix * g.ld_off + (gi * P + p) * 2] = from_f32<T>(gpx * m * (float)(g.Win - 2) * g.s / (float)g.Win);
+                doffset[pix * g.ld_off + (gi * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
             }
         }
     }
@@ -424,10 +429,10 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
 #pragma unroll
     for (int p = 0; p < DCN_PMAX; ++p) {
         const int pp = p < P ? p : P - 1;
-        const int64_t e = live ? (pix * g.G + gi) * P + pp : 0;
-        offs[p][0] = to_f32(offset[e * 2]);
-        offs[p][1] = to_f32(offset[e * 2 + 1]);
-        mk[p] = to_f32(mask[e]);
+        const int64_t eo = live ? pix * g.ld_off + (gi * P + pp) * 2 : 0, em = live ? pix * g.ld_mask + gi * P + pp : 0;
+        offs[p][0] = to_f32(offset[eo]);
+        offs[p][1] = to_f32(offset[eo + 1]);
+        mk[p] = to_f32(mask[em]);
     }
     float scale = 0.f, inv_scale = 0.f;
     if constexpr (FIX32) {
@@ -549,16 +554,17 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
         const int pl = e / P, p = e - pl * P;
         const int hh = ty * DCN_TS + (pl >> 4), ww = tx * DCN_TS + (pl & 15);
         if (hh < g.Ho && ww < g.Wo) {
-            const int64_t run = ((((int64_t)n * g.Ho + hh) * g.Wo + ww) * g.G + gi) * P + p;
+            const int64_t opix = ((int64_t)n * g.Ho + hh) * g.Wo + ww;
+            const int64_t run_m = opix * g.ld_mask + gi * P + p, run_o = opix * g.ld_off + (gi * P + p) * 2;      // (ld_off even: checked on the host)
             const T* sp = stage + pl * (3 * DCN_PMAX);
-            dmask[run] = sp[p];
+            dmask[run_m] = sp[p];
             if constexpr (sizeof(T) == 2) {      // the (x, y) pair of a point as one dword
                 const unsigned pair = (unsigned)__builtin_bit_cast(unsigned short, sp[DCN_PMAX + 2 * p]) |
                                       ((unsigned)__builtin_bit_cast(unsigned short, sp[DCN_PMAX + 2 * p + 1]) << 16);
-                reinterpret_cast<unsigned*>(doffset)[run] = pair;
+                *reinterpret_cast<unsigned*>(doffset + run_o) = pair;
             } else {
-                doffset[run * 2] = sp[DCN_PMAX + 2 * p];
-                doffset[run * 2 + 1] = sp[DCN_PMAX + 2 * p + 1];
+                doffset[run_o] = sp[DCN_PMAX + 2 * p];
+                doffset[run_o + 1] = sp[DCN_PMAX + 2 * p + 1];
             }
         }
     }
@@ -746,6 +752,8 @@ static int make_geom(DcnGeom* g, int N, int H, int W, int G, int Cg, int kh, int
     g->Ho = (g->Hin - (dil * (kh - 1) + 1)) / stride + 1;
     g->Wo = (g->Win - (dil * (kw - 1) + 1)) / stride + 1;
     g->s = s;
+    g->ld_off = 2 * G * kh * kw;
+    g->ld_mask = G * kh * kw;
     ISEG_REQUIRE(g->Ho > 0 && g->Wo > 0, "%s: empty output", who);
     ISEG_REQUIRE((int64_t)N * g->Hin * g->Win * G * Cg < (1ll << 40), "%s: tensor too large", who);
     return ISEG_OK;
@@ -794,11 +802,31 @@ static size_t dcn_win_bytes(const DcnGeom& g, const DcnWin& wn, size_t* side_off
 }
 }  // namespace
 
+// row pitches of the offset / mask operands (and of their gradients): 0 = dense; otherwise >= the dense run, ld_off even (bf16 gradient pairs are
+// stored as one dword)
+static int set_pitches(DcnGeom* g, int64_t ld_off, int64_t ld_mask, const char* who) {
+    if (ld_off == 0) ld_off = g->ld_off;
+    if (ld_mask == 0) ld_mask = g->ld_mask;
+    ISEG_REQUIRE(ld_off >= g->ld_off && ld_mask >= g->ld_mask && ld_off % 2 == 0 && ld_off < (1 << 30) && ld_mask < (1 << 30),
+                 "%s: offset / mask row pitches %lld / %lld (dense runs %d / %d; the offset pitch must be even)", who, (long long)ld_off,
+                 (long long)ld_mask, g->ld_off, g->ld_mask);
+    g->ld_off = (int)ld_off;
+    g->ld_mask = (int)ld_mask;
+    return ISEG_OK;
+}
+
 extern "C" int iseg_dcnv3_fwd(const void* x, const void* offset, const void* mask, void* y, int N, int H, int W, int G, int Cg, int kh,
                               int kw, int stride, int dil, int pad, float offset_scale, int dtype, hipStream_t stream) {
+    return iseg_dcnv3_fwd_ld(x, offset, mask, 0, 0, y, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, dtype, stream);
+}
+
+extern "C" int iseg_dcnv3_fwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, void* y, int N, int H, int W,
+                                 int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(x && offset && mask && y, "iseg_dcnv3_fwd: null pointer");
     DcnGeom g;
-    const int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_fwd");
+    int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_fwd");
+    if (rc != ISEG_OK) return rc;
+    rc = set_pitches(&g, ld_off, ld_mask, "iseg_dcnv3_fwd_ld");
     if (rc != ISEG_OK) return rc;
     const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
     const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
@@ -841,10 +869,20 @@ extern "C" size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int
 extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset,
                               void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
                               float offset_scale, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+    return iseg_dcnv3_bwd_ld(x, offset, mask, 0, 0, dy, dx_f32, doffset, dmask, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, dtype, ws,
+                             ws_bytes, stream);
+}
+
+extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, float* dx_f32,
+                                 void* doffset, void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
+                                 float offset_scale, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
     ISEG_REQUIRE(x && offset && mask && dy && dx_f32 && doffset && dmask, "iseg_dcnv3_bwd: null pointer");
     DcnGeom g;
-    const int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd");
+    int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd");
     if (rc != ISEG_OK) return rc;
+    rc = set_pitches(&g, ld_off, ld_mask, "iseg_dcnv3_bwd_ld");
+    if (rc != ISEG_OK) return rc;
+    ISEG_REQUIRE(dtype != ISEG_BF16 || (uintptr_t)doffset % 4 == 0, "iseg_dcnv3_bwd_ld: doffset must be 4-byte aligned");
     DcnWin wn;
     static const bool allow_win = [] { const char* e = getenv("ISEG_DCN_BWD_WIN"); return !e || atoi(e) != 0; }();
     if (allow_win && dcn_window(g, &wn)) {
@@ -1241,4 +1279,107 @@ extern "C" int iseg_dcnv2_sample_bwd(const void* x, const void* offset, const vo
                            (const float*)dcol, acc, (float*)doffset, N, H, W, C);
     hipLaunchKernelGGL(dcn_unfix_kernel, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel);
     return iseg_check_launch("iseg_dcnv2_sample_bwd");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The joint offset | mask projection of a DCNv3 layer (layers/dcn_v3/dcn_v3.py:116-123: two Dense layers on the same input, a softmax over each
+// group's P mask logits) as ONE product into a [pixels][ld] buffer: columns [0, 2GP) offsets, [2GP, 3GP) mask, then padding up to ld (% 8 == 0, the
+// LDS-DMA GEMM's output width).  The pieces around the GEMM:
+//   softmax over the P mask entries of every (pixel, group), in place, rows `ld` apart;
+//   its backward, which also clears the padding columns of the gradient buffer (they meet zero weights in the data-gradient product, and 0 x NaN
+//   is NaN);
+//   the weight / bias gradient of the joint product ([rows][ld] fp32) added column-range-wise into the two layers' gradients.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void dcn_mask_softmax_fwd_kernel(T* __restrict__ om, int64_t pixels, int G, int P, int ld, int col0) {
+    const int64_t total = pixels * G;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        T* r = om + (i / G) * ld + col0 + (int)(i % G) * P;
+        float v[DCN_PMAX], mx = -3.0e38f;
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p) {
+            v[p] = p < P ? to_f32(r[p]) : -3.0e38f;
+            mx = fmaxf(mx, v[p]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p) {
+            v[p] = p < P ? expf(v[p] - mx) : 0.f;
+            sum += v[p];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p)
+            if (p < P) r[p] = from_f32<T>(v[p] * inv);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dcn_mask_softmax_bwd_kernel(const T* __restrict__ om, T* __restrict__ dom, int64_t pixels, int G, int P, int ld,
+                                                                   int col0) {
+    const int64_t total = pixels * G;
+    const int pad0 = col0 + G * P;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i / G;
+        const int gi = (int)(i % G);
+        const T* y = om + pix * ld + col0 + gi * P;
+        T* d = dom + pix * ld + col0 + gi * P;
+        float yv[DCN_PMAX], dv[DCN_PMAX], dot = 0.f;
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p) {
+            yv[p] = p < P ? to_f32(y[p]) : 0.f;
+            dv[p] = p < P ? to_f32(d[p]) : 0.f;
+            dot = fmaf(yv[p], dv[p], dot);
+        }
+#pragma unroll
+        for (int p = 0; p < DCN_PMAX; ++p)
+            if (p < P) d[p] = from_f32<T>(yv[p] * (dv[p] - dot));
+        if (gi == 0)
+            for (int c = pad0; c < ld; ++c) dom[pix * ld + c] = from_f32<T>(0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void split_cols_accumulate_kernel(const float* __restrict__ src, int64_t rows, int ld, float* __restrict__ dst0, int n0,
+                                                                    float* __restrict__ dst1, int n1) {
+    const int64_t total = rows * (n0 + n1);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (n0 + n1);
+        const int c = (int)(i % (n0 + n1));
+        const float v = src[r * ld + c];
+        if (c < n0) {
+            if (dst0) dst0[r * n0 + c] += v;
+        } else if (dst1) {
+            dst1[r * n1 + (c - n0)] += v;
+        }
+    }
+}
+
+extern "C" int iseg_dcn_mask_softmax_fwd(void* om, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(om && pixels > 0 && G > 0 && P > 0 && P <= DCN_PMAX && col0 >= 0 && ld >= col0 + (int64_t)G * P && ld < (1 << 30),
+                 "iseg_dcn_mask_softmax_fwd: bad arguments (P <= %d)", DCN_PMAX);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL(dcn_mask_softmax_fwd_kernel<bf16_t>, dim3(lane_blocks(pixels * G)), dim3(256), 0, stream, (bf16_t*)om, pixels, G, P, (int)ld, col0);
+    else
+        hipLaunchKernelGGL(dcn_mask_softmax_fwd_kernel<float>, dim3(lane_blocks(pixels * G)), dim3(256), 0, stream, (float*)om, pixels, G, P, (int)ld, col0);
+    return iseg_check_launch("iseg_dcn_mask_softmax_fwd");
+}
+
+extern "C" int iseg_dcn_mask_softmax_bwd(const void* om, void* dom, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, hipStream_t stream) {
+    ISEG_REQUIRE(om && dom && pixels > 0 && G > 0 && P > 0 && P <= DCN_PMAX && col0 >= 0 && ld >= col0 + (int64_t)G * P && ld < (1 << 30),
+                 "iseg_dcn_mask_softmax_bwd: bad arguments (P <= %d)", DCN_PMAX);
+    if (dtype == ISEG_BF16)
+        hipLaunchKernelGGL(dcn_mask_softmax_bwd_kernel<bf16_t>, dim3(lane_blocks(pixels * G)), dim3(256), 0, stream, (const bf16_t*)om, (bf16_t*)dom, pixels, G,
+                           P, (int)ld, col0);
+    else
+        hipLaunchKernelGGL(dcn_mask_softmax_bwd_kernel<float>, dim3(lane_blocks(pixels * G)), dim3(256), 0, stream, (const float*)om, (float*)dom, pixels, G, P,
+                           (int)ld, col0);
+    return iseg_check_launch("iseg_dcn_mask_softmax_bwd");
+}
+
+// dst0 [rows][n0] += src[:, 0:n0],  dst1 [rows][n1] += src[:, n0:n0+n1]   (src [rows][ld] fp32; a null destination is skipped)
+extern "C" int iseg_split_cols_accumulate(const float* src, int64_t rows, int64_t ld, float* dst0, int n0, float* dst1, int n1, hipStream_t stream) {
+    ISEG_REQUIRE(src && rows > 0 && n0 >= 0 && n1 >= 0 && n0 + n1 > 0 && ld >= n0 + n1 && ld < (1 << 30), "iseg_split_cols_accumulate: bad arguments");
+    hipLaunchKernelGGL(split_cols_accumulate_kernel, dim3(lane_blocks(rows * (n0 + n1))), dim3(256), 0, stream, src, rows, (int)ld, dst0, n0, dst1, n1);
+    return iseg_check_launch("iseg_split_cols_accumulate");
 }

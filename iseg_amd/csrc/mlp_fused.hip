@@ -636,6 +636,26 @@ __global__ void convnext_weight_prep_batched_kernel(const int64_t* __restrict__ 
     if (e[0] == 1) {
         mlp_prep_elements(reinterpret_cast<const float*>(e[1]), reinterpret_cast<const float*>(e[2]), reinterpret_cast<const float*>(e[3]),
                           reinterpret_cast<bf16_t*>(e[4]), reinterpret_cast<bf16_t*>(e[5]), (int)e[6], first, stride);
+    } else if (e[0] == 2) {
+        // kind 2: two kernels on the same input, [C][Na] and [C][Nb] (+ their biases), as the images of ONE product of width ld >= Na + Nb (zero
+        // columns behind): dst = { [C][ld] bf16 (the data gradient's operand) | [ld][C] bf16 (the forward product's K-contiguous operand) |
+        // [ld] fp32 bias }.  Entry: {2, Wa, Wb, ba, dst, bb, C, Na | Nb << 20 | ld << 40}   (the DCNv3 offset | mask projection, csrc/dcnv3.hip)
+        const float* wa = reinterpret_cast<const float*>(e[1]);
+        const float* wb = reinterpret_cast<const float*>(e[2]);
+        const float* ba = reinterpret_cast<const float*>(e[3]);
+        const float* bb = reinterpret_cast<const float*>(e[5]);
+        const int Cc = (int)e[6], na = (int)(e[7] & 0xFFFFF), nb = (int)((e[7] >> 20) & 0xFFFFF), ld = (int)(e[7] >> 40);
+        bf16_t* rowcat = reinterpret_cast<bf16_t*>(e[4]);
+        bf16_t* tr = rowcat + (int64_t)Cc * ld;
+        float* bias = reinterpret_cast<float*>(tr + (int64_t)Cc * ld);
+        const int64_t total = (int64_t)Cc * ld;
+        for (int64_t i = first; i < total; i += stride) {
+            const int c = (int)(i / ld), j = (int)(i % ld);
+            const float v = j < na ? wa[(int64_t)c * na + j] : (j < na + nb ? wb[(int64_t)c * nb + (j - na)] : 0.f);
+            rowcat[i] = (bf16_t)v;
+            tr[(int64_t)j * Cc + c] = (bf16_t)v;
+        }
+        for (int j = first; j < ld; j += stride) bias[j] = j < na ? (ba ? ba[j] : 0.f) : (j < na + nb ? (bb ? bb[j - na] : 0.f) : 0.f);
     } else {
         const float* src = reinterpret_cast<const float*>(e[1]);
         const float* g = reinterpret_cast<const float*>(e[3]);

@@ -2478,6 +2478,84 @@ class _Dcnv3Fn(Function):
         return dx, doff, dmask, None
 
 
+_DCN_JOINT = os.environ.get("ISEG_DCN_JOINT", "1") != "0"      # experiment knob: 0 = offset and mask as two Dense layers + softmax_groups
+
+
+class _DcnJointFn(Function):
+    """offset | mask projection, mask softmax and the DCNv3 sampling core of one layer (layers/dcn_v3/dcn_v3.py:116-131) with the two Dense layers
+    run as ONE product of width ld = 3 G P rounded up to 8 into a [pixels, ld] matrix whose column ranges the sampling kernels read in place
+    (csrc/dcnv3.hip iseg_dcnv3_fwd_ld): widths like 126 / 63 (G = 7) or 252 (G = 28) keep two products off the LDS-DMA GEMM each way, their sum
+    padded to 192 / 768 does not.  Backward: sampling gradients in the same layout, softmax backward in place, ONE data-gradient product, ONE
+    weight-gradient product whose [C, ld] result (and ones-row bias gradient) is added column-range-wise into the two layers' gradients."""
+
+    @staticmethod
+    def forward(ctx, x_proj, x1, W_off, b_off, W_mask, b_mask, cfg):
+        G, Cg, kh, kw, stride, dil, pad, s = cfg
+        P = kh * kw
+        Cin = x1.shape[-1]
+        x2 = _c(x1).reshape(-1, Cin)
+        rowcat, tr, bias = nn.joint_kernels(W_off, W_mask, b_off, b_mask)
+        om = K.dense_fwd_t(x2, tr, bias)
+        K.dcn_mask_softmax_fwd(om, G, P)
+        xp = _c(x_proj)
+        y = K.dcnv3_fwd_joint(xp, om, G, Cg, kh, kw, stride, dil, pad, s)
+        ctx.cfg, ctx.params = cfg, (W_off, b_off, W_mask, b_mask)
+        ctx.save_for_backward(xp, x2, om)
+        ctx.x1_shape = x1.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, x2, om = ctx.saved_tensors
+        G, Cg, kh, kw, stride, dil, pad, s = ctx.cfg
+        P = kh * kw
+        W_off, b_off, W_mask, b_mask = ctx.params
+        dxp, dom = K.dcnv3_bwd_joint(xp, om, _c(dy), G, Cg, kh, kw, stride, dil, pad, s)
+        if dxp.dtype != xp.dtype:
+            dxp = K.cast(dxp, xp.dtype)
+        K.dcn_mask_softmax_bwd(om, dom, G, P)
+        rowcat, tr, bias = nn.joint_kernels(W_off, W_mask, b_off, b_mask)
+        Cin, ld = rowcat.shape
+        na, nb = 2 * G * P, G * P
+        want_w = W_off.requires_grad or W_mask.requires_grad
+        want_b = b_off.requires_grad or b_mask.requires_grad
+        if want_w:
+            dW = torch.empty((Cin, ld), dtype=torch.float32, device=dom.device)
+            db = torch.empty(ld, dtype=torch.float32, device=dom.device) if want_b else None
+            K.dense_wgrad(x2, dom, dW, accumulate=False, bias_grad=db)
+            K.split_cols_accumulate(dW, _grad(W_off).reshape(Cin, na) if W_off.requires_grad else None, na,
+                                    _grad(W_mask).reshape(Cin, nb) if W_mask.requires_grad else None, nb)
+        elif want_b:
+            db = torch.empty(ld, dtype=torch.float32, device=dom.device)
+            K.colsum(dom, ld, 0, 1, dom.shape[0], ld, db, accumulate=False)
+        if want_b:
+            K.split_cols_accumulate(db, _grad(b_off).reshape(-1) if b_off.requires_grad else None, na,
+                                    _grad(b_mask).reshape(-1) if b_mask.requires_grad else None, nb)
+        dx1 = None
+        if ctx.needs_input_grad[1]:
+            dx1 = K.dense_dgrad(dom, rowcat).reshape(ctx.x1_shape)
+        dist.grads_ready(W_off, b_off, W_mask, b_mask)
+        return dxp, dx1, None, None, None, None, None
+
+
+def dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size):
+    kh, kw = kernel_size
+    return (_DCN_JOINT and not nn.dry_run() and x1.dtype == torch.bfloat16 and kh * kw <= 9 and getattr(offset_layer, "kernel", None) is not None
+            and getattr(mask_layer, "kernel", None) is not None and offset_layer.bias is not None and mask_layer.bias is not None
+            and x1.shape[-1] % 8 == 0 and x1.shape[-1] >= 64)
+
+
+def dcnv3_joint(x_proj, x1, offset_layer, mask_layer, groups, group_channels, kernel_size=(3, 3), stride=1, dilation=1, pad=1, offset_scale=1.0):
+    """F.dcnv3_core(x_proj, offset_layer(x1), softmax_groups(mask_layer(x1)), ...) as one node (see _DcnJointFn), or None when this form does not
+    apply (fp32 storage, more than nine sampling points, a projection without bias, ISEG_DCN_JOINT=0): the caller then takes the layer-by-layer
+    route"""
+    kh, kw = kernel_size
+    if not dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size):
+        return None
+    cfg = (int(groups), int(group_channels), int(kh), int(kw), int(stride), int(dilation), int(pad), float(offset_scale))
+    return _DcnJointFn.apply(x_proj, x1, offset_layer.kernel, offset_layer.bias, mask_layer.kernel, mask_layer.bias, cfg)
+
+
 class _DcnCenterBlendFn(Function):
     @staticmethod
     def forward(ctx, x, x_proj, scale, G, Cg):

@@ -1293,6 +1293,59 @@ def dcnv3_bwd(x, offset, mask, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale
     return dx, doff, dmask
 
 
+def dcnv3_fwd_joint(x, om, G, Cg, kh, kw, stride, dil, pad, offset_scale):
+    """dcnv3_fwd with the offsets and the (soft-maxed) mask as column ranges [0, 2GP) and [2GP, 3GP) of ONE matrix om [pixels, ld]"""
+    _require_cuda(x, om)
+    N, H, W, Cc = x.shape
+    Ho, Wo = dcnv3_out_hw(H, W, kh, kw, stride, dil, pad)
+    gp = G * kh * kw
+    if Cc != G * Cg or om.dim() != 2 or om.shape[0] != N * Ho * Wo or om.shape[1] < 3 * gp or om.stride(1) != 1:
+        raise ValueError(f"dcnv3_fwd_joint: x {tuple(x.shape)} / om {tuple(om.shape)} do not match G={G} Cg={Cg} k={kh}x{kw} -> {Ho}x{Wo}")
+    y = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    ld = om.stride(0)
+    _hip.check(_hip.lib().iseg_dcnv3_fwd_ld(ptr(x), ptr(om), ptr(om[:, 2 * gp:]), ld, ld, ptr(y), N, H, W, G, Cg, kh, kw, stride, dil, pad,
+                                           float(offset_scale), dt(x), stream()), "iseg_dcnv3_fwd_ld")
+    return y
+
+
+def dcnv3_bwd_joint(x, om, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale):
+    """-> (dx fp32, dom [pixels, ld]): the offset / mask gradients in om's layout; the columns behind 3GP are NOT written (dcn_mask_softmax_bwd
+    clears them)"""
+    _require_cuda(x, om, dy)
+    N, H, W, Cc = x.shape
+    Ho, Wo = dcnv3_out_hw(H, W, kh, kw, stride, dil, pad)
+    if tuple(dy.shape) != (N, Ho, Wo, Cc) or Cc != G * Cg:
+        raise ValueError("dcnv3_bwd_joint: dy shape does not match the forward geometry")
+    gp = G * kh * kw
+    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
+    dom = torch.empty_like(om)
+    ld = om.stride(0)
+    L = _hip.lib()
+    ws, wsb = workspace(L.iseg_dcnv3_bwd_workspace_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
+    _hip.check(L.iseg_dcnv3_bwd_ld(ptr(x), ptr(om), ptr(om[:, 2 * gp:]), ld, ld, ptr(dy), ptr(dx), ptr(dom), ptr(dom[:, 2 * gp:]), N, H, W, G, Cg,
+                                   kh, kw, stride, dil, pad, float(offset_scale), dt(x), ptr(ws), wsb, stream()), "iseg_dcnv3_bwd_ld")
+    return dx, dom
+
+
+def dcn_mask_softmax_fwd(om, G, P):
+    """softmax over each (pixel, group)'s P mask logits, in place on columns [2GP, 3GP) of om [pixels, ld]"""
+    _hip.call("iseg_dcn_mask_softmax_fwd", ptr(om), om.shape[0], G, P, om.stride(0), 2 * G * P, dt(om), stream())
+    return om
+
+
+def dcn_mask_softmax_bwd(om, dom, G, P):
+    """in place on dom: the softmax backward on the mask columns, zeros in the padding columns behind 3GP"""
+    _hip.call("iseg_dcn_mask_softmax_bwd", ptr(om), ptr(dom), om.shape[0], G, P, om.stride(0), 2 * G * P, dt(om), stream())
+    return dom
+
+
+def split_cols_accumulate(src, dst0, n0, dst1, n1):
+    """dst0 [rows, n0] += src[:, :n0]; dst1 [rows, n1] += src[:, n0:n0 + n1]   (fp32; src [rows, ld]; None destinations are skipped)"""
+    rows = src.shape[0] if src.dim() == 2 else 1
+    ld = src.stride(0) if src.dim() == 2 else src.numel()
+    _hip.call("iseg_split_cols_accumulate", ptr(src), rows, ld, ptr(dst0), int(n0), ptr(dst1), int(n1), stream())
+
+
 def dcn_center_blend_fwd(x, x_proj, scale, G, Cg):
     """x (1 - s) + x_proj s, s [.., G] broadcast over each group's Cg channels"""
     _require_cuda(x, x_proj, scale)

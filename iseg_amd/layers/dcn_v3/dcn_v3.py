@@ -42,16 +42,26 @@ class DeformableConvolutionV3(Layer):
         x1 = self.dw_norm(self.dw_conv(xb))
         if self.activation == "gelu":
             x1 = F.gelu(x1)
-        if self.center_feature_scale:
-            x1a, x1b, x1c = F.fork(x1, 3)
-            x_proj, x_proj_skip = F.fork(x_proj, 2)
-        else:
-            x1a, x1b = F.fork(x1, 2)
-        offset = self.offset(x1a)
-        mask = F.softmax_groups(self.mask(x1b), self.kernel_size * self.kernel_size)
         pad = self.kernel_size // 2 if self.padding.upper() == "SAME" else 0
-        x = F.dcnv3_core(x_proj, offset, mask, self.groups, self.filters_per_group, (self.kernel_size, self.kernel_size),
-                         self.strides, self.dilation_rate, pad, self.offset_scale)
+        ks = (self.kernel_size, self.kernel_size)
+        if F.dcnv3_joint_ok(x1, self.offset, self.mask, ks):
+            # bf16 storage: the two projections as one product, the sampling kernels reading its column ranges in place (F._DcnJointFn)
+            if self.center_feature_scale:
+                x1a, x1c = F.fork(x1, 2)
+                x_proj, x_proj_skip = F.fork(x_proj, 2)
+            else:
+                x1a = x1
+            x = F.dcnv3_joint(x_proj, x1a, self.offset, self.mask, self.groups, self.filters_per_group, ks, self.strides, self.dilation_rate, pad,
+                              self.offset_scale)
+        else:
+            if self.center_feature_scale:
+                x1a, x1b, x1c = F.fork(x1, 3)
+                x_proj, x_proj_skip = F.fork(x_proj, 2)
+            else:
+                x1a, x1b = F.fork(x1, 2)
+            offset = self.offset(x1a)
+            mask = F.softmax_groups(self.mask(x1b), self.kernel_size * self.kernel_size)
+            x = F.dcnv3_core(x_proj, offset, mask, self.groups, self.filters_per_group, ks, self.strides, self.dilation_rate, pad, self.offset_scale)
         if self.center_feature_scale:      # (:138-146) x (1 - s) + x_proj s, one s per (pixel, group)
             x = F.dcn_center_blend(x, x_proj_skip, self.center_feature_scale_proj(x1c), self.groups, self.filters_per_group)
         return self.output_proj(x)

@@ -356,6 +356,14 @@ def _prep_rows(e):
         Cc = w1.shape[0]
         return [1, w1.data.data_ptr(), w2.data.data_ptr(), gamma.data.data_ptr() if gamma is not None else 0, fw.data_ptr(),
                 bw.data_ptr() if bw is not None else 0, Cc, 0], 5 * 4 * Cc * Cc
+    if e["kind"] == 2:
+        wa, wb = ps[0], ps[1]
+        ba, bb = (ps[2], ps[3]) if len(ps) > 2 else (None, None)
+        blob = e["bufs"][3]
+        Cc, na, nb = wa.shape[0], wa.shape[1], wb.shape[1]
+        ld = (na + nb + 7) // 8 * 8
+        return [2, wa.data.data_ptr(), wb.data.data_ptr(), ba.data.data_ptr() if ba is not None else 0, blob.data_ptr(),
+                bb.data.data_ptr() if bb is not None else 0, Cc, na | (nb << 20) | (ld << 40)], Cc * ld
     w2, gamma = ps
     (dst,) = e["bufs"]
     rows, cols = w2.shape
@@ -401,6 +409,25 @@ def mlp_tiled(w1, w2, gamma):
 def w_colscaled(w2, gamma):
     """bf16 copy of the 2-D kernel w2 with its columns scaled by gamma (layer scale folded into the data-gradient product)"""
     return _prep_request(0, [w2, gamma], lambda: (torch.empty(tuple(w2.shape), dtype=torch.bfloat16, device=w2.device),))[0]
+
+
+def joint_kernels(wa, wb, ba=None, bb=None):
+    """two 2-D kernels [C, Na], [C, Nb] on the same input (and their biases) as the operands of ONE product of width ld = Na + Nb rounded up to 8:
+    (rowcat [C, ld] bf16 -- the data gradient's operand, transposed [ld, C] bf16 -- the forward product's K-contiguous operand, bias [ld] fp32),
+    zero in the padding columns, valid for the current weights (re-derived with the other per-update images, csrc/mlp_fused.hip kind 2).  The
+    DCNv3 layer's offset | mask projection (layers/dcn_v3/dcn_v3.py)."""
+    Cc, na, nb = wa.shape[0], wa.shape[1], wb.shape[1]
+    ld = (na + nb + 7) // 8 * 8
+
+    def make():
+        blob = torch.empty(2 * Cc * ld * 2 + ld * 4, dtype=torch.uint8, device=wa.device)
+        rowcat = blob[:Cc * ld * 2].view(torch.bfloat16).view(Cc, ld)
+        tr = blob[Cc * ld * 2:2 * Cc * ld * 2].view(torch.bfloat16).view(ld, Cc)
+        bias = blob[2 * Cc * ld * 2:].view(torch.float32)
+        return (rowcat, tr, bias, blob)
+
+    params = [wa, wb] + ([ba, bb] if ba is not None and bb is not None else [])
+    return _prep_request(2, params, make)[:3]
 
 
 _DRY = [False]

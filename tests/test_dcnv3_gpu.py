@@ -266,3 +266,53 @@ def test_fapn_decoder_matches_oracle(cuda, dtype):
             assert all(torch.isfinite(a.grad.float()).all() for a in xg)
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("C,G,shape", [(112, 7, (2, 20, 24)), (64, 4, (1, 33, 17)), (224, 14, (1, 16, 16))])
+def test_dcnv3_layer_joint_projection_matches_layerwise(cuda, monkeypatch, C, G, shape):
+    """bf16 storage: the offset | mask projections as ONE product with the sampling kernels reading its column ranges (F._DcnJointFn, round 5)
+    against the layer-by-layer route (two Dense layers, softmax_groups, dcnv3_core) on the same weights: output, input gradient and every parameter
+    gradient (offset / mask kernels and biases included) to bf16 rounding of the intermediate tensors"""
+    from iseg_amd import functional as F
+    from iseg_amd import nn
+    from iseg_amd.layers.dcn_v3.dcn_v3 import DeformableConvolutionV3
+    from iseg_amd.param_store import ParamStore
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    try:
+        N, H, W = shape
+        layer = DeformableConvolutionV3(filters=C, groups=G, name="dcn_joint_test")
+        with nn.dry_run_scope():
+            layer(torch.empty((N, H, W, C), dtype=torch.bfloat16, device="cuda"))
+        store = ParamStore(list(layer.parameters()))
+        randomize_parameters(layer, 3)
+        g = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for p in layer.parameters():
+                if "offset" in p.iseg_name or "mask" in p.iseg_name:      # zeros-initialised by default: make the sampling genuinely deformed
+                    p.copy_((torch.randn(p.shape, generator=g) * (0.5 if p.dim() == 1 else 0.05)).to(p.device))
+        store.sync_shadow()
+        x = torch.randn((N, H, W, C), generator=g).bfloat16()
+        dy = torch.randn((N, H, W, C), generator=g).bfloat16()
+
+        def run(joint):
+            monkeypatch.setattr(F, "_DCN_JOINT", joint)
+            store.zero_grad()
+            xg = x.cuda().requires_grad_(True)
+            y = layer(xg, training=True)
+            y.backward(dy.cuda())
+            return y.detach().float().cpu(), xg.grad.float().cpu(), {p.iseg_name: p.grad.detach().float().cpu().clone() for p in layer.parameters()}
+
+        ya, dxa, ga = run(True)
+        yb, dxb, gb = run(False)
+
+        def rel(a, b):
+            return (a - b).norm().item() / max(b.norm().item(), 1e-12)
+
+        assert rel(ya, yb) < 1e-2, rel(ya, yb)
+        assert rel(dxa, dxb) < 2e-2, rel(dxa, dxb)
+        bad = {k: rel(ga[k], gb[k]) for k in ga if rel(ga[k], gb[k]) > 3e-2}
+        assert not bad, bad
+    finally:
+        nn.set_compute_dtype(torch.float32)
