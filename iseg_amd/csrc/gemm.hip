@@ -66,8 +66,8 @@ int dma_mode() {
 int dma_min_k() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_DMA_MIN_K");
-        const int k = e ? atoi(e) : 64;
-        return k < 64 ? 64 : k;
+        const int k = e ? atoi(e) : 32;
+        return k < 16 ? 16 : k;
     }();
     return v;
 }

@@ -74,7 +74,7 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
 // sixteen zero bytes in device memory: what a lane past the K tail asks the DMA for
 static __device__ __attribute__((aligned(16))) unsigned int dma_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
-int dma_min_k();      // ISEG_GEMM_DMA_MIN_K (default 64): shortest reduction the pipeline takes
+int dma_min_k();      // ISEG_GEMM_DMA_MIN_K (default 32): shortest reduction the pipeline takes (262144 x 96 x 48: 22.4 -> 19.4 us)
 
 inline int epi_kind(const Epi& e, const float* slabs) {
     if (slabs || e.alpha != 1.f || e.accumulate) return EK_ANY;
@@ -85,7 +85,9 @@ inline int epi_kind(const Epi& e, const float* slabs) {
     return EK_ANY;
 }
 
-template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY>
+// KT: the instantiation that handles a K tail (launched only for K % 64 != 0: the tail's address selects cost the whole-K flagship launches 0.5 %
+// of the step when they were compiled into every instantiation -- tools/ab_ktail.sh, 8.28 vs 8.24 ms)
+template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY, bool KT = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     // K tail: a last K-step of fewer than eight 16-B chunks.  The lanes whose source chunk lies beyond it request a 16-B run of zeros instead
     // (the stage slot must hold zeros for BOTH operands: whatever lies behind the row's end times zero is not zero when it decodes as inf / NaN)
-    const int nk = (int)((kend - kbeg + 63) / 64);
-    const int tail_chunks = (int)(((kend - kbeg) & 63) >> 3);      // 0: the last K-step is whole
+    const int nk = KT ? (int)((kend - kbeg + 63) / 64) : (int)((kend - kbeg) / 64);
+    const int tail_chunks = KT ? (int)(((kend - kbeg) & 63) >> 3) : 0;      // 0: the last K-step is whole
 
     // per-lane DMA sources: piece p of this wavefront covers stage rows 8*(wid + p*NW) .. +7 (A rows first, then B rows);
     // lane l fills LDS slot (row l>>3, chunk l&7) with source chunk (l&7) ^ (l>>3)
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     point(m0, n0);
     // kstep: the K-step the stage is filled with (only the last one can be a tail)
     auto issue = [&](int stage, int kstep) {
-        if (tail_chunks != 0 && kstep == nk - 1) {
+        if (KT && tail_chunks != 0 && kstep == nk - 1) {
 #pragma unroll
             for (int p = 0; p < PPW; ++p) {
                 const bf16_t* s = beyond[p] ? reinterpret_cast<const bf16_t*>(dma_zero_chunk) : src[p];
@@ -325,7 +327,17 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
     const int batch = g->batch > 1 ? g->batch : 1;
     dim3 grid(ntiles, nsplit, batch);
     constexpr int lds = NS * (BM + BN) * 128;
-    static const bool raised = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
+    if (g->K % 64 != 0) {
+        static const bool raised_kt = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        }();
+        (void)raised_kt;
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+                           (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
+        return;
+    }
+    static const bool raised = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     }();
@@ -406,7 +418,7 @@ inline int dma_form(const iseg_gemm_args* g, int nsplit) {
         const double e128 = (double)t128 / (double)(ceil_div64(t128, cus) * cus), e192 = (double)t192 / (double)(ceil_div64(t192, cus) * cus);
         if (t192 >= cus && e192 >= e128 + 0.1) return 6;      // only where it fills the rounds better: equal rounds measured equal in situ
     }
-    if (persist && t128 > cus) return 5;
+    if (persist && t128 > cus && g->K % 64 == 0) return 5;      // (the persistent instantiation has no K-tail form)
     return variant;
 }
 

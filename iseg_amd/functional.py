@@ -81,12 +81,12 @@ class _CastFn(Function):
 # Dense / 1x1 conv:  y = act(x @ W + b)         keras.layers.Dense, Conv2D(1x1)
 # ---------------------------------------------------------------------------------------------------------
 _FWD_KCONTIG = os.environ.get("ISEG_FWD_KCONTIG", "1") != "0"      # experiment knob: 0 = forward products read the Keras [K][N] kernels
-_DMA_MIN_K = max(64, int(os.environ.get("ISEG_GEMM_DMA_MIN_K", "64")))      # the same knob csrc/gemm.hip reads (dma_min_k)
+_DMA_MIN_K = max(16, int(os.environ.get("ISEG_GEMM_DMA_MIN_K", "32")))      # the same knob csrc/gemm.hip reads (dma_min_k)
 
 
 def _kcontig_kernel(W, x2, Kd, N):
     """the [N][K] copy of a forward product's kernel (nn.wt) when the LDS-DMA GEMM can take the product (csrc/gemm_dma.h dma_eligible: bf16,
-    K a multiple of 8 and >= 64, N a multiple of 8 and >= 64, M >= 64), else None: the register-staged kernel reads [K][N] as it lies"""
+    K a multiple of 8 and >= 32, N a multiple of 8 and >= 64, M >= 64), else None: the register-staged kernel reads [K][N] as it lies"""
     if not _FWD_KCONTIG or x2.dtype != torch.bfloat16 or Kd % 8 or Kd < _DMA_MIN_K or N % 8 or N < 64 or x2.shape[0] < 64:
         return None
     return nn.wt(W, (Kd, N))
