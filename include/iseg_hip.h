@@ -544,9 +544,13 @@ int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const vo
  * joint weight / bias gradient handed back to the two layers. */
 int iseg_dcnv3_fwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, void* y, int N, int H, int W, int G,
                       int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale, int dtype, iseg_stream_t stream);
-int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, float* dx_f32,
+/* _bwd_ld further takes the storage type of dx (ISEG_F32, or ISEG_BF16: the input gradient is written in the activations' type, no fp32 image
+ * and cast pass) and, optionally, a caller-kept side buffer of iseg_dcnv3_bwd_side_bytes(...) bytes that is ALL ZERO on entry and is left all zero
+ * (the per-call zeroing of 8 bytes per input element goes away; null = the side buffer lives in `ws` and is zeroed per call). */
+size_t iseg_dcnv3_bwd_side_bytes(int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale);
+int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, void* dx, int dx_dtype,
                       void* doffset, void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
-                      float offset_scale, int dtype, void* ws, size_t ws_bytes, iseg_stream_t stream);
+                      float offset_scale, int dtype, void* ws, size_t ws_bytes, void* side_keep, size_t side_keep_bytes, iseg_stream_t stream);
 int iseg_dcn_mask_softmax_fwd(void* om, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, iseg_stream_t stream);
 int iseg_dcn_mask_softmax_bwd(const void* om, void* dom, int64_t pixels, int G, int P, int64_t ld, int col0, int dtype, iseg_stream_t stream);
 int iseg_split_cols_accumulate(const float* src, int64_t rows, int64_t ld, float* dst0, int n0, float* dst1, int n1, iseg_stream_t stream);

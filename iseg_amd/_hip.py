@@ -158,7 +158,8 @@ SIGNATURES = {
     "iseg_dcnv3_bwd_workspace_bytes": (_z, [_i] * 10 + [_f]),
     "iseg_dcnv3_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _p, _z, _p]),
     "iseg_dcnv3_fwd_ld": (_i, [_p, _p, _p, _l, _l, _p] + [_i] * 10 + [_f, _i, _p]),
-    "iseg_dcnv3_bwd_ld": (_i, [_p, _p, _p, _l, _l, _p, _p, _p, _p] + [_i] * 10 + [_f, _i, _p, _z, _p]),
+    "iseg_dcnv3_bwd_side_bytes": (_z, [_i] * 10 + [_f]),
+    "iseg_dcnv3_bwd_ld": (_i, [_p, _p, _p, _l, _l, _p, _p, _i, _p, _p] + [_i] * 10 + [_f, _i, _p, _z, _p, _z, _p]),
     "iseg_dcn_mask_softmax_fwd": (_i, [_p, _l, _i, _i, _l, _i, _i, _p]),
     "iseg_dcn_mask_softmax_bwd": (_i, [_p, _p, _l, _i, _i, _l, _i, _i, _p]),
     "iseg_split_cols_accumulate": (_i, [_p, _l, _l, _p, _i, _p, _i, _p]),

@@ -578,9 +578,11 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
 }
 
 // dx[n, uy, ux, g, :] = sum of the windows that cover padded pixel (uy + pad, ux + pad), tile-row-major, + the side buffer
-template <int CG>
-__global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __restrict__ windows, const unsigned long long* __restrict__ side,
-                                                               const int* __restrict__ side_used, float* __restrict__ dx, DcnGeom g,
+// TO: the storage type of dx (fp32, or bf16 directly: no fp32 image and cast pass in between).  RESET: the side buffer is a caller-kept one that is
+// all zero between calls (no 8-B-per-element zeroing pass per backward): a lane that consumed its entries writes the zeros back.
+template <int CG, class TO, bool RESET>
+__global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __restrict__ windows, unsigned long long* __restrict__ side,
+                                                               const int* __restrict__ side_used, TO* __restrict__ dx, DcnGeom g,
                                                                DcnWin wn) {
     constexpr int WPIX = DCN_WS * DCN_WS, Q = CG / 4;
     // (the host keeps N H W G Q and the bracket products below 2^31: 32-bit index arithmetic -- the 64-bit divisions of the first form were
@@ -626,13 +628,23 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
             acc.y += (float)((double)(long long)side[e + 1] * DCN_UNFIX);
             acc.z += (float)((double)(long long)side[e + 2] * DCN_UNFIX);
             acc.w += (float)((double)(long long)side[e + 3] * DCN_UNFIX);
+            if (RESET) side[e] = side[e + 1] = side[e + 2] = side[e + 3] = 0ull;
         }
-        *reinterpret_cast<float4*>(dx + e) = acc;
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(dx + e) = acc;
+        } else {
+            const bf16_t o[4] = {(bf16_t)acc.x, (bf16_t)acc.y, (bf16_t)acc.z, (bf16_t)acc.w};
+            *reinterpret_cast<uint2*>(dx + e) = *reinterpret_cast<const uint2*>(o);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void dcn_unfix_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ dx, int64_t n) {
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = (float)((double)(long long)acc[i] * DCN_UNFIX);
+__global__ void dcn_flag_reset_kernel(int* __restrict__ flag) { *flag = 0; }
+
+template <class TO>
+__global__ __launch_bounds__(256) void dcn_unfix_kernel(const unsigned long long* __restrict__ acc, TO* __restrict__ dx, int64_t n) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = from_f32<TO>((float)((double)(long long)acc[i] * DCN_UNFIX));
 }
 
 __global__ __launch_bounds__(256) void dcn_zero_kernel(uint4* __restrict__ p, int64_t n16) {
@@ -869,14 +881,28 @@ extern "C" size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int
 extern "C" int iseg_dcnv3_bwd(const void* x, const void* offset, const void* mask, const void* dy, float* dx_f32, void* doffset,
                               void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
                               float offset_scale, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
-    return iseg_dcnv3_bwd_ld(x, offset, mask, 0, 0, dy, dx_f32, doffset, dmask, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, dtype, ws,
-                             ws_bytes, stream);
+    return iseg_dcnv3_bwd_ld(x, offset, mask, 0, 0, dy, dx_f32, ISEG_F32, doffset, dmask, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, dtype,
+                             ws, ws_bytes, nullptr, 0, stream);
 }
 
-extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, float* dx_f32,
-                                 void* doffset, void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
-                                 float offset_scale, int dtype, void* ws, size_t ws_bytes, hipStream_t stream) {
+// bytes of the caller-kept side buffer of iseg_dcnv3_bwd_ld (0: this geometry does not take the window route)
+extern "C" size_t iseg_dcnv3_bwd_side_bytes(int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad, float offset_scale) {
+    DcnGeom g;
+    if (make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd_side_bytes") != ISEG_OK) return 0;
+    DcnWin wn;
+    if (!dcn_window(g, &wn)) return 0;
+    size_t so, fo;
+    const size_t all = dcn_win_bytes(g, wn, &so, &fo);
+    return all - so;
+}
+
+extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* mask, int64_t ld_off, int64_t ld_mask, const void* dy, void* dx,
+                                 int dx_dtype, void* doffset, void* dmask, int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil,
+                                 int pad, float offset_scale, int dtype, void* ws, size_t ws_bytes, void* side_keep, size_t side_keep_bytes,
+                                 hipStream_t stream) {
+    void* const dx_f32 = dx;
     ISEG_REQUIRE(x && offset && mask && dy && dx_f32 && doffset && dmask, "iseg_dcnv3_bwd: null pointer");
+    ISEG_REQUIRE(dx_dtype == ISEG_F32 || dx_dtype == ISEG_BF16, "iseg_dcnv3_bwd_ld: dx_dtype %d", dx_dtype);
     DcnGeom g;
     int rc = make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd");
     if (rc != ISEG_OK) return rc;
@@ -895,8 +921,16 @@ extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* 
         float* windows = (float*)ws;
         unsigned long long* side = (unsigned long long*)((char*)ws + side_off);
         int* flag = (int*)((char*)ws + flag_off);
-        const int64_t n16 = (int64_t)(need - side_off) / 16;      // side buffer + flag
-        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)side, n16);
+        const bool keep = side_keep != nullptr;
+        if (keep) {      // all zero on entry (the caller's promise), all zero again when the gather kernel and the flag reset have run
+            ISEG_REQUIRE(side_keep_bytes >= need - side_off && (uintptr_t)side_keep % 16 == 0, "iseg_dcnv3_bwd_ld: the kept side buffer needs %zu bytes, got %zu",
+                         need - side_off, side_keep_bytes);
+            side = (unsigned long long*)side_keep;
+            flag = (int*)((char*)side_keep + (flag_off - side_off));
+        } else {
+            const int64_t n16 = (int64_t)(need - side_off) / 16;      // side buffer + flag
+            hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)side, n16);
+        }
         const unsigned blocks = (unsigned)((int64_t)N * wn.tiles_y * wn.tiles_x * G);
         const size_t cells = Cg == 16 ? DcnWinLds<16>::CELLS : DcnWinLds<8>::CELLS;
         const size_t stage_bytes = (size_t)256 * 3 * DCN_PMAX * (dtype == ISEG_BF16 ? 2 : 4);      // staged mask / offset gradients
@@ -920,10 +954,17 @@ extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* 
         }
 #undef DCN_WIN
         const int64_t threads = (int64_t)N * H * W * G * (Cg / 4);
-        if (Cg == 16)
-            hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<16>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, dx_f32, g, wn);
-        else
-            hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<8>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, dx_f32, g, wn);
+#define DCN_GATHER(CG, TO, RESET)                                                                                                          \
+    hipLaunchKernelGGL((dcnv3_bwd_gather_kernel<CG, TO, RESET>), dim3(lane_blocks(threads)), dim3(256), 0, stream, windows, side, flag, (TO*)dx, g, wn)
+        if (dx_dtype == ISEG_BF16) {
+            if (Cg == 16) { if (keep) DCN_GATHER(16, bf16_t, true); else DCN_GATHER(16, bf16_t, false); }
+            else { if (keep) DCN_GATHER(8, bf16_t, true); else DCN_GATHER(8, bf16_t, false); }
+        } else {
+            if (Cg == 16) { if (keep) DCN_GATHER(16, float, true); else DCN_GATHER(16, float, false); }
+            else { if (keep) DCN_GATHER(8, float, true); else DCN_GATHER(8, float, false); }
+        }
+#undef DCN_GATHER
+        if (keep) hipLaunchKernelGGL(dcn_flag_reset_kernel, dim3(1), dim3(1), 0, stream, flag);
         return iseg_check_launch("iseg_dcnv3_bwd");
     }
     // general route (other group widths, footprints wider than the window): int64 fixed-point atomics into a zeroed workspace, then one
@@ -969,7 +1010,8 @@ extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* 
 #undef DCN_BWD_CL_ANY
 #undef DCN_BWD_CL
 #undef DCN_BWD
-    hipLaunchKernelGGL(dcn_unfix_kernel, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel);
+    if (dx_dtype == ISEG_BF16) hipLaunchKernelGGL(dcn_unfix_kernel<bf16_t>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (bf16_t*)dx, nel);
+    else hipLaunchKernelGGL(dcn_unfix_kernel<float>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (float*)dx, nel);
     return iseg_check_launch("iseg_dcnv3_bwd");
 }
 

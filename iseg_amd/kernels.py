@@ -1317,14 +1317,36 @@ def dcnv3_bwd_joint(x, om, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale):
     if tuple(dy.shape) != (N, Ho, Wo, Cc) or Cc != G * Cg:
         raise ValueError("dcnv3_bwd_joint: dy shape does not match the forward geometry")
     gp = G * kh * kw
-    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
+    dx = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
     dom = torch.empty_like(om)
     ld = om.stride(0)
     L = _hip.lib()
     ws, wsb = workspace(L.iseg_dcnv3_bwd_workspace_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
-    _hip.check(L.iseg_dcnv3_bwd_ld(ptr(x), ptr(om), ptr(om[:, 2 * gp:]), ld, ld, ptr(dy), ptr(dx), ptr(dom), ptr(dom[:, 2 * gp:]), N, H, W, G, Cg,
-                                   kh, kw, stride, dil, pad, float(offset_scale), dt(x), ptr(ws), wsb, stream()), "iseg_dcnv3_bwd_ld")
+    side = _dcn_side(L.iseg_dcnv3_bwd_side_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
+    _hip.check(L.iseg_dcnv3_bwd_ld(ptr(x), ptr(om), ptr(om[:, 2 * gp:]), ld, ld, ptr(dy), ptr(dx), dt(dx), ptr(dom), ptr(dom[:, 2 * gp:]), N, H, W, G,
+                                   Cg, kh, kw, stride, dil, pad, float(offset_scale), dt(x), ptr(ws), wsb, ptr(side),
+                                   side.numel() if side is not None else 0, stream()), "iseg_dcnv3_bwd_ld")
     return dx, dom
+
+
+# The kept side buffer of the DCNv3 backward (iseg_dcnv3_bwd_ld): zero-filled once when it is (re)allocated, left all zero by every call.  One per
+# device, grown to the largest geometry seen; a growth re-homes it, which a captured graph must notice (nn.buffers_generation).
+_DCN_SIDE = {}
+
+
+def _dcn_side(nbytes, device):
+    if nbytes == 0:
+        return None
+    key = str(device)
+    buf = _DCN_SIDE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        from . import nn
+
+        buf = torch.empty((nbytes + 3) // 4 * 4, dtype=torch.uint8, device=device)
+        fill_f32(buf.view(torch.float32), 0.0)
+        _DCN_SIDE[key] = buf
+        nn.bump_buffers_generation()
+    return buf
 
 
 def dcn_mask_softmax_fwd(om, G, P):

@@ -213,6 +213,11 @@ def buffers_generation():
     return _BUFFERS_GENERATION[0]
 
 
+def bump_buffers_generation():
+    """a long-lived device buffer that captured graphs point into was re-allocated outside this module (kernels._dcn_side)"""
+    _BUFFERS_GENERATION[0] += 1
+
+
 def weights_changed():
     """the bf16 compute copies were rewritten (optimizer step, ParamStore.sync_shadow): transposed copies are stale"""
     _WEIGHTS_VERSION[0] += 1

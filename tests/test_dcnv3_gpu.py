@@ -316,3 +316,37 @@ def test_dcnv3_layer_joint_projection_matches_layerwise(cuda, monkeypatch, C, G,
         assert not bad, bad
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,G,spread", [((1, 40, 37, 32), 2, 1.5), ((2, 33, 30, 16), 2, 9.0), ((1, 44, 50, 48), 3, 4.0)])
+def test_dcnv3_joint_layout_backward_and_kept_side_buffer(cuda, dtype, shape, G, spread):
+    """iseg_dcnv3_fwd_ld / _bwd_ld (round 5): offsets and mask as column ranges of one [pixels, ld] matrix, dx in the storage type, the side buffer
+    kept between calls instead of zeroed per call -- with offsets far beyond the window margin, so that the side buffer IS used: the same values
+    as the dense entry points (forward bit-identical; dx to the storage rounding), bit-identical from call to call, and the kept buffer all zero
+    again afterwards"""
+    from iseg_amd import kernels as K
+
+    N, H, W, C = shape
+    Cg = C // G
+    gp = G * 9
+    ld = (3 * gp + 7) // 8 * 8 + 8      # (one more chunk of padding than the projection would leave)
+    x, _ = q(rnd(shape, 11), dtype)
+    off, _ = q(rnd((N, H, W, 2 * gp), 12) * spread, dtype)
+    m, _ = q(torch.softmax(rnd((N, H, W, G, 9), 13), -1).reshape(N, H, W, gp), dtype)
+    dy, _ = q(rnd(shape, 14), dtype)
+    om = torch.full((N * H * W, ld), float("nan"), dtype=dtype, device="cuda")
+    om[:, :2 * gp] = off.reshape(-1, 2 * gp)
+    om[:, 2 * gp:3 * gp] = m.reshape(-1, gp)
+    y = K.dcnv3_fwd(x, off, m, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    yj = K.dcnv3_fwd_joint(x, om, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(y, yj)
+    dx, doff, dm = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    dxj, dom = K.dcnv3_bwd_joint(x, om, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert dxj.dtype == dtype
+    assert torch.equal(dom[:, :2 * gp], doff.reshape(-1, 2 * gp)) and torch.equal(dom[:, 2 * gp:3 * gp], dm.reshape(-1, gp))
+    assert torch.equal(dxj, dx.to(dtype))
+    dxj2, dom2 = K.dcnv3_bwd_joint(x, om, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(dxj, dxj2) and torch.equal(dom[:, :3 * gp], dom2[:, :3 * gp])
+    side = K._DCN_SIDE[str(x.device)]
+    assert int(side.view(torch.int32).ne(0).sum().item()) == 0, "the kept side buffer was not left all zero"
