@@ -20,7 +20,13 @@ for (S, C) in [(128, 112), (64, 224), (32, 448), (16, 896)]:
     m = torch.softmax(torch.randn(8, S, S, G, 9, device="cuda"), -1).reshape(8, S, S, G * 9).to(torch.bfloat16)
     f = timeit(lambda: K.dcnv3_fwd(x, off, m, G, 16, 3, 3, 1, 1, 1, 1.0))
     b = timeit(lambda: K.dcnv3_bwd(x, off, m, x, G, 16, 3, 3, 1, 1, 1, 1.0))
-    out.append(f"S{S}C{C} fwd {f:7.1f} bwd {b:7.1f}")
+    # the layer's route since round 5: offsets | mask as column ranges of one matrix, dx in bf16, side buffer kept zero (K.dcnv3_bwd_joint)
+    gp = G * 9
+    om = torch.zeros(8 * S * S, (3 * gp + 7) // 8 * 8, device="cuda", dtype=torch.bfloat16)
+    om[:, :2 * gp] = off.reshape(-1, 2 * gp)
+    om[:, 2 * gp:3 * gp] = m.reshape(-1, gp)
+    bj = timeit(lambda: K.dcnv3_bwd_joint(x, om, x, G, 16, 3, 3, 1, 1, 1, 1.0))
+    out.append(f"S{S}C{C} fwd {f:7.1f} bwd {b:7.1f} joint bwd {bj:7.1f} ({bj / f:.2f}x)")
 print(os.environ.get("TAG"), " | ".join(out), flush=True)
 ''' % os.path.abspath(__file__)
 for win in ("1", "0"):
