@@ -349,7 +349,8 @@ def _dma_symbol(key):
     ek = 1 if (int(act) == 2 and has_pre) else 2 if int(act) == 5 else 3 if (int(act) == 0 and has_res) else 4 if (int(act) == 0 and not has_aux) else 0
     bm, bn = wm * 64, wn * fn * 16
     tiles = -(-M // bm) * -(-N // bn)
-    return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}EE", tiles * wm * wn * 64
+    kt = 1 if K % 64 else 0      # (the K-tail instantiation, gemm_dma.h)
+    return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}ELb{kt}EE", tiles * wm * wn * 64
 
 
 def pick_dominant(report):
