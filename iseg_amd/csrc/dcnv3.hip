@@ -435,6 +435,18 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
         mk[p] = to_f32(mask[em]);
     }
     float scale = 0.f, inv_scale = 0.f;
+    {
+        // a non-finite arriving gradient or mask must stay visible: the integer accumulators would turn it into finite garbage, so the workgroup
+        // raises bit 1 of the flag word and the gather kernel then writes NaN for the whole input gradient (what fp32 atomics used to spread)
+        float s = 0.f;
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) s += d[c] * 0.f;      // 0 for finite values, NaN for inf / NaN
+#pragma unroll
+            for (int p = 0; p < DCN_PMAX; ++p) s += mk[p] * 0.f;
+        }
+        if (s != s) atomicOr(side_used, 2);
+    }
     if constexpr (FIX32) {
         float bd = 0.f, bm = 0.f;
         if (live) {
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_win_kernel(const T* __restrict_
             for (int p = 0; p < DCN_PMAX; ++p) bm = fmaxf(bm, fabsf(mk[p]));
         }
         float bound = bd * bm;
-        if (!(bound < 3.0e38f)) bound = 3.0e38f;      // (inf / NaN gradients: the sums saturate instead of wrapping)
+        if (!(bound < 3.0e38f)) bound = 3.0e38f;      // (inf / NaN gradients: the sums saturate instead of wrapping; the flag above reports them)
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) bound = fmaxf(bound, __shfl_xor(bound, o));
         if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = bound;
@@ -588,7 +600,8 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
     // (the host keeps N H W G Q and the bracket products below 2^31: 32-bit index arithmetic -- the 64-bit divisions of the first form were
     // most of this kernel's 600 VALU instructions per wavefront)
     const unsigned total = (unsigned)g.N * g.H * g.W * g.G * Q;
-    const bool use_side = *side_used != 0;
+    const int flags = *side_used;      // bit 0: some workgroup spilled into the side buffer; bit 1: a non-finite gradient / mask was seen
+    const bool use_side = (flags & 1) != 0, poisoned = (flags & 2) != 0;
     const int kx = DCN_TS * g.stride * (g.Win - 2), ky = DCN_TS * g.stride * (g.Hin - 2);
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         const int qc = (int)(i % (unsigned)Q);
@@ -630,6 +643,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
             acc.w += (float)((double)(long long)side[e + 3] * DCN_UNFIX);
             if (RESET) side[e] = side[e + 1] = side[e + 2] = side[e + 3] = 0ull;
         }
+        if (poisoned) acc.x = acc.y = acc.z = acc.w = __builtin_nanf("");
         if constexpr (sizeof(TO) == 4) {
             *reinterpret_cast<float4*>(dx + e) = acc;
         } else {

@@ -350,3 +350,33 @@ def test_dcnv3_joint_layout_backward_and_kept_side_buffer(cuda, dtype, shape, G,
     assert torch.equal(dxj, dxj2) and torch.equal(dom[:, :3 * gp], dom2[:, :3 * gp])
     side = K._DCN_SIDE[str(x.device)]
     assert int(side.view(torch.int32).ne(0).sum().item()) == 0, "the kept side buffer was not left all zero"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dcnv3_backward_reports_non_finite_gradients(cuda, dtype):
+    """the integer window accumulators would turn an inf / NaN arriving gradient into finite garbage: the window kernel raises a flag instead and the
+    gather kernel writes NaN for the input gradient (both entry points); the next call with finite operands is clean again (the kept flag word is
+    reset)"""
+    from iseg_amd import kernels as K
+
+    shape, G = (1, 40, 37, 32), 2
+    N, H, W, C = shape
+    Cg, gp = C // G, G * 9
+    x, _ = q(rnd(shape, 11), dtype)
+    off, _ = q(rnd((N, H, W, 2 * gp), 12), dtype)
+    m, _ = q(torch.softmax(rnd((N, H, W, G, 9), 13), -1).reshape(N, H, W, gp), dtype)
+    dy, _ = q(rnd(shape, 14), dtype)
+    bad = dy.clone()
+    bad[0, 7, 9, 3] = float("inf")
+    dx, _, _ = K.dcnv3_bwd(x, off, m, bad, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert bool(torch.isnan(dx).all())
+    ld = (3 * gp + 7) // 8 * 8
+    om = torch.zeros((N * H * W, ld), dtype=dtype, device="cuda")
+    om[:, :2 * gp] = off.reshape(-1, 2 * gp)
+    om[:, 2 * gp:3 * gp] = m.reshape(-1, gp)
+    dxj, _ = K.dcnv3_bwd_joint(x, om, bad, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert bool(torch.isnan(dxj).all())
+    dxj, _ = K.dcnv3_bwd_joint(x, om, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert bool(torch.isfinite(dxj).all())
+    dx, _, _ = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(dxj, dx.to(dtype))
