@@ -140,7 +140,9 @@ int iseg_gemm_tn_pair(const iseg_gemm_args* g0, void* ws0, size_t ws0_bytes, con
 
 /* ---------------------------------------------------------------------------------------------------------
  * LayerNorm over the last axis: keras.layers.LayerNormalization(axis=-1, epsilon)
- * (backbones/convnext.py:27,71; backbones/swin.py norm1/norm2; backbones/vit.py). x,y: [rows, C], C % 8 == 0.
+ * (backbones/convnext.py:27,71; backbones/swin.py norm1/norm2; backbones/vit.py). x,y: [rows, C].  C % 8 == 0 takes the 16-byte-vector kernels;
+ * any other C (<= 4096 for the backward; EVA02-large's 2730 hidden units, backbones/eva/swiglu.py:74-80) a one-wavefront-per-row form -- plain
+ * iseg_layernorm_fwd / _bwd only, not the gather / post-norm entry points.
  * mean/rstd [rows] are saved for the backward.  bwd: dx (= dx_add + LN^T dy), dgamma, dbeta.
  * --------------------------------------------------------------------------------------------------------- */
 int iseg_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
@@ -324,7 +326,9 @@ int iseg_dcnv2_sample_bwd(const void* x, const void* offset, const void* dcol, f
  *   (apply_rot_embed_cat, rotar_embedding_cat.py:117-135; the class token keeps its values, attention.py:136-146).  emb fp32 [tokens - prefix][2 head_dim]
  *   = [sin | cos] (RotaryEmbeddingCat.get_embed), NULL = no rotation.  inverse = 1 applies the transposed rotation (the backward pass; pass NULL biases).
  * iseg_glu_fwd / _bwd: out = act(gate) * x on strided [rows, cols] operands (SwiGLU: two Dense outputs, swiglu.py:88-92; GluMlp: the two column halves
- *   of one Dense output, glumlp.py:96-103); act = ISEG_ACT_GELU | ISEG_ACT_SWISH | ISEG_ACT_SIGMOID; bwd: dgate = dout x act'(gate), dx = dout act(gate). */
+ *   of one Dense output, glumlp.py:96-103); act = ISEG_ACT_GELU | ISEG_ACT_SWISH | ISEG_ACT_SIGMOID; bwd: dgate = dout x act'(gate), dx = dout act(gate).
+ *   Operands with cols / row strides that are multiples of 8 and 16-byte aligned bases move 16-byte pieces; anything else (EVA02-large: 2730 columns) takes
+ *   the one-element-per-lane form. */
 int iseg_qkv_rope(const void* qkv, void* out, const float* q_bias, const float* v_bias, const float* emb, int64_t rows, int tokens, int prefix, int C, int head_dim,
                   int inverse, int dtype, iseg_stream_t stream);
 int iseg_glu_fwd(const void* gate, int64_t ld_gate, const void* x, int64_t ld_x, void* out, int64_t ld_out, int64_t rows, int cols, int act, int dtype,

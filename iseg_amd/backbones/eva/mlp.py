@@ -9,9 +9,11 @@ LAYER_NORM_EPSILON = 1e-6
 
 
 def _check_hidden(name, hidden):
-    if hidden % 8 != 0:
-        raise NotImplementedError(f"{name}: hidden width {hidden} is not a multiple of 8 -- this package's row kernels move 16-byte pieces "
-                                  "(EVA02-large at 1024 channels has int(1024 * 8 / 3) = 2730 hidden units; widths such as 192, 384, 768, 1536 work)")
+    """Hidden widths that are not a multiple of 8 (EVA02-large: int(1024 * 8 / 3) = 2730) take the any-width forms of the row kernels -- scalar GLU,
+    one-wavefront-per-row LayerNorm (csrc/eva.hip, csrc/norm.hip) -- and the register-staged GEMM (rows of such a tensor are not 16-byte aligned, so
+    neither the 16-byte vector kernels nor the LDS-DMA pipeline can take them): correct, not fast.  Only GluMlp's packed halves need the alignment."""
+    if name == "GluMlp" and hidden % 8 != 0:
+        raise NotImplementedError(f"{name}: half width {hidden} is not a multiple of 8 (the two halves of one Dense output are read in place as 16-byte pieces)")
 
 
 class Mlp(Layer):

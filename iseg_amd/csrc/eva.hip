@@ -129,6 +129,36 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const T* __restrict__ dout
     }
 }
 
+// any width / any row pitch (EVA02-large: int(1024 * 8 / 3) = 2730 hidden units, rows 4-byte aligned only): one element per lane and trip
+template <class T>
+__global__ __launch_bounds__(256) void glu_fwd_any_kernel(const T* __restrict__ g, int64_t ldg, const T* __restrict__ x, int64_t ldx, T* __restrict__ out,
+                                                          int64_t ldo, int64_t rows, int cols, int act) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        float a, da;
+        glu_act<sizeof(T) == 2>(to_f32(g[r * ldg + c]), act, a, da);
+        out[r * ldo + c] = from_f32<T>(to_f32(x[r * ldx + c]) * a);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void glu_bwd_any_kernel(const T* __restrict__ dout, int64_t ldd, const T* __restrict__ g, int64_t ldg,
+                                                          const T* __restrict__ x, int64_t ldx, T* __restrict__ dg, int64_t ldgg, T* __restrict__ dx,
+                                                          int64_t ldxg, int64_t rows, int cols, int act) {
+    const int64_t total = rows * cols;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / cols;
+        const int c = (int)(i - r * cols);
+        float a, da;
+        glu_act<sizeof(T) == 2>(to_f32(g[r * ldg + c]), act, a, da);
+        const float d = to_f32(dout[r * ldd + c]);
+        dg[r * ldgg + c] = from_f32<T>(d * to_f32(x[r * ldx + c]) * da);
+        dx[r * ldxg + c] = from_f32<T>(d * a);
+    }
+}
+
 unsigned eva_blocks(int64_t work) {
     int64_t b = (work + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -158,8 +188,16 @@ static bool glu_act_ok(int act) { return act == ISEG_ACT_GELU || act == ISEG_ACT
 extern "C" int iseg_glu_fwd(const void* gate, int64_t ld_gate, const void* x, int64_t ld_x, void* out, int64_t ld_out, int64_t rows, int cols, int act,
                             int dtype, hipStream_t stream) {
     ISEG_REQUIRE(gate && x && out && rows > 0 && cols > 0 && glu_act_ok(act), "iseg_glu_fwd: bad arguments (act = %d)", act);
-    ISEG_REQUIRE(cols % 8 == 0 && ld_gate % 8 == 0 && ld_x % 8 == 0 && ld_out % 8 == 0, "iseg_glu_fwd: cols / row strides must be multiples of 8");
-    ISEG_REQUIRE((((uintptr_t)gate | (uintptr_t)x | (uintptr_t)out) & 15) == 0, "iseg_glu_fwd: operands must be 16-byte aligned");
+    if (cols % 8 || ld_gate % 8 || ld_x % 8 || ld_out % 8 || (((uintptr_t)gate | (uintptr_t)x | (uintptr_t)out) & 15)) {      // no 16-byte pieces: the scalar form
+        const unsigned nb = eva_blocks(rows * cols);
+        if (dtype == ISEG_BF16)
+            hipLaunchKernelGGL((glu_fwd_any_kernel<bf16_t>), dim3(nb), dim3(256), 0, stream, (const bf16_t*)gate, ld_gate, (const bf16_t*)x, ld_x, (bf16_t*)out,
+                               ld_out, rows, cols, act);
+        else
+            hipLaunchKernelGGL((glu_fwd_any_kernel<float>), dim3(nb), dim3(256), 0, stream, (const float*)gate, ld_gate, (const float*)x, ld_x, (float*)out, ld_out,
+                               rows, cols, act);
+        return iseg_check_launch("iseg_glu_fwd");
+    }
     const unsigned blocks = eva_blocks(rows * (cols / 8));
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((glu_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)gate, ld_gate, (const bf16_t*)x, ld_x, (bf16_t*)out,
@@ -173,9 +211,17 @@ extern "C" int iseg_glu_fwd(const void* gate, int64_t ld_gate, const void* x, in
 extern "C" int iseg_glu_bwd(const void* dout, int64_t ld_dout, const void* gate, int64_t ld_gate, const void* x, int64_t ld_x, void* dgate,
                             int64_t ld_dgate, void* dx, int64_t ld_dx, int64_t rows, int cols, int act, int dtype, hipStream_t stream) {
     ISEG_REQUIRE(dout && gate && x && dgate && dx && rows > 0 && cols > 0 && glu_act_ok(act), "iseg_glu_bwd: bad arguments (act = %d)", act);
-    ISEG_REQUIRE(cols % 8 == 0 && ld_dout % 8 == 0 && ld_gate % 8 == 0 && ld_x % 8 == 0 && ld_dgate % 8 == 0 && ld_dx % 8 == 0,
-                 "iseg_glu_bwd: cols / row strides must be multiples of 8");
-    ISEG_REQUIRE((((uintptr_t)dout | (uintptr_t)gate | (uintptr_t)x | (uintptr_t)dgate | (uintptr_t)dx) & 15) == 0, "iseg_glu_bwd: operands must be 16-byte aligned");
+    if (cols % 8 || ld_dout % 8 || ld_gate % 8 || ld_x % 8 || ld_dgate % 8 || ld_dx % 8 ||
+        (((uintptr_t)dout | (uintptr_t)gate | (uintptr_t)x | (uintptr_t)dgate | (uintptr_t)dx) & 15)) {      // no 16-byte pieces: the scalar form
+        const unsigned nb = eva_blocks(rows * cols);
+        if (dtype == ISEG_BF16)
+            hipLaunchKernelGGL((glu_bwd_any_kernel<bf16_t>), dim3(nb), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, (const bf16_t*)gate, ld_gate,
+                               (const bf16_t*)x, ld_x, (bf16_t*)dgate, ld_dgate, (bf16_t*)dx, ld_dx, rows, cols, act);
+        else
+            hipLaunchKernelGGL((glu_bwd_any_kernel<float>), dim3(nb), dim3(256), 0, stream, (const float*)dout, ld_dout, (const float*)gate, ld_gate,
+                               (const float*)x, ld_x, (float*)dgate, ld_dgate, (float*)dx, ld_dx, rows, cols, act);
+        return iseg_check_launch("iseg_glu_bwd");
+    }
     const unsigned blocks = eva_blocks(rows * (cols / 8));
     if (dtype == ISEG_BF16)
         hipLaunchKernelGGL((glu_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)dout, ld_dout, (const bf16_t*)gate, ld_gate,

@@ -297,6 +297,93 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Any width (C not a multiple of 8: rows are not 16-byte aligned).  EVA02-large normalises int(1024 * 8 / 3) = 2730 hidden units
+// (backbones/eva/swiglu.py:74-80).  One wavefront per row, lane l owns columns l, l + 64, ...: scalar loads, the same two-pass statistics; the
+// backward keeps its column sums in one LDS slab per wavefront (a lane owns its columns there, so no atomics and a fixed order) and writes the
+// per-workgroup partials the ordinary reduce consumes.  Plain LayerNorm only (no gather table, no post-norm tail).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ln_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void layernorm_fwd_any_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                T* __restrict__ y, float* __restrict__ mean_out, float* __restrict__ rstd_out, int64_t rows,
+                                                                int C, float eps) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wid; row < rows; row += (int64_t)gridDim.x * 4) {
+        const T* xr = x + row * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += to_f32(xr[c]);
+        const float mean = ln_wave_sum(s) / (float)C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = to_f32(xr[c]) - mean;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(ln_wave_sum(q) / (float)C + eps);
+        T* yr = y + row * C;
+        for (int c = lane; c < C; c += 64) yr[c] = from_f32<T>((to_f32(xr[c]) - mean) * rstd * gamma[c] + beta[c]);
+        if (lane == 0) {
+            if (mean_out) mean_out[row] = mean;
+            if (rstd_out) rstd_out[row] = rstd;
+        }
+    }
+}
+
+constexpr int LN_ANY_WAVES = 2;      // wavefronts per workgroup of the any-width backward: 2 x 2 x C floats of LDS (C <= 4096: 64 KiB)
+
+template <class T>
+__global__ __launch_bounds__(64 * LN_ANY_WAVES) void layernorm_bwd_any_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                               const float* __restrict__ rstd, T* __restrict__ dx,
+                                                                               const T* __restrict__ dx_add, float* __restrict__ partials, int64_t rows,
+                                                                               int C) {
+    extern __shared__ __attribute__((aligned(16))) float ln_any_slab[];      // [LN_ANY_WAVES][2][C]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* const sg = ln_any_slab + (size_t)wid * 2 * C;
+    float* const sb = sg + C;
+    for (int c = lane; c < C; c += 64) sg[c] = sb[c] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * LN_ANY_WAVES + wid; row < rows; row += (int64_t)gridDim.x * LN_ANY_WAVES) {
+        const T* dr = dy + row * C;
+        const T* xr = x + row * C;
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = to_f32(dr[c]), h = (to_f32(xr[c]) - mu) * rs, gv = d * gamma[c];
+            s1 += gv;
+            s2 += gv * h;
+            sg[c] += d * h;
+            sb[c] += d;
+        }
+        s1 = ln_wave_sum(s1) / (float)C;
+        s2 = ln_wave_sum(s2) / (float)C;
+        T* or_ = dx + row * C;
+        for (int c = lane; c < C; c += 64) {
+            const float d = to_f32(dr[c]), h = (to_f32(xr[c]) - mu) * rs;
+            float o = rs * (d * gamma[c] - s1 - h * s2);
+            if (dx_add) o += to_f32(dx_add[row * C + c]);
+            or_[c] = from_f32<T>(o);
+        }
+    }
+    __syncthreads();
+    float* out = partials + (int64_t)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 64 * LN_ANY_WAVES) {
+        float a = ln_any_slab[i];
+#pragma unroll
+        for (int w = 1; w < LN_ANY_WAVES; ++w) a += ln_any_slab[(size_t)w * 2 * C + i];
+        out[i] = a;
+    }
+}
+
+static int ln_any_bwd_blocks(int64_t rows) {
+    int64_t b = ceil_div64(rows, LN_ANY_WAVES * 4);      // four rows per wavefront at least
+    return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
 // parameter gradients of a post-norm residual branch from the two column sums of layernorm_bwd_kernel (see LnPost): sums = [A | B]
 __global__ void ln_post_finish_kernel(const float* __restrict__ sums, const float* __restrict__ colscale, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -730,7 +817,19 @@ extern "C" int iseg_layernorm_gather_fwd(const void* x, const int32_t* src_index
 static int layernorm_fwd_launch(const void* x, const int32_t* src_index, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                                 int64_t rows, int C, float eps, int dtype, hipStream_t stream, const LnPost& post) {
     ISEG_REQUIRE(x && gamma && beta && y, "iseg_layernorm_fwd: null pointer");
-    ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_fwd: C=%d must be a positive multiple of 8", C);
+    ISEG_REQUIRE(rows > 0 && C > 0, "iseg_layernorm_fwd: empty problem (rows %lld, C %d)", (long long)rows, C);
+    if (C % 8 != 0) {      // rows without 16-byte alignment: the one-wavefront-per-row kernel (plain LayerNorm only)
+        ISEG_REQUIRE(!src_index && !post.colscale && !post.rowscale && !post.residual, "iseg_layernorm_fwd: C=%d is not a multiple of 8: plain LayerNorm only", C);
+        int64_t nb = ceil_div64(rows, 4);
+        if (nb > 256 * 8) nb = 256 * 8;
+        if (dtype == ISEG_BF16)
+            hipLaunchKernelGGL((layernorm_fwd_any_kernel<bf16_t>), dim3((unsigned)nb), dim3(256), 0, stream, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd,
+                               rows, C, eps);
+        else
+            hipLaunchKernelGGL((layernorm_fwd_any_kernel<float>), dim3((unsigned)nb), dim3(256), 0, stream, (const float*)x, gamma, beta, (float*)y, mean, rstd,
+                               rows, C, eps);
+        return iseg_check_launch("iseg_layernorm_fwd");
+    }
     // (bf16 storage only: in fp32 storage the other lane split changes the order of the row sums in the last bit, and the fp32 path is held to
     // bit-exact argmax masks against the oracle at 512 x 512 -- test_cfg2_at_the_benchmark_shape flipped one near-tie with it)
     const int lpr = ln_lanes_per_row(C, dtype == ISEG_BF16);
@@ -798,6 +897,7 @@ static int ln_bwd_blocks(int64_t rows, int C) {
 }
 
 extern "C" size_t iseg_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+    if (C % 8 != 0) return (size_t)ln_any_bwd_blocks(rows) * 2 * C * sizeof(float);
     return (size_t)ln_bwd_blocks(rows, C) * 2 * C * sizeof(float);
 }
 
@@ -838,7 +938,26 @@ static int layernorm_bwd_launch(const void* dy, const int32_t* dy_index, const v
                                 void* dx, const void* dx_add, float* dgamma, float* dbeta, int accumulate_param_grads, int64_t rows, int C,
                                 int dtype, void* ws, size_t ws_bytes, hipStream_t stream, const LnPost& post, const float* beta, float* dcolscale) {
     ISEG_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "iseg_layernorm_bwd: null pointer");
-    ISEG_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, "iseg_layernorm_bwd: C=%d must be a positive multiple of 8", C);
+    ISEG_REQUIRE(rows > 0 && C > 0, "iseg_layernorm_bwd: empty problem (rows %lld, C %d)", (long long)rows, C);
+    if (C % 8 != 0) {      // the any-width form (see layernorm_bwd_any_kernel)
+        ISEG_REQUIRE(!dy_index && !post.colscale && !post.rowscale && C <= 4096, "iseg_layernorm_bwd: C=%d is not a multiple of 8: plain LayerNorm, C <= 4096", C);
+        const int nb = ln_any_bwd_blocks(rows);
+        const size_t need_any = (size_t)nb * 2 * C * sizeof(float);
+        if (!ws || ws_bytes < need_any) {
+            iseg_set_error("iseg_layernorm_bwd: needs %zu workspace bytes, got %zu", need_any, ws_bytes);
+            return ISEG_ERR_WORKSPACE;
+        }
+        float* parts = (float*)ws;
+        const size_t lds_any = (size_t)LN_ANY_WAVES * 2 * C * sizeof(float);
+        if (dtype == ISEG_BF16)
+            hipLaunchKernelGGL((layernorm_bwd_any_kernel<bf16_t>), dim3(nb), dim3(64 * LN_ANY_WAVES), lds_any, stream, (const bf16_t*)dy, (const bf16_t*)x, gamma,
+                               mean, rstd, (bf16_t*)dx, (const bf16_t*)dx_add, parts, rows, C);
+        else
+            hipLaunchKernelGGL((layernorm_bwd_any_kernel<float>), dim3(nb), dim3(64 * LN_ANY_WAVES), lds_any, stream, (const float*)dy, (const float*)x, gamma,
+                               mean, rstd, (float*)dx, (const float*)dx_add, parts, rows, C);
+        launch_reduce_rows(parts, nb, 2 * C, 0, 1, 2 * C, dgamma, dbeta, C, 0, 1.f, accumulate_param_grads, stream);
+        return iseg_check_launch("iseg_layernorm_bwd");
+    }
     const int lpr = ln_lanes_per_row(C);
     ISEG_REQUIRE((C / 8 + lpr - 1) / lpr <= LN_MAX_CHUNKS, "iseg_layernorm_bwd: C=%d too wide", C);
     const int blocks = ln_bwd_blocks(rows, C);

@@ -49,8 +49,8 @@ def test_qkv_rope_kernel_matches_the_reference_formula_and_its_inverse_is_the_tr
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("activation", ["gelu", "swish", "sigmoid"])
-@pytest.mark.parametrize("packed", [0, 1, 2])
-def test_glu_forward_and_gradients(cuda, dtype, activation, packed):
+@pytest.mark.parametrize("packed,width", [(0, 8), (1, 8), (2, 8), (0, 2), (0, 1)])      # width: 8 = 16-byte pieces; 2 / 1 = the scalar form (2730 / 263 columns)
+def test_glu_forward_and_gradients(cuda, dtype, activation, packed, width):
     """F.glu / F.glu_packed (csrc/eva.hip iseg_glu_fwd / _bwd): act(gate) * x on separate and on packed operands, both gate positions"""
     from iseg_amd import functional as F
     from iseg_amd import nn
@@ -59,7 +59,7 @@ def test_glu_forward_and_gradients(cuda, dtype, activation, packed):
     nn.set_device("cuda:0")
     try:
         act = OM._eva_act(activation)
-        M, Hd = 37, 48
+        M, Hd = (37, 48) if width == 8 else (41, 2730 if width == 2 else 263)
         dy = rnd((M, Hd), 3).to(dtype)
         if packed:
             p = rnd((M, 2 * Hd), 1).to(dtype)
@@ -95,6 +95,12 @@ _BLOCKS = [
      dict(fused=False, mlp_kind="swiglu", scale_attention_inner=True)),
     (dict(num_heads=4, qkv_fused=True, mlp_ratio=2.0, swiglu_mlp=False, scale_mlp=True, init_values=0.7, use_post_norm=True),
      dict(fused=True, mlp_kind="mlp_norm", post_norm=True)),
+    # hidden widths that are not multiples of 8 (EVA02-large: int(1024 * 8 / 3) = 2730): 96 * 2.73 -> 262 (rows 4-byte aligned), 96 * 2.74 -> 263 (2-byte):
+    # scalar GLU, one-wavefront-per-row LayerNorm over the hidden units, register-staged GEMMs
+    (dict(num_heads=2, qkv_fused=False, mlp_ratio=2.73, swiglu_mlp=True, scale_mlp=True, scale_attention_inner=True),
+     dict(fused=False, mlp_kind="swiglu", scale_attention_inner=True)),
+    (dict(num_heads=2, qkv_fused=False, mlp_ratio=2.74, swiglu_mlp=True, scale_mlp=True, scale_attention_inner=True),
+     dict(fused=False, mlp_kind="swiglu", scale_attention_inner=True)),
 ]
 
 
@@ -109,7 +115,7 @@ def test_eva_block_variants(cuda, dtype, variant):
     nn.set_compute_dtype(dtype)
     nn.set_device("cuda:0")
     try:
-        C, H, W, B = (96, 192, 96)[variant], 3, 5, 2
+        C, H, W, B = (96, 192, 96, 96, 96)[variant], 3, 5, 2
         heads = kw["num_heads"]
         blk = EvaBlock(drop_path_rate=0.2, class_token_size=1, name="blk", **kw)
         x = rnd((B, 1 + H * W, C), 1).to(dtype)
@@ -165,7 +171,7 @@ def test_eva02_reduced_trunk_with_position_embedding_resampling(cuda, dtype):
         nn.set_compute_dtype(torch.float32)
 
 
-def test_eva02_names_are_registered_and_large_reports_its_hidden_width(cuda):
+def test_eva02_names_are_registered_and_large_builds_with_its_2730_hidden_units(cuda):
     from iseg_amd import nn
     from iseg_amd.backbones.feature_extractor import _builtin_backbones
     from iseg_amd import static_strings as ss
@@ -178,7 +184,38 @@ def test_eva02_names_are_registered_and_large_reports_its_hidden_width(cuda):
         ends = tiny(torch.empty((1, 112, 112, 3), device="cuda"))
     assert len(ends) == 14 and tuple(ends[-1].shape) == (1, 8, 8, 192)
     assert sum(p.numel() for p in tiny.parameters()) == 5464896      # 5.57 M of the published model minus its 24 x 24 position grid (here 8 x 8)
-    large = d[ss.EVA02_LARGE]()
-    with pytest.raises(NotImplementedError, match="2730"):
+    large = d[ss.EVA02_LARGE](return_endpoints=True)      # 2730 hidden units: the any-width row kernels (test_eva_block_variants covers them)
+    with nn.dry_run_scope():
+        ends = large(torch.empty((1, 64, 64, 3), device="cuda"))
+    assert tuple(ends[-1].shape) == (1, 4, 4, 1024)
+    shapes = {p.iseg_name.split("/", 1)[1]: tuple(p.shape) for p in large.parameters() if "/blocks/0/" in p.iseg_name or "blocks_0" in p.iseg_name}
+    assert any(sh == (1024, 2730) for sh in shapes.values()) and any(sh == (2730, 1024) for sh in shapes.values()) and any(sh == (2730,) for sh in shapes.values())
+
+
+def test_eva02_large_forward_backward_is_finite_in_bf16(cuda):
+    """the registered large model (24 blocks, 1024 channels, 2730 hidden units, sub-LN over the hidden units) runs forward and backward in bf16 at
+    64 x 64 and every parameter receives a finite gradient (its block arithmetic is pinned against the oracle by test_eva_block_variants 3 / 4)"""
+    from iseg_amd import nn
+    from iseg_amd import static_strings as ss
+    from iseg_amd.backbones.feature_extractor import _builtin_backbones
+    from iseg_amd.param_store import ParamStore
+
+    nn.set_compute_dtype(torch.bfloat16)
+    nn.set_device("cuda:0")
+    try:
+        large = _builtin_backbones()[ss.EVA02_LARGE](return_endpoints=True)
         with nn.dry_run_scope():
             large(torch.empty((1, 64, 64, 3), device="cuda"))
+        store = ParamStore(list(large.parameters()))
+        store.sync_shadow()
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn((1, 64, 64, 3), generator=g).cuda()
+        ends = large(x, training=True)
+        assert tuple(ends[-1].shape) == (1, 4, 4, 1024) and bool(torch.isfinite(ends[-1].float()).all())
+        ends[-1].backward(torch.randn(tuple(ends[-1].shape), generator=g).cuda().to(ends[-1].dtype))
+        bad = [p.iseg_name for p in large.parameters() if p.requires_grad and not bool(torch.isfinite(p.grad).all())]
+        assert not bad, bad[:5]
+        touched = sum(1 for p in large.parameters() if p.requires_grad and float(p.grad.abs().max()) > 0)
+        assert touched > 0.9 * sum(1 for p in large.parameters() if p.requires_grad)
+    finally:
+        nn.set_compute_dtype(torch.float32)

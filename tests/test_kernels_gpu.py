@@ -216,7 +216,8 @@ def test_gemm_strided_output_into_concat(cuda, dtype):
 
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("rows,C", [(1003, 96), (517, 192), (300, 384), (129, 768), (65, 1536), (40, 3072), (7, 8), (1, 96)])
+@pytest.mark.parametrize("rows,C", [(1003, 96), (517, 192), (300, 384), (129, 768), (65, 1536), (40, 3072), (7, 8), (1, 96),
+                                    (203, 2730), (1000, 262), (77, 263), (9, 5)])      # widths that are not multiples of 8: the one-wavefront-per-row kernels
 def test_layernorm_fwd_bwd(cuda, dtype, rows, C):
     k = K()
     x, xr = q(rnd((rows, C), 1) * 2 + 0.3, dtype)
