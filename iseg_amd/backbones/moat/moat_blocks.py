@@ -115,8 +115,12 @@ class MOATBlock(_MBConvPart):
         self._attention_norm = LayerNormalization(epsilon=self.ln_epsilon, name=f"{self.name}/attention_norm")
         if self.relative_position_embedding_type and self.position_embedding_size is None:
             raise ValueError("The position embedding size need to be specified if relative position embedding is used.")
+        scale_ratio = None
+        if self.relative_position_embedding_type:      # (:380-392)
+            scale_ratio = [self._window_height / self.position_embedding_size, self._window_width / self.position_embedding_size]
         self._attention = Attention(hidden_size=self.hidden_size, head_size=self.head_size,
-                                    relative_position_embedding_type=self.relative_position_embedding_type, name=f"{self.name}/attention")
+                                    relative_position_embedding_type=self.relative_position_embedding_type, scale_ratio=scale_ratio,
+                                    name=f"{self.name}/attention")
         self.built = True
 
     def call(self, inputs, training=None):

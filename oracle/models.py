@@ -316,13 +316,37 @@ def _moat_mbconv(w, p, x, stride, with_se, training, new_stats, bn_eps=1e-3):
     return O.conv2d(y, w[f"{p}/shrink_conv/kernel"], w[f"{p}/shrink_conv/bias"], 1, 1, "same"), shortcut
 
 
+def moat_position_bias(table, height, width, resize):
+    """backbones/moat/attention.py:68-120,258-306: the [heads, e_h, e_w] table, resized bilinearly to [2 h - 1, 2 w - 1] when the layer has a scale
+    ratio, then re-indexed by two one-hot lookups (max relative distance h - 1 / w - 1): bias[n, (i, j), (x, y)] = R[n, x - i + h - 1, y - j + w - 1].
+    The reference evaluates this once, in build() (a constant: detached here)."""
+    r = table.detach()
+    if resize:
+        r = O.resize_bilinear(r.unsqueeze(-1), (2 * height - 1, 2 * width - 1)).squeeze(-1)
+    hl = torch.zeros(height, height, 2 * height - 1, dtype=r.dtype)
+    for i in range(height):
+        for x in range(height):
+            hl[i, x, x - i + height - 1] = 1
+    wl = torch.zeros(width, width, 2 * width - 1, dtype=r.dtype)
+    for j in range(width):
+        for y in range(width):
+            wl[j, y, y - j + width - 1] = 1
+    t = torch.einsum("nhw,ixh->nixw", r, hl)
+    t = torch.einsum("nixw,jyw->nijxy", t, wl)
+    return t.reshape(r.shape[0], height * width, height * width)
+
+
 def _moat_attention(w, p, x, head_size):
     B, H, W, C = x.shape
     t = x.reshape(B, H * W, C)
     q = torch.einsum("btc,cnk->btnk", t, w[f"{p}/q/weight"]) + w[f"{p}/q/bias"]
     k = torch.einsum("btc,cnk->btnk", t, w[f"{p}/k/weight"]) + w[f"{p}/k/bias"]
     v = torch.einsum("btc,cnk->btnk", t, w[f"{p}/v/weight"]) + w[f"{p}/v/bias"]
-    a = torch.softmax(torch.einsum("bsnk,btnk->bnst", q * head_size ** -0.5, k), dim=-1)
+    logits = torch.einsum("bsnk,btnk->bnst", q * head_size ** -0.5, k)
+    table = w.get(f"{p}/relative_position_embedding")
+    if table is not None:      # (:320-323) the table is resized whenever the block hands a scale ratio over, i.e. whenever it exists in a MOAT block
+        logits = logits + moat_position_bias(table, H, W, resize=tuple(table.shape[1:]) != (2 * H - 1, 2 * W - 1))
+    a = torch.softmax(logits, dim=-1)
     o = torch.einsum("bnst,btnk->bsnk", a, v)
     return (torch.einsum("bsnk,nkc->bsc", o, w[f"{p}/o/weight"]) + w[f"{p}/o/bias"]).reshape(B, H, W, -1)
 
