@@ -30,7 +30,7 @@ __device__ __forceinline__ int b_key(int row) { return (row & 3) | (((row >> 3) 
 // EK: epilogue kind known at compile time (0 = whatever the Epi struct says at run time).  The flagship's three fused epilogues get their
 // own instantiation: dead branches of epi_finish8 fold away, and a kernel trace / PMC pass can tell the forward product (gelu + gelu'
 // outputs) from the data gradient (x aux) -- with one symbol for both, rocprof's per-kernel traffic was a mean over two different epilogues.
-enum { EK_ANY = 0, EK_GELU_DERIV = 1, EK_MUL_AUX = 2, EK_BIAS_RESIDUAL = 3, EK_PLAIN = 4 };
+enum { EK_ANY = 0, EK_GELU_DERIV = 1, EK_MUL_AUX = 2, EK_BIAS_RESIDUAL = 3, EK_PLAIN = 4, EK_BIAS = 5 };
 
 template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
     if (EK == EK_GELU_DERIV) {          // bias -> gelu, second output gelu'(pre): pwconv1 forward of an un-fused ConvNeXt block
@@ -61,6 +61,15 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
         e.rowscale = nullptr;
         e.accumulate = 0;
         e.alpha = 1.f;
+    } else if (EK == EK_BIAS) {         // + bias only: the Dense / projection forward products of the transformer and DCNv3 layers
+        e.act = ISEG_ACT_NONE;
+        e.aux = nullptr;
+        e.pre_out = nullptr;
+        e.residual = nullptr;
+        e.colscale = nullptr;
+        e.rowscale = nullptr;
+        e.accumulate = 0;
+        e.alpha = 1.f;
     } else if (EK == EK_BIAS_RESIDUAL) {      // bias, layer scale / drop-path factor (run time), + residual: pwconv2 forward
         e.act = ISEG_ACT_NONE;
         e.aux = nullptr;
@@ -81,6 +90,8 @@ inline int epi_kind(const Epi& e, const float* slabs) {
     if (e.act == ISEG_ACT_GELU && e.pre_out && e.pre_deriv && e.bias && !e.residual && !e.aux && !e.colscale && !e.rowscale) return EK_GELU_DERIV;
     if (e.act == ISEG_ACT_MUL_AUX && e.aux && !e.bias && !e.pre_out && !e.residual && !e.colscale && !e.rowscale) return EK_MUL_AUX;
     if (e.act == ISEG_ACT_NONE && e.bias && e.residual && !e.aux && !e.pre_out) return EK_BIAS_RESIDUAL;
+    static const bool bias_kind = [] { const char* v = getenv("ISEG_GEMM_EK_BIAS"); return !v || atoi(v) != 0; }();      // 0: A/B against the run-time epilogue
+    if (bias_kind && e.act == ISEG_ACT_NONE && e.bias && !e.residual && !e.aux && !e.pre_out && !e.colscale && !e.rowscale) return EK_BIAS;
     if (e.act == ISEG_ACT_NONE && !e.bias && !e.residual && !e.aux && !e.pre_out && !e.colscale && !e.rowscale) return EK_PLAIN;
     return EK_ANY;
 }
@@ -431,6 +442,7 @@ void launch_dma_kinds(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64
             case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX>(g, epi, nsplit, kps, slabs, s); return;
             case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL>(g, epi, nsplit, kps, slabs, s); return;
             case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS: launch_dma<WM, WN, NS, TO, FN, EK_BIAS>(g, epi, nsplit, kps, slabs, s); return;
             default: break;
         }
     }
