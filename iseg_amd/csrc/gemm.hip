@@ -40,10 +40,11 @@ bool gemm_log_on() {
 void gemm_log(const iseg_gemm_args* g, int nsplit) {
     static GemmCensus census;
     char buf[256];
-    snprintf(buf, sizeof buf, "%s %s->%s M=%lld N=%lld K=%lld batch=%d split=%d form=%d act=%d a_act=%d%s%s%s%s%s", g->a_kcontig ? (g->b_kcontig ? "NT" : "NN") : (g->b_kcontig ? "TT" : "TN"),
+    snprintf(buf, sizeof buf, "%s %s->%s M=%lld N=%lld K=%lld batch=%d split=%d form=%d act=%d a_act=%d%s%s%s%s%s%s%s%s%s%s", g->a_kcontig ? (g->b_kcontig ? "NT" : "NN") : (g->b_kcontig ? "TT" : "TN"),
              g->in_dtype == ISEG_BF16 ? "bf16" : "f32", g->out_dtype == ISEG_BF16 ? "bf16" : "f32", (long long)g->M, (long long)g->N, (long long)g->K,
              g->batch > 1 ? g->batch : 1, nsplit, iseg_gemm_variant(g), g->act, g->a_act, g->bias ? " bias" : "", g->residual ? " residual" : "",
-             g->aux ? " aux" : "", g->pre_out ? " pre_out" : "", g->colsum_out ? " colsum" : "");
+             g->aux ? " aux" : "", g->pre_out ? " pre_out" : "", g->colsum_out ? " colsum" : "", g->colscale ? " colscale" : "", g->rowscale ? " rowscale" : "",
+             g->pre_deriv ? " pre_deriv" : "", g->accumulate ? " accumulate" : "", g->alpha != 1.f ? " alpha" : "");
     std::lock_guard<std::mutex> lock(census.mu);
     ++census.seen[buf];
 }
