@@ -58,10 +58,11 @@ class BlockType1(Layer):
         self.conv2_conv.dilation_rate = _pair(value)
 
     def call(self, inputs, training=None, **kwargs):
+        inputs, skip = F.fork(inputs, 2)      # two consumers: their gradients are summed by our own kernel, not by the engine's add
         if self.conv_shortcut:
-            shortcut = self.shortcut_bn(self.shortcut_conv(inputs), training=training)
+            shortcut = self.shortcut_bn(self.shortcut_conv(skip), training=training)
         else:
-            shortcut = inputs
+            shortcut = skip
         x = _bn_relu(self.conv1_bn, self.conv1_conv(inputs), training)
         x = _bn_relu(self.conv2_bn, self.conv2_conv(x), training)
         x = self.conv3_bn(self.conv3_conv(x), training=training)
@@ -105,7 +106,7 @@ class BlockType2(Layer):
         self.conv2_conv.dilation_rate = _pair(value)
 
     def call(self, inputs, training=None, **kwargs):
-        shortcut = inputs
+        inputs, shortcut = F.fork(inputs, 2)      # two consumers: their gradients are summed by our own kernel, not by the engine's add
         if self.conv_shortcut:
             shortcut = self.shortcut_bn(self.shortcut_conv(shortcut), training=training)
         if self.strides > 1:

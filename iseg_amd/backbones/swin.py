@@ -245,6 +245,8 @@ class BasicLayer(Layer):
             x = block(x, attention_mask=attn_mask, training=training)
         before_downsample = x
         if self.downsample is not None:
+            # two consumers (the endpoint list and the patch merging): forked, so their gradients are summed by our own kernel, not by the engine's add
+            x, before_downsample = F.fork(x, 2)
             x = self.downsample(x, training=training)
         return x, before_downsample
 

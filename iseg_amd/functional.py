@@ -937,6 +937,9 @@ class _ForkFn(Function):
 
     @staticmethod
     def forward(ctx, x, n):
+        # an alias nobody differentiates through must arrive as None, not as a tensor of zeros the engine fills with an ATen kernel and this node
+        # then adds (Swin-T + FPN: two such maps of 100 MB and 25 MB per step)
+        ctx.set_materialize_grads(False)
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
