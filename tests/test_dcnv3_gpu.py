@@ -314,6 +314,19 @@ def test_dcnv3_layer_joint_projection_matches_layerwise(cuda, monkeypatch, C, G,
         assert rel(dxa, dxb) < 2e-2, rel(dxa, dxb)
         bad = {k: rel(ga[k], gb[k]) for k in ga if rel(ga[k], gb[k]) > 3e-2}
         assert not bad, bad
+        # a weight update: the joint weight images are per-update derivations (nn.joint_kernels, refreshed with the other prepared images) -- stale
+        # images would reproduce the OLD projection
+        with torch.no_grad():
+            for p in layer.parameters():
+                if "offset" in p.iseg_name or "mask" in p.iseg_name:
+                    p.add_((torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else 0.03)).to(p.device))
+        store.sync_shadow()
+        yc, dxc, gc = run(True)
+        yd, dxd, gd = run(False)
+        assert rel(yc, ya) > 5e-2, "the update did not change the output: the test is vacuous"
+        assert rel(yc, yd) < 1e-2 and rel(dxc, dxd) < 2e-2, (rel(yc, yd), rel(dxc, dxd))
+        bad = {k: rel(gc[k], gd[k]) for k in gc if rel(gc[k], gd[k]) > 3e-2}
+        assert not bad, bad
     finally:
         nn.set_compute_dtype(torch.float32)
 
