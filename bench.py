@@ -66,6 +66,72 @@ def visible_gpu_count():
     return n
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_nodes():
+    """NUMA node of every GPU in kfd order, from sysfs only (no HIP call): kfd topology node -> PCI address (domain, location_id) ->
+    /sys/bus/pci/devices/<bdf>/numa_node.  [] when the topology is not readable (containers without /sys/class/kfd)."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    out = []
+    try:
+        nodes = sorted(os.listdir(root), key=int)
+    except (OSError, ValueError):
+        return out
+    for node in nodes:
+        try:
+            with open(os.path.join(root, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+                out.append(int(f.read().strip()))
+        except (OSError, ValueError):
+            out.append(-1)
+    return out
+
+
+def pin_to_gpu_numa(local_rank, ranks_on_node):
+    """Pin this rank to cores of its GPU's NUMA node (a contiguous share when several ranks sit on one node).  In the c10d + eager fallback every
+    rank's host thread enqueues ~7 ms of launches per 8 ms step: a thread that migrates across sockets, or eight ranks packed on one socket,
+    starves the GPUs.  Affinity of THIS process only, set before it touches the GPU (never an exec); ISEG_BENCH_PIN=0 switches it off.  Returns a
+    short description for the JSON line, or None when nothing was changed."""
+    if os.environ.get("ISEG_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity") or ranks_on_node <= 1:
+        return None      # (one rank: nothing competes for the cores, and the CPU baseline wants all of them)
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        numa = gpu_numa_nodes()
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        order = [int(t) for t in vis.split(",") if t.strip().isdigit()] if vis else list(range(len(numa)))
+        gpu = order[local_rank] if local_rank < len(order) else local_rank
+        node = numa[gpu] if gpu < len(numa) else -1
+        cores = allowed
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                on_node = [c for c in _cpulist(f.read()) if c in set(allowed)]
+            if on_node:
+                cores = on_node
+        # ranks that share the node (or the whole allowed set) take equal contiguous shares, at least two cores each
+        peers = [r for r in range(ranks_on_node) if (numa[order[r]] if r < len(order) and order[r] < len(numa) else -1) == node] or [local_rank]
+        share = max(2, len(cores) // max(1, len(peers)))
+        k = peers.index(local_rank) if local_rank in peers else 0
+        mine = cores[k * share:(k + 1) * share] or cores
+        os.sched_setaffinity(0, mine)
+        return f"gpu {gpu} numa {node}: cores {mine[0]}-{mine[-1]} ({len(mine)})"
+    except (OSError, ValueError, IndexError) as e:
+        print(f"bench.py: NUMA pinning skipped ({type(e).__name__}: {e})", file=sys.stderr)
+        return None
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This parent never touches the GPU (no HIP call, no
     torch.cuda.*: the device count comes from the visibility list / kfd topology), the children are fresh interpreters with RANK /
@@ -82,16 +148,19 @@ def self_launch(args):
     if not args.check_launch and have is not None and have < n:
         print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s)", file=sys.stderr)
         return 2
-    sock = socket.socket()
+    sock, sock2 = socket.socket(), socket.socket()      # two free ports: the job's rendezvous and the exchange probe's (choose_exchange)
     sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
+    sock2.bind(("127.0.0.1", 0))
+    port, probe_port = sock.getsockname()[1], sock2.getsockname()[1]
     sock.close()
+    sock2.close()
     log_dir = os.environ.get("ISEG_BENCH_LOG_DIR") or tempfile.mkdtemp(prefix="iseg_bench_")
     os.makedirs(log_dir, exist_ok=True)
     limit = float(os.environ.get("ISEG_BENCH_TIMEOUT_S", "900"))
     procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ISEG_BENCH_PROBE_PORT=os.environ.get("ISEG_BENCH_PROBE_PORT", str(probe_port)),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         log = open(os.path.join(log_dir, f"rank{r}.log"), "wb")
         logs.append(log)
@@ -153,6 +222,7 @@ def joined_ranks(device):
 def check_launch(args):
     from iseg_amd import dist
 
+    affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), max(args.gpus, 1))
     use_gpu = (visible_gpu_count() or 0) >= max(args.gpus, 1) and torch.cuda.is_available()
     if os.environ.get("ISEG_BENCH_TEST_HANG") == str(os.environ.get("RANK", "0")):      # (tests/test_bench_launch.py: the watchdog)
         time.sleep(3600)
@@ -161,19 +231,70 @@ def check_launch(args):
     # (the launch check probes only when a test scripts the probe's outcome: its other cases are about the launcher itself)
     exchange = choose_exchange(args) if (use_gpu or os.environ.get("ISEG_BENCH_TEST_PROBE")) else "not probed"
     dist.init(backend=None if use_gpu else "gloo")
-    n = joined_ranks(torch.device("cuda", dist.local_rank()) if use_gpu else torch.device("cpu"))
+    dev = torch.device("cuda", dist.local_rank()) if use_gpu else torch.device("cpu")
+    if os.environ.get("ISEG_BENCH_TEST_SPLIT_DECISION") == str(os.environ.get("RANK", "0")):      # (tests: this rank's parent lost its probe to the limit)
+        os.environ["ISEG_DIST_NATIVE"] = "0"
+        exchange = "c10d work objects (test: split decision)"
+    exchange = agree_exchange(exchange, dev)
+    n = joined_ranks(dev)
     if n != args.gpus:
         print(f"bench.py: {n} ranks joined, --gpus {args.gpus}", file=sys.stderr)
         sys.exit(3)
     dist.barrier()
     if dist.rank() == 0:
         print(json.dumps({"metric": "launch_check", "n_gpus": n, "backend": torch.distributed.get_backend() if n > 1 else "none",
-                          "exchange": exchange}))
+                          "exchange": exchange, "host_affinity": affinity}))
     if dist.is_initialized():
         torch.distributed.destroy_process_group()
 
 
 PROBE_MARK = "ISEG_PROBE_NATIVE_OK"
+
+
+def probe_port():
+    """rendezvous port of the probe job, the same on every rank and known to be free when it was chosen: (1) ISEG_BENCH_PROBE_PORT -- bench.py's own
+    launcher binds a second free port and exports it; (2) under torch.distributed.run the agent's TCP store (MASTER_ADDR:MASTER_PORT, no GPU
+    involved): rank 0 asks the kernel for a free port and publishes it, the others read it; (3) MASTER_PORT + 23 when neither exists."""
+    p = os.environ.get("ISEG_BENCH_PROBE_PORT")
+    if p:
+        return int(p)
+    base = int(os.environ.get("MASTER_PORT", "29500"))
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+        try:
+            import datetime
+            import socket
+
+            store = torch.distributed.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base, is_master=False,
+                                               timeout=datetime.timedelta(seconds=60))
+            key = "iseg_bench_probe_port_" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+            if os.environ.get("RANK", "0") == "0":
+                sock = socket.socket()
+                sock.bind(("", 0))
+                free = sock.getsockname()[1]
+                sock.close()
+                store.set(key, str(free))
+            return int(store.get(key))
+        except Exception as e:      # noqa: BLE001 -- any store problem: the documented fallback
+            print(f"bench.py: probe port through the agent store failed ({type(e).__name__}: {e}); using MASTER_PORT + 23", file=sys.stderr)
+    return base + 23
+
+
+def agree_exchange(exchange, device):
+    """The ranks decided alone (choose_exchange: each from its own probe child, under its own wall-clock limit), so start-up skew around the limit
+    could leave one rank with the marker and another with a killed child -- a mixed native / c10d job hangs in its first collective.  Once the
+    process group is up and BEFORE the first SyncBN message or gradient bucket: all-reduce(MIN) of the local decision over c10d; every rank then
+    runs what the slowest one can run.  (iseg_amd.dist reads ISEG_DIST_NATIVE at every collective, so setting it here is in time.)"""
+    if not torch.distributed.is_available() or not torch.distributed.is_initialized() or torch.distributed.get_world_size() <= 1:
+        return exchange
+    mine = 1.0 if os.environ.get("ISEG_DIST_NATIVE", "0") not in ("0", "") else 0.0
+    flag = torch.tensor([mine], dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+    agreed = float(flag.item())
+    if agreed != mine:      # this rank's probe passed, another rank's did not
+        os.environ["ISEG_DIST_NATIVE"] = "0"
+        print(f"bench.py: rank {os.environ.get('RANK', '?')}: another rank's probe did not pass; all ranks take c10d + eager step", file=sys.stderr)
+        return "c10d work objects (another rank's native-exchange probe did not pass: agreed by all-reduce(MIN) of the ranks' decisions)"
+    return exchange
 
 
 def choose_exchange(args):
@@ -193,9 +314,11 @@ def choose_exchange(args):
         return "stream-ordered RCCL through the C ABI (ISEG_DIST_NATIVE set by the caller)" if os.environ["ISEG_DIST_NATIVE"] not in ("0", "") \
             else "c10d work objects (ISEG_DIST_NATIVE=0 set by the caller)"
     limit = float(os.environ.get("ISEG_BENCH_PROBE_TIMEOUT_S", "240"))
-    port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+    port = probe_port()
     env = dict(os.environ, ISEG_DIST_NATIVE="1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--probe-native", "--batch", str(args.batch), "--size", str(args.size)]
+    if args.fp32:      # the probe must exercise the exchange the measured job runs (fp32 storage changes every message and bucket)
+        cmd.append("--fp32")
     if args.check_launch:
         cmd.append("--check-launch")
     try:
@@ -353,9 +476,36 @@ def _dma_symbol(key):
     return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}ELb{kt}EE", tiles * wm * wn * 64
 
 
+def pick_dominant_memory(report):
+    """the non-GEMM group (today: the depthwise 7 x 7 launches, instrumented in kernels.dwconv2d) with the largest total time, or None"""
+    totals = {k: v[0] * v[1] for k, v in report.items() if k[0] != "gemm"}
+    return max(totals, key=totals.get) if totals else None
+
+
+def roofline_memory(key, sec, launches, steps, step_seconds):
+    """`roofline_memory`: the largest non-GEMM launch group of the step against the HBM roofline (round-5 verdict item 7: over the whole trace the top
+    row is a depthwise kernel, not a GEMM).  Algorithmic bytes = the activation read once + written once (+ the residual-branch gradient read once
+    for the data-gradient form); the 49 K fp32 weights are noise.  The vector-pipe rate is reported beside it: a 7 x 7 depthwise pass is 49 MACs per
+    4 bytes, so at 64 T MAC/s (v_pk_fma_f32 peak) its arithmetic needs about as long as its bytes do."""
+    _, N, H, W, C, K, dil, flip, has_add, dtype = key
+    es = 2 if dtype == torch.bfloat16 else 4
+    elems = N * H * W * C
+    nbytes = elems * es * (2 + int(has_add))
+    macs = elems * K * K
+    ach = nbytes / sec / 1e9
+    return {"kernel": (f"depthwise {K}x{K} {'data gradient (+ residual-branch gradient)' if flip else 'forward'}: dwconv_fwd_dma_kernel / dwconv7_mfma_kernel "
+                       f"(csrc/dwconv.hip, csrc/dwconv_mfma.hip), N={N} {H}x{W}x{C}"),
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "launch_us": round(sec * 1e6, 2), "launches_per_step": launches / steps, "algorithmic_bytes_per_launch": int(nbytes),
+            "share_of_step": round(sec * launches / steps / step_seconds, 4),
+            "valu_tmacs": round(macs / sec / 1e12, 2), "valu_peak_tmacs": 64.0, "traffic": None}
+
+
 def pick_dominant(report):
-    """the group with the largest total time; several stage-2 GEMM groups sit within a few per cent of each other, so among the
-    groups within 10 % of the maximum prefer one whose launches a PMC pass can attribute (see _dma_symbol)"""
+    """the GEMM group with the largest total time; several stage-2 GEMM groups sit within a few per cent of each other, so among the
+    groups within 10 % of the maximum prefer one whose launches a PMC pass can attribute (see _dma_symbol).  (The largest non-GEMM group gets its
+    own entry: pick_dominant_memory / roofline_memory.)"""
+    report = {k: v for k, v in report.items() if k[0] == "gemm"}
     totals = {k: v[0] * v[1] for k, v in report.items()}
     top = max(totals.values())
     near = sorted((k for k, t in totals.items() if t >= 0.9 * top), key=lambda k: -totals[k])
@@ -368,6 +518,9 @@ def pick_dominant(report):
 def roofline_from_timer(report, steps, survey=None):
     """the GEMM launch group (kernel template + shape) with the largest share of the step; `report` holds the live
     HIP-event timings of the timed region, `survey` (all GEMM groups, one warm-up step) gives its share of GEMM time"""
+    report = {k: v for k, v in report.items() if k[0] == "gemm"}
+    if survey is not None:
+        survey = {k: v for k, v in survey.items() if k[0] == "gemm"}
     best = max(report.items(), key=lambda kv: kv[1][0] * kv[1][1])
     key, (sec, launches) = best
     flops, nbytes = _gemm_group_model(key)
@@ -523,9 +676,14 @@ def main():
         return probe_native(args)
     if args.check_launch:
         return check_launch(args)
+    affinity = pin_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), max(args.gpus, 1))      # (before any GPU call: affinity only, no exec)
     exchange = choose_exchange(args)      # (N > 1: before this process touches the GPU; sets ISEG_DIST_NATIVE for the measured job)
     from iseg_amd import dist
     from iseg_amd.data import synthetic_batch
+
+    if args.gpus > 1:      # the ranks agree on the exchange before the first collective of the job (see agree_exchange)
+        dist.init()
+        exchange = agree_exchange(exchange, torch.device("cuda", dist.local_rank()))
 
     # stdout carries the ONE JSON line and nothing else: until that line is printed, file descriptor 1 points at stderr, so neither the
     # reference's build-time chatter mirrored by the host code ("Use the random seed ...") nor a native library's banner (RCCL prints its
@@ -562,13 +720,14 @@ def main():
     timer = None
     survey_report = None
     if want_roofline:
-        dominant = None
+        dominant = dominant_mem = None
         if survey is not None:
             survey_report = survey.report()
             dominant = pick_dominant(survey_report)
+            dominant_mem = pick_dominant_memory(survey_report)
         # eager headline: one launch in four of the dominant group carries an event pair (>= 40 samples over the default 20 steps): every pair idles
         # the stream for a few microseconds, and 19 pairs per step had taxed the headline by 2.5 %
-        timer = K.KernelTimer(only=dominant, every=1 if replay else 4)
+        timer = K.KernelTimer(only=[k for k in (dominant, dominant_mem) if k is not None] or None, every=1 if replay else 4)
         K.KERNEL_TIMER[0] = timer
     step_fn = trainer.train_step
     roofline_steps = args.steps
@@ -592,16 +751,23 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    enqueue = 0.0      # host time inside the step calls (nothing in the loop waits for the GPU): what this rank's CPU needs to keep its GPU fed
     for _ in range(args.steps):
+        te = time.perf_counter()
         losses = step_fn(x, y)
+        enqueue += time.perf_counter() - te
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t0
     K.KERNEL_TIMER[0] = None
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    enq = torch.zeros(world, dtype=torch.float64, device="cuda")
+    enq[rank] = enqueue / args.steps * 1e3
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(enq, op=torch.distributed.ReduceOp.SUM)
     elapsed = float(t.item())
+    host_enqueue_ms = [round(float(v), 3) for v in enq.tolist()]
     loss_val = float(losses[0])
     if rank != 0:
         return
@@ -618,12 +784,19 @@ def main():
         "mfma_roofline_frac": round(ips / world * TRAIN_GFLOP_PER_IMAGE / 1e3 / MFMA_BF16_PEAK_TF, 4),
         "final_loss": round(loss_val, 5),
         "exchange": exchange,
+        "host_enqueue_ms_per_step": host_enqueue_ms,      # per rank; graph replay: one launch call, eager: every kernel's enqueue
+        "host_affinity": affinity,      # rank 0's own (every rank pins itself the same way)
         "step_mode": ("hip-graph replay of the whole step (one graph launch per step)" if replay and any(e.get("graph") is not None for e in getattr(step_fn, "entries", {}).values())
                       else "eager (every kernel enqueued from the host)"),
     }
     res["step"] = step_fractions(args, ips / world, elapsed / args.steps)
     if timer is not None:
-        res["roofline"] = roofline_from_timer(timer.report(), roofline_steps, survey_report)
+        rep = timer.report()
+        res["roofline"] = roofline_from_timer(rep, roofline_steps, survey_report)
+        mem = [(k, v) for k, v in rep.items() if k[0] != "gemm"]
+        if mem:
+            k, (sec, launches) = max(mem, key=lambda kv: kv[1][0] * kv[1][1])
+            res["roofline_memory"] = roofline_memory(k, sec, launches, roofline_steps, elapsed / args.steps)
         res["roofline"]["measured_in"] = (f"{roofline_steps} eager steps directly in front of the timed region, every launch of the group bracketed by HIP events on the launch stream"
                                           if replay else "the timed region, one launch in four of the group bracketed by HIP events on the launch stream")
     if world == 1 and not args.no_cpu_baseline:

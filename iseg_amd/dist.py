@@ -87,25 +87,35 @@ def _native_comm(which="comm"):
     backward pass's next SyncBN message instead of overlapping it.  Every rank creates both in the same order (first use is the first forward
     SyncBN message / the first bucket of the first step, identical on all ranks)."""
     if _NATIVE[which] is None:
-        import ctypes as C
-
-        from . import _hip
-
-        L = _hip.lib()
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank() == 0:
-            buf = C.create_string_buffer(128)
-            _hip.check(L.iseg_comm_unique_id(buf), "iseg_comm_unique_id")
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        if world_size() > 1:
-            dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
-            u = uid.to(dev)
-            td.broadcast(u, 0)
-            uid = u.cpu()
-        comm = C.c_void_p()
-        _hip.check(L.iseg_comm_init(C.byref(comm), world_size(), rank(), bytes(uid.numpy().tobytes())), "iseg_comm_init")
-        _NATIVE[which] = comm
+        # BOTH communicators come up at the first request for EITHER, in one fixed order ("comm", then "comm_side"): communicator creation is a
+        # collective (an id broadcast over c10d + ncclCommInitRank), so a rank that met its first gradient bucket before its first SyncBN message
+        # (a model whose first trainable layer has no SyncBN in front of it on one rank's code path, a resumed step) must not pair its
+        # "comm_side" creation with another rank's "comm" creation (tests/test_dist_gloo.py::test_native_communicators_come_up_in_one_order)
+        for name in ("comm", "comm_side"):
+            if _NATIVE[name] is None:
+                _NATIVE[name] = _create_native_comm()
     return _NATIVE[which]
+
+
+def _create_native_comm():
+    import ctypes as C
+
+    from . import _hip
+
+    L = _hip.lib()
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank() == 0:
+        buf = C.create_string_buffer(128)
+        _hip.check(L.iseg_comm_unique_id(buf), "iseg_comm_unique_id")
+        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    if world_size() > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if td.get_backend() == "nccl" else torch.device("cpu")
+        u = uid.to(dev)
+        td.broadcast(u, 0)
+        uid = u.cpu()
+    comm = C.c_void_p()
+    _hip.check(L.iseg_comm_init(C.byref(comm), world_size(), rank(), bytes(uid.numpy().tobytes())), "iseg_comm_init")
+    return comm
 
 
 def _stream_all_reduce(t, raw_stream, which="comm"):

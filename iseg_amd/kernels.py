@@ -81,11 +81,12 @@ class KernelTimer:
         self.records = {}
         self.seen = {}          # key -> launches seen (timed or not)
         self._cur = None
-        self.only = only        # None: every instrumented launch; else the one shape key to time
+        self.only = only        # None: every instrumented launch; else the one shape key (or a set / list of keys) to time
+        self._only = None if only is None else (set(only) if isinstance(only, (set, list, frozenset)) else {only})
         self.every = max(1, int(every))      # time every k-th matching launch: an event pair costs the stream a few microseconds of idle time
 
     def begin(self, key):
-        if self.only is not None and key != self.only:
+        if self._only is not None and key not in self._only:
             self._cur = None
             return
         n = self.seen.get(key, 0)
@@ -569,8 +570,13 @@ def dwconv2d(x, w, bias, K, dil, pad_t, pad_l, *, flip=False, add=None):
     _require_cuda(x)
     N, H, W, Cc = x.shape
     y = torch.empty_like(x)
+    timer = KERNEL_TIMER[0]
+    if timer is not None:      # (bench.py's roofline_memory entry: the depthwise family is the largest non-GEMM group of the flagship step)
+        timer.begin(("dwconv", int(N), int(H), int(W), int(Cc), int(K), int(dil), bool(flip), add is not None, x.dtype))
     _hip.call("iseg_dwconv2d_fwd", ptr(x), ptr(w), ptr(bias), ptr(add), ptr(y), N, H, W, Cc, K, dil, pad_t, pad_l, int(flip), dt(x),
               stream())
+    if timer is not None:
+        timer.end()
     return y
 
 

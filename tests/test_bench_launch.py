@@ -101,3 +101,43 @@ def test_an_explicit_exchange_choice_skips_the_probe():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert "set by the caller" in out["exchange"]
+
+
+def test_ranks_that_decided_differently_agree_on_the_fallback(tmp_path):
+    """round-5 advisor: each rank decides alone from its own probe child; when the decisions differ (start-up skew around the probe's limit) the
+    ranks meet in an all-reduce(MIN) of their decisions before the first collective of the job -- here rank 1's parent pretends it lost its probe
+    while rank 0's passed: rank 0 must come down to the c10d exchange too"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TEST_PROBE="ok", ISEG_BENCH_TEST_SPLIT_DECISION="1", ISEG_BENCH_PROBE_TIMEOUT_S="60",
+                                ISEG_BENCH_TIMEOUT_S="200", ISEG_BENCH_LOG_DIR=str(tmp_path)), capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["exchange"].startswith("c10d work objects (another rank"), out
+    log0 = open(os.path.join(tmp_path, "rank0.log")).read()
+    assert "all ranks take c10d" in log0, log0[-800:]
+
+
+def test_probe_port_comes_from_the_launcher_and_fp32_reaches_the_probe():
+    """the launcher parent binds a free port for the probe's rendezvous (no MASTER_PORT + 23 guess); --fp32 is part of the probe's command line"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "ISEG_BENCH_PROBE_PORT" in src[src.index("def self_launch"):src.index("def joined_ranks")]
+    body = src[src.index("def choose_exchange"):src.index("def probe_native")]
+    assert 'cmd.append("--fp32")' in body and "probe_port()" in body
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; os.environ['ISEG_BENCH_PROBE_PORT'] = '43210'; print(bench.probe_port()); "
+            "del os.environ['ISEG_BENCH_PROBE_PORT']; os.environ['MASTER_PORT'] = '30000'; print(bench.probe_port())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
+    assert out.stdout.split()[-2:] == ["43210", "30023"], out.stderr[-500:]
+
+
+def test_two_ranks_pin_themselves_to_disjoint_core_shares(tmp_path):
+    """round-5 verdict item 6: every rank pins itself (affinity only, before any GPU call) to a share of its GPU's NUMA node -- without a kfd
+    topology (this box) the allowed cores are split evenly"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                       env=_env(ISEG_BENCH_TIMEOUT_S="200", ISEG_BENCH_LOG_DIR=str(tmp_path)), capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    if len(os.sched_getaffinity(0)) >= 4:
+        assert out["host_affinity"] and "cores" in out["host_affinity"], out
+    code = "import os, sys; sys.path.insert(0, %r); import bench; print(bench.pin_to_gpu_numa(0, 1)); print(bench._cpulist('0-3,8,10-11'))" % ROOT
+    o = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=120)
+    assert o.stdout.strip().splitlines()[-2:] == ["None", "[0, 1, 2, 3, 8, 10, 11]"], o.stderr[-500:]

@@ -183,3 +183,61 @@ def test_two_rank_evaluate_enters_every_collective_on_every_rank():
     assert p.exitcode == 0
     _, miou1, loss1 = q1.get(timeout=5)
     assert abs(res[0][1] - miou1) < 1e-9 and abs(res[0][2] - loss1) < 1e-6
+
+
+def _comm_order_worker(rank, world, port, q):
+    """rank 1 asks for its gradient-bucket communicator FIRST, rank 0 for the SyncBN one: both must end up with the same id on "comm" and the same id
+    on "comm_side" (creation = one c10d broadcast per communicator; a fake C ABI records the ids, no RCCL on this box)"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes as C
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from iseg_amd import _hip, dist
+
+    class FakeLib:
+        def __init__(self):
+            self.n = 0
+            self.inits = []
+
+        def iseg_comm_unique_id(self, buf):
+            self.n += 1
+            buf.raw = bytes([self.n]) * 128      # rank 0 draws id 1 for its first communicator, id 2 for the second
+            return 0
+
+        def iseg_comm_init(self, comm_ref, world_size, rank_, uid):
+            self.inits.append(uid[0])
+            comm_ref._obj.value = 1000 + uid[0]      # the "handle" carries the id it was created from
+            return 0
+
+    fake = FakeLib()
+    _hip.lib = lambda: fake
+    _hip.check = lambda code, what: None
+    dist.init(backend="gloo")
+    first, second = ("comm", "comm_side") if rank == 0 else ("comm_side", "comm")
+    a = dist._native_comm(first)
+    b = dist._native_comm(second)
+    ids = {first: a.value, second: b.value}
+    q.put((rank, ids["comm"], ids["comm_side"], fake.inits))
+    import torch.distributed as td
+
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_native_communicators_come_up_in_one_order():
+    """round-5 verdict item 6: the C-ABI communicators ("comm": SyncBN messages, "comm_side": gradient buckets) are created in the same order on
+    every rank even when a rank reaches its first bucket before its first SyncBN message"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_order_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, c0, s0, i0), (_, c1, s1, i1) = res
+    assert (c0, s0) == (1001, 1002) and (c1, s1) == (1001, 1002), res      # same id behind the same name on both ranks
+    assert i0 == [1, 2] and i1 == [1, 2], res                               # and created in the same order
