@@ -843,8 +843,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
     int cur_slab = -1;
     f32x2 bv[4];
     for (int u = lb; u < units; u += gridDim.x) {
-        const int slab = u / ntiles;
-        int b = u - slab * ntiles;
+        // tile-major, slab-minor (round 6): the channel slabs of one pixel tile are consecutive units, i.e. neighbouring workgroups of ONE XCD (lb is
+        // XCD-contiguous) running at the same time -- a 128-byte line holds two 64-byte slab pieces of a pixel, and with the slab-major order of
+        // rounds 3-5 its second half was fetched again by another XCD much later (PMC: 59.9 MB per launch for 39 MB algorithmic)
+        int b = u / slabs;
+        const int slab = u - b * slabs;
         const int tw_i = b % tiles_w;
         b /= tiles_w;
         const int th_i = b % tiles_h;
@@ -862,7 +865,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
                 const int rr = rc >> 16, cc = rc & 0xffff;
                 const bool ok = (unsigned)(h0 - pad_t + rr) < (unsigned)H && (unsigned)(w0 - pad_l + cc) < (unsigned)W;
                 const bf16_t* src = ok ? xb + __mul24(__mul24(rr, W) + cc, C) : zero;
+#ifndef DWF_ABL_NODMA      // (ablation builds, tools/ab_build.py: no tile fill / no taps / no stores)
                 __builtin_amdgcn_global_load_lds((dw_glb_ptr)src, (dw_lds_ptr)(xt + p * 1024), 16, 0, 0);
+#else
+                asm volatile("" ::"v"(src));
+#endif
             }
         }
         // (behind the tile's DMA, so the two round trips overlap: staged in front of it, the weights cost a dependent trip of their own per slab)
@@ -884,8 +891,13 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
         for (int t = 0; t < TWO; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[t][q] = bv[q];
+#ifdef DWF_ABL_NOTAPS
+        constexpr int KY_END = 1;
+#else
+        constexpr int KY_END = K;
+#endif
 #pragma unroll 1
-        for (int ky = 0; ky < K; ++ky) {
+        for (int ky = 0; ky < KY_END; ++ky) {
             f32x2 wr[K][4];
             const float* wrow = wl + (ky * K) * 32 + cg * 8;
 #pragma unroll
@@ -931,7 +943,11 @@ __global__ __launch_bounds__(256, 2) void dwconv_fwd_dma_kernel(const bf16_t* __
             }
 #pragma unroll
             for (int t = 0; t < TWO; ++t)
+#ifdef DWF_ABL_NOOUT
+                if (ow0 + t < W && acc[t][0].x == 1234.5f) {
+#else
                 if (ow0 + t < W) {
+#endif
                     bf16x8 o;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {

@@ -78,7 +78,15 @@ __global__ __launch_bounds__(64 * WAVES) void dwconv7_mfma_kernel(const bf16_t* 
     const unsigned lds0 = (unsigned)(uintptr_t)(dwm_lds_ptr)smem_dwm;
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntiles = N * tiles_h * tiles_w, units = ntiles * slabs;
-    const int u_begin = blockIdx.x * units_per_wg, u_end = min(units, u_begin + units_per_wg);
+    // Unit order (round 6).  A workgroup still walks a contiguous run of `units_per_wg` logical units, but (1) the runs are dealt XCD-contiguously
+    // (workgroups b and b + 8 share an XCD under the round-robin placement: speed only), and (2) logical units are enumerated in BLOCKS of
+    // units_per_wg tiles x all slabs, slab-major inside a block: the `slabs` workgroups of a block sit next to each other on one XCD, start together
+    // and walk the SAME tiles in the same order, one channel slab each -- the 128-byte lines a 64-byte slab piece shares with its neighbour slab,
+    // and the halo rows of vertically adjacent tiles, are then served by that XCD's L2 instead of being fetched again (PMC round 5: 245 MB per
+    // launch at 128 x 128 x 96 for 100-150 MB algorithmic).  A run stays inside one slab, so the Toeplitz fragments are still built once.
+    int lb = blockIdx.x;
+    if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+    const int u_begin = lb * units_per_wg, u_end = min(units, u_begin + units_per_wg);
     if (u_begin >= u_end) return;      // (workgroup-uniform)
 
     // ---- per-lane constants ----
@@ -111,27 +119,35 @@ __global__ __launch_bounds__(64 * WAVES) void dwconv7_mfma_kernel(const bf16_t* 
     }
     struct Unit {
         int slab, n, th, tw;
+        int blk, k, tib;      // block of the enumeration, tile inside the block, tiles in this block (the last block may be short)
     };
-    Unit cur;      // (workgroup-uniform: scalar registers) one division chain per workgroup, then increments
-    {
-        cur.slab = u_begin / ntiles;
-        int t = u_begin - cur.slab * ntiles;
-        cur.tw = t % tiles_w;
+    Unit cur;      // (workgroup-uniform: scalar registers)
+    auto place = [&](Unit& q) {      // (n, th, tw) of tile blk * units_per_wg + k
+        int t = q.blk * units_per_wg + q.k;
+        q.tw = t % tiles_w;
         t /= tiles_w;
-        cur.th = t % tiles_h;
-        cur.n = t / tiles_h;
+        q.th = t % tiles_h;
+        q.n = t / tiles_h;
+    };
+    {
+        const int bsz = units_per_wg * slabs;      // logical units per full block
+        cur.blk = u_begin / bsz;
+        const int r = u_begin - cur.blk * bsz;
+        cur.tib = min(units_per_wg, ntiles - cur.blk * units_per_wg);
+        cur.slab = r / cur.tib;
+        cur.k = r - cur.slab * cur.tib;
+        place(cur);
     }
     auto advance = [&](Unit& q) {
-        if (++q.tw == tiles_w) {
-            q.tw = 0;
-            if (++q.th == tiles_h) {
-                q.th = 0;
-                if (++q.n == N) {
-                    q.n = 0;
-                    ++q.slab;
-                }
+        if (++q.k == q.tib) {
+            q.k = 0;
+            if (++q.slab == slabs) {
+                q.slab = 0;
+                ++q.blk;
+                q.tib = min(units_per_wg, ntiles - q.blk * units_per_wg);
             }
         }
+        place(q);
     };
     int poff[NPW];      // element offset of this lane's pixel of piece i from the tile's first halo pixel: (rr W + cc) C, the same for every unit
 #pragma unroll
