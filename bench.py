@@ -453,6 +453,8 @@ def _kernel_label(key):
     name = "iseg_mm::gemm_bf16_kernel" if not variant else \
         "iseg_mm::gemm_bf16_dma_kernel<%s>" % {1: "128x64,4 stages", 2: "256x128,3 stages", 3: "128x128,2 stages", 4: "128x128,3 stages",
                                               5: "256x128,3 stages,persistent", 6: "256x192,2 stages"}[variant]
+    if variant == 2 and _dma_symbol(key)[0] and "ELi32EE" in _dma_symbol(key)[0]:
+        name = "iseg_mm::gemm_bf16_dma_kernel<256x128,3 stages of 32 K,two workgroups per CU>"
     return f"{name} ({orient}; M={M} N={N} K={K}{', split-K slabs' if split else ''}{'; epilogue ' + epi if epi else ''})"
 
 
@@ -473,7 +475,11 @@ def _dma_symbol(key):
     bm, bn = wm * 64, wn * fn * 16
     tiles = -(-M // bm) * -(-N // bn)
     kt = 1 if K % 64 else 0      # (the K-tail instantiation, gemm_dma.h)
-    return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}ELb{kt}EE", tiles * wm * wn * 64
+    # (round 6: the 256 x 128 form runs 32-deep ring stages, two workgroups per CU, for whole-K problems with K <= 512 -- gemm_dma.h dispatch_dma)
+    bks = 32 if (variant == 2 and K <= 512 and K % 32 == 0 and K >= 96 and os.environ.get("ISEG_GEMM_DMA_BK32", "1") != "0") else 64
+    if os.environ.get("ISEG_GEMM_DMA_BK32") == "2" and variant == 2 and K % 32 == 0 and K >= 96:
+        bks = 32
+    return f"gemm_bf16_dma_kernelILi{wm}ELi{wn}ELi{ns}EDF16bLb0ELi{fn}ELi{ek}ELb{kt}ELi{bks}EE", tiles * wm * wn * 64
 
 
 def pick_dominant_memory(report):

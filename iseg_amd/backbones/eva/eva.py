@@ -54,6 +54,14 @@ class Eva(Layer):
         self.class_token = self.add_weight("class_token", (1, 1, self.embed_filters), "zeros") if self.use_class_token else None
         self.position_embedding = (self.add_weight("pos_embed", (1, num_patches + self.num_prefix_tokens, self.embed_filters), "zeros")
                                    if self.use_abs_pos_emb else None)
+        if self.position_embedding is not None:
+            # (:131-165) the reference wraps pos_embed.assign: the FIRST value assigned (the pretrained table, laid out on the pretrain grid
+            # pretrain_img_size // pretrain_patch_size) is resampled bicubically to the build grid, prefix tokens passed through
+            # (utils/common.py:206-262 resample_absolute_position_embedding); later assignments are taken as they come
+            ph, pw = to_2d_tuple(self.pretrain_img_size)
+            self._pretrain_grid = (int(ph) // self.pretrain_patch_size, int(pw) // self.pretrain_patch_size)
+            self._pos_embed_assigned = False
+            self.position_embedding.iseg_assign_hook = self._resample_on_first_assign
         self.pos_droppout = Dropout(self.pos_droppout_rate, name="pos_droppout")
         self.rope = None
         if self.use_rot_pos_emb:
@@ -68,6 +76,32 @@ class Eva(Layer):
                      use_post_norm=self.use_post_norm, class_token_size=self.num_prefix_tokens, name=f"{self.name}/blocks/{i}")
             for i in range(self.depth)])
         self.built = True
+
+    def _resample_on_first_assign(self, value):
+        """value [1, prefix + ph * pw, C] (the pretrain grid) -> [1, prefix + gh * gw, C] by tf.image.resize(method="bicubic") arithmetic
+        (utils/bicubic.bicubic_matrix: half-pixel centres, Keys a = -0.5 table, no antialias); a value already on the build grid passes"""
+        from ...utils.bicubic import bicubic_matrix
+
+        value = np.asarray(value, dtype=np.float32)
+        if self._pos_embed_assigned:
+            return value
+        self._pos_embed_assigned = True
+        n_prefix = self.num_prefix_tokens
+        (ph, pw), (gh, gw) = self._pretrain_grid, self.grid_size
+        tokens = value.shape[-2] - n_prefix
+        if tokens == gh * gw and (ph, pw) == (gh, gw):
+            return value
+        if tokens != ph * pw:
+            if tokens == gh * gw:      # a table already on the build grid (a checkpoint of this model)
+                return value
+            raise ValueError(f"{self.name}/pos_embed: {tokens} stored position tokens, expected the pretrain grid {ph} x {pw} "
+                             f"(pretrain_img_size {self.pretrain_img_size} // patch {self.pretrain_patch_size}) or the build grid {gh} x {gw}")
+        value = value.reshape(1, n_prefix + tokens, -1)
+        spatial = value[0, n_prefix:].reshape(ph, pw, -1)
+        wy, wx = bicubic_matrix(gh, ph), bicubic_matrix(gw, pw)
+        out = np.einsum("oh,hwc->owc", wy, spatial)
+        out = np.einsum("pw,owc->opc", wx, out).reshape(gh * gw, -1).astype(np.float32)
+        return np.concatenate([value[0, :n_prefix], out], axis=0)[None]
 
     def _resize_matrices(self, height, width):
         key = (height, width)

@@ -236,9 +236,10 @@ __device__ __forceinline__ unsigned long long dcn_to_fixed(float v256) {      //
 template <class T, int CV>
 __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x, const T* __restrict__ offset, const T* __restrict__ mask,
                                                         const T* __restrict__ dy, unsigned long long* __restrict__ dx, T* __restrict__ doffset,
-                                                        T* __restrict__ dmask, DcnGeom g) {
+                                                        T* __restrict__ dmask, int* __restrict__ flag, DcnGeom g) {
     const int P = g.kh * g.kw;
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;
+    bool bad = false;      // a non-finite contribution: the fixed-point conversion would saturate it to finite garbage (see dcn_unfix_kernel)
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int gi = (int)(i % g.G);
         int64_t t = i / g.G;
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
 #pragma unroll
                     for (int u = 0; u < CV; ++u) {
                         dot = fmaf(d[u], v[u], dot);
-                        atomicAdd(dx + src + gi * g.Cg + c0 + u, dcn_to_fixed(d[u] * m * wgt[k] * DCN_FIX));
+                        const float contrib = d[u] * m * wgt[k] * DCN_FIX;
+                        bad |= !(fabsf(contrib) < 3.0e38f);
+                        atomicAdd(dx + src + gi * g.Cg + c0 + u, dcn_to_fixed(contrib));
                     }
                 }
                 gm = fmaf(wgt[k], dot, gm);
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_kernel(const T* __restrict__ x,
             doffset[pix * g.ld_off + (gi * P + p) * 2 + 1] = from_f32<T>(gpy * m * (float)(g.Hin - 2) * g.s / (float)g.Hin);
         }
     }
+    if (bad) atomicOr(flag, 2);      // (rare; integer OR: order-free)
 }
 
 // Channel-lane variant of the backward pass for power-of-two group widths (InternImage: Cg = 16 everywhere): LC = Cg lanes
@@ -295,10 +299,11 @@ template <class T, int LC>
 __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__ x, const T* __restrict__ offset,
                                                            const T* __restrict__ mask, const T* __restrict__ dy,
                                                            unsigned long long* __restrict__ dx, T* __restrict__ doffset,
-                                                           T* __restrict__ dmask, DcnGeom g) {
+                                                           T* __restrict__ dmask, int* __restrict__ flag, DcnGeom g) {
     const int P = g.kh * g.kw;
     const int64_t total = (int64_t)g.N * g.Ho * g.Wo * g.G;          // (pixel, group) items
     const int c = threadIdx.x % LC;
+    bool bad = false;      // (as in dcnv3_bwd_kernel)
     constexpr int IPB = 256 / LC;                                     // items per workgroup sweep
     for (int64_t i = blockIdx.x * (int64_t)IPB + threadIdx.x / LC; i < total; i += (int64_t)gridDim.x * IPB) {
         const int gi = (int)(i % g.G);
@@ -327,7 +332,9 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
                 if (src < 0) continue;        // uniform across the LC lanes of an item
                 const float v = to_f32(x[src + gi * g.Cg + c]);
                 const float dv = d * v;       // this lane's share of sum_c dy[c] * xp[corner][c]
-                atomicAdd(dx + src + gi * g.Cg + c, dcn_to_fixed(dm * wgt[k] * DCN_FIX));
+                const float contrib = dm * wgt[k] * DCN_FIX;
+                bad |= !(fabsf(contrib) < 3.0e38f);
+                atomicAdd(dx + src + gi * g.Cg + c, dcn_to_fixed(contrib));
                 gm = fmaf(wgt[k], dv, gm);
                 gpx = fmaf(wpx[k], dv, gpx);
                 gpy = fmaf(wpy[k], dv, gpy);
@@ -342,6 +349,7 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_cl_kernel(const T* __restrict__
             }
         }
     }
+    if (bad) atomicOr(flag, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -655,10 +663,14 @@ __global__ __launch_bounds__(256) void dcnv3_bwd_gather_kernel(const float* __re
 
 __global__ void dcn_flag_reset_kernel(int* __restrict__ flag) { *flag = 0; }
 
+// flag (may be null): bit 1 set by an accumulating kernel that met a non-finite contribution -- the fixed-point conversion saturates those to finite
+// garbage, so the whole input gradient is written as NaN instead (what a chain of fp32 atomics would have spread; the window route does the same)
 template <class TO>
-__global__ __launch_bounds__(256) void dcn_unfix_kernel(const unsigned long long* __restrict__ acc, TO* __restrict__ dx, int64_t n) {
+__global__ __launch_bounds__(256) void dcn_unfix_kernel(const unsigned long long* __restrict__ acc, TO* __restrict__ dx, int64_t n,
+                                                        const int* __restrict__ flag = nullptr) {
+    const bool poisoned = flag != nullptr && (*flag & 2) != 0;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        dx[i] = from_f32<TO>((float)((double)(long long)acc[i] * DCN_UNFIX));
+        dx[i] = from_f32<TO>(poisoned ? __builtin_nanf("") : (float)((double)(long long)acc[i] * DCN_UNFIX));
 }
 
 __global__ __launch_bounds__(256) void dcn_zero_kernel(uint4* __restrict__ p, int64_t n16) {
@@ -880,12 +892,15 @@ extern "C" int iseg_dcnv3_fwd_ld(const void* x, const void* offset, const void* 
     return iseg_check_launch("iseg_dcnv3_fwd");
 }
 
+// general route: nel int64 accumulators (rounded up to 16 bytes) + a 16-byte slot whose first word is the non-finite flag
+static size_t dcn_general_bytes(int64_t nel) { return ((size_t)nel * sizeof(unsigned long long) + 15) / 16 * 16 + 16; }
+
 extern "C" size_t iseg_dcnv3_bwd_workspace_bytes(int N, int H, int W, int G, int Cg, int kh, int kw, int stride, int dil, int pad,
                                                  float offset_scale) {
     DcnGeom g;
     if (make_geom(&g, N, H, W, G, Cg, kh, kw, stride, dil, pad, offset_scale, "iseg_dcnv3_bwd_workspace_bytes") != ISEG_OK) return 0;
     DcnWin wn;
-    const size_t fallback = (size_t)N * H * W * G * Cg * sizeof(unsigned long long);      // int64 accumulators of the general kernels
+    const size_t fallback = dcn_general_bytes((int64_t)N * H * W * G * Cg);      // int64 accumulators of the general kernels + their flag word
     if (!dcn_window(g, &wn)) return fallback;
     size_t so, fo;
     const size_t win = dcn_win_bytes(g, wn, &so, &fo);
@@ -984,25 +999,25 @@ extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* 
     // general route (other group widths, footprints wider than the window): int64 fixed-point atomics into a zeroed workspace, then one
     // conversion pass -- order-free like the window kernels
     const int64_t nel = (int64_t)N * H * W * G * Cg;
+    const size_t need = dcn_general_bytes(nel);
     {
-        const size_t need = (size_t)nel * sizeof(unsigned long long);
         if (!ws || ws_bytes < need) {
             iseg_set_error("iseg_dcnv3_bwd: needs %zu workspace bytes, got %zu", need, ws_bytes);
             return ISEG_ERR_WORKSPACE;
         }
-        const int64_t n16 = (int64_t)need / 16;
-        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16 + 1)), dim3(256), 0, stream, (uint4*)ws, n16);
-        if (need % 16) (void)hipMemsetAsync((char*)ws + n16 * 16, 0, need % 16, stream);
+        const int64_t n16 = (int64_t)need / 16;      // (a multiple of 16: accumulators and the flag slot are zeroed by one launch)
+        hipLaunchKernelGGL(dcn_zero_kernel, dim3(lane_blocks(n16)), dim3(256), 0, stream, (uint4*)ws, n16);
     }
     unsigned long long* const acc = (unsigned long long*)ws;
+    int* const gflag = (int*)((char*)ws + need - 16);
     const int64_t lanes = (int64_t)N * g.Ho * g.Wo * G;
     const bool v8 = Cg % 8 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0;
 #define DCN_BWD(T, CV)                                                                                                              \
     hipLaunchKernelGGL((dcnv3_bwd_kernel<T, CV>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const T*)x, (const T*)offset,   \
-                       (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, g)
+                       (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, gflag, g)
 #define DCN_BWD_CL(T, LC)                                                                                                            \
     hipLaunchKernelGGL((dcnv3_bwd_cl_kernel<T, LC>), dim3(lane_blocks(lanes * LC)), dim3(256), 0, stream, (const T*)x,              \
-                       (const T*)offset, (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, g)
+                       (const T*)offset, (const T*)mask, (const T*)dy, acc, (T*)doffset, (T*)dmask, gflag, g)
 #define DCN_BWD_CL_ANY(T)                    \
     do {                                     \
         if (Cg == 4) DCN_BWD_CL(T, 4);       \
@@ -1024,8 +1039,9 @@ extern "C" int iseg_dcnv3_bwd_ld(const void* x, const void* offset, const void* 
 #undef DCN_BWD_CL_ANY
 #undef DCN_BWD_CL
 #undef DCN_BWD
-    if (dx_dtype == ISEG_BF16) hipLaunchKernelGGL(dcn_unfix_kernel<bf16_t>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (bf16_t*)dx, nel);
-    else hipLaunchKernelGGL(dcn_unfix_kernel<float>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (float*)dx, nel);
+    if (dx_dtype == ISEG_BF16)
+        hipLaunchKernelGGL(dcn_unfix_kernel<bf16_t>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (bf16_t*)dx, nel, (const int*)gflag);
+    else hipLaunchKernelGGL(dcn_unfix_kernel<float>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, (float*)dx, nel, (const int*)gflag);
     return iseg_check_launch("iseg_dcnv3_bwd");
 }
 
@@ -1333,7 +1349,7 @@ extern "C" int iseg_dcnv2_sample_bwd(const void* x, const void* offset, const vo
     else
         hipLaunchKernelGGL((dcnv2_sample_bwd_kernel<float, LC>), dim3(lane_blocks(lanes)), dim3(256), 0, stream, (const float*)x, (const float*)offset,
                            (const float*)dcol, acc, (float*)doffset, N, H, W, C);
-    hipLaunchKernelGGL(dcn_unfix_kernel, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel);
+    hipLaunchKernelGGL(dcn_unfix_kernel<float>, dim3(lane_blocks(nel)), dim3(256), 0, stream, acc, dx_f32, nel, (const int*)nullptr);
     return iseg_check_launch("iseg_dcnv2_sample_bwd");
 }
 

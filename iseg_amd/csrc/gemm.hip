@@ -64,6 +64,13 @@ int dma_mode() {
     }();
     return v;
 }
+int dma_bk32() {
+    static const int v = [] {
+        const char* e = getenv("ISEG_GEMM_DMA_BK32");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
 int dma_min_k() {
     static const int v = [] {
         const char* e = getenv("ISEG_GEMM_DMA_MIN_K");

@@ -98,18 +98,29 @@ inline int epi_kind(const Epi& e, const float* slabs) {
 
 // KT: the instantiation that handles a K tail (launched only for K % 64 != 0: the tail's address selects cost the whole-K flagship launches 0.5 %
 // of the step when they were compiled into every instantiation -- tools/ab_ktail.sh, 8.28 vs 8.24 ms)
-template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY, bool KT = false>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
+// BKS: K elements per ring stage.  64 (one 128-byte row per stage row: the form of rounds 1-5) or 32 (round 6: 64-byte stage rows, half the ring,
+// so TWO 256 x 128 workgroups fit a CU -- 72 KB each -- and one's register epilogue (GELU evaluations, operand loads, stores) overlaps the other's
+// main loop; one barrier per 16 MFMAs instead of per 32).  The 64-byte image is swizzled with a 2-bit key per group of four rows,
+// key = {0, 3, 2, 1}[(row >> 2) & 3] for A and {0, 3, 2, 1}[(row >> 3) & 3] for the permuted B rows: every 16-lane ds_read_b128 group
+// ({0-3, 12-15, 20-27}, ...) then covers the sixteen 16-byte slots of a 256-byte bank row exactly once.
+__device__ __forceinline__ int key32(int quad) { return (0x6C >> (2 * (quad & 3))) & 3; }      // {0, 3, 2, 1}
+
+template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY, bool KT = false, int BKS = 64>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS == 32 ? 4 : 1, BKS == 32 ? 4 : 8))) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
                                                                      float* __restrict__ slabs, Epi epi, int vecD) {
     constexpr int NW = WM * WN;
     constexpr int BM = WM * 64, BN = WN * FN * 16;      // a wavefront owns 64 rows x FN*16 columns (FN = 4, or 6 for the 256 x 192 tile)
     static_assert(FN % 2 == 0, "column fragments come in pairs (eight consecutive columns per lane)");
-    constexpr int PIECES = (BM + BN) / 8;      // 1-KiB DMA pieces (8 rows x 128 B) per stage
+    static_assert(BKS == 64 || (BKS == 32 && !KT && !PERSIST), "ring stages hold 64 or 32 K elements; the 32 form has no K tail and no persistent walk");
+    constexpr int RB = BKS * 2;                // bytes per stage row
+    constexpr int CPR = BKS / 8;               // 16-byte chunks per stage row
+    constexpr int RPP = 1024 / RB;             // stage rows per 1-KiB DMA piece
+    constexpr int PIECES = (BM + BN) / RPP;    // 1-KiB DMA pieces per stage
     constexpr int PPW = PIECES / NW;           // pieces each wavefront issues per stage
     static_assert(PIECES % NW == 0, "stage pieces must divide over the wavefronts");
-    constexpr int STAGE = (BM + BN) * 128;     // bytes
+    constexpr int STAGE = (BM + BN) * RB;      // bytes
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // NS * STAGE bytes
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     const int64_t kend = (kbeg + k_per_split < K) ? kbeg + k_per_split : K;
     // K tail: a last K-step of fewer than eight 16-B chunks.  The lanes whose source chunk lies beyond it request a 16-B run of zeros instead
     // (the stage slot must hold zeros for BOTH operands: whatever lies behind the row's end times zero is not zero when it decodes as inf / NaN)
-    const int nk = KT ? (int)((kend - kbeg + 63) / 64) : (int)((kend - kbeg) / 64);
+    const int nk = KT ? (int)((kend - kbeg + 63) / 64) : (int)((kend - kbeg) / BKS);
     const int tail_chunks = KT ? (int)(((kend - kbeg) & 63) >> 3) : 0;      // 0: the last K-step is whole
 
     // per-lane DMA sources: piece p of this wavefront covers stage rows 8*(wid + p*NW) .. +7 (A rows first, then B rows);
@@ -144,14 +155,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     const bf16_t* src[PPW];
     bool beyond[PPW];      // this lane's source chunk of piece p is past the K tail
     auto point = [&](int64_t pm0, int64_t pn0) {
-        const int rsub = lane >> 3;
+        const int rsub = lane / CPR;
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
-            const int r = (wid + p * NW) * 8 + rsub;
+            const int r = (wid + p * NW) * RPP + rsub;
             if (r < BM) {
                 int64_t row = pm0 + r;
                 row = row < M ? row : M - 1;
-                const int ch = (lane & 7) ^ (r & 7);
+                const int ch = (lane & (CPR - 1)) ^ (BKS == 64 ? (r & 7) : key32(r >> 2));
                 src[p] = A + row * lda + kbeg + ch * 8;
                 beyond[p] = ch >= tail_chunks;
             } else {
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
                 row = row < N ? row : N - 1;
                 // (B per row group: a tile never straddles two groups, b_group_rows % 256 == 0 is checked on the host)
                 const bf16_t* Bg = epi.b_group_rows > 0 ? B + (pm0 / epi.b_group_rows) * epi.b_group_stride : B;
-                const int ch = (lane & 7) ^ b_key(rb);
+                const int ch = (lane & (CPR - 1)) ^ (BKS == 64 ? b_key(rb) : key32(rb >> 3));
                 src[p] = Bg + row * ldb + kbeg + ch * 8;
                 beyond[p] = ch >= tail_chunks;
             }
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
 #pragma unroll
         for (int p = 0; p < PPW; ++p) {
             __builtin_amdgcn_global_load_lds((glb_void_ptr)src[p], (lds_void_ptr)(smem + stage * STAGE + (wid + p * NW) * 1024), 16, 0, 0);
-            src[p] += 64;
+            src[p] += BKS;
         }
     };
 
@@ -193,22 +204,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_bf16_dma_kernel(const bf16_t
     // registers of fragments (2h, 2h+1), the eight CONSECUTIVE columns 32*h + 8*g .. + 7 -- the epilogue stores 16-B vectors
     // straight from registers (four lanes = 64 contiguous bytes of a row), no LDS transpose.
     const int g = lane >> 4, c15 = lane & 15;
-    const int a_sw = (g ^ (lane & 7)) * 16;      // ks = 0; ks = 1 flips bit 6 of the byte offset (chunk ^ 4)
-    const int a_off = (wm * 64 + c15) * 128;
+    // BKS = 64: ks = 0; ks = 1 flips bit 6 of the byte offset (chunk ^ 4).  BKS = 32: one k-step per stage, the key of the row's group of four
+    // (rows wm * 64 + 16 i + c15: the group index is c15 >> 2 whatever i)
+    const int a_sw = (BKS == 64 ? (g ^ (lane & 7)) : (g ^ key32(c15 >> 2))) * 16;
+    const int a_off = (wm * 64 + c15) * RB;
     const int b_row0 = wn * (FN * 16) + 8 * (c15 >> 2) + (c15 & 3);
-    const int b_sw = (g ^ b_key(b_row0)) * 16;   // + 32*(j >> 1) + 4*(j & 1) leaves the key (bits 0,1,3 of the row) unchanged
-    const int b_off = BM * 128 + b_row0 * 128;
+    // + 32*(j >> 1) + 4*(j & 1) leaves the key unchanged (BKS = 64: bits 0,1,3 of the row; BKS = 32: bits 3,4 = c15 >> 2)
+    const int b_sw = (BKS == 64 ? (g ^ b_key(b_row0)) : (g ^ key32(c15 >> 2))) * 16;
+    const int b_off = BM * RB + b_row0 * RB;
 
     auto compute = [&](int stage) {
         const char* sa = smem + stage * STAGE + a_off;
         const char* sb = smem + stage * STAGE + b_off;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BKS / 32; ++ks) {
             bf16x8 af[4], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 2048 + (a_sw ^ (ks * 64)));
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RB + (a_sw ^ (ks * 64)));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * 128 + (b_sw ^ (ks * 64)));
+            for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * RB + (b_sw ^ (ks * 64)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -329,7 +343,7 @@ inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
     return true;
 }
 
-template <int WM, int WN, int NS, class TO, int FN = 4, int EK = EK_ANY>
+template <int WM, int WN, int NS, class TO, int FN = 4, int EK = EK_ANY, int BKS = 64>
 void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
     constexpr int BM = WM * 64, BN = WN * FN * 16;
     const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
@@ -337,7 +351,17 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
     const int vecD = 1;
     const int batch = g->batch > 1 ? g->batch : 1;
     dim3 grid(ntiles, nsplit, batch);
-    constexpr int lds = NS * (BM + BN) * 128;
+    constexpr int lds = NS * (BM + BN) * BKS * 2;
+    if constexpr (BKS == 32) {      // (dispatch_dma sends only whole-K problems here: K % 32 == 0, splits cut at multiples of 64)
+        static const bool raised32 = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, false, 32>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+        }();
+        (void)raised32;
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, false, 32>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+                           (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
+        return;
+    }
     if (g->K % 64 != 0) {
         static const bool raised_kt = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
             return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true>),
@@ -434,26 +458,37 @@ inline int dma_form(const iseg_gemm_args* g, int nsplit) {
 }
 
 // one instantiation per fused epilogue kind for bf16 outputs (the other output type keeps the run-time epilogue)
-template <int WM, int WN, int NS, class TO, int FN>
+template <int WM, int WN, int NS, class TO, int FN, int BKS = 64>
 void launch_dma_kinds(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     if (sizeof(TO) == 2) {
         switch (epi_kind(epi, slabs)) {
-            case EK_GELU_DERIV: launch_dma<WM, WN, NS, TO, FN, EK_GELU_DERIV>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_BIAS: launch_dma<WM, WN, NS, TO, FN, EK_BIAS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_GELU_DERIV: launch_dma<WM, WN, NS, TO, FN, EK_GELU_DERIV, BKS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX, BKS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL, BKS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN, BKS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS: launch_dma<WM, WN, NS, TO, FN, EK_BIAS, BKS>(g, epi, nsplit, kps, slabs, s); return;
             default: break;
         }
     }
-    launch_dma<WM, WN, NS, TO, FN>(g, epi, nsplit, kps, slabs, s);
+    launch_dma<WM, WN, NS, TO, FN, EK_ANY, BKS>(g, epi, nsplit, kps, slabs, s);
 }
+
+// ISEG_GEMM_DMA_BK32: the 256 x 128 form with 32-deep ring stages, two workgroups per CU (see the kernel's BKS note): 1 (default) = for K <= 512,
+// 2 = every whole-K problem of the 256 x 128 form, 0 = never
+int dma_bk32();
 
 template <class TO>
 void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     switch (dma_form(g, nsplit)) {
         case 1: launch_dma<2, 1, 4, TO>(g, epi, nsplit, kps, slabs, s); break;
-        case 2: launch_dma_kinds<4, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 128: the flagship's stage-2 products
+        case 2:      // 256 x 128: the flagship's stage-2 products
+            // measured (tools/kbench_pitch.py, M = 16384, one box): K = 384 with the gelu + gelu' epilogue 44.8 -> 41.2 us, with the x aux epilogue
+            // 39.7 -> 35.7; K = 1536 plain 31.8 -> 34.0, + bias + residual 35.6 -> 34.9 -- the short-K products are epilogue-bound and gain from the
+            // second resident workgroup, the long-K ones pay for twice the barriers: taken for K <= 512 (ISEG_GEMM_DMA_BK32 = 0 never, 2 always)
+            if (dma_bk32() && (dma_bk32() == 2 || g->K <= 512) && g->K % 32 == 0 && g->K >= 96 && (kps == g->K || kps % 64 == 0) && sizeof(TO) == 2)
+                launch_dma_kinds<4, 2, 3, TO, 4, 32>(g, epi, nsplit, kps, slabs, s);
+            else launch_dma_kinds<4, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s);
+            break;
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 5: launch_dma_persistent<TO>(g, epi, kps, dma_cus(), s); break;
         case 6: launch_dma_kinds<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 192: stage 3

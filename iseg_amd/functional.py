@@ -2541,8 +2541,12 @@ class _DcnJointFn(Function):
         return dxp, dx1, None, None, None, None, None
 
 
-def dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size):
+def dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size, stride=1, out_hw=None):
+    """stride / out_hw: the joint form projects x1 pixel by pixel, so the offset / mask rows are x1's pixels -- they are the sampling kernel's OUTPUT
+    pixels only at stride 1 with an unchanged map size (round-5 advisor: a strided layer must fall back to the layer-by-layer route, not raise)"""
     kh, kw = kernel_size
+    if int(stride) != 1 or (out_hw is not None and tuple(out_hw) != tuple(x1.shape[1:3])):
+        return False
     return (_DCN_JOINT and not nn.dry_run() and x1.dtype == torch.bfloat16 and kh * kw <= 9 and getattr(offset_layer, "kernel", None) is not None
             and getattr(mask_layer, "kernel", None) is not None and offset_layer.bias is not None and mask_layer.bias is not None
             and x1.shape[-1] % 8 == 0 and x1.shape[-1] >= 64)
@@ -2553,7 +2557,7 @@ def dcnv3_joint(x_proj, x1, offset_layer, mask_layer, groups, group_channels, ke
     apply (fp32 storage, more than nine sampling points, a projection without bias, ISEG_DCN_JOINT=0): the caller then takes the layer-by-layer
     route"""
     kh, kw = kernel_size
-    if not dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size):
+    if not dcnv3_joint_ok(x1, offset_layer, mask_layer, kernel_size, stride, K.dcnv3_out_hw(x_proj.shape[1], x_proj.shape[2], kh, kw, stride, dilation, pad)):
         return None
     cfg = (int(groups), int(group_channels), int(kh), int(kw), int(stride), int(dilation), int(pad), float(offset_scale))
     return _DcnJointFn.apply(x_proj, x1, offset_layer.kernel, offset_layer.bias, mask_layer.kernel, mask_layer.bias, cfg)

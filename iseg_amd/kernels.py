@@ -1323,15 +1323,21 @@ def dcnv3_bwd_joint(x, om, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale):
     if tuple(dy.shape) != (N, Ho, Wo, Cc) or Cc != G * Cg:
         raise ValueError("dcnv3_bwd_joint: dy shape does not match the forward geometry")
     gp = G * kh * kw
+    if om.dim() != 2 or om.shape[0] != N * Ho * Wo or om.shape[1] < 3 * gp or om.stride(1) != 1:
+        raise ValueError(f"dcnv3_bwd_joint: om {tuple(om.shape)} does not match {N * Ho * Wo} output pixels x >= {3 * gp} columns")
     dx = torch.empty((N, H, W, Cc), dtype=x.dtype, device=x.device)
-    dom = torch.empty_like(om)
+    # the C ABI takes ONE pitch pair for om and dom, so dom is allocated AT om's row pitch: empty_like(om) of a column-sliced om (shape[1] < stride)
+    # keeps om's shape but comes back dense, i.e. with a different pitch than the om.stride(0) that was passed for it (round-5 advisor)
     ld = om.stride(0)
+    dom = torch.empty((om.shape[0], ld), dtype=om.dtype, device=om.device)[:, :om.shape[1]]
     L = _hip.lib()
     ws, wsb = workspace(L.iseg_dcnv3_bwd_workspace_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
     side = _dcn_side(L.iseg_dcnv3_bwd_side_bytes(N, H, W, G, Cg, kh, kw, stride, dil, pad, float(offset_scale)), x.device)
+    _dcn_side_guard(x.device, True)
     _hip.check(L.iseg_dcnv3_bwd_ld(ptr(x), ptr(om), ptr(om[:, 2 * gp:]), ld, ld, ptr(dy), ptr(dx), dt(dx), ptr(dom), ptr(dom[:, 2 * gp:]), N, H, W, G,
                                    Cg, kh, kw, stride, dil, pad, float(offset_scale), dt(x), ptr(ws), wsb, ptr(side),
                                    side.numel() if side is not None else 0, stream()), "iseg_dcnv3_bwd_ld")
+    _dcn_side_guard(x.device, False)
     return dx, dom
 
 
@@ -1340,11 +1346,29 @@ def dcnv3_bwd_joint(x, om, dy, G, Cg, kh, kw, stride, dil, pad, offset_scale):
 _DCN_SIDE = {}
 
 
+_DCN_SIDE_DIRTY = set()      # devices whose side buffer a backward call may have left non-zero
+
+
+def _dcn_side_guard(device, entering):
+    """Host-side dirty bit around every call that uses the side buffer (round-5 advisor): set before the launch, cleared once the call has
+    returned without an error.  A call that raises in between (a launch error surfacing there, KeyboardInterrupt, a failed graph capture that is
+    retried) leaves it set, and the NEXT request for the buffer zero-fills it again instead of feeding stale fixed-point partials or a set poison
+    flag into every later input gradient of every DCNv3 layer."""
+    key = str(device)
+    if entering:
+        _DCN_SIDE_DIRTY.add(key)
+    else:
+        _DCN_SIDE_DIRTY.discard(key)
+
+
 def _dcn_side(nbytes, device):
     if nbytes == 0:
         return None
     key = str(device)
     buf = _DCN_SIDE.get(key)
+    if buf is not None and key in _DCN_SIDE_DIRTY:      # a call that used it did not finish: restore the all-zero invariant
+        fill_f32(buf.view(torch.float32), 0.0)
+        _DCN_SIDE_DIRTY.discard(key)
     if buf is None or buf.numel() < nbytes:
         from . import nn
 

@@ -69,6 +69,9 @@ def _norm(name):
 def _assign(pairs):
     with torch.no_grad():
         for target, value in pairs:
+            hook = getattr(target, "iseg_assign_hook", None)      # e.g. Eva's position embedding: resampled to the build grid on its first assignment
+            if hook is not None:
+                value = hook(np.asarray(value))
             t = torch.as_tensor(np.asarray(value), dtype=torch.float32).reshape(tuple(target.shape)).to(target.device)
             (target.data if isinstance(target, torch.nn.Parameter) else target).copy_(t)
             shadow = getattr(target, "iseg_compute", None)
@@ -101,7 +104,8 @@ def load_weights_from_group_by_name(f, model, skip_mismatch=False):
                 raise ValueError(msg)
             loaded_layers += 1
             for wname, target in symbolic:
-                stored = search_weights(wname, kv, tuple(target.shape))
+                # (a weight with an assign hook -- Eva's position embedding -- is taken at its stored shape: the hook resamples it)
+                stored = search_weights(wname, kv, None if getattr(target, "iseg_assign_hook", None) is not None else tuple(target.shape))
                 if stored is None:
                     msg = f"Shape mismatch in layer #{k} (named {layer.name}) for weight {wname}. Weight expects shape {tuple(target.shape)}."
                     if skip_mismatch:

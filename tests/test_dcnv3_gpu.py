@@ -393,3 +393,62 @@ def test_dcnv3_backward_reports_non_finite_gradients(cuda, dtype):
     assert bool(torch.isfinite(dxj).all())
     dx, _, _ = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
     assert torch.equal(dxj, dx.to(dtype))
+
+
+def test_dcnv3_joint_backward_with_a_column_sliced_matrix_and_after_an_unfinished_call(cuda):
+    """round-5 advisor: (1) an offset | mask matrix handed over as a column slice (shape[1] < row pitch) gets its gradient matrix at the SAME pitch
+    (the C ABI takes one pitch pair for both); (2) a backward call that did not finish leaves the kept side buffer in an unknown state: the
+    host-side dirty bit makes the next call zero-fill it first, so stale fixed-point partials or a set poison flag cannot reach later gradients"""
+    from iseg_amd import kernels as K
+
+    dtype, shape, G, spread = torch.bfloat16, (2, 33, 30, 16), 2, 9.0
+    N, H, W, C = shape
+    Cg, gp = C // G, G * 9
+    ld = (3 * gp + 7) // 8 * 8 + 8
+    x, _ = q(rnd(shape, 11), dtype)
+    off, _ = q(rnd((N, H, W, 2 * gp), 12) * spread, dtype)
+    m, _ = q(torch.softmax(rnd((N, H, W, G, 9), 13), -1).reshape(N, H, W, gp), dtype)
+    dy, _ = q(rnd(shape, 14), dtype)
+    full = torch.zeros((N * H * W, ld), dtype=dtype, device="cuda")
+    full[:, :2 * gp] = off.reshape(-1, 2 * gp)
+    full[:, 2 * gp:3 * gp] = m.reshape(-1, gp)
+    dx0, dom0 = K.dcnv3_bwd_joint(x, full, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    sliced = full[:, :3 * gp]
+    assert sliced.stride(0) == ld and sliced.shape[1] == 3 * gp
+    dx1, dom1 = K.dcnv3_bwd_joint(x, sliced, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert dom1.stride(0) == ld and tuple(dom1.shape) == tuple(sliced.shape)
+    assert torch.equal(dx0, dx1) and torch.equal(dom0[:, :3 * gp], dom1)
+    # an "unfinished" call: the guard is still set and the buffer holds garbage
+    key = str(x.device)
+    side = K._DCN_SIDE[key]
+    side.view(torch.int32).fill_(0x7F7F7F7F)
+    K._dcn_side_guard(x.device, True)
+    dx2, dom2 = K.dcnv3_bwd_joint(x, full, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(dx0, dx2) and torch.equal(dom0[:, :3 * gp], dom2[:, :3 * gp])
+    assert key not in K._DCN_SIDE_DIRTY
+    assert int(K._DCN_SIDE[key].view(torch.int32).ne(0).sum().item()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,G", [(8, 2), (24, 2), (24, 1), (64, 2)])      # Cg = 4 (channel-lane kernel), 12 (scalar), 24 (8-wide), 32 (channel-lane)
+def test_dcnv3_general_backward_route_reports_non_finite_gradients(cuda, dtype, C, G):
+    """round-5 verdict item 5(d) / advisor: the general route (group widths other than 8 / 16) accumulates the input gradient in int64 fixed point
+    too, and its conversion saturated an inf / NaN contribution to a finite value: the accumulating kernels now raise a flag word in the workspace and
+    the conversion pass writes NaN for the input gradient, as the window route does; a following call with finite operands is clean"""
+    from iseg_amd import kernels as K
+
+    N, H, W = 1, 20, 18
+    Cg, gp = C // G, G * 9
+    x, _ = q(rnd((N, H, W, C), 11), dtype)
+    off, _ = q(rnd((N, H, W, 2 * gp), 12), dtype)
+    m, _ = q(torch.softmax(rnd((N, H, W, G, 9), 13), -1).reshape(N, H, W, gp), dtype)
+    dy, _ = q(rnd((N, H, W, C), 14), dtype)
+    clean, _, _ = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert bool(torch.isfinite(clean).all())
+    for poison in (float("inf"), float("nan")):
+        bad = dy.clone()
+        bad[0, 7, 9, 3] = poison
+        dx, _, _ = K.dcnv3_bwd(x, off, m, bad, G, Cg, 3, 3, 1, 1, 1, 1.0)
+        assert bool(torch.isnan(dx).all()), poison
+    again, _, _ = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    assert torch.equal(clean, again)

@@ -352,3 +352,19 @@ def test_mobilenetv2_names_count_and_atrous_surgery():
     assert sr[1] == (2, 1) and sr[3] == (2, 1) and sr[6] == (1, 2) and sr[7] == (1, 2) and sr[13] == (1, 4) and sr[16] == (1, 4)
     assert _make_divisible(32 * 0.35, 8) == 16 and _make_divisible(24 * 1.4, 8) == 32
     assert correct_pad((None, 64, 63, 8), 3) == ((0, 1), (1, 1))
+
+
+def test_dcnv3_joint_form_is_refused_for_strided_layers():
+    """round-5 advisor: the joint offset | mask projection has one row per INPUT pixel of x1, the sampling kernel wants one per OUTPUT pixel: a
+    stride > 1 layer (or any geometry whose output map differs from x1's) must take the layer-by-layer route, not raise from the kernel wrapper"""
+    import types
+
+    import torch
+
+    from iseg_amd import functional as F
+
+    lay = types.SimpleNamespace(kernel=torch.zeros(64, 54), bias=torch.zeros(54))
+    x1 = torch.zeros(1, 16, 16, 64, dtype=torch.bfloat16)
+    assert F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 1, (16, 16)) == bool(F._DCN_JOINT)
+    assert not F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 2, (8, 8))
+    assert not F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 1, (14, 14))      # pad 0: the output map shrinks

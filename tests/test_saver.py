@@ -171,3 +171,46 @@ def test_resnet_takes_the_strict_by_name_route(tmp_path):
     broken[first] = dict(list(layers[first].items())[:-1]) if len(layers[first]) > 1 else {**layers[first], "extra:0": np.zeros(3, np.float32)}
     with pytest.raises(ValueError, match="Weight count mismatch"):
         get_backbone("resnet50", image_shape=(1, 64, 64, 3), return_endpoints=True, weights_path=write_npz(str(tmp_path / "broken.h5.npz"), broken))
+
+
+def test_eva_position_embedding_is_resampled_from_the_pretrain_grid_on_its_first_assignment(tmp_path):
+    """round-5 advisor: the reference's Eva.build wraps pos_embed.assign so the first value assigned -- the pretrained table on the grid
+    pretrain_img_size // patch -- is resampled bicubically to the build grid, prefix token passed through (backbones/eva/eva.py:131-165,
+    utils/common.py:206-262); e.g. the 24 x 24 table of a 336-pixel EVA02 checkpoint poured into a 448-pixel (32 x 32) build"""
+    from iseg_amd.backbones.eva.eva import Eva
+    from iseg_amd.utils.bicubic import bicubic_matrix
+
+    def make(size):
+        nn.set_seed(3)
+        m = Eva(pretrain_img_size=56, pretrain_patch_size=14, patch_size=14, embed_filters=16, depth=1, num_heads=2, name="eva_small")
+        with nn.dry_run_scope():
+            m(torch.empty(1, size, size, 3))
+        return m
+
+    src, dst = make(56), make(84)      # grids 4 x 4 (= the pretrain grid) and 6 x 6
+    assert tuple(src.position_embedding.shape) == (1, 17, 16) and tuple(dst.position_embedding.shape) == (1, 37, 16)
+    table = torch.randn(1, 17, 16)
+    with torch.no_grad():
+        src.position_embedding.copy_(table)
+
+    class Holder(nn.Layer):
+        def __init__(self, inner):
+            super().__init__(name="holder")
+            self.inner = inner
+            self.built = True
+
+    path = save_weights(Holder(src), str(tmp_path / "eva.npz"))
+    n = load_h5_weight_by_name(Holder(dst), path)
+    assert n > 0
+    want = np.einsum("oh,hwc->owc", bicubic_matrix(6, 4), table[0, 1:].reshape(4, 4, 16).numpy())
+    want = np.einsum("pw,owc->opc", bicubic_matrix(6, 4), want).reshape(36, 16)
+    got = dst.position_embedding.detach().numpy()
+    assert np.array_equal(got[0, 0], table[0, 0].numpy())                  # the class-token slot passes through
+    assert np.abs(got[0, 1:] - want).max() < 1e-6
+    # a second assignment (a checkpoint of THIS model, already on the build grid) is taken as it comes
+    again = torch.randn(1, 37, 16).numpy()
+    assert np.array_equal(dst._resample_on_first_assign(again), again)
+    # a table on neither grid is an error, not a silent reshape
+    fresh = make(84)
+    with pytest.raises(ValueError):
+        fresh._resample_on_first_assign(np.zeros((1, 1 + 25, 16), np.float32))
