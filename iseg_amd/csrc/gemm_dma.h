@@ -485,6 +485,8 @@ void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k
             // measured (tools/kbench_pitch.py, M = 16384, one box): K = 384 with the gelu + gelu' epilogue 44.8 -> 41.2 us, with the x aux epilogue
             // 39.7 -> 35.7; K = 1536 plain 31.8 -> 34.0, + bias + residual 35.6 -> 34.9 -- the short-K products are epilogue-bound and gain from the
             // second resident workgroup, the long-K ones pay for twice the barriers: taken for K <= 512 (ISEG_GEMM_DMA_BK32 = 0 never, 2 always)
+            // (128 x 128 tiles with 48 KB rings, THREE workgroups per CU, measured 45.4 / 38.6 us on the two K = 384 launches: the extra fill
+            // traffic of the smaller tile costs more than the third resident workgroup returns)
             if (dma_bk32() && (dma_bk32() == 2 || g->K <= 512) && g->K % 32 == 0 && g->K >= 96 && (kps == g->K || kps % 64 == 0) && sizeof(TO) == 2)
                 launch_dma_kinds<4, 2, 3, TO, 4, 32>(g, epi, nsplit, kps, slabs, s);
             else launch_dma_kinds<4, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s);
