@@ -354,6 +354,13 @@ int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, cons
  * launch and the Z tensor disappear.  N % 4 == 0. */
 int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2, float* dgamma,
                                 float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes, iseg_stream_t stream);
+/* The same plus, in the SAME launch, the slab sum of the pair launch's other product (iseg_gemm_tn_pair: dW1 = y2^T dH with its ones-row db1,
+ * backbones/convnext.py:51-57 backward): out0[j] (+)= sum_p partials2[p * n2 + j] for j < n0, out1[j - n0] likewise beyond (out1 may be null) --
+ * what iseg_gemm_reduce would have launched (same slab order, same arithmetic).  partials2 must not alias ws; n2, n0 % 4 == 0, 16-byte aligned. */
+int iseg_layerscale_grads_slabs_reduce(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                       float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                       const float* partials2, int P2, int64_t n2, float* out0, float* out1, int64_t n0, int accumulate2,
+                                       iseg_stream_t stream);
 /* ---------------------------------------------------------------------------------------------------------
  * tf.image.resize (half-pixel, no antialias): utils/common.py:107-134 resize_image
  * --------------------------------------------------------------------------------------------------------- */

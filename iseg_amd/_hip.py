@@ -128,6 +128,7 @@ SIGNATURES = {
     "iseg_layerscale_grads_workspace_bytes": (_z, [_i, _i]),
     "iseg_layerscale_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "iseg_layerscale_grads_slabs": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "iseg_layerscale_grads_slabs_reduce": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _i, _l, _p, _p, _l, _i, _p]),
     "iseg_replace_nan_or_inf": (_i, [_p, _p, _l, _f, _i, _p, _z, _p]),
     "iseg_replace_nan_or_inf_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_groupnorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),

@@ -451,17 +451,17 @@ __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __r
 // slabs [nslabs][K + 1][N] fp32, row K = the virtual ones-row = column sums of dout): Z and S are summed in slab order while they are loaded,
 // so neither the slab-sum launch nor the Z tensor exists.  A lane owns four consecutive columns (16-byte loads), blocks are 16 columns-quads x
 // 16 row lanes over a strip of rows; partial column dots per block row as in the kernel above.
-__global__ __launch_bounds__(256) void layerscale_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
-                                                               const float* __restrict__ W2, const float* __restrict__ gamma,
-                                                               const float* __restrict__ b2, float* __restrict__ dW2, float* __restrict__ db2,
-                                                               float* __restrict__ partials, int Kdim, int Ndim, int accumulate) {
+__device__ __forceinline__ void layerscale_slabs_body(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
+                                                      const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                      const float* __restrict__ b2, float* __restrict__ dW2, float* __restrict__ db2,
+                                                      float* __restrict__ partials, int Kdim, int Ndim, int accumulate, int bx, int by, int gy) {
     __shared__ float4 red[16][16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int n = (blockIdx.x * 16 + tx) * 4;
+    const int n = (bx * 16 + tx) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n < Ndim) {
         const float4 g = *reinterpret_cast<const float4*>(gamma + n);
-        for (int k = blockIdx.y * 16 + ty; k < Kdim; k += gridDim.y * 16) {
+        for (int k = by * 16 + ty; k < Kdim; k += gy * 16) {
             const int64_t o = (int64_t)k * Ndim + n;
             float4 z = *reinterpret_cast<const float4*>(slabs + o);
             for (int q = 1; q < nslabs; ++q) {      // slab order: the sum the reduction kernel would have formed
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void layerscale_slabs_kernel(const float* __re
         float4 part = red[0][tx];
 #pragma unroll
         for (int i = 1; i < 16; ++i) part.x += red[i][tx].x, part.y += red[i][tx].y, part.z += red[i][tx].z, part.w += red[i][tx].w;
-        if (blockIdx.y == 0) {      // the S terms ride the first partial row (S = the ones-row of the slabs, summed in slab order)
+        if (by == 0) {      // the S terms ride the first partial row (S = the ones-row of the slabs, summed in slab order)
             const int64_t o = (int64_t)Kdim * Ndim + n;
             float4 S = *reinterpret_cast<const float4*>(slabs + o);
             for (int q = 1; q < nslabs; ++q) {
@@ -500,8 +500,67 @@ __global__ __launch_bounds__(256) void layerscale_slabs_kernel(const float* __re
             }
             *reinterpret_cast<float4*>(db2 + n) = dbv;
         }
-        *reinterpret_cast<float4*>(partials + (int64_t)blockIdx.y * Ndim + n) = part;
+        *reinterpret_cast<float4*>(partials + (int64_t)by * Ndim + n) = part;
     }
+}
+
+__global__ __launch_bounds__(256) void layerscale_slabs_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
+                                                               const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                               const float* __restrict__ b2, float* __restrict__ dW2, float* __restrict__ db2,
+                                                               float* __restrict__ partials, int Kdim, int Ndim, int accumulate) {
+    layerscale_slabs_body(slabs, nslabs, slab_stride, W2, gamma, b2, dW2, db2, partials, Kdim, Ndim, accumulate, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Round 6: the layer-scale bookkeeping AND the slab sum of the block's other weight gradient (dW1 / db1 from the same pair launch,
+// gemm_bf16_dma_tn_pair_kernel) as ONE launch: workgroups [0, gx * gy) are layerscale_slabs_kernel's (bx = id % gx, by = id / gx), the rest run
+// reduce_rows_wide_kernel's arithmetic (same slab order, same per-element operations: bit-identical to the two launches it replaces).
+struct SlabReduceJob {
+    const float* partials;      // [P][pstride]
+    int P;
+    int64_t pstride, n, n0;
+    float* out0;
+    float* out1;
+    float scale;
+    int accumulate;
+};
+
+__global__ __launch_bounds__(256) void layerscale_slabs_reduce_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
+                                                                      const float* __restrict__ W2, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ b2, float* __restrict__ dW2,
+                                                                      float* __restrict__ db2, float* __restrict__ partials, int Kdim, int Ndim,
+                                                                      int accumulate, int gx, int gy, SlabReduceJob job) {
+    const int id = blockIdx.x;
+    if (id < gx * gy) {      // (workgroup-uniform)
+        layerscale_slabs_body(slabs, nslabs, slab_stride, W2, gamma, b2, dW2, db2, partials, Kdim, Ndim, accumulate, id % gx, id / gx, gy);
+        return;
+    }
+    const int64_t j = ((int64_t)(id - gx * gy) * 256 + threadIdx.x) * 4;
+    if (j >= job.n) return;
+    const float* __restrict__ pp = job.partials;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = 0;
+    for (; p + 3 < job.P; p += 4) {      // (reduce_rows_wide_kernel's order, common.h)
+        const float4 a = *reinterpret_cast<const float4*>(pp + (int64_t)p * job.pstride + j);
+        const float4 b = *reinterpret_cast<const float4*>(pp + (int64_t)(p + 1) * job.pstride + j);
+        const float4 c = *reinterpret_cast<const float4*>(pp + (int64_t)(p + 2) * job.pstride + j);
+        const float4 d = *reinterpret_cast<const float4*>(pp + (int64_t)(p + 3) * job.pstride + j);
+        s.x += (a.x + b.x) + (c.x + d.x);
+        s.y += (a.y + b.y) + (c.y + d.y);
+        s.z += (a.z + b.z) + (c.z + d.z);
+        s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; p < job.P; ++p) {
+        const float4 a = *reinterpret_cast<const float4*>(pp + (int64_t)p * job.pstride + j);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    s.x *= job.scale; s.y *= job.scale; s.z *= job.scale; s.w *= job.scale;
+    float* dst = j < job.n0 ? job.out0 + j : (job.out1 ? job.out1 + (j - job.n0) : nullptr);
+    if (!dst) return;
+    if (job.accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(dst);
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dst) = s;
 }
 
 static int layerscale_ksplits(int K) {
@@ -849,9 +908,33 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
     return iseg_check_launch("iseg_layerscale_grads");
 }
 
+static int layerscale_grads_slabs_impl(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                       float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                       const SlabReduceJob* job, hipStream_t stream);
+
 extern "C" int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
                                            float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
                                            hipStream_t stream) {
+    return layerscale_grads_slabs_impl(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, K, N, accumulate, ws, ws_bytes, nullptr, stream);
+}
+
+// iseg_layerscale_grads_slabs plus, in the same launch, out0[j] / out1[j - n0] (+)= sum_p partials2[p][j] for j < n2 (the slab sum
+// iseg_gemm_reduce would run for the pair launch's second product: n2 = (M + 1) N with the ones-row, n0 = M N, pstride = n2); partials2 must
+// not alias `ws`.  n2, n0 multiples of 4, 16-byte aligned pointers.
+extern "C" int iseg_layerscale_grads_slabs_reduce(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                                  float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                                  const float* partials2, int P2, int64_t n2, float* out0, float* out1, int64_t n0,
+                                                  int accumulate2, hipStream_t stream) {
+    ISEG_REQUIRE(partials2 && P2 >= 1 && n2 > 0 && out0 && n0 > 0 && n0 <= n2, "iseg_layerscale_grads_slabs_reduce: bad second job");
+    ISEG_REQUIRE(n2 % 4 == 0 && n0 % 4 == 0 && (((uintptr_t)partials2 | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0,
+                 "iseg_layerscale_grads_slabs_reduce: the second job needs n %% 4 == 0 and 16-byte aligned pointers");
+    SlabReduceJob job{partials2, P2, n2, n2, n0, out0, out1, 1.f, accumulate2};
+    return layerscale_grads_slabs_impl(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, K, N, accumulate, ws, ws_bytes, &job, stream);
+}
+
+static int layerscale_grads_slabs_impl(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                       float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                       const SlabReduceJob* job, hipStream_t stream) {
     ISEG_REQUIRE(slabs && nslabs >= 1 && W2 && b2 && gamma && dW2 && dgamma && db2, "iseg_layerscale_grads_slabs: null pointer");
     ISEG_REQUIRE(N % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)W2 | (uintptr_t)b2 | (uintptr_t)gamma | (uintptr_t)dW2 | (uintptr_t)db2) & 15) == 0,
                  "iseg_layerscale_grads_slabs: N %% 4 == 0 and 16-byte aligned operands");
@@ -868,8 +951,15 @@ extern "C" int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const
     }
     float* const arena = iseg_deferred_partials(need, dgamma, nullptr, accumulate, stream);
     if (arena) ws = arena;
-    hipLaunchKernelGGL(layerscale_slabs_kernel, dim3((N / 4 + 15) / 16, P), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2, gamma, b2,
-                       dW2, db2, (float*)ws, K, N, accumulate);
+    if (job) {
+        const int gx = (N / 4 + 15) / 16;
+        const int64_t b2n = (job->n / 4 + 255) / 256;
+        hipLaunchKernelGGL(layerscale_slabs_reduce_kernel, dim3((unsigned)(gx * P + b2n)), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2,
+                           gamma, b2, dW2, db2, (float*)ws, K, N, accumulate, gx, P, *job);
+    } else {
+        hipLaunchKernelGGL(layerscale_slabs_kernel, dim3((N / 4 + 15) / 16, P), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2, gamma, b2,
+                           dW2, db2, (float*)ws, K, N, accumulate);
+    }
     if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
     else launch_reduce_rows((const float*)ws, P, N, 0, 1, N, dgamma, nullptr, N, 0, 1.f, accumulate, stream);
     return iseg_check_launch("iseg_layerscale_grads_slabs");

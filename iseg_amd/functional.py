@@ -1191,6 +1191,7 @@ _MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: La
 _WGRAD_PAIR = os.environ.get("ISEG_WGRAD_PAIR", "1") == "1"      # 0: the two weight-gradient products of an un-fused block as two launches (A/B measurements)
 _LAYERSCALE_FROM_SLABS = os.environ.get("ISEG_LAYERSCALE_FROM_SLABS", "1") == "1"      # 0: slab sum + Z tensor + layer-scale kernel (A/B measurements)
 _MLP_LN_BWD_FUSED = os.environ.get("ISEG_MLP_LN_BWD_FUSED", "1") == "1"      # 0: LayerNorm backward of the fused stages as its own kernel (A/B measurements)
+_SLAB_REDUCE_MERGED = os.environ.get("ISEG_SLAB_REDUCE_MERGED", "1") == "1"      # 0: slab sum of dW1 as its own launch (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
 
@@ -1323,9 +1324,11 @@ class _ConvNeXtBlockFn(Function):
                 if s_on_gemm and _LAYERSCALE_FROM_SLABS and _WGRAD_PAIR and p.b1 is not None:
                     # round 5: both weight-gradient products of the block as ONE launch (36 tiles x 7 splits instead of 2 x 18 x 13): Z stops at its
                     # slabs for the layer-scale kernel, dW1 / db1 are summed by the generic slab reduce
-                    sl = K.dense_wgrad_pair(g, dbr, y2, dh, _grad(p.w1), _grad(p.b1))
+                    # (round 6: the slab sum of dW1 / db1 rides the layer-scale launch -- _SLAB_REDUCE_MERGED=0 keeps the two launches)
+                    sl = K.dense_wgrad_pair(g, dbr, y2, dh, _grad(p.w1), _grad(p.b1), defer_second=_SLAB_REDUCE_MERGED)
                     if sl is not None:
-                        K.layerscale_grads_slabs(sl[0], sl[1], p.w2.data, p.b2.data, p.gamma.data, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+                        K.layerscale_grads_slabs(sl[0], sl[1], p.w2.data, p.b2.data, p.gamma.data, _grad(p.w2), _grad(p.gamma), _grad(p.b2),
+                                                 extra=sl[2] if len(sl) > 2 else None)
                         return
                 sl = K.dense_wgrad_slabs(g, dbr) if (s_on_gemm and _LAYERSCALE_FROM_SLABS) else None
                 if sl is not None:      # the layer-scale kernel sums the split-K slabs of Z (and its ones-row S) while it reads them

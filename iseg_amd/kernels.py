@@ -257,7 +257,7 @@ def dense_wgrad_slabs(x2d, dy2d):
     return slabs, int(eff)
 
 
-def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True):
+def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True, defer_second=False):
     """The two weight-gradient products of an un-fused ConvNeXt block as ONE launch (csrc/gemm_dma_tn.h, round 5): Z = g^T dbr [4C, C] with its
     ones-row, stopped at its slabs for layerscale_grads_slabs, and dW1 (+)= x^T dh [C, 4C] (+ db1 from its ones-row), summed by iseg_gemm_reduce.
     Returns (slabs of Z, slab count) or None when the problems do not pair (the caller then runs them one by one)."""
@@ -291,7 +291,16 @@ def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True):
     need0, need1 = L.iseg_gemm_workspace_bytes(C.byref(g0)), L.iseg_gemm_workspace_bytes(C.byref(g1))
     eff = int(L.iseg_gemm_slabs(C.byref(g0)))
     slabs0 = torch.empty(need0 // 4, dtype=torch.float32, device=g2d.device)      # (its own buffer: the consumer's partials use the workspace)
-    ws1, wsb1 = workspace(need1, g2d.device)
+    # defer_second (round 6): the second product's slabs get their own buffer and are NOT summed here -- layerscale_grads_slabs(extra=...) sums them
+    # in the launch that consumes the first product's slabs (one launch instead of two); only for the plain dense case the wide reducer covers
+    n2 = (x2d.shape[1] + 1) * dh2d.shape[1]
+    n0 = x2d.shape[1] * dh2d.shape[1]
+    defer_second = bool(defer_second and dW1.stride(0) == dh2d.shape[1] and n2 % 4 == 0 and n0 % 4 == 0 and dW1.is_contiguous() and db1 is not None)
+    if defer_second:
+        ws1 = torch.empty(need1 // 4, dtype=torch.float32, device=g2d.device)
+        wsb1 = need1
+    else:
+        ws1, wsb1 = workspace(need1, g2d.device)
     timer = KERNEL_TIMER[0]
     if timer is not None:
         # (variant 9 = the pair launch: bench.py models it as two products [4C, C] and [C, 4C] over `rows`)
@@ -299,6 +308,9 @@ def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True):
     _hip.check(L.iseg_gemm_tn_pair(C.byref(g0), ptr(slabs0), need0, C.byref(g1), ptr(ws1), wsb1, stream()), "iseg_gemm_tn_pair")
     if timer is not None:
         timer.end()
+    if defer_second:
+        eff1 = int(L.iseg_gemm_slabs(C.byref(g1)))
+        return slabs0, eff, (ws1, eff1, n2, dW1, db1, n0, bool(accumulate))
     _hip.check(L.iseg_gemm_reduce(C.byref(g1), ptr(ws1), wsb1, stream()), "iseg_gemm_reduce")
     return slabs0, eff
 
@@ -874,11 +886,17 @@ def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
               int(accumulate), ptr(ws), wsb, stream())
 
 
-def layerscale_grads_slabs(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, accumulate=True):
-    """layerscale_grads from the unreduced split-K slabs of Z = g^T dout (dense_wgrad_slabs): Z and S = colsum(dout) are summed on load"""
+def layerscale_grads_slabs(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, accumulate=True, extra=None):
+    """layerscale_grads from the unreduced split-K slabs of Z = g^T dout (dense_wgrad_slabs): Z and S = colsum(dout) are summed on load.
+    extra = dense_wgrad_pair(..., defer_second=True)[2]: the other product's slabs are summed into their gradients by the same launch"""
     Kd, Nd = W2.shape
     need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
     ws, wsb = workspace(need, slabs.device)
+    if extra is not None:
+        part2, p2, n2, out0, out1, n0, acc2 = extra
+        _hip.call("iseg_layerscale_grads_slabs_reduce", ptr(slabs), int(nslabs), ptr(W2), ptr(b2), ptr(gamma), ptr(dW2), ptr(dgamma), ptr(db2), Kd,
+                  Nd, int(accumulate), ptr(ws), wsb, ptr(part2), int(p2), int(n2), ptr(out0), ptr(out1), int(n0), int(acc2), stream())
+        return
     _hip.call("iseg_layerscale_grads_slabs", ptr(slabs), int(nslabs), ptr(W2), ptr(b2), ptr(gamma), ptr(dW2), ptr(dgamma), ptr(db2), Kd, Nd,
               int(accumulate), ptr(ws), wsb, stream())
 

@@ -815,3 +815,33 @@ def test_weight_gradient_pair_launch(cuda, rows, Cc):
     assert (dW1.cpu().double() - W_ref).abs().max().item() < 1e-4 * W_ref.abs().max().item()
     b_ref = db1_0.double() + dh.double().sum(0)
     assert (db1.cpu().double() - b_ref).abs().max().item() < 1e-4 * b_ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("rows,Cc", [(4096, 384), (16384, 384)])
+def test_weight_gradient_pair_with_the_slab_sum_in_the_layer_scale_launch(cuda, rows, Cc):
+    """round 6: dense_wgrad_pair(defer_second=True) leaves dW1 / db1 in their split-K slabs and layerscale_grads_slabs(extra=...) sums them in the
+    launch that consumes Z's slabs -- one launch instead of two, and BIT-identical to the two it replaces (same slab order, same operations) for
+    every gradient of the block's MLP: dW1, db1, dW2, dgamma, db2 (backbones/convnext.py:51-63 backward)"""
+    k = K()
+    bf = torch.bfloat16
+    g = rnd((rows, 4 * Cc), 1).to(bf).cuda()
+    dbr = rnd((rows, Cc), 2).to(bf).cuda()
+    y2 = rnd((rows, Cc), 3).to(bf).cuda()
+    dh = rnd((rows, 4 * Cc), 4).to(bf).cuda()
+    W2, b2, gamma = rnd((4 * Cc, Cc), 7).float().cuda(), rnd((Cc,), 8).float().cuda(), rnd((Cc,), 9).float().cuda()
+    init = [rnd((Cc, 4 * Cc), 5).float(), rnd((4 * Cc,), 6).float(), rnd((4 * Cc, Cc), 10).float(), rnd((Cc,), 11).float(), rnd((Cc,), 12).float()]
+
+    def run(merged):
+        dW1, db1, dW2, dgam, db2 = [t.clone().cuda() for t in init]
+        sl = k.dense_wgrad_pair(g, dbr, y2, dh, dW1, db1, defer_second=merged)
+        assert sl is not None and (len(sl) == 3) == merged
+        k.layerscale_grads_slabs(sl[0], sl[1], W2, b2, gamma, dW2, dgam, db2, extra=sl[2] if merged else None)
+        k.deferred_flush()
+        torch.cuda.synchronize()
+        return [dW1, db1, dW2, dgam, db2]
+
+    two, one = run(False), run(True)
+    for a, b, name in zip(two, one, ("dW1", "db1", "dW2", "dgamma", "db2")):
+        assert torch.equal(a, b), name
+    W_ref = init[0].double() + y2.cpu().double().T @ dh.cpu().double()
+    assert (one[0].cpu().double() - W_ref).abs().max().item() < 1e-4 * W_ref.abs().max().item()
