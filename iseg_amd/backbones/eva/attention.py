@@ -22,7 +22,10 @@ class EvaAttention(Layer):
         c = int(input_shape[-1])
         head_filters = c // self.num_heads if self.attention_head_filters is None else int(self.attention_head_filters)
         if head_filters * self.num_heads != c:
-            raise NotImplementedError("EvaAttention: attention_head_filters * num_heads != channels is not built")
+            # (:57-58 sizes the projections with attention_head_filters * num_heads, but :163 reshapes the attention output to
+            # [batch, tokens, CHANNELS]: the reference itself fails for any other product -- an argument error, not a missing feature)
+            raise ValueError(f"EvaAttention: attention_head_filters * num_heads = {head_filters * self.num_heads} must equal the input channels {c} "
+                             "(the reference reshapes the attention output to the input width, backbones/eva/attention.py:163)")
         self.head_filters = head_filters
         self.attention_scale = head_filters ** -0.5
         if self.qkv_fused:

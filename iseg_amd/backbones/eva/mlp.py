@@ -81,25 +81,33 @@ class GluMlp(Layer):
     def __init__(self, hidden_filters=None, output_filters=None, activation="sigmoid", use_bias=True, use_norm=True, dropout_rate=0.0, use_conv=False,
                  gate_last=True, trainable=True, name=None):
         super().__init__(name=name, trainable=trainable)
-        if use_conv:
-            raise NotImplementedError("GluMlp(use_conv=True) is not built (no EVA variant of the reference uses it)")
         self.hidden_filters, self.output_filters, self.activation = hidden_filters, output_filters, activation
         self.use_bias, self.use_norm, self.dropout_rate, self.gate_last = use_bias, use_norm, dropout_rate, gate_last
+        self.use_conv = bool(use_conv)      # (:41-56) fc1 / fc2 as 1 x 1 Conv2D on [N, H, W, C] maps instead of Dense: kernels [1, 1, Cin, Cout]
         get_activation(activation)
+
+    def _fc(self, filters, name):
+        if self.use_conv:
+            from ...layers.base_layers import Conv2D
+
+            return Conv2D(filters, (1, 1), use_bias=self.use_bias, name=name)
+        return Dense(filters, use_bias=self.use_bias, name=name)
 
     def build(self, input_shape):
         c = int(input_shape[-1])
         hidden = self.hidden_filters or c
         assert hidden % 2 == 0
         _check_hidden("GluMlp", hidden // 2)
-        self.fc1 = Dense(hidden, use_bias=self.use_bias, name=f"{self.name}/fc1")
+        self.fc1 = self._fc(hidden, f"{self.name}/fc1")
         self.drop1 = Dropout(self.dropout_rate, name=f"{self.name}/drop1")
         self.norm = LayerNormalization(epsilon=LAYER_NORM_EPSILON, name=f"{self.name}/norm") if self.use_norm else None
-        self.fc2 = Dense(self.output_filters or c, use_bias=self.use_bias, name=f"{self.name}/fc2")
+        self.fc2 = self._fc(self.output_filters or c, f"{self.name}/fc2")
         self.drop2 = Dropout(self.dropout_rate, name="drop2")
         self.built = True
 
     def call(self, inputs, training=None):
+        if self.use_conv and inputs.dim() != 4:
+            raise ValueError(f"GluMlp(use_conv=True) takes [N, H, W, C] maps (1 x 1 Conv2D projections), got {tuple(inputs.shape)}")
         x = F.glu_packed(self.fc1(inputs), self.activation, gate_last=self.gate_last)
         x = self.drop1(x, training=training)
         if self.norm is not None:

@@ -2,6 +2,8 @@
 MBConvBlock (:98-245), MOATBlock (:248-508)."""
 import math
 
+import torch
+
 from ... import functional as F
 from ... import nn as _nn
 from ...layers.base_layers import Conv2D, DepthwiseConv2D, LayerNormalization
@@ -97,9 +99,12 @@ class MOATBlock(_MBConvPart):
                  head_size=32, window_size=None, relative_position_embedding_type="2d_multi_head", position_embedding_size=7, ln_epsilon=1e-5,
                  survival_prob=None, use_checkpointing_for_attention=False, name="moat", trainable=True, **kwargs):
         super().__init__(name=name, trainable=trainable)
-        if window_size:
-            raise NotImplementedError("MOATBlock(window_size=...): windowed attention is not built (every moat0-4 constructor leaves it at None, "
-                                      "backbones/moat/moat.py:245-299)")
+        # window_size = [height, width] (:317-327): the attention runs inside non-overlapping windows (_make_windows / _remove_windows, :407-434);
+        # None: one window = the whole (strided) map, as every moat0-4 constructor leaves it (backbones/moat/moat.py:245-299)
+        if window_size and not (isinstance(window_size, (list, tuple)) and len(window_size) == 2):
+            raise ValueError("The window size should be a list of two ints [height, width], if specified.")
+        self.window_size = [int(v) for v in window_size] if window_size else None
+        self._window_tables = {}
         self.hidden_size, self.kernel_size, self.expansion_rate = hidden_size, kernel_size, expansion_rate
         self.block_stride, self.pool_size, self._norm_class = block_stride, pool_size, norm_class
         self.head_size, self.ln_epsilon, self.survival_prob = head_size, ln_epsilon, survival_prob
@@ -109,8 +114,11 @@ class MOATBlock(_MBConvPart):
 
     def build(self, input_shape):
         height, width, input_size = (int(v) for v in input_shape[-3:])
-        self._window_height = math.ceil(float(height) / self.block_stride)
-        self._window_width = math.ceil(float(width) / self.block_stride)
+        if self.window_size:
+            self._window_height, self._window_width = self.window_size
+        else:
+            self._window_height = math.ceil(float(height) / self.block_stride)
+            self._window_width = math.ceil(float(width) / self.block_stride)
         self._build_mbconv(input_size, False)
         self._attention_norm = LayerNormalization(epsilon=self.ln_epsilon, name=f"{self.name}/attention_norm")
         if self.relative_position_embedding_type and self.position_embedding_size is None:
@@ -130,6 +138,28 @@ class MOATBlock(_MBConvPart):
         x = residual_add_with_drop_path(x, shortcut, self.survival_prob, training, masks[0])
         x, attention_shortcut = F.fork(x, 2)
         b, h, w, c = x.shape
-        y = self._attention(self._attention_norm(x), training=training)
-        y = y.reshape(b, h, w, c)
+        y = self._attention_norm(x)
+        if self.window_size:
+            part, rev = self._partition_tables(b, h, w, y.device)
+            wh, ww = self._window_height, self._window_width
+            y = F.permute_rows(y.reshape(b * h * w, c), part, rev, (b * (h // wh) * (w // ww), wh, ww, c))      # _make_windows
+            y = self._attention(y, training=training)
+            y = F.permute_rows(y.reshape(b * h * w, c), rev, part, (b, h, w, c))                                  # _remove_windows
+        else:
+            y = self._attention(y, training=training)
+            y = y.reshape(b, h, w, c)
         return residual_add_with_drop_path(y, attention_shortcut, self.survival_prob, training, masks[1])
+
+    def _partition_tables(self, b, h, w, device):
+        """row tables of the window partition (:407-424): windowed row r = ((n, wy, wx), (iy, ix)) takes map row (n, wy wh + iy, wx ww + ix); the
+        reverse table is its inverse (a permutation: every map pixel sits in exactly one window)"""
+        key = (b, h, w, str(device))
+        if key not in self._window_tables:
+            wh, ww = self._window_height, self._window_width
+            if h % wh or w % ww:
+                raise ValueError(f"MOATBlock(window_size={self.window_size}): the {h} x {w} map is not a whole number of windows")
+            idx = torch.arange(b * h * w, dtype=torch.int64).reshape(b, h // wh, wh, w // ww, ww).permute(0, 1, 3, 2, 4).reshape(-1)
+            inv = torch.empty_like(idx)
+            inv[idx] = torch.arange(idx.numel(), dtype=torch.int64)
+            self._window_tables[key] = (idx.to(torch.int32).to(device), inv.to(torch.int32).to(device))
+        return self._window_tables[key]

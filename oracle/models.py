@@ -351,11 +351,22 @@ def _moat_attention(w, p, x, head_size):
     return (torch.einsum("bsnk,nkc->bsc", o, w[f"{p}/o/weight"]) + w[f"{p}/o/bias"]).reshape(B, H, W, -1)
 
 
+def _moat_windowed_attention(w, p, x, head_size, window):
+    """backbones/moat/moat_blocks.py:407-434,486-497: _make_windows -> attention inside each window -> _remove_windows"""
+    B, H, W, C = x.shape
+    wh, ww = window
+    t = x.reshape(B, H // wh, wh, W // ww, ww, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, wh, ww, C)
+    a = _moat_attention(w, p, t, head_size)
+    a = a.reshape(B, H // wh, W // ww, wh, ww, -1).permute(0, 1, 3, 2, 4, 5)
+    return a.reshape(B, H, W, -1)
+
+
 def moat_forward(w, x, name, block_types, num_blocks, stage_stride=(2, 2, 2, 2), head_size=32, stem=2, training=False, dp_factors=None,
-                 new_stats=None, ln_eps=1e-5):
+                 new_stats=None, ln_eps=1e-5, window_size=None):
     """MOAT.call with return_endpoints=True: [stem, stage 0 .. 3]; dp_factors[block name] = per-sample factors (one vector for an MBConv block, a
-    pair for a MOAT block) or absent"""
+    pair for a MOAT block) or absent; window_size[stage] = [height, width] or None (MOAT stages only, moat.py:177-209)"""
     dp_factors = dp_factors or {}
+    window_size = window_size or [None] * len(block_types)
     for i in range(stem):
         x = O.conv2d(x, w[f"{name}/stem/conv_{i}/kernel"], w[f"{name}/stem/conv_{i}/bias"], 2 if i == 0 else 1, 1, "same")
         if i < stem - 1:
@@ -371,7 +382,11 @@ def moat_forward(w, x, name, block_types, num_blocks, stage_stride=(2, 2, 2, 2),
                 x = shortcut + (y if f is None else y * f.reshape(-1, 1, 1, 1))
             else:
                 x = shortcut + (y if f is None else y * f[0].reshape(-1, 1, 1, 1))
-                a = _moat_attention(w, f"{p}/attention", O.layer_norm(x, w[f"{p}/attention_norm/gamma"], w[f"{p}/attention_norm/beta"], ln_eps), head_size)
+                normed = O.layer_norm(x, w[f"{p}/attention_norm/gamma"], w[f"{p}/attention_norm/beta"], ln_eps)
+                if window_size[s]:
+                    a = _moat_windowed_attention(w, f"{p}/attention", normed, head_size, window_size[s])
+                else:
+                    a = _moat_attention(w, f"{p}/attention", normed, head_size)
                 x = x + (a if f is None else a * f[1].reshape(-1, 1, 1, 1))
         ends.append(x)
     return ends

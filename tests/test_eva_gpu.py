@@ -219,3 +219,50 @@ def test_eva02_large_forward_backward_is_finite_in_bf16(cuda):
         assert touched > 0.9 * sum(1 for p in large.parameters() if p.requires_grad)
     finally:
         nn.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("gate_last,use_norm", [(True, True), (False, False)])
+def test_glumlp_with_1x1_conv_projections_equals_the_dense_form(cuda, dtype, gate_last, use_norm):
+    """GluMlp(use_conv=True) (backbones/eva/glumlp.py:41-56): fc1 / fc2 as 1 x 1 Conv2D on [N, H, W, C] maps -- the same arithmetic as the Dense form
+    on the flattened tokens with kernels reshaped [1, 1, Cin, Cout] <-> [Cin, Cout]: outputs and every gradient agree"""
+    from iseg_amd import nn
+    from iseg_amd.backbones.eva.mlp import GluMlp
+
+    nn.set_compute_dtype(dtype)
+    nn.set_device("cuda:0")
+    try:
+        N, H, W, C, hid = 2, 6, 5, 32, 64
+        nn.set_seed(5)
+        conv = GluMlp(hidden_filters=hid, activation="swish", use_conv=True, gate_last=gate_last, use_norm=use_norm, name="glu_conv")
+        dense = GluMlp(hidden_filters=hid, activation="swish", use_conv=False, gate_last=gate_last, use_norm=use_norm, name="glu_dense")
+        x = rnd((N, H, W, C), 3).to(dtype).cuda()
+        xc, xd = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        from iseg_amd.saver.h5_saver import _assign
+
+        _setup(conv, torch.empty((N, H, W, C), dtype=dtype, device="cuda"))
+        _setup(dense, torch.empty((N, H * W, C), dtype=dtype, device="cuda"))
+        assert tuple(conv.fc1.kernel.shape) == (1, 1, C, hid) and tuple(conv.fc2.kernel.shape) == (1, 1, hid // 2, C)
+        pairs = []
+        for a, b in ((conv.fc1, dense.fc1), (conv.fc2, dense.fc2)):
+            pairs += [(b.kernel, a.kernel.detach().cpu().numpy().reshape(tuple(b.kernel.shape))), (b.bias, a.bias.detach().cpu().numpy())]
+        if use_norm:
+            pairs += [(dense.norm.gamma, conv.norm.gamma.detach().cpu().numpy()), (dense.norm.beta, conv.norm.beta.detach().cpu().numpy())]
+        _assign(pairs)
+        yc = conv(xc, training=True)
+        yd = dense(xd.reshape(N, H * W, C), training=True)
+        assert tuple(yc.shape) == (N, H, W, C)
+        tol = 1e-5 if dtype == torch.float32 else 2.0 ** -6
+        scale = yd.float().abs().max().item()
+        assert (yc.float().reshape(N, H * W, C) - yd.float()).abs().max().item() <= tol * scale
+        g = rnd((N, H, W, C), 4).to(dtype).cuda()
+        yc.backward(g)
+        yd.backward(g.reshape(N, H * W, C))
+        assert (xc.grad.float() - xd.grad.float()).abs().max().item() <= tol * xd.grad.float().abs().max().item()
+        for a, b in ((conv.fc1, dense.fc1), (conv.fc2, dense.fc2)):
+            ga, gb = a.kernel.grad.float().reshape(-1), b.kernel.grad.float().reshape(-1)
+            assert (ga - gb).abs().max().item() <= 4 * tol * gb.abs().max().item()
+        with pytest.raises(ValueError):
+            conv(x.reshape(N, H * W, C))
+    finally:
+        nn.set_compute_dtype(torch.float32)
