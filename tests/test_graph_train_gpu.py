@@ -123,6 +123,36 @@ def test_graphed_train_steps_follow_eager(cuda, optimizer):
     assert abs(float(opt._hp_fixed[0]) - want_lr) <= 1e-7 * want_lr
 
 
+def test_batches_written_into_the_captured_input_buffers_replay_the_same_steps(cuda):
+    """round 6: GraphedTrainStep.input_buffers() hands out the captured step's own input tensors; a producer that writes the next batch there and
+    passes THEM saves the per-step device-to-device copy (36 us of the flagship step) -- the steps are bit for bit the copying ones"""
+    from iseg_amd import functional as F
+    from iseg_amd.graphs import GraphedTrainStep
+
+    OPTIMIZER[0] = "adamw"
+    batches = _batches()
+    lc, wc, _, cmc, _, w0c = _run(True, 8, batches)
+    F._RNG_COUNTER[0] = 0
+    F._DROP_PATH_POOL.__init__()
+    tm = _trainer()
+    assert torch.equal(w0c, tm.store.flat_w)
+    step = GraphedTrainStep(tm, warmup=2)
+    losses = []
+    for i in range(8):
+        x, y = batches[i % len(batches)]
+        bufs = step.input_buffers(x, y)
+        if bufs is None:
+            assert i <= 2      # two warm-up calls + the capturing call
+        else:
+            bufs[0].copy_(x)
+            bufs[1].copy_(y)
+            x, y = bufs
+        losses.append(float(step(x, y)[0]))
+    torch.cuda.synchronize()
+    assert losses == lc, (losses, lc)
+    assert torch.equal(tm.store.flat_w, wc)
+
+
 def test_two_input_signatures_share_the_optimizer_slot(cuda):
     """a second input signature (here: a smaller last batch) captures a second graph; both graphs read the optimizer's scalars -- learning rate,
     bias correction -- from the SAME fixed device slot, so replays of the first graph after the second capture still follow the eager run bit for
