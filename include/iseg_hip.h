@@ -113,6 +113,11 @@ typedef struct iseg_gemm_args {
        folded into its kernel (backbones/convnext_v2.py:92-93).  Every epilogue option stays available (rows keep their global index).
        bf16, both operands K-contiguous, b_group_rows % 256 == 0, no split-K, no batch; anything else returns ISEG_ERR_UNSUPPORTED. */
     int64_t b_group_rows, b_group_stride;
+    int bias_rowscaled; /* 1 (needs bias and rowscale): the row factor multiplies the BIAS instead of the result, D = (acc + bias * rowscale[m / rows_per_group])
+                           * colscale + residual -- the pwconv2 forward of a ConvNeXt block whose A operand already carries the drop-path factor
+                           (the pwconv1 epilogue wrote rowscale * gelu(h)): x + s gamma (g W2 + b2) = x + gamma ((s g) W2 + s b2),
+                           backbones/convnext.py:56-63.  The scaled activation then serves the weight gradient Z = (s g)^T dout directly, and the
+                           backward pass needs no scaled copy of dout. */
 } iseg_gemm_args;
 
 int iseg_gemm_splits(const iseg_gemm_args* args_h);
@@ -361,6 +366,15 @@ int iseg_layerscale_grads_slabs_reduce(const float* slabs, int nslabs, const flo
                                        float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
                                        const float* partials2, int P2, int64_t n2, float* out0, float* out1, int64_t n0, int accumulate2,
                                        iseg_stream_t stream);
+/* The same when the product Z was formed from the ROW-SCALED activation (s g)^T dout and carries no ones-row (slabs [nslabs][K][N]): the column sums
+ * S = sum_r rowscale[r / rows_per_group] dout[r][:] that dgamma / db2 need are formed by further workgroups of the same launch from the unscaled
+ * bf16 gradient dout [M, ld_dout] and the drop-path factors (utils/drops.py:8-22; rowscale NULL = 1) -- no scaled copy of dout exists.
+ * partials2 may be NULL (no second slab job).  N % 8 == 0, N <= 2048. */
+int iseg_layerscale_grads_slabs_srow(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                     float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                     const float* partials2, int P2, int64_t n2, float* out0, float* out1, int64_t n0, int accumulate2,
+                                     const void* dout, int64_t ld_dout, int64_t M, const float* rowscale, int64_t rows_per_group,
+                                     iseg_stream_t stream);
 /* ---------------------------------------------------------------------------------------------------------
  * tf.image.resize (half-pixel, no antialias): utils/common.py:107-134 resize_image
  * --------------------------------------------------------------------------------------------------------- */

@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("pre_deriv", C.c_int),
         ("b_group_rows", C.c_int64),
         ("b_group_stride", C.c_int64),
+        ("bias_rowscaled", C.c_int),
     ]
 
 
@@ -129,6 +130,7 @@ SIGNATURES = {
     "iseg_layerscale_grads": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "iseg_layerscale_grads_slabs": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "iseg_layerscale_grads_slabs_reduce": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _i, _l, _p, _p, _l, _i, _p]),
+    "iseg_layerscale_grads_slabs_srow": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _z, _p, _i, _l, _p, _p, _l, _i, _p, _l, _l, _p, _l, _p]),
     "iseg_replace_nan_or_inf": (_i, [_p, _p, _l, _f, _i, _p, _z, _p]),
     "iseg_replace_nan_or_inf_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "iseg_groupnorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p]),

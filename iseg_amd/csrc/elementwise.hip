@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256) void layerscale_stage1_kernel(const float* __r
 __device__ __forceinline__ void layerscale_slabs_body(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
                                                       const float* __restrict__ W2, const float* __restrict__ gamma,
                                                       const float* __restrict__ b2, float* __restrict__ dW2, float* __restrict__ db2,
-                                                      float* __restrict__ partials, int Kdim, int Ndim, int accumulate, int bx, int by, int gy) {
+                                                      float* __restrict__ partials, int Kdim, int Ndim, int accumulate, int bx, int by, int gy,
+                                                      bool srow = false) {
     __shared__ float4 red[16][16];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int n = (bx * 16 + tx) * 4;
@@ -484,7 +485,7 @@ __device__ __forceinline__ void layerscale_slabs_body(const float* __restrict__ 
         float4 part = red[0][tx];
 #pragma unroll
         for (int i = 1; i < 16; ++i) part.x += red[i][tx].x, part.y += red[i][tx].y, part.z += red[i][tx].z, part.w += red[i][tx].w;
-        if (by == 0) {      // the S terms ride the first partial row (S = the ones-row of the slabs, summed in slab order)
+        if (by == 0 && !srow) {      // the S terms ride the first partial row (S = the ones-row of the slabs, summed in slab order)
             const int64_t o = (int64_t)Kdim * Ndim + n;
             float4 S = *reinterpret_cast<const float4*>(slabs + o);
             for (int q = 1; q < nslabs; ++q) {
@@ -500,7 +501,12 @@ __device__ __forceinline__ void layerscale_slabs_body(const float* __restrict__ 
             }
             *reinterpret_cast<float4*>(db2 + n) = dbv;
         }
-        *reinterpret_cast<float4*>(partials + (int64_t)by * Ndim + n) = part;
+        if (srow) {      // partial rows are [dgamma part | db2 part]: the S terms come from the SRowJob workgroups' rows
+            *reinterpret_cast<float4*>(partials + (int64_t)by * 2 * Ndim + n) = part;
+            *reinterpret_cast<float4*>(partials + (int64_t)by * 2 * Ndim + Ndim + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            *reinterpret_cast<float4*>(partials + (int64_t)by * Ndim + n) = part;
+        }
     }
 }
 
@@ -524,14 +530,68 @@ struct SlabReduceJob {
     int accumulate;
 };
 
+// Round 6, third job of the same launch: S[n] = sum_r rowscale[r / rows_per_group] * dout[r][n] -- the column sums the layer-scale / bias gradients need
+// (dgamma += b2 S, db2 += gamma S) -- straight from the UNSCALED gradient and the drop-path factors, so the backward pass needs neither a scaled
+// copy of dout (rowscale_kernel) nor a ones-row in the weight-gradient product.  Workgroup c sums a contiguous run of rows in row order (lanes own
+// 8-column chunks and every `lanes`-th row, combined through LDS in lane order) and writes ONE partial row [b2 S_c | gamma S_c] behind the
+// layer-scale rows; the fixed-order row reduction that sums those (deferred or not) adds them into dgamma and db2.
+struct SRowJob {
+    const bf16_t* dout;      // [M][ld] bf16 (null: no job)
+    int64_t ld, M;
+    const float* rowscale;      // (null: factor 1)
+    int64_t rows_per_group;
+    int nblocks;
+};
+
+__device__ __forceinline__ void srow_body(const SRowJob& sj, const float* __restrict__ gamma, const float* __restrict__ b2, float* __restrict__ prow,
+                                          int Ndim, int c) {
+    __shared__ float red2[2048];      // [lanes][N]: lanes * N = (256 / (N / 8)) * N <= 2048
+    const int nch = Ndim / 8, lanes = 256 / nch;
+    const int tx = threadIdx.x % nch, ty = threadIdx.x / nch;
+    const int64_t rpb = (sj.M + sj.nblocks - 1) / sj.nblocks;
+    const int64_t r0 = (int64_t)c * rpb, r1 = r0 + rpb < sj.M ? r0 + rpb : sj.M;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ty < lanes) {
+        // four rows of a lane in flight (clamped addresses, zero factor past the end: a branch per load would serialise the round trips)
+        for (int64_t r = r0 + ty; r < r1; r += 4 * lanes) {
+            float v[4][8], sc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t rq = r + q * lanes, rc = rq < r1 ? rq : r1 - 1;
+                load8<bf16_t>(sj.dout + rc * sj.ld + tx * 8, v[q]);
+                sc[q] = rq < r1 ? (sj.rowscale ? sj.rowscale[rc / sj.rows_per_group] : 1.f) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] = fmaf(v[q][u], sc[q], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) red2[ty * Ndim + tx * 8 + u] = acc[u];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ndim; i += 256) {
+        float t = red2[i];
+        for (int l = 1; l < lanes; ++l) t += red2[l * Ndim + i];
+        prow[i] = b2[i] * t;
+        prow[Ndim + i] = gamma[i] * t;
+    }
+}
+
 __global__ __launch_bounds__(256) void layerscale_slabs_reduce_kernel(const float* __restrict__ slabs, int nslabs, int64_t slab_stride,
                                                                       const float* __restrict__ W2, const float* __restrict__ gamma,
                                                                       const float* __restrict__ b2, float* __restrict__ dW2,
                                                                       float* __restrict__ db2, float* __restrict__ partials, int Kdim, int Ndim,
-                                                                      int accumulate, int gx, int gy, SlabReduceJob job) {
+                                                                      int accumulate, int gx, int gy, SlabReduceJob job, int job_blocks, SRowJob sj) {
     const int id = blockIdx.x;
+    const bool srow = sj.dout != nullptr;
     if (id < gx * gy) {      // (workgroup-uniform)
-        layerscale_slabs_body(slabs, nslabs, slab_stride, W2, gamma, b2, dW2, db2, partials, Kdim, Ndim, accumulate, id % gx, id / gx, gy);
+        layerscale_slabs_body(slabs, nslabs, slab_stride, W2, gamma, b2, dW2, db2, partials, Kdim, Ndim, accumulate, id % gx, id / gx, gy, srow);
+        return;
+    }
+    if (id >= gx * gy + job_blocks) {
+        const int c = id - gx * gy - job_blocks;
+        srow_body(sj, gamma, b2, partials + (int64_t)(gy + c) * 2 * Ndim, Ndim, c);
         return;
     }
     const int64_t j = ((int64_t)(id - gx * gy) * 256 + threadIdx.x) * 4;
@@ -886,7 +946,7 @@ extern "C" size_t iseg_layerscale_grads_workspace_bytes(int K, int N) {
     int p = K / 16;      // (the slab form's finer row strips; the tensor form uses the first layerscale_ksplits(K) rows of it)
     if (p > 128) p = 128;
     if (p < layerscale_ksplits(K)) p = layerscale_ksplits(K);
-    return (size_t)p * N * sizeof(float);
+    return (size_t)(p + 512) * 2 * N * sizeof(float);      // (+ the row-sum job's <= 512 partial rows, rows twice as wide: iseg_layerscale_grads_slabs_srow)
 }
 
 extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const float* b2, const float* gamma, const float* S,
@@ -910,7 +970,7 @@ extern "C" int iseg_layerscale_grads(const float* Z, const float* W2, const floa
 
 static int layerscale_grads_slabs_impl(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
                                        float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
-                                       const SlabReduceJob* job, hipStream_t stream);
+                                       const SlabReduceJob* job, hipStream_t stream, const SRowJob* sj = nullptr);
 
 extern "C" int iseg_layerscale_grads_slabs(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
                                            float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
@@ -934,35 +994,71 @@ extern "C" int iseg_layerscale_grads_slabs_reduce(const float* slabs, int nslabs
 
 static int layerscale_grads_slabs_impl(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
                                        float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
-                                       const SlabReduceJob* job, hipStream_t stream) {
+                                       const SlabReduceJob* job, hipStream_t stream, const SRowJob* sj) {
     ISEG_REQUIRE(slabs && nslabs >= 1 && W2 && b2 && gamma && dW2 && dgamma && db2, "iseg_layerscale_grads_slabs: null pointer");
     ISEG_REQUIRE(N % 4 == 0 && (((uintptr_t)slabs | (uintptr_t)W2 | (uintptr_t)b2 | (uintptr_t)gamma | (uintptr_t)dW2 | (uintptr_t)db2) & 15) == 0,
                  "iseg_layerscale_grads_slabs: N %% 4 == 0 and 16-byte aligned operands");
     // (one row strip of 16 per block row where the partial buffer allows it: 13 slab loads per element are latency, more lanes hide it --
     // 1536 x 384 from 13 slabs: 17.7 us with K / 32 block rows)
+    const bool srow = sj != nullptr;      // S from dout and the row factors (SRowJob): the slabs carry no ones-row, partial rows are [dgamma | db2]
+    if (srow) ISEG_REQUIRE(sj->dout && sj->M > 0 && N % 8 == 0 && N <= 2048 && sj->ld % 8 == 0 && ((uintptr_t)sj->dout & 15) == 0 &&
+                               (!sj->rowscale || sj->rows_per_group > 0),
+                           "iseg_layerscale_grads_slabs: bad row-sum job (N %% 8, 16-byte aligned bf16 rows, rows_per_group > 0)");
+    const int pw = srow ? 2 * N : N;
+    // row-sum workgroups: ~64 rows each (a lane then walks three or four strides of four rows), at most 512 partial rows
+    int PC = 0;
+    if (srow) {
+        const int64_t want = (sj->M + 63) / 64;
+        PC = (int)(want < 1 ? 1 : (want > 512 ? 512 : want));
+    }
     int P = K / 16;
-    if ((size_t)P * N * sizeof(float) > ws_bytes) P = layerscale_ksplits(K);
+    if ((size_t)(P + PC) * pw * sizeof(float) > ws_bytes) P = layerscale_ksplits(K);
     if (P > 128) P = 128;
     if (P < 1) P = 1;
-    const size_t need = (size_t)P * N * sizeof(float);
+    const size_t need = (size_t)(P + PC) * pw * sizeof(float);
     if (!ws || ws_bytes < need) {
         iseg_set_error("iseg_layerscale_grads_slabs: needs %zu workspace bytes, got %zu", need, ws_bytes);
         return ISEG_ERR_WORKSPACE;
     }
-    float* const arena = iseg_deferred_partials(need, dgamma, nullptr, accumulate, stream);
+    float* const arena = iseg_deferred_partials(need, dgamma, srow ? db2 : nullptr, accumulate, stream);
     if (arena) ws = arena;
-    if (job) {
+    const int64_t slab_stride = (int64_t)(K + (srow ? 0 : 1)) * N;
+    if (job || srow) {
         const int gx = (N / 4 + 15) / 16;
-        const int64_t b2n = (job->n / 4 + 255) / 256;
-        hipLaunchKernelGGL(layerscale_slabs_reduce_kernel, dim3((unsigned)(gx * P + b2n)), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2,
-                           gamma, b2, dW2, db2, (float*)ws, K, N, accumulate, gx, P, *job);
+        const int64_t b2n = job ? (job->n / 4 + 255) / 256 : 0;
+        SlabReduceJob none{nullptr, 0, 0, 0, 0, nullptr, nullptr, 1.f, 0};
+        SRowJob sr = srow ? *sj : SRowJob{nullptr, 0, 0, nullptr, 1, 0};
+        sr.nblocks = PC;
+        hipLaunchKernelGGL(layerscale_slabs_reduce_kernel, dim3((unsigned)(gx * P + b2n + PC)), dim3(256), 0, stream, slabs, nslabs, slab_stride, W2,
+                           gamma, b2, dW2, db2, (float*)ws, K, N, accumulate, gx, P, job ? *job : none, (int)b2n, sr);
     } else {
-        hipLaunchKernelGGL(layerscale_slabs_kernel, dim3((N / 4 + 15) / 16, P), dim3(256), 0, stream, slabs, nslabs, (int64_t)(K + 1) * N, W2, gamma, b2,
+        hipLaunchKernelGGL(layerscale_slabs_kernel, dim3((N / 4 + 15) / 16, P), dim3(256), 0, stream, slabs, nslabs, slab_stride, W2, gamma, b2,
                            dW2, db2, (float*)ws, K, N, accumulate);
     }
-    if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
+    if (srow) {      // (db2 is summed from the partial rows too: its direct store in the by == 0 workgroups is off)
+        if (arena) iseg_deferred_push((const float*)ws, P + PC, pw, pw, dgamma, db2, N, 1.f, stream);
+        else launch_reduce_rows((const float*)ws, P + PC, pw, 0, 1, pw, dgamma, db2, N, 0, 1.f, accumulate, stream);
+    } else if (arena) iseg_deferred_push((const float*)ws, P, N, N, dgamma, nullptr, N, 1.f, stream);
     else launch_reduce_rows((const float*)ws, P, N, 0, 1, N, dgamma, nullptr, N, 0, 1.f, accumulate, stream);
     return iseg_check_launch("iseg_layerscale_grads_slabs");
+}
+
+// iseg_layerscale_grads_slabs_reduce whose S = colsum(rowscale * dout) comes from the unscaled gradient and the row factors (see SRowJob): the
+// slabs are [nslabs][K][N] (NO ones-row); partials2 may be null (no second slab job).
+extern "C" int iseg_layerscale_grads_slabs_srow(const float* slabs, int nslabs, const float* W2, const float* b2, const float* gamma, float* dW2,
+                                                float* dgamma, float* db2, int K, int N, int accumulate, void* ws, size_t ws_bytes,
+                                                const float* partials2, int P2, int64_t n2, float* out0, float* out1, int64_t n0, int accumulate2,
+                                                const void* dout, int64_t ld_dout, int64_t M, const float* rowscale, int64_t rows_per_group,
+                                                hipStream_t stream) {
+    SlabReduceJob job{partials2, P2, n2, n2, n0, out0, out1, 1.f, accumulate2};
+    if (partials2) {
+        ISEG_REQUIRE(P2 >= 1 && n2 > 0 && out0 && n0 > 0 && n0 <= n2 && n2 % 4 == 0 && n0 % 4 == 0 &&
+                         (((uintptr_t)partials2 | (uintptr_t)out0 | (uintptr_t)out1) & 15) == 0,
+                     "iseg_layerscale_grads_slabs_srow: bad second job");
+    }
+    SRowJob sj{(const bf16_t*)dout, ld_dout, M, rowscale, rows_per_group, 0};
+    return layerscale_grads_slabs_impl(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, K, N, accumulate, ws, ws_bytes, partials2 ? &job : nullptr, stream,
+                                       &sj);
 }
 
 extern "C" int iseg_act_fwd(const void* x, void* y, int64_t n, int act, int dtype, hipStream_t stream) {

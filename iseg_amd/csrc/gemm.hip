@@ -240,11 +240,12 @@ extern "C" int iseg_gemm(const iseg_gemm_args* g, void* ws, size_t ws_bytes, hip
                  "iseg_gemm: act needs aux");
     ISEG_REQUIRE(g->act >= ISEG_ACT_NONE && g->act <= ISEG_ACT_MUL_AUX, "iseg_gemm: bad act %d", g->act);
     ISEG_REQUIRE(!g->pre_deriv || (g->act == ISEG_ACT_GELU && g->pre_out), "iseg_gemm: pre_deriv needs act = GELU and pre_out");
+    ISEG_REQUIRE(!g->bias_rowscaled || (g->bias && g->rowscale), "iseg_gemm: bias_rowscaled needs bias and rowscale");
     ISEG_REQUIRE(g->a_act == ISEG_ACT_NONE || g->a_act == ISEG_ACT_GELU, "iseg_gemm: a_act must be NONE or GELU");
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
             g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
-            g->pre_deriv, g->b_group_rows, g->b_group_stride};
+            g->pre_deriv, g->b_group_rows, g->b_group_stride, g->bias_rowscaled};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);
@@ -369,7 +370,7 @@ extern "C" int iseg_gemm_reduce(const iseg_gemm_args* g, void* ws, size_t ws_byt
     Epi epi{g->bias, g->colscale, g->rowscale, g->rows_per_group, g->residual, g->ldr, g->aux, g->ldaux, g->pre_out, g->ldp,
             g->act, g->alpha, g->accumulate, g->colsum_out, g->colsum_accumulate,
             g->batch_inner > 0 ? g->batch_inner : 1, g->sa_outer, g->sa_inner, g->sb_outer, g->sb_inner, g->sd_outer, g->sd_inner,
-            g->pre_deriv, g->b_group_rows, g->b_group_stride};
+            g->pre_deriv, g->b_group_rows, g->b_group_stride, g->bias_rowscaled};
     const int batch = g->batch > 1 ? g->batch : 1;
     if (batch > 1) {
         ISEG_REQUIRE(batch <= 65535, "iseg_gemm: batch %d exceeds the grid z limit (65535)", batch);

@@ -39,18 +39,18 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
         e.residual = nullptr;
         e.aux = nullptr;
         e.colscale = nullptr;
-        e.rowscale = nullptr;
         e.accumulate = 0;
         e.alpha = 1.f;
+        e.bias_rowscaled = 0;      // (rowscale stays a run-time option: round 6 writes rowscale * gelu(h), the drop-path factor of the block)
     } else if (EK == EK_MUL_AUX) {      // x aux (saved gelu'): pwconv2 data gradient
         e.act = ISEG_ACT_MUL_AUX;
         e.bias = nullptr;
         e.pre_out = nullptr;
         e.residual = nullptr;
         e.colscale = nullptr;
-        e.rowscale = nullptr;
         e.accumulate = 0;
         e.alpha = 1.f;
+        e.bias_rowscaled = 0;      // (rowscale stays a run-time option: the drop-path factor on the arriving gradient)
     } else if (EK == EK_PLAIN) {        // nothing fused: pwconv1 data gradient
         e.act = ISEG_ACT_NONE;
         e.bias = nullptr;
@@ -59,6 +59,7 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
         e.residual = nullptr;
         e.colscale = nullptr;
         e.rowscale = nullptr;
+        e.bias_rowscaled = 0;
         e.accumulate = 0;
         e.alpha = 1.f;
     } else if (EK == EK_BIAS) {         // + bias only: the Dense / projection forward products of the transformer and DCNv3 layers
@@ -68,6 +69,7 @@ template <int EK> __device__ __forceinline__ Epi epi_known(Epi e) {
         e.residual = nullptr;
         e.colscale = nullptr;
         e.rowscale = nullptr;
+        e.bias_rowscaled = 0;
         e.accumulate = 0;
         e.alpha = 1.f;
     } else if (EK == EK_BIAS_RESIDUAL) {      // bias, layer scale / drop-path factor (run time), + residual: pwconv2 forward
@@ -87,8 +89,8 @@ int dma_min_k();      // ISEG_GEMM_DMA_MIN_K (default 32): shortest reduction th
 
 inline int epi_kind(const Epi& e, const float* slabs) {
     if (slabs || e.alpha != 1.f || e.accumulate) return EK_ANY;
-    if (e.act == ISEG_ACT_GELU && e.pre_out && e.pre_deriv && e.bias && !e.residual && !e.aux && !e.colscale && !e.rowscale) return EK_GELU_DERIV;
-    if (e.act == ISEG_ACT_MUL_AUX && e.aux && !e.bias && !e.pre_out && !e.residual && !e.colscale && !e.rowscale) return EK_MUL_AUX;
+    if (e.act == ISEG_ACT_GELU && e.pre_out && e.pre_deriv && e.bias && !e.residual && !e.aux && !e.colscale && !e.bias_rowscaled) return EK_GELU_DERIV;
+    if (e.act == ISEG_ACT_MUL_AUX && e.aux && !e.bias && !e.pre_out && !e.residual && !e.colscale) return EK_MUL_AUX;
     if (e.act == ISEG_ACT_NONE && e.bias && e.residual && !e.aux && !e.pre_out) return EK_BIAS_RESIDUAL;
     static const bool bias_kind = [] { const char* v = getenv("ISEG_GEMM_EK_BIAS"); return !v || atoi(v) != 0; }();      // 0: A/B against the run-time epilogue
     if (bias_kind && e.act == ISEG_ACT_NONE && e.bias && !e.residual && !e.aux && !e.pre_out && !e.colscale && !e.rowscale) return EK_BIAS;

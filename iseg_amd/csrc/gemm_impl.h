@@ -37,6 +37,7 @@ struct Epi {
     int64_t sa_outer, sa_inner, sb_outer, sb_inner, sd_outer, sd_inner;
     int pre_deriv;          // pre_out receives gelu'(pre) instead of pre (act == GELU)
     int64_t b_group_rows, b_group_stride;      // B per row group (LDS-DMA kernel only): rows [i*b_group_rows, ...) use B + i*b_group_stride
+    int bias_rowscaled;     // the row factor multiplies the bias, not the result (iseg_gemm_args.bias_rowscaled)
     __device__ __forceinline__ int64_t off_a(int z) const { return (z / batch_inner) * sa_outer + (z % batch_inner) * sa_inner; }
     __device__ __forceinline__ int64_t off_b(int z) const { return (z / batch_inner) * sb_outer + (z % batch_inner) * sb_inner; }
     __device__ __forceinline__ int64_t off_d(int z) const { return (z / batch_inner) * sd_outer + (z % batch_inner) * sd_inner; }
@@ -45,7 +46,8 @@ struct Epi {
 template <class TO>
 __device__ __forceinline__ float epi_apply(const Epi& e, float acc, int64_t m, int64_t n, const TO* D, int64_t ldd) {
     float v = acc * e.alpha;
-    if (e.bias) v += e.bias[n];
+    const bool brs = e.bias_rowscaled && e.rowscale;
+    if (e.bias) v += brs ? e.bias[n] * e.rowscale[m / e.rows_per_group] : e.bias[n];
     if (e.pre_out) reinterpret_cast<TO*>(e.pre_out)[m * e.ldp + n] = from_f32<TO>(e.pre_deriv ? gelu_erf_grad(v) : v);
     if (e.act == ISEG_ACT_RELU) v = fmaxf(v, 0.f);
     else if (e.act == ISEG_ACT_GELU) v = gelu_erf(v);
@@ -53,7 +55,7 @@ __device__ __forceinline__ float epi_apply(const Epi& e, float acc, int64_t m, i
     else if (e.act == ISEG_ACT_RELU_GRAD) v = to_f32(reinterpret_cast<const TO*>(e.aux)[m * e.ldaux + n]) > 0.f ? v : 0.f;
     else if (e.act == ISEG_ACT_MUL_AUX) v *= to_f32(reinterpret_cast<const TO*>(e.aux)[m * e.ldaux + n]);
     if (e.colscale) v *= e.colscale[n];
-    if (e.rowscale) v *= e.rowscale[m / e.rows_per_group];
+    if (e.rowscale && !brs) v *= e.rowscale[m / e.rows_per_group];
     if (e.residual) v += to_f32(reinterpret_cast<const TO*>(e.residual)[m * e.ldr + n]);
     if (e.accumulate) v += to_f32(D[m * ldd + n]);
     return v;
@@ -64,11 +66,13 @@ template <class TO>
 __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, int64_t n, TO* D, int64_t ldd) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+    const bool brs = e.bias_rowscaled && e.rowscale;      // (the row factor goes on the bias: see iseg_gemm_args.bias_rowscaled)
     if (e.bias) {
         float b[8];
         load8<float>(e.bias + n, b);
+        const float bs = brs ? e.rowscale[m / e.rows_per_group] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += b[i];
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(b[i], bs, v[i]);
     }
     constexpr bool FAST = sizeof(TO) == 2;  // bf16 storage: approximation error << output rounding; fp32 parity path: libm erf
     if (e.pre_out && !e.pre_deriv) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
@@ -113,7 +117,7 @@ __device__ __forceinline__ void epi_apply8(const Epi& e, float* v, int64_t m, in
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= c[i];
     }
-    if (e.rowscale) {
+    if (e.rowscale && !brs) {
         const float s = e.rowscale[m / e.rows_per_group];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= s;
@@ -167,11 +171,13 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
     constexpr bool FAST = sizeof(TO) == 2;
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= e.alpha;
+    const bool brs = e.bias_rowscaled && e.rowscale;      // (the row factor goes on the bias: see iseg_gemm_args.bias_rowscaled)
     if (e.bias) {
         float b[8];
         load8<float>(e.bias + n, b);
+        const float bs = brs ? e.rowscale[m / e.rows_per_group] : 1.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] += b[i];
+        for (int i = 0; i < 8; ++i) v[i] = fmaf(b[i], bs, v[i]);
     }
     if (e.pre_out && !e.pre_deriv) store8<TO>(reinterpret_cast<TO*>(e.pre_out) + m * e.ldp + n, v);
     if (e.act == ISEG_ACT_RELU) {
@@ -209,7 +215,7 @@ __device__ __forceinline__ void epi_finish8(const Epi& e, float* v, const EpiPre
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= c[i];
     }
-    if (e.rowscale) {
+    if (e.rowscale && !brs) {
         const float s = e.rowscale[m / e.rows_per_group];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] *= s;

@@ -1191,6 +1191,11 @@ _MLP_LN_ON_LOAD = os.environ.get("ISEG_MLP_LN_ON_LOAD", "1") == "1"      # 0: La
 _WGRAD_PAIR = os.environ.get("ISEG_WGRAD_PAIR", "1") == "1"      # 0: the two weight-gradient products of an un-fused block as two launches (A/B measurements)
 _LAYERSCALE_FROM_SLABS = os.environ.get("ISEG_LAYERSCALE_FROM_SLABS", "1") == "1"      # 0: slab sum + Z tensor + layer-scale kernel (A/B measurements)
 _MLP_LN_BWD_FUSED = os.environ.get("ISEG_MLP_LN_BWD_FUSED", "1") == "1"      # 0: LayerNorm backward of the fused stages as its own kernel (A/B measurements)
+# 1: the drop-path factor rides the saved activation of the un-fused stages and rowscale_kernel disappears (round 6, see _ConvNeXtBlockFn.forward).
+# Measured on the flagship, interleaved on one box: 8.196 / 8.210 / 8.227 ms without, 8.225 / 8.237 / 8.256 ms with it -- the 12 row-scale passes it
+# removes (25 MB each) come back as the row-sum job's read of dout, two wider epilogues and wider partial rows.  Off by default; kept for the
+# launch count (11 instead of 12 per stage-2 block) and tested (tests/test_blocks_gpu.py, tests/test_kernels_gpu.py).
+_DP_FOLDED = os.environ.get("ISEG_DP_FOLDED", "0") == "1"
 _SLAB_REDUCE_MERGED = os.environ.get("ISEG_SLAB_REDUCE_MERGED", "1") == "1"      # 0: slab sum of dW1 as its own launch (A/B measurements)
 _MLP_BWD_NO_HIDDEN = os.environ.get("ISEG_MLP_BWD_NO_HIDDEN", "1") == "1"      # 0: the round-2 backward route of the fused stages (A/B measurements)
 
@@ -1209,6 +1214,7 @@ class _ConvNeXtBlockFn(Function):
         y1 = K.dwconv2d(xc, p.dw_kernel.data.reshape(Kk * Kk, C), p.dw_bias.data, Kk, dil, pad, pad)
         M = N * H * W
         ctx.fused = K.convnext_mlp_supported(C, xc.dtype)
+        ctx.dp_folded = False
         # round 3: on the fused stages LayerNorm rides the MLP kernels' row loads (forward: statistics + normalisation, backward: normalisation
         # from the saved statistics), so y2 is never written or read -- needs the backward route that keeps nothing [M, 4C]-shaped either
         ctx.ln_on_load = ctx.fused and _MLP_LN_ON_LOAD and _MLP_BWD_NO_HIDDEN and (dp_mask is None or (H * W) % 64 == 0)
@@ -1239,7 +1245,17 @@ class _ConvNeXtBlockFn(Function):
         else:
             h = torch.empty((M, 4 * C), dtype=xc.dtype, device=xc.device) if grad else None
             w1t, w2t = (nn.wt(p.w1), nn.wt(p.w2)) if xc.dtype == torch.bfloat16 else (None, None)
-            if w1t is not None and w2t is not None:
+            # round 6: the drop-path factor s rides the SAVED activation.  x + s gamma (g W2 + b2) = x + gamma ((s g) W2 + s b2): the pwconv1 epilogue
+            # writes s g (gelu' stays unscaled), pwconv2 scales its bias row-wise instead of its result, and the backward pass then works on the
+            # UNSCALED dout -- the row factor goes into the x-aux epilogue of dH, Z = (s g)^T dout needs no scaled operand, and the column sums
+            # S = colsum(s dout) are formed inside the layer-scale launch: rowscale_kernel (one pass over [M, C] per block) disappears.
+            ctx.dp_folded = bool(_DP_FOLDED and grad and dp_mask is not None and w1t is not None and w2t is not None and p.gamma is not None and
+                                 p.b1 is not None and _WGRAD_PAIR and _LAYERSCALE_FROM_SLABS and 4 * C >= 768 and C % 8 == 0)
+            if ctx.dp_folded:
+                g = K.dense_fwd_t(y2, w1t, p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=True, rowscale=dp_mask, rows_per_group=H * W)
+                out = K.dense_fwd_t(g, w2t, p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C),
+                                    bias_rowscaled=True)
+            elif w1t is not None and w2t is not None:
                 # K-contiguous kernel copies: the forward products run on the LDS-DMA GEMM like the data gradients (256 x 128 tiles)
                 g = K.dense_fwd_t(y2, w1t, p.b1.data, act=K.ACT_GELU, pre_out=h, pre_deriv=grad)
                 out = K.dense_fwd_t(g, w2t, p.b2.data, colscale=gam, rowscale=dp_mask, rows_per_group=H * W, residual=xc.reshape(M, C))
@@ -1299,6 +1315,31 @@ class _ConvNeXtBlockFn(Function):
     @staticmethod
     def _mlp_backward_with_hidden(ctx, p, do2, y2, h, g, dp_mask, side, H, W, C, M, cdt, xc):
         """the round-2 route: g / dh materialised ([M, 4C] each), two weight-gradient GEMMs; still the path of the un-fused stages (C >= 384)"""
+        if ctx.dp_folded:      # (forward: g = s gelu(h) was saved; see there)
+            w2eff = nn.w_colscaled(p.w2, p.gamma) if _BATCHED_PREP else K.scale_cols_cast(p.w2.data, p.gamma.data, cdt)
+            dh = K.dense_dgrad(do2, w2eff, act=K.ACT_MUL_AUX, aux=h, rowscale=dp_mask, rows_per_group=H * W)      # s (dout W2g^T) gelu'(pre)
+            del h
+
+            def folded_param_grads():
+                srow = (do2, dp_mask, H * W)
+                sl = K.dense_wgrad_pair(g, do2, y2, dh, _grad(p.w1), _grad(p.b1), defer_second=_SLAB_REDUCE_MERGED, ones_first=False)
+                if sl is not None:      # stage 2: both weight gradients in one launch, every slab sum + S in the layer-scale launch
+                    K.layerscale_grads_slabs(sl[0], sl[1], p.w2.data, p.b2.data, p.gamma.data, _grad(p.w2), _grad(p.gamma), _grad(p.b2),
+                                             extra=sl[2] if len(sl) > 2 else None, srow=srow)
+                    return
+                slz = K.dense_wgrad_slabs(g, do2, ones_row=False)      # stage 3 (the two products do not pair): Z = (s g)^T dout, no ones-row
+                if slz is not None:
+                    K.layerscale_grads_slabs(slz[0], slz[1], p.w2.data, p.b2.data, p.gamma.data, _grad(p.w2), _grad(p.gamma), _grad(p.b2), srow=srow)
+                else:      # (not split: the tensor form, with S from a scaled copy after all)
+                    Z = torch.empty((4 * C, C), dtype=torch.float32, device=xc.device)
+                    K.dense_wgrad(g, do2, Z, accumulate=False)
+                    S_ = torch.empty(C, dtype=torch.float32, device=xc.device)
+                    K.colsum(K.rowscale(do2, dp_mask, H * W), C, 0, 1, M, C, S_)
+                    K.layerscale_grads(Z, p.w2.data, p.b2.data, p.gamma.data, S_, _grad(p.w2), _grad(p.gamma), _grad(p.b2))
+                K.dense_wgrad(y2, dh, _grad(p.w1), bias_grad=_grad(p.b1))
+
+            side.run(folded_param_grads, do2, g, dh, y2)
+            return K.dense_dgrad(dh, nn.w(p.w1))
         dbr = K.rowscale(do2, dp_mask, H * W) if dp_mask is not None else do2
         S = torch.empty(C, dtype=torch.float32, device=xc.device)      # column sums of dbr (layer-scale and bias gradients)
         s_on_gemm = p.gamma is not None and (ctx.fused or g is not None) and xc.dtype == torch.bfloat16 and 4 * C >= 768      # rides Z = g^T dbr below

@@ -121,7 +121,7 @@ class KernelTimer:
 def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, colscale=None, rowscale=None,
          rows_per_group=0, residual=None, ldr=0, aux=None, ldaux=0, pre_out=None, ldp=0, act=ACT_NONE, alpha=1.0,
          accumulate=False, split_k=0, a_act=ACT_NONE, colsum_out=None, colsum_accumulate=False, batch=1, batch_inner=1,
-         sa=(0, 0), sb=(0, 0), sd=(0, 0), pre_deriv=False, b_group=None):
+         sa=(0, 0), sb=(0, 0), sd=(0, 0), pre_deriv=False, b_group=None, bias_rowscaled=False):
     """batch > 1: problem z uses X + (z // batch_inner) * sX[0] + (z % batch_inner) * sX[1] (element strides);
     b_group=(rows, stride): rows [i*rows, (i+1)*rows) of A / D use B + i*stride (one kernel per sample; LDS-DMA path only)"""
     _require_cuda(A, B, D)
@@ -141,6 +141,7 @@ def gemm(A, B, D, M, N, K, *, lda, ldb, ldd, a_kcontig, b_kcontig, bias=None, co
     g.colsum_out, g.colsum_accumulate = ptr(colsum_out), int(colsum_accumulate)
     g.batch, g.batch_inner = int(batch), int(batch_inner)
     g.pre_deriv = int(bool(pre_deriv))
+    g.bias_rowscaled = int(bool(bias_rowscaled))
     g.b_group_rows, g.b_group_stride = (int(b_group[0]), int(b_group[1])) if b_group is not None else (0, 0)
     (g.sa_outer, g.sa_inner), (g.sb_outer, g.sb_inner), (g.sd_outer, g.sd_inner) = sa, sb, sd
     for t in (residual, aux, pre_out):
@@ -180,7 +181,7 @@ def dense_fwd(x2d, W, bias=None, *, act=ACT_NONE, out=None, ldd=None, out_dtype=
 
 
 def dense_fwd_t(x2d, Wt, bias=None, *, act=ACT_NONE, out=None, pre_out=None, colscale=None, rowscale=None, rows_per_group=0, residual=None,
-                pre_deriv=False):
+                pre_deriv=False, bias_rowscaled=False):
     """dense_fwd with the kernel given K-contiguous: Wt [N,K] (nn.wt): both operands K-contiguous, so the LDS-DMA GEMM serves it"""
     M, K = x2d.shape
     N = Wt.shape[0]
@@ -188,7 +189,8 @@ def dense_fwd_t(x2d, Wt, bias=None, *, act=ACT_NONE, out=None, pre_out=None, col
         out = torch.empty((M, N), dtype=x2d.dtype, device=x2d.device)
     return gemm(x2d, Wt, out, M, N, K, lda=x2d.stride(0), ldb=Wt.stride(0), ldd=out.stride(0), a_kcontig=1, b_kcontig=1, bias=bias, act=act,
                 pre_out=pre_out, ldp=(pre_out.stride(0) if pre_out is not None else 0), colscale=colscale, rowscale=rowscale,
-                rows_per_group=rows_per_group, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), pre_deriv=pre_deriv)
+                rows_per_group=rows_per_group, residual=residual, ldr=(residual.stride(0) if residual is not None else 0), pre_deriv=pre_deriv,
+                bias_rowscaled=bias_rowscaled)
 
 
 def dense_dgrad(dy2d, W, *, out=None, act=ACT_NONE, aux=None, rowscale=None, rows_per_group=0, residual=None, accumulate=False):
@@ -222,13 +224,13 @@ def dense_wgrad(x2d, dy2d, out, *, accumulate=True, alpha=1.0, a_act=ACT_NONE, b
                 colsum_accumulate=accumulate)
 
 
-def dense_wgrad_slabs(x2d, dy2d):
+def dense_wgrad_slabs(x2d, dy2d, ones_row=True):
     """the weight-gradient product X^T dY with its bias-gradient ones-row, stopped in front of the slab sum: (slabs [n, K + 1, N] fp32, n) for a
     consumer that sums the split-K slabs while it reads them (layerscale_grads_slabs), or None when the problem is not split / cannot carry
     the ones-row"""
     M, K = x2d.shape
     N = dy2d.shape[1]
-    if not wgrad_can_fuse_bias(x2d) or N % 4 != 0:
+    if (ones_row and not wgrad_can_fuse_bias(x2d)) or N % 4 != 0 or x2d.dtype != torch.bfloat16:
         return None
     _require_cuda(x2d, dy2d)
     g = GemmArgs()
@@ -239,7 +241,7 @@ def dense_wgrad_slabs(x2d, dy2d):
     g.M, g.N, g.K = K, N, M
     g.in_dtype, g.out_dtype = dt(x2d), 0
     g.alpha, g.accumulate = 1.0, 0
-    g.colsum_out, g.colsum_accumulate = ptr(dummy), 0
+    g.colsum_out, g.colsum_accumulate = (ptr(dummy) if ones_row else None), 0      # ones_row=False: slabs [n, K, N] (layerscale_grads_slabs srow=...)
     g.batch, g.batch_inner = 1, 1
     L = _hip.lib()
     need = L.iseg_gemm_workspace_bytes(C.byref(g))
@@ -257,7 +259,7 @@ def dense_wgrad_slabs(x2d, dy2d):
     return slabs, int(eff)
 
 
-def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True, defer_second=False):
+def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True, defer_second=False, ones_first=True):
     """The two weight-gradient products of an un-fused ConvNeXt block as ONE launch (csrc/gemm_dma_tn.h, round 5): Z = g^T dbr [4C, C] with its
     ones-row, stopped at its slabs for layerscale_grads_slabs, and dW1 (+)= x^T dh [C, 4C] (+ db1 from its ones-row), summed by iseg_gemm_reduce.
     Returns (slabs of Z, slab count) or None when the problems do not pair (the caller then runs them one by one)."""
@@ -281,7 +283,8 @@ def dense_wgrad_pair(g2d, dbr2d, x2d, dh2d, dW1, db1, accumulate=True, defer_sec
         g.defer_reduce = 1
         return g
 
-    g0 = args(g2d, dbr2d, dummy, Cc, dummy, False)
+    # ones_first=False (round 6): Z carries no ones-row -- its column sums S come from layerscale_grads_slabs(srow=...) instead
+    g0 = args(g2d, dbr2d, dummy, Cc, dummy if ones_first else None, False)
     g1 = args(x2d, dh2d, dW1, dW1.stride(0), db1, accumulate)
     L = _hip.lib()
     s = int(L.iseg_gemm_tn_pair_splits(C.byref(g0), C.byref(g1)))
@@ -886,12 +889,20 @@ def layerscale_grads(Z, W2, b2, gamma, S, dW2, dgamma, db2, accumulate=True):
               int(accumulate), ptr(ws), wsb, stream())
 
 
-def layerscale_grads_slabs(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, accumulate=True, extra=None):
+def layerscale_grads_slabs(slabs, nslabs, W2, b2, gamma, dW2, dgamma, db2, accumulate=True, extra=None, srow=None):
     """layerscale_grads from the unreduced split-K slabs of Z = g^T dout (dense_wgrad_slabs): Z and S = colsum(dout) are summed on load.
     extra = dense_wgrad_pair(..., defer_second=True)[2]: the other product's slabs are summed into their gradients by the same launch"""
     Kd, Nd = W2.shape
     need = _hip.lib().iseg_layerscale_grads_workspace_bytes(Kd, Nd)
     ws, wsb = workspace(need, slabs.device)
+    if srow is not None:
+        # srow = (dout2d bf16 [M, C], rowscale or None, rows_per_group): the slabs carry no ones-row; S = colsum(rowscale * dout) is formed in this launch
+        dout2d, rs, rpg = srow
+        part2, p2, n2, out0, out1, n0, acc2 = extra if extra is not None else (None, 0, 0, None, None, 0, False)
+        _hip.call("iseg_layerscale_grads_slabs_srow", ptr(slabs), int(nslabs), ptr(W2), ptr(b2), ptr(gamma), ptr(dW2), ptr(dgamma), ptr(db2), Kd, Nd,
+                  int(accumulate), ptr(ws), wsb, ptr(part2), int(p2), int(n2), ptr(out0), ptr(out1), int(n0), int(acc2), ptr(dout2d),
+                  dout2d.stride(0), dout2d.shape[0], ptr(rs), int(rpg if rs is not None else 1), stream())
+        return
     if extra is not None:
         part2, p2, n2, out0, out1, n0, acc2 = extra
         _hip.call("iseg_layerscale_grads_slabs_reduce", ptr(slabs), int(nslabs), ptr(W2), ptr(b2), ptr(gamma), ptr(dW2), ptr(dgamma), ptr(db2), Kd,

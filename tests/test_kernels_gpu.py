@@ -845,3 +845,43 @@ def test_weight_gradient_pair_with_the_slab_sum_in_the_layer_scale_launch(cuda, 
         assert torch.equal(a, b), name
     W_ref = init[0].double() + y2.cpu().double().T @ dh.cpu().double()
     assert (one[0].cpu().double() - W_ref).abs().max().item() < 1e-4 * W_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,Cc,rpg", [(4096, 384, 1024), (16384, 384, 1024), (2048, 768, 256)])
+def test_layer_scale_gradients_from_the_unscaled_gradient_and_the_drop_path_factors(cuda, rows, Cc, rpg):
+    """round 6 (drop-path factor folded into the saved activation, backbones/convnext.py:56-63 + utils/drops.py:8-22): Z = (s g)^T dout has no
+    ones-row; S = colsum(s dout) is formed inside the layer-scale launch from the unscaled bf16 gradient and the per-sample factors.  dW2 = Z gamma,
+    dgamma = sum_k W2 o Z + b2 S, db2 = gamma S (accumulated into non-zero buffers) against fp64 from the same bf16 operands; bit-reproducible"""
+    k = K()
+    bf = torch.bfloat16
+    nb = rows // rpg
+    s = torch.tensor([1.25, 0.0, 1.0 / 0.9, 1.0, 0.0, 1.111, 1.05, 1.3][:nb] + [1.0] * max(0, nb - 8), dtype=torch.float32)
+    gs = (rnd((rows, 4 * Cc), 1) * s.repeat_interleave(rpg).reshape(-1, 1)).to(bf)      # what the pwconv1 epilogue saves: s * gelu(h)
+    dout = rnd((rows, Cc), 2).to(bf)
+    y2 = rnd((rows, Cc), 3).to(bf)
+    dh = rnd((rows, 4 * Cc), 4).to(bf)
+    W2, b2, gamma = rnd((4 * Cc, Cc), 7).float(), rnd((Cc,), 8).float(), rnd((Cc,), 9).float()
+    init = [rnd((Cc, 4 * Cc), 5).float(), rnd((4 * Cc,), 6).float(), rnd((4 * Cc, Cc), 10).float(), rnd((Cc,), 11).float(), rnd((Cc,), 12).float()]
+    outs = []
+    for _ in range(2):
+        dW1, db1, dW2, dgam, db2 = [t.clone().cuda() for t in init]
+        sl = k.dense_wgrad_pair(gs.cuda(), dout.cuda(), y2.cuda(), dh.cuda(), dW1, db1, defer_second=True, ones_first=False)
+        if sl is None:      # (C = 768: the products do not pair -- the caller's stage-3 route)
+            slz = k.dense_wgrad_slabs(gs.cuda(), dout.cuda(), ones_row=False)
+            assert slz is not None
+            k.layerscale_grads_slabs(slz[0], slz[1], W2.cuda(), b2.cuda(), gamma.cuda(), dW2, dgam, db2, srow=(dout.cuda(), s.cuda(), rpg))
+        else:
+            k.layerscale_grads_slabs(sl[0], sl[1], W2.cuda(), b2.cuda(), gamma.cuda(), dW2, dgam, db2, extra=sl[2], srow=(dout.cuda(), s.cuda(), rpg))
+        k.deferred_flush()
+        torch.cuda.synchronize()
+        outs.append([dW2.clone(), dgam.clone(), db2.clone(), dW1.clone(), db1.clone()])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    dW2, dgam, db2, dW1, db1 = outs[0]
+    Z = gs.double().T @ dout.double()
+    S = (dout.double() * s.double().repeat_interleave(rpg).reshape(-1, 1)).sum(0)
+    refs = [init[2].double() + Z * gamma.double(), init[3].double() + (W2.double() * Z).sum(0) + b2.double() * S, init[4].double() + gamma.double() * S]
+    for got, ref, name in zip((dW2, dgam, db2), refs, ("dW2", "dgamma", "db2")):
+        assert (got.cpu().double() - ref).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-3, name
+    if sl is not None:
+        W_ref = init[0].double() + y2.double().T @ dh.double()
+        assert (dW1.cpu().double() - W_ref).abs().max().item() < 1e-4 * W_ref.abs().max().item()
