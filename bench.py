@@ -542,7 +542,7 @@ def roofline_from_timer(report, steps, survey=None):
               "share_of_gemm_time": round(share, 4), "algorithmic_bytes_per_launch": int(nbytes),
               "algorithmic_flops_per_launch": int(flops), "flop_per_byte": round(intensity, 1), "traffic": None}
     # HBM bytes per launch from the PMC counters: they cannot be read inside this process, so the figure comes from the separate rocprofv3
-    # --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_evidence.sh -> profiles/r05_pmc.json, corrections per
+    # --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/collect_evidence.sh -> profiles/r06_pmc.json, corrections per
     # MI355X_MICROARCH.md), looked up by kernel symbol (the epilogue kind is part of it since round 3) and grid; null when the file was
     # taken on another source tree or holds no such kernel.
     sym, grid = _dma_symbol(key)
@@ -567,11 +567,11 @@ def roofline_from_timer(report, steps, survey=None):
     return common
 
 
-PMC_FILE = os.path.join("profiles", "r05_pmc.json")
+PMC_FILE = os.path.join("profiles", "r06_pmc.json")
 
 
 def _pmc_on_this_tree():
-    """profiles/r05_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes over this same command, tools/collect_evidence.sh) when it was taken
+    """profiles/r06_pmc.json (rocprofv3 FETCH_SIZE / WRITE_SIZE / SQ passes over this same command, tools/collect_evidence.sh) when it was taken
     on EXACTLY this source tree (tools/source_stamp.py), else (None, why)"""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:

@@ -20,6 +20,6 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES S
 done
 python3 tools/pmc_summary.py "$out" 5 "$out/pmc.json" 40
 rm -rf "$out/fetch" "$out/write" "$out/sq"
-cp "$out/pmc.json" profiles/r05_pmc.json      # (on the box only: lets the bench run below report the counters it was just profiled with)
+cp "$out/pmc.json" profiles/r06_pmc.json      # (on the box only: lets the bench run below report the counters it was just profiled with)
 python3 bench.py --steps 20 --warmup 5 > "$out/bench.json" 2> "$out/bench.err"
 tail -1 "$out/bench.json"
