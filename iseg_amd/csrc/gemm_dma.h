@@ -107,13 +107,14 @@ inline int epi_kind(const Epi& e, const float* slabs) {
 // ({0-3, 12-15, 20-27}, ...) then covers the sixteen 16-byte slots of a 256-byte bank row exactly once.
 __device__ __forceinline__ int key32(int quad) { return (0x6C >> (2 * (quad & 3))) & 3; }      // {0, 3, 2, 1}
 
-template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY, bool KT = false, int BKS = 64>
+// FM: 16-row blocks per wavefront (4; 2 for the 128 x 192 tile of round 6: eight wavefronts of 32 x 96)
+template <int WM, int WN, int NS, class TO, bool PERSIST = false, int FN = 4, int EK = EK_ANY, bool KT = false, int BKS = 64, int FM = 4>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS == 32 ? 4 : 1, BKS == 32 ? 4 : 8))) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A, int64_t lda, const bf16_t* __restrict__ B,
                                                                      int64_t ldb, TO* __restrict__ D, int64_t ldd, int64_t M, int64_t N,
                                                                      int64_t K, int tiles_n, int ntiles, int64_t k_per_split,
                                                                      float* __restrict__ slabs, Epi epi, int vecD) {
     constexpr int NW = WM * WN;
-    constexpr int BM = WM * 64, BN = WN * FN * 16;      // a wavefront owns 64 rows x FN*16 columns (FN = 4, or 6 for the 256 x 192 tile)
+    constexpr int BM = WM * FM * 16, BN = WN * FN * 16;      // a wavefront owns FM*16 rows x FN*16 columns (FN = 4, or 6 for the 256 x 192 tile)
     static_assert(FN % 2 == 0, "column fragments come in pairs (eight consecutive columns per lane)");
     static_assert(BKS == 64 || (BKS == 32 && !KT && !PERSIST), "ring stages hold 64 or 32 K elements; the 32 form has no K tail and no persistent walk");
     constexpr int RB = BKS * 2;                // bytes per stage row
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS
         }
     };
 
-    f32x4 acc[4][FN];
+    f32x4 acc[FM][FN];
 
     // Fragment addresses.  A: row (lane & 15) of 16-row block i, chunk (4*ks + (lane >> 4)) ^ (row & 7).
     // B: fragment j of the wave tile takes the rows 32*(j >> 1) + 8*(c >> 2) + 4*(j & 1) + (c & 3), c = lane & 15, and is the FIRST
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS
     // BKS = 64: ks = 0; ks = 1 flips bit 6 of the byte offset (chunk ^ 4).  BKS = 32: one k-step per stage, the key of the row's group of four
     // (rows wm * 64 + 16 i + c15: the group index is c15 >> 2 whatever i)
     const int a_sw = (BKS == 64 ? (g ^ (lane & 7)) : (g ^ key32(c15 >> 2))) * 16;
-    const int a_off = (wm * 64 + c15) * RB;
+    const int a_off = (wm * (FM * 16) + c15) * RB;
     const int b_row0 = wn * (FN * 16) + 8 * (c15 >> 2) + (c15 & 3);
     // + 32*(j >> 1) + 4*(j & 1) leaves the key unchanged (BKS = 64: bits 0,1,3 of the row; BKS = 32: bits 3,4 = c15 >> 2)
     const int b_sw = (BKS == 64 ? (g ^ b_key(b_row0)) : (g ^ key32(c15 >> 2))) * 16;
@@ -220,13 +221,13 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS
         const char* sb = smem + stage * STAGE + b_off;
 #pragma unroll
         for (int ks = 0; ks < BKS / 32; ++ks) {
-            bf16x8 af[4], bfr[FN];
+            bf16x8 af[FM], bfr[FN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RB + (a_sw ^ (ks * 64)));
+            for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + i * 16 * RB + (a_sw ^ (ks * 64)));
 #pragma unroll
             for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + ((j >> 1) * 32 + (j & 1) * 4) * RB + (b_sw ^ (ks * 64)));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
         }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS
     }
     for (int vt = blockIdx.x;;) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (NS == 2) {
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(BKS
     const bool split = slabs != nullptr;
     float* const slab = split ? slabs + (int64_t)ksplit * M * N : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t m = em0 + wm * 64 + i * 16 + c15;
+    for (int i = 0; i < FM; ++i) {
+        const int64_t m = em0 + wm * (FM * 16) + i * 16 + c15;
 #pragma unroll
         for (int h = 0; h < FN / 2; ++h) {
             const int64_t n = en0 + wn * (FN * 16) + 32 * h + 8 * g;
@@ -345,15 +346,16 @@ inline bool dma_eligible(const iseg_gemm_args* g, int64_t kps) {
     return true;
 }
 
-template <int WM, int WN, int NS, class TO, int FN = 4, int EK = EK_ANY, int BKS = 64>
+template <int WM, int WN, int NS, class TO, int FN = 4, int EK = EK_ANY, int BKS = 64, int FM = 4>
 void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_per_split, float* slabs, hipStream_t s) {
-    constexpr int BM = WM * 64, BN = WN * FN * 16;
+    constexpr int BM = WM * FM * 16, BN = WN * FN * 16;
     const int tiles_m = (int)ceil_div64(g->M, BM), tiles_n = (int)ceil_div64(g->N, BN);
     const int ntiles = tiles_m * tiles_n;
     const int vecD = 1;
     const int batch = g->batch > 1 ? g->batch : 1;
     dim3 grid(ntiles, nsplit, batch);
     constexpr int lds = NS * (BM + BN) * BKS * 2;
+    static_assert(FM == 4 || BKS == 64, "the 32-deep stages exist for the 256 x 128 tile");
     if constexpr (BKS == 32) {      // (dispatch_dma sends only whole-K problems here: K % 32 == 0, splits cut at multiples of 64)
         static const bool raised32 = [] {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, false, 32>),
@@ -366,20 +368,20 @@ void launch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k_p
     }
     if (g->K % 64 != 0) {
         static const bool raised_kt = [] {      // > 64 KiB of dynamic LDS needs the attribute once per instantiation
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true>),
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true, 64, FM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
         }();
         (void)raised_kt;
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, true, 64, FM>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
                            (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
         return;
     }
     static const bool raised = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK>),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, false, 64, FM>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
     }();
     (void)raised;
-    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<WM, WN, NS, TO, false, FN, EK, false, 64, FM>), grid, dim3(WM * WN * 64), lds, s, (const bf16_t*)g->A, g->lda,
                        (const bf16_t*)g->B, g->ldb, (TO*)g->D, g->ldd, g->M, g->N, g->K, tiles_n, ntiles, k_per_split, slabs, epi, vecD);
 }
 
@@ -450,6 +452,13 @@ inline int dma_form(const iseg_gemm_args* g, int nsplit) {
     static const int persist = [] { const char* e = getenv("ISEG_GEMM_DMA_PERSIST"); return e ? atoi(e) : 0; }();
     const int cus = dma_cus();
     const int64_t t128 = ceil_div64(g->M, 256) * ceil_div64(g->N, 128);
+    // 8 (round 6): 128 x 192 tiles where the 256 x 128 ones leave more than an eighth of the CUs idle in their single round and these fit one
+    // round with at least a sixth more workgroups -- M = 16384, N = 384 (the K = 1536 products of stage 2): 256 workgroups instead of 192
+    static const int tall = [] { const char* e = getenv("ISEG_GEMM_DMA_128X192"); return e ? atoi(e) : 1; }();
+    if (tall && g->N % 192 == 0 && t128 * 8 <= (int64_t)cus * 7) {
+        const int64_t t8 = ceil_div64(g->M, 128) * (g->N / 192);
+        if (t8 <= cus && t8 * 6 >= t128 * 7) return 8;
+    }
     if (wide && g->N % 192 == 0) {
         const int64_t t192 = ceil_div64(g->M, 256) * (g->N / 192);
         const double e128 = (double)t128 / (double)(ceil_div64(t128, cus) * cus), e192 = (double)t192 / (double)(ceil_div64(t192, cus) * cus);
@@ -460,19 +469,19 @@ inline int dma_form(const iseg_gemm_args* g, int nsplit) {
 }
 
 // one instantiation per fused epilogue kind for bf16 outputs (the other output type keeps the run-time epilogue)
-template <int WM, int WN, int NS, class TO, int FN, int BKS = 64>
+template <int WM, int WN, int NS, class TO, int FN, int BKS = 64, int FM = 4>
 void launch_dma_kinds(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t kps, float* slabs, hipStream_t s) {
     if (sizeof(TO) == 2) {
         switch (epi_kind(epi, slabs)) {
-            case EK_GELU_DERIV: launch_dma<WM, WN, NS, TO, FN, EK_GELU_DERIV, BKS>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX, BKS>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL, BKS>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN, BKS>(g, epi, nsplit, kps, slabs, s); return;
-            case EK_BIAS: launch_dma<WM, WN, NS, TO, FN, EK_BIAS, BKS>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_GELU_DERIV: launch_dma<WM, WN, NS, TO, FN, EK_GELU_DERIV, BKS, FM>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_MUL_AUX: launch_dma<WM, WN, NS, TO, FN, EK_MUL_AUX, BKS, FM>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS_RESIDUAL: launch_dma<WM, WN, NS, TO, FN, EK_BIAS_RESIDUAL, BKS, FM>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_PLAIN: launch_dma<WM, WN, NS, TO, FN, EK_PLAIN, BKS, FM>(g, epi, nsplit, kps, slabs, s); return;
+            case EK_BIAS: launch_dma<WM, WN, NS, TO, FN, EK_BIAS, BKS, FM>(g, epi, nsplit, kps, slabs, s); return;
             default: break;
         }
     }
-    launch_dma<WM, WN, NS, TO, FN, EK_ANY, BKS>(g, epi, nsplit, kps, slabs, s);
+    launch_dma<WM, WN, NS, TO, FN, EK_ANY, BKS, FM>(g, epi, nsplit, kps, slabs, s);
 }
 
 // ISEG_GEMM_DMA_BK32: the 256 x 128 form with 32-deep ring stages, two workgroups per CU (see the kernel's BKS note): 1 (default) = for K <= 512,
@@ -496,6 +505,7 @@ void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 5: launch_dma_persistent<TO>(g, epi, kps, dma_cus(), s); break;
         case 6: launch_dma_kinds<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 192: stage 3
+        case 8: launch_dma_kinds<4, 2, 3, TO, 6, 64, 2>(g, epi, nsplit, kps, slabs, s); break;      // 128 x 192, eight wavefronts of 32 x 96
         default: launch_dma_kinds<2, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s); break;
     }
 }

@@ -885,3 +885,59 @@ def test_layer_scale_gradients_from_the_unscaled_gradient_and_the_drop_path_fact
     if sl is not None:
         W_ref = init[0].double() + y2.double().T @ dh.double()
         assert (dW1.cpu().double() - W_ref).abs().max().item() < 1e-4 * W_ref.abs().max().item()
+
+
+# --------------------------------------------------------------------------------------------------------
+def _dma_stage_depth_outputs(check=False):
+    """every LDS-DMA epilogue kind on shapes the 32-deep ring stages take by default (whole K <= 512, K % 32 == 0, K >= 96), ragged M and N included"""
+    k = K()
+    outs = []
+    # the last three: problems whose 256 x 128 tiles leave CUs idle in their single round and that take 128 x 192 tiles instead (ragged M included)
+    for M, N, Kd in ((256, 128, 96), (1000, 384, 128), (4096, 520, 160), (777, 1536, 384), (2048, 256, 512), (300, 136, 352),
+                     (16384, 384, 1536), (16300, 384, 64), (10800, 576, 192)):
+        g = torch.Generator().manual_seed(M + N + Kd)
+        x = (torch.randn(M, Kd, generator=g)).bfloat16().cuda()
+        w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).bfloat16().cuda()
+        aux = torch.randn(M, N, generator=g).bfloat16().cuda()
+        res = torch.randn(M, N, generator=g).bfloat16().cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        scale = torch.rand(N, generator=g).cuda()
+        rs = torch.rand((M + 63) // 64, generator=g).cuda()
+        kw = dict(lda=Kd, ldb=Kd, ldd=N, a_kcontig=1, b_kcontig=1)
+        d = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        k.gemm(x, w, d, M, N, Kd, **kw)
+        outs.append(d.clone())
+        if check:      # the plain product against fp32 arithmetic on the same bf16 operands
+            want = x.float() @ w.float().t()
+            err = (d.float() - want).abs().max().item()
+            assert err <= 1.2e-2 * want.abs().max().item(), (M, N, Kd, err)
+        p = torch.empty_like(d)
+        k.gemm(x, w, d, M, N, Kd, bias=bias, act=k.ACT_GELU, pre_out=p, ldp=N, pre_deriv=True, **kw)
+        outs += [d.clone(), p.clone()]
+        k.gemm(x, w, d, M, N, Kd, act=k.ACT_MUL_AUX, aux=aux, ldaux=N, **kw)
+        outs.append(d.clone())
+        k.gemm(x, w, d, M, N, Kd, bias=bias, colscale=scale, residual=res, ldr=N, rowscale=rs, rows_per_group=64, **kw)
+        outs.append(d.clone())
+    return [o.cpu() for o in outs]
+
+
+def test_gemm_dma_stage_depths_agree_bit_for_bit(cuda, tmp_path):
+    """the two-workgroups-per-CU form (32-deep stages) and the 128 x 192 tiles (both round 6) walk K in the same order as the 256 x 128 form on
+    64-deep stages: same bits.  The forms are chosen once per process (ISEG_GEMM_DMA_BK32, ISEG_GEMM_DMA_128X192), so the plain run is a child process."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "deep64.pt")
+    code = ("import torch, tests.test_kernels_gpu as t; "
+            f"torch.save(t._dma_stage_depth_outputs(), {path!r})")
+    env = dict(os.environ, ISEG_GEMM_DMA_BK32="0", ISEG_GEMM_DMA_128X192="0", PYTHONPATH=root)
+    subprocess.run([sys.executable, "-c", code], cwd=root, env=env, check=True, timeout=600)
+    deep64 = torch.load(path)
+    deep32 = _dma_stage_depth_outputs(check=True)
+    assert len(deep32) == len(deep64) == 45
+    for i, (a, b) in enumerate(zip(deep32, deep64)):
+        assert torch.isfinite(a.float()).all()
+
+        assert torch.equal(a, b), f"output {i}: {(a.float() - b.float()).abs().max().item()}"

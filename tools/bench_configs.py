@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--each-step", action="store_true", help="also print every step's own synchronised time, warm-up included (looks for transients)")
     ap.add_argument("--graph-step", action="store_true", help="replay the train step from one HIP graph (iseg_amd/graphs.py GraphedTrainStep)")
     args = ap.parse_args()
     from iseg_amd import heads
@@ -76,19 +77,33 @@ def main():
             def step():
                 with torch.no_grad():
                     return inference_with_sliding_window(x, model, training=False, windows_size=(512, 512))
+        each = []
         for _ in range(args.warmup):
+            t1 = time.perf_counter()
             step()
+            if args.each_step:
+                torch.cuda.synchronize()
+                each.append(round((time.perf_counter() - t1) * 1e3, 2))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        host = 0.0
         for _ in range(args.steps):
+            t1 = time.perf_counter()
             out = step()
+            host += time.perf_counter() - t1
+            if args.each_step:
+                torch.cuda.synchronize()
+                each.append(round((time.perf_counter() - t1) * 1e3, 2))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         rec = {"config": name, "workload": desc, "batch": batch, "dtype": "bf16", "ms_per_step": round(dt * 1e3, 3),
                "images_per_sec": round(batch / dt, 2), "params_M": round(sum(p.numel() for p in model.parameters()) / 1e6, 2)}
         rec["step"] = "hip graph replay" if args.graph_step else "eager"
+        rec["host_enqueue_ms_per_step"] = round(host / args.steps * 1e3, 3)      # wall time the host spent inside step() (no synchronisation)
         if training:
             rec["loss"] = round(float(out[0]), 4)
+        if args.each_step:
+            rec["each_step_ms"] = each
         print(json.dumps(rec), flush=True)
         del model, helper
         torch.cuda.empty_cache()

@@ -31,7 +31,7 @@ def padded(rows, cols, pad):
 
 PADS = [int(p) for p in os.environ.get("KB_PADS", "0,64,128,32").split(",")]
 print("pads (elements):", PADS)
-for C, M in ((384, 16384), (768, 4096)):
+for C, M in ((384, int(os.environ.get("KB_M2", "16384"))), (768, int(os.environ.get("KB_M3", "4096")))):
     H = 4 * C
     bias = torch.randn(H, device="cuda")
     bias_c = torch.randn(C, device="cuda")
