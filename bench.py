@@ -492,7 +492,7 @@ def roofline_memory(key, sec, launches, steps, step_seconds):
     """`roofline_memory`: the largest non-GEMM launch group of the step against the HBM roofline (round-5 verdict item 7: over the whole trace the top
     row is a depthwise kernel, not a GEMM).  Algorithmic bytes = the activation read once + written once (+ the residual-branch gradient read once
     for the data-gradient form); the 49 K fp32 weights are noise.  The vector-pipe rate is reported beside it: a 7 x 7 depthwise pass is 49 MACs per
-    4 bytes, so at 64 T MAC/s (v_pk_fma_f32 peak) its arithmetic needs about as long as its bytes do."""
+    4 bytes, so at 64 T MAC/s (v_pk_fma_f32 peak, EXPERIMENTS.md) its arithmetic needs about as long as its bytes do."""
     _, N, H, W, C, K, dil, flip, has_add, dtype = key
     es = 2 if dtype == torch.bfloat16 else 4
     elems = N * H * W * C
@@ -710,7 +710,7 @@ def main():
     # Roofline: the last warm-up step times every GEMM launch with HIP events on the launch stream to find the dominant
     # (template, shape) group.  Eager headline (--eager-step, or data parallel): the timed region brackets one launch in four of that group.
     # Replayed headline (default on one GPU): `--roofline-steps` eager steps right in front of the timed region bracket EVERY launch of the
-    # group -- event-record nodes inside a captured graph carry no timestamps on ROCm 7.2, and the kernels, shapes and buffers
+    # group -- event-record nodes inside a captured graph carry no timestamps on ROCm 7.2 (EXPERIMENTS.md), and the kernels, shapes and buffers
     # are the same ones the replay runs.
     from iseg_amd.graphs import GraphedTrainStep
 

@@ -444,6 +444,13 @@ inline int dma_cus() {
 //      (ISEG_GEMM_DMA_PERSIST=1; see below why it is not the default).
 inline int dma_form(const iseg_gemm_args* g, int nsplit) {
     const int variant = dma_variant(g, nsplit);
+    // 9 (round 6): 64 x 192 tiles (eight wavefronts of 16 x 96) where the thin-grid 128 x 128 form leaves a quarter of the CUs idle --
+    // M = 4096, N = 768 (the K = 3072 products of stage 3): 256 workgroups instead of 192; + bias + residual 40.0 -> 34.7 us, plain 36.0 -> 32.4 us
+    static const int flat = [] { const char* e = getenv("ISEG_GEMM_DMA_64X192"); return e ? atoi(e) : 1; }();
+    if (flat && variant == 4 && nsplit == 1 && g->batch <= 1 && g->N % 192 == 0 && g->K % 64 == 0) {
+        const int64_t t4 = ceil_div64(g->M, 128) * ceil_div64(g->N, 128), t9 = ceil_div64(g->M, 64) * (g->N / 192);
+        if (t4 * 8 <= (int64_t)dma_cus() * 7 && t9 <= dma_cus() && t9 * 6 >= t4 * 7) return 9;
+    }
     if (variant != 2 || nsplit != 1 || g->batch > 1) return variant;
     static const int wide = [] { const char* e = getenv("ISEG_GEMM_DMA_WIDE"); return e ? atoi(e) : 1; }();
     // off by default: 1 us per launch faster back to back (tools/kbench_gemm_ref.py) but slower inside the training step -- 59.8 vs 53.9 us for the
@@ -505,6 +512,7 @@ void dispatch_dma(const iseg_gemm_args* g, const Epi& epi, int nsplit, int64_t k
         case 3: launch_dma<2, 2, 2, TO>(g, epi, nsplit, kps, slabs, s); break;
         case 5: launch_dma_persistent<TO>(g, epi, kps, dma_cus(), s); break;
         case 6: launch_dma_kinds<4, 2, 2, TO, 6>(g, epi, nsplit, kps, slabs, s); break;      // 256 x 192: stage 3
+        case 9: launch_dma_kinds<4, 2, 3, TO, 6, 64, 1>(g, epi, nsplit, kps, slabs, s); break;      // 64 x 192, eight wavefronts of 16 x 96
         case 8: launch_dma_kinds<4, 2, 3, TO, 6, 64, 2>(g, epi, nsplit, kps, slabs, s); break;      // 128 x 192, eight wavefronts of 32 x 96
         default: launch_dma_kinds<2, 2, 3, TO, 4>(g, epi, nsplit, kps, slabs, s); break;
     }

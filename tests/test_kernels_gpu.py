@@ -892,9 +892,9 @@ def _dma_stage_depth_outputs(check=False):
     """every LDS-DMA epilogue kind on shapes the 32-deep ring stages take by default (whole K <= 512, K % 32 == 0, K >= 96), ragged M and N included"""
     k = K()
     outs = []
-    # the last three: problems whose 256 x 128 tiles leave CUs idle in their single round and that take 128 x 192 tiles instead (ragged M included)
+    # the last five: problems whose 256 x 128 (128 x 128) tiles leave CUs idle in their single round and that take 128 x 192 (64 x 192) tiles instead
     for M, N, Kd in ((256, 128, 96), (1000, 384, 128), (4096, 520, 160), (777, 1536, 384), (2048, 256, 512), (300, 136, 352),
-                     (16384, 384, 1536), (16300, 384, 64), (10800, 576, 192)):
+                     (16384, 384, 1536), (16300, 384, 64), (10800, 576, 192), (4000, 768, 256), (4096, 768, 3072)):
         g = torch.Generator().manual_seed(M + N + Kd)
         x = (torch.randn(M, Kd, generator=g)).bfloat16().cuda()
         w = (torch.randn(N, Kd, generator=g) * Kd ** -0.5).bfloat16().cuda()
@@ -923,7 +923,7 @@ def _dma_stage_depth_outputs(check=False):
 
 def test_gemm_dma_stage_depths_agree_bit_for_bit(cuda, tmp_path):
     """the two-workgroups-per-CU form (32-deep stages) and the 128 x 192 tiles (both round 6) walk K in the same order as the 256 x 128 form on
-    64-deep stages: same bits.  The forms are chosen once per process (ISEG_GEMM_DMA_BK32, ISEG_GEMM_DMA_128X192), so the plain run is a child process."""
+    64-deep stages: same bits.  The forms are chosen once per process (ISEG_GEMM_DMA_BK32, ISEG_GEMM_DMA_128X192, ISEG_GEMM_DMA_64X192), so the plain run is a child process."""
     import os
     import subprocess
     import sys
@@ -932,11 +932,11 @@ def test_gemm_dma_stage_depths_agree_bit_for_bit(cuda, tmp_path):
     path = str(tmp_path / "deep64.pt")
     code = ("import torch, tests.test_kernels_gpu as t; "
             f"torch.save(t._dma_stage_depth_outputs(), {path!r})")
-    env = dict(os.environ, ISEG_GEMM_DMA_BK32="0", ISEG_GEMM_DMA_128X192="0", PYTHONPATH=root)
+    env = dict(os.environ, ISEG_GEMM_DMA_BK32="0", ISEG_GEMM_DMA_128X192="0", ISEG_GEMM_DMA_64X192="0", PYTHONPATH=root)
     subprocess.run([sys.executable, "-c", code], cwd=root, env=env, check=True, timeout=600)
     deep64 = torch.load(path)
     deep32 = _dma_stage_depth_outputs(check=True)
-    assert len(deep32) == len(deep64) == 45
+    assert len(deep32) == len(deep64) == 55
     for i, (a, b) in enumerate(zip(deep32, deep64)):
         assert torch.isfinite(a.float()).all()
 

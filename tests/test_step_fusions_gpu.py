@@ -1,5 +1,5 @@
 """One launch for all drop-path masks of a training step (reference utils/drops.py:8-22).  (Two other small fusions were measured and
-dropped: drop-path gradient + column sums in one pass, and layer-scale gradients straight from the split-K slabs -- DESIGN 5.2.)"""
+dropped: drop-path gradient + column sums in one pass, and layer-scale gradients straight from the split-K slabs -- EXPERIMENTS.md.)"""
 import pytest
 import torch
 

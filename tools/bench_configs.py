@@ -78,7 +78,9 @@ def main():
                 with torch.no_grad():
                     return inference_with_sliding_window(x, model, training=False, windows_size=(512, 512))
         each = []
-        for _ in range(args.warmup):
+        # a capture leaves the GPU idle for ~0.4 s and the first replays behind it run slow (13.3, 12.7, 12.5, 12.4, 12.3 ms on cfg3: clocks coming back up;
+        # profiles/r06_cfg3_replay_vs_eager.txt) -- how long that lasts differs from box to box, so the replayed form gets twelve more untimed steps
+        for _ in range(args.warmup + (12 if args.graph_step else 0)):
             t1 = time.perf_counter()
             step()
             if args.each_step:
