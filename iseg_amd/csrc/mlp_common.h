@@ -6,6 +6,16 @@
 // (norm.hip), so that a kernel which re-forms y2 = LN(y1) while staging its operand sees the values the forward pass used.
 __device__ __forceinline__ float iseg_ln_apply(float x, float mean, float rstd, float g, float b) { return (x - mean) * rstd * g + b; }
 
+// Byte offset of the 16-byte fragment (row r < 32, k-half h) inside a 1-KiB piece of the tiled weight images (mlp_fused.hip header: the
+// k-half is the outer index, so the offset is 16 x the lane that reads it and a ds_read_b128 of a piece is bank-conflict-free)
+__device__ __forceinline__ int mlp_frag_offset(int r, int h) {
+#ifdef ISEG_MLP_PIECE_ROWMAJOR
+    return r * 32 + h * 16;
+#else
+    return h * 512 + r * 16;
+#endif
+}
+
 // LayerNorm in front of the fused MLP kernels (mlp_fused.hip).  gamma == NULL: the kernel's row operand is y2 as before.
 struct MlpLayerNorm {
     const float* gamma = nullptr;

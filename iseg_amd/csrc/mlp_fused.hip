@@ -17,11 +17,15 @@
 // Weight images.  A tiny per-step kernel (iseg_convnext_mlp_prep) rewrites the fp32 master kernels as bf16 *tiled* copies that are
 // byte-for-byte the LDS images, slab after slab, so a ring stage is ONE contiguous run of 1-KiB pieces (piece p, lane l <- 16 bytes at
 // p * 1024 + 16 l: perfectly coalesced DMA, no per-lane address math) and every A fragment is ONE plain ds_read_b128 of
-// [row (lane & 31)][k-half (lane >> 5)] from a [32 rows][16 k] piece -- a wavefront reads 1 KiB contiguous, conflict-free:
-//     A1 (H = y2 W1):            [kk < C/16][32 hid][16 c]            value W1[16 kk + k][hid]
-//     A2 (O = G W2):             [cb < C/32][s < 2][32 c][16 k*]      value W2[hid(s, k*)][32 cb + c]
-//     A3 (dG = dbr (W2 gamma)^T):[kk < C/16][32 hid][16 c]            value W2[hid][16 kk + k] * gamma[16 kk + k]
-//     A4 (dy2 = dH W1^T):        [cb < C/32][s < 2][32 c][16 k*]      value W1[32 cb + c][hid(s, k*)]
+// (row lane & 31, k-half lane >> 5) from a 1-KiB piece of 32 rows x 16 k.  Inside a piece the k-half is the OUTER index -- [2 k-halves][32 rows][8 k],
+// so lane l reads bytes 16 l .. 16 l + 15: ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and + 32), and
+// only the lane-contiguous image puts each group on sixteen different 16-byte slots of the 256-byte bank row.  (Rounds 2-5 had the row outer,
+// [32 rows][16 k]: 32-byte lane stride, every group on eight slots twice -- SQ_LDS_BANK_CONFLICT = 40 % of the LDS cycles, and with four SIMDs
+// each asking for 1 KiB per 32-cycle MFMA a two-way conflict is exactly the LDS array's whole bandwidth.)  Pieces of a slab:
+//     A1 (H = y2 W1):            [kk < C/16] pieces of (32 hid, 16 c)            value W1[16 kk + k][hid]
+//     A2 (O = G W2):             [cb < C/32][s < 2] pieces of (32 c, 16 k*)      value W2[hid(s, k*)][32 cb + c]
+//     A3 (dG = dbr (W2 gamma)^T):[kk < C/16] pieces of (32 hid, 16 c)            value W2[hid][16 kk + k] * gamma[16 kk + k]
+//     A4 (dy2 = dH W1^T):        [cb < C/32][s < 2] pieces of (32 c, 16 k*)      value W1[32 cb + c][hid(s, k*)]
 // k* is the accumulator's register order: position 8 h + j of k-step s is hidden unit 16 s + 8 (j >> 2) + 4 h + (j & 3) of the slab.
 // (Plain C++ loads matter: hipcc orders a ds_read *builtin* behind every LDS-DMA in flight with s_waitcnt vmcnt(0) -- it carries no
 // alias information -- which drained the ring on every stage in the first version of this file, built on ds_read_b64_tr_b16.)
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(C ==
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[cb][j] = 0.f;
 
-    const int fo = r * 32 + h * 16;      // this lane's fragment inside a [32 rows][16 k] piece
+    const int fo = mlp_frag_offset(r, h);      // this lane's fragment inside a piece
 
     // A ring stage is one contiguous run of NF = SUB * (KK + 2 CB) fragment pieces (A1 then A2 of each slab) consumed in address order:
     // the fragments go through a rolling window of FD registers sets, FD pieces ahead of the MFMA that uses them.  Left to itself hipcc
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES) void convnext_mlp_bwd_kernel(const bf16
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[cb][j] = 0.f;
 
-    const int fo = r * 32 + h * 16;
+    const int fo = mlp_frag_offset(r, h);
     // this lane's 16-byte pieces of row m0 + r of G / dH: hidden units 8 h .. + 7 and 16 + 8 h .. + 7 of the current slab
     const bool row_ok = m0 + r < M;
     const int64_t row_o = (row_ok ? m0 + r : 0) * HID + 8 * h;
@@ -606,7 +610,11 @@ __device__ __forceinline__ void mlp_prep_elements(const float* __restrict__ W1, 
         const int i = bw ? e - nfw : e, nimg = bw ? 3 : 2;
         const int slab = i / (nimg * per_img), rem = i % (nimg * per_img);
         const int img = rem / per_img, x = rem % per_img;
+#ifdef ISEG_MLP_PIECE_ROWMAJOR      // (the piece layout of rounds 2-5, kept for A/B builds: [32 rows][16 k], 2-way bank conflicts on every fragment read)
         const int piece = x / 512, y = x % 512, rr = y / 16, kq = y % 16, hh = kq / 8, j = kq % 8;
+#else                               // [k-half][32 rows][8 k]: lane l = 32 (k-half) + row reads the piece's bytes 16 l .. 16 l + 15
+        const int piece = x / 512, y = x % 512, hh = y / 256, rr = (y % 256) / 8, j = y % 8, kq = 8 * hh + j;
+#endif
         // image kinds: 0 = A1, 1 = A2 (forward) ; 0 = A1, 1 = A3, 2 = A4 (backward)
         const int kind = bw ? (img == 0 ? 1 : img + 2) : img + 1;      // 1 = A1, 2 = A2, 3 = A3, 4 = A4
         float v;

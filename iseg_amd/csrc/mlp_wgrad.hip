@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512) void convnext_mlp_wgrad_kernel(const bf16_t* _
         const int row = (hid0 & 16) + li;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int off = (2 * ks + (q >> 1)) * 1024 + row * 32 + (q & 1) * 16;
+            const int off = (2 * ks + (q >> 1)) * 1024 + mlp_frag_offset(row, q & 1);
             w1f[ks] = *reinterpret_cast<const bf16x8*>(slab + off);
             w3f[ks] = *reinterpret_cast<const bf16x8*>(slab + G::IMG + off);
         }

@@ -108,8 +108,12 @@ def test_convnext_mlp_prep_images(cuda):
     fw, bw = K.convnext_mlp_prep(W1.cuda(), W2.cuda(), gamma.cuda())
     fw, bw = fw.cpu().float(), bw.cpu().float()
     per = C * 32
-    fw = fw.reshape(4 * C // 32, 2, per)
-    bw = bw.reshape(4 * C // 32, 3, per)
+
+    def rows_outer(t):      # a 1-KiB piece is stored [k-half][32 rows][8 k] (conflict-free ds_read_b128, round 6); the checks below read it as [32 rows][16 k]
+        return t.reshape(-1, 2, 32, 8).permute(0, 2, 1, 3).reshape(t.shape)
+
+    fw = rows_outer(fw).reshape(4 * C // 32, 2, per)
+    bw = rows_outer(bw).reshape(4 * C // 32, 3, per)
     bf = torch.bfloat16
     for slab in (0, 5, 11):
         a1 = fw[slab, 0].reshape(C // 16, 32, 16)      # [kk][hid][c]

@@ -14,7 +14,7 @@ def main():
     path = src if os.path.exists(src) else os.path.join(ROOT, "iseg_amd", "csrc", src)
     out = "/tmp/asm_stats.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{ROOT}/iseg_amd/csrc",
-                           "-S", "--cuda-device-only", "-o", out, path], stderr=subprocess.DEVNULL)
+                           "-S", "--cuda-device-only"] + [f"-D{d}" for d in os.environ.get("ASM_DEFINES", "").split()] + ["-o", out, path], stderr=subprocess.DEVNULL)
     text = open(out).read()
     for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)^\s*\.amdhsa_kernel \1\n(.*?)\.end_amdhsa_kernel", text, re.S | re.M):
         name, body, meta = m.groups()
