@@ -640,7 +640,9 @@ def cpu_baseline(args):
             n += 1
         return (time.time() - t0) / n, n
 
-    cores = torch.get_num_threads()
+    from oracle import host_threads
+
+    cores = host_threads.apply()      # the container's real core budget (cgroup quota): `cores` is what the baseline ran on
     w = OM.export_weights(build(convnext_tiny_aspp, build_input_size=(args.size, args.size)), dtype=torch.float32)
     x, y = synthetic_batch(1, args.size, args.size, seed=0)
 

@@ -50,9 +50,11 @@ def _oracle_steps(model, x, y, eps, tau):
 def run_smoke(steps=4):
     from .core_env import common_env_setup
     from .data import synthetic_batch
+    from oracle import host_threads
     from oracle import models as OM
 
     assert torch.cuda.is_available(), "smoke() needs a GPU"
+    host_threads.apply()      # the oracle at the container's real core budget (cgroup quota), not one thread per core of the machine
     strategy = common_env_setup(use_one_device_strategy=True, mixed_precision=False, random_seed=0)
     x, y = synthetic_batch(2, 64, 64, seed=0)
     x, y = x.cuda(), y.cuda()

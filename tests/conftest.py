@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the CPU oracle at the container's real core budget: torch would start 128 threads on a 16-core cgroup quota and run 8 x slower
+    from oracle import host_threads
+
+    host_threads.apply()
 
 
 # Collection order (the driver runs `pytest -x`): the oracle / golden PARITY suites first -- kernels, fused blocks, optimizers, whole models --

@@ -336,13 +336,13 @@ def test_cfg2_at_the_benchmark_shape(cuda):
 
 
 def test_cfg2_benchmark_shape_fp32_gradients_against_the_oracle(cuda):
-    """The flagship's backward pass at the benchmark's plane sizes (512 x 512 crop: 128 / 64 / 32 / 16 pixel planes, 32 768-row products per image at stage 0), fp32 storage, one image: logits / argmax / loss and SIX named weight gradients -- stem, a stage-0 depthwise
+    """The flagship's backward pass at the benchmark's plane sizes (512 x 512 crop: 128 / 64 / 32 / 16 pixel planes, 32 768-row products per image at stage 0), fp32 storage, two images: logits / argmax / loss and SIX named weight gradients -- stem, a stage-0 depthwise
     kernel, a stage-1 layer scale, a stage-2 MLP kernel, a stage-3 downsample kernel, an ASPP kernel, the logits kernel -- against fp64 autograd through the
     oracle (round-4 verdict, item 3b).  This is what pins the fp32-storage run that the bf16 test below is compared with."""
     from iseg_amd.data import synthetic_batch
 
     model = _flagship((512, 512))
-    x, y = synthetic_batch(1, 512, 512, seed=33)      # (one image: the statistics are frozen, so images are independent, and the fp64 oracle pass is 40 s per image)
+    x, y = synthetic_batch(2, 512, 512, seed=33)
     _whole_model_parity(model, lambda w, t: OM.convnext_aspp_forward(w, t, training=False), x, y,
                         ["downsample_layers/0/0/kernel", "stages/0/1/dwconv/depthwise_kernel", "stages/1/2/gamma", "stages/2/4/pwconv1/kernel",
                          "downsample_layers/3/1/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"], tie_margin=1e-5)
