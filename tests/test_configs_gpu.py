@@ -73,7 +73,7 @@ def test_full_architectures_train_in_bf16(cuda, factory, size):
     assert tuple(logits.shape) == (2, size, size, 21) and torch.isfinite(logits).all()
 
 
-def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3, tie_margin=0.0):
+def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3, tie_margin=0.0, grad_tol=None):
     """fp32 storage: logits < logit_tol abs and the argmax mask bit-exact against the oracle's whole-model forward, the mean ignore-label
     loss within 1e-4, and selected weight gradients of that loss against fp64 autograd through the oracle"""
     from iseg_amd import functional as F
@@ -110,37 +110,47 @@ def _whole_model_parity(model, oracle_fn, x, y, grad_names, logit_tol=1e-3, tie_
         g_ref = wg[name].grad
         g = params[name].grad.cpu().double()
         scale = max(g_ref.abs().max().item(), 1e-12)
-        assert (g - g_ref).abs().max().item() <= 5e-3 * scale, (name, (g - g_ref).abs().max().item(), scale)
+        tol = (grad_tol or {}).get(name, 5e-3)
+        assert (g - g_ref).abs().max().item() <= tol * scale, (name, (g - g_ref).abs().max().item(), scale)
 
 
-def test_cfg3_swin_tiny_fpn_whole_model_against_the_oracle(cuda):
+@pytest.mark.parametrize("size,batch", [((96, 128), 2), ((512, 512), 1)])
+def test_cfg3_swin_tiny_fpn_whole_model_against_the_oracle(cuda, size, batch):
     """BASELINE config 3 at full depth (Swin-T 2/2/6/2, heads 3/6/12/24, window 7 + FPN + 1x1 head) on an odd size: 96x128 gives 24x32
-    tokens -> padded to 28x35 windows at stage 0 and 1-2 windows deeper down, every stage with its shift mask and patch-merging pad"""
+    tokens -> padded to 28x35 windows at stage 0 and 1-2 windows deeper down, every stage with its shift mask and patch-merging pad; and at
+    the size BASELINE quotes it on, 512 x 512 (128 x 128 tokens at stage 0: 19 x 19 windows of 49 after the pad; round 6)"""
     from iseg_amd import heads, nn
     from iseg_amd.data import synthetic_batch
 
     nn.set_compute_dtype(torch.float32)
     nn.set_device("cuda:0")
-    model = _prep(heads.swin_tiny_fpn(build_input_size=(96, 128)), seed=7)
-    x, y = synthetic_batch(2, 96, 128, seed=14)
+    model = _prep(heads.swin_tiny_fpn(build_input_size=size), seed=7)
+    x, y = synthetic_batch(batch, size[0], size[1], seed=14)
     _whole_model_parity(model, lambda w, t: OM.swin_fpn_forward(w, t, training=False), x, y,
                         ["patch_embed/proj/kernel", "layers/0/blocks/1/attn/relative_position_bias_table", "layers/2/blocks/3/mlp/fc1/kernel",
                          "layers/1/downsample/reduction/kernel", "fpn_head/fpn/skip_conv_filters0/conv/kernel", "fpn_head/end_conv/bn/gamma",
-                         "seg/logits_conv/kernel"])
+                         "seg/logits_conv/kernel"], tie_margin=1e-5 if size[0] >= 512 else 0.0)
 
 
-def test_cfg5_intern_image_base_aspp_whole_model_against_the_oracle(cuda):
-    """BASELINE config 5 at full depth (InternImage-B: 112 channels, depths 4/4/21/4, DCNv3 groups 7/14/28/56, post-norm) + ASPP on an odd size"""
+@pytest.mark.parametrize("size", [(96, 128), (512, 512)])
+def test_cfg5_intern_image_base_aspp_whole_model_against_the_oracle(cuda, size):
+    """BASELINE config 5 at full depth (InternImage-B: 112 channels, depths 4/4/21/4, DCNv3 groups 7/14/28/56, post-norm) + ASPP on an odd size,
+    and at the size BASELINE quotes it on, 512 x 512 (round 6)"""
     from iseg_amd import heads, nn
     from iseg_amd.data import synthetic_batch
 
     nn.set_compute_dtype(torch.float32)
     nn.set_device("cuda:0")
-    model = _prep(heads.intern_image_base_aspp(build_input_size=(96, 128), dropout_rate=0.0), seed=8)
-    x, y = synthetic_batch(1, 96, 128, seed=15)
+    model = _prep(heads.intern_image_base_aspp(build_input_size=size, dropout_rate=0.0), seed=8)
+    x, y = synthetic_batch(1, size[0], size[1], seed=15)
     _whole_model_parity(model, lambda w, t: OM.intern_image_aspp_forward(w, t, training=False), x, y,
                         ["patch_embed/conv1/kernel", "block/0/layer/1/dcn/offset/kernel", "block/2/layer/10/mlp/fc1/kernel", "block/2/layer/20/gamma1",
-                         "block/1/downsample/conv/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"])
+                         "block/1/downsample/conv/kernel", "aspp_head/aspp/asp_convs_6/conv/kernel", "seg/logits_conv/kernel"],
+                        tie_margin=1e-5 if size[0] >= 512 else 0.0,
+                        # the offset projection of the FIRST stage at 512 x 512: its gradient is a sum over 16 384 pixels of differences of neighbouring
+                        # samples -- the ORACLE ITSELF run in float32 is 7.6e-3 (max) / 2.1e-3 (L2) away from its float64 run there, this path 9.8e-3 /
+                        # 2.8e-3 (tools/diag_cfg5_grads.py); every other gradient of the list stays inside 5e-3 (measured <= 2.5e-4)
+                        grad_tol={"block/0/layer/1/dcn/offset/kernel": 2e-2} if size[0] >= 512 else None)
 
 
 def _flagship(size):
@@ -203,6 +213,30 @@ def test_cfg4_vit_base_simple_decoder_through_the_sliding_window(cuda):
     assert count[0, 0] == 1 and count[80, 0] == 2 and count[0, 100] == 2 and count[80, 100] == 4
     single = OM.vit_simple_decoder_forward(w, x.double()[:, :128, :128], training=False)["logits"]
     assert (got[:, :32, :80].cpu().double() - single[:, :32, :80]).abs().max().item() < 1e-3      # count-1 corner = the first window alone
+
+
+def test_cfg4_at_the_benchmark_shape(cuda):
+    """BASELINE config 4 at the size it is quoted on: a 640 x 640 image through the 512 x 512 sliding window (2 x 2 windows starting at 0 / 128,
+    1 025 tokens each with the class token, 24 x 24 -> 32 x 32 bicubic position embedding), the full ViT-B/16 + SimpleDecoder, fp32 storage (round 6)"""
+    from iseg_amd import nn
+    from iseg_amd.core_inference import inference_with_sliding_window
+    from iseg_amd.data import synthetic_batch
+    from iseg_amd.heads import vit_base_simple_decoder
+
+    nn.set_compute_dtype(torch.float32)
+    nn.set_device("cuda:0")
+    model = _prep(vit_base_simple_decoder(build_input_size=(512, 512)), seed=4)
+    x, _ = synthetic_batch(1, 640, 640, seed=19)
+    with torch.no_grad():
+        got = inference_with_sliding_window(x.cuda(), model, training=False, windows_size=(512, 512))
+    w = OM.export_weights(model)
+    ref = OM.sliding_window_inference(lambda t: OM.vit_simple_decoder_forward(w, t, training=False)["logits"], x.double(), (512, 512))
+    assert O.sliding_start_indexs(640, 512) == [0, 128] and tuple(got.shape) == tuple(ref.shape) == (1, 640, 640, 21)
+    assert (got.cpu().double() - ref).abs().max().item() < 1e-3
+    differ = got.argmax(-1).cpu() != O.argmax_first(ref)
+    if bool(differ.any()):      # (410 K pixels: a pixel may differ only where the oracle's own two best classes agree to fp32 rounding of a
+        top2 = ref.topk(2, dim=-1).values      # twelve-layer transformer -- measured: 2 pixels, margins 1.8e-5 and 7.3e-6)
+        assert int(differ.sum()) <= 16 and (top2[..., 0] - top2[..., 1])[differ].max().item() < 5e-5, int(differ.sum())
 
 
 def test_multi_scale_flip_inference_matches_oracle(cuda):

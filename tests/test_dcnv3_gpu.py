@@ -172,6 +172,29 @@ def test_dcnv3_general_backward_is_bit_identical_and_right(cuda, dtype, shape, G
         assert all(torch.equal(a, b) for a, b in zip(outs[0], o))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,G,spread", [((1, 40, 37, 32), 2, 1.5), ((1, 30, 26, 8), 2, 9.0), ((1, 17, 23, 12), 4, 2.0)])
+def test_dcnv3_input_gradient_keeps_its_precision_for_tiny_gradients(cuda, dtype, shape, G, spread):
+    """output gradients of 1e-8 -- the order a mean loss over 512 x 512 pixels hands a first-stage layer -- on the window route and on the general
+    route (4- and 3-wide groups), side buffer included: single contributions are ~3e-10 and the 2^-40 = 9.1e-13 accumulators must resolve them.
+    (Rounds 4-5 converted the SIGNED value: the fraction of a small negative number was rounded to fp32 next to 1, a resolution of 2.3e-10 -- every
+    negative contribution of this test off by tens of per cent; found by the 512 x 512 whole-model parity of round 6.)"""
+    from iseg_amd import kernels as K
+
+    N, H, W, C = shape
+    Cg = C // G
+    x, xr = q(rnd(shape, 31), dtype)
+    off, offr = q(rnd((N, H, W, G * 9 * 2), 32) * spread, dtype)
+    m, mr = q(torch.softmax(rnd((N, H, W, G, 9), 33), -1).reshape(N, H, W, G * 9), dtype)
+    dy, dyr = q(rnd(shape, 34) * 1e-8, dtype)
+    xr.requires_grad_(True)
+    O.dcnv3_op(xr, offr, mr, (3, 3), (1, 1), "SAME", (1, 1), G, Cg, 1.0).backward(dyr)
+    dx, _, _ = K.dcnv3_bwd(x, off, m, dy, G, Cg, 3, 3, 1, 1, 1, 1.0)
+    want = xr.grad
+    err = (dx.double().cpu() - want).norm().item() / want.norm().item()
+    assert err < (5e-3 if dtype == torch.float32 else 1.5e-2), err
+
+
 # ---- DCNv2 / FaPN (layers/dcn_v2.py, layers/fapn.py; round 5) ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("N,H,W,C,Fo,custom", [(2, 9, 7, 16, 24, True), (1, 12, 12, 32, 32, False), (2, 5, 6, 8, 16, True)])
