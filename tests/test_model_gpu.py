@@ -152,7 +152,8 @@ def test_train_steps_follow_oracle_adamw(cuda, eps, tau):
     assert got[-1] < got[0]
 
 
-def test_train_steps_follow_oracle_sgd(cuda):
+@pytest.mark.parametrize("size,steps", [(64, 5), (512, 3)])      # 512 x 512 = the crop BASELINE configs[1] is quoted on (round 6: three steps there)
+def test_train_steps_follow_oracle_sgd(cuda, size, steps):
     """SURVEY section 8(c)'s bar: 5 optimisation steps on a fixed batch (fp32 storage, drop-path / dropout 0, SGD with momentum 0.9 as
     optimizers/modern/sgd.py:12-51, NO gradient mask -- 0 % of the gradient elements are masked) reproduce the restatement's loss curve to 1e-4
     relative and its weight movement to 1e-3.  SGD divides by nothing, so this separates "a gradient is slightly wrong" from "the AdamW comparison
@@ -165,8 +166,8 @@ def test_train_steps_follow_oracle_sgd(cuda):
     from iseg_amd.distribution.distribution_utils import Strategy
     from iseg_amd.trainer import TrainableModel
 
-    model = _setup(torch.float32)
-    x, y = synthetic_batch(2, 64, 64, seed=9)
+    model = _setup(torch.float32, size=(size, size))
+    x, y = synthetic_batch(2, size, size, seed=9)
     lr0 = 5e-3
     opt = get_optimizer(Strategy(one_device=True), initial_lr=lr0, end_lr=0.0, epoch_steps=10, train_epoch=1, optimizer="sgd", sgd_momentum_rate=0.9)
     tm = TrainableModel(model, optimizer=opt, loss=model.custom_losses(21, 255, 2), loss_weights=model.custom_losses_weights(),
@@ -177,7 +178,7 @@ def test_train_steps_follow_oracle_sgd(cuda):
                                      lambda s: O.warmup_poly_decay(s, lr0, 10, end_lr=0.0, warmup_steps=0, warmup_lr=0.0, power=0.9), momentum=0.9)
     got, want = [], []
     xc, yc = x.cuda(), y.cuda()
-    for step in range(5):
+    for step in range(steps):
         want.append(oracle.forward_backward()[0])
         got.append(float(tm.train_step(xc, yc)[0]))
         if step == 0:      # per-variable gradients of step 1 against fp64, worst first: the message of a failure names the variable
