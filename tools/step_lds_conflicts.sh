@@ -1,12 +1,15 @@
 #!/bin/bash
 # LDS bank conflicts per kernel of the flagship step (one rocprofv3 --pmc pass over bench.py --eager-step):   bash tools/step_lds_conflicts.sh <out dir>
+# or of another configuration:   bash tools/step_lds_conflicts.sh <out dir> tools/bench_configs.py cfg3 --steps 3 --warmup 2
 # per kernel and grid: launches, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (share of the LDS cycles spent on conflicts), SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
 set -e
-out=$1
+out=$1; shift
+if [ $# -eq 0 ]; then set -- bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --eager-step; fi
+script=$1; shift
 export TMPDIR=/tmp
 R=$(pwd)
 mkdir -p "$out"
-(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$R/$out/lds" -- python3 "$R/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --eager-step > "$R/$out/lds.log" 2>&1) || { tail -5 "$out/lds.log"; exit 1; }
+(cd /tmp && rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$R/$out/lds" -- python3 "$R/$script" "$@" > "$R/$out/lds.log" 2>&1) || { tail -5 "$out/lds.log"; exit 1; }
 python3 - "$out" <<'PY' > "$out/step_lds_conflicts.md"
 import csv, glob, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
