@@ -368,3 +368,32 @@ def test_dcnv3_joint_form_is_refused_for_strided_layers():
     assert F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 1, (16, 16)) == bool(F._DCN_JOINT)
     assert not F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 2, (8, 8))
     assert not F.dcnv3_joint_ok(x1, lay, lay, (3, 3), 1, (14, 14))      # pad 0: the output map shrinks
+
+
+def test_oracle_thread_budget_follows_the_cgroup_quota(monkeypatch):
+    """oracle/host_threads.py (test infrastructure): the CPU oracle's thread count is the affinity mask capped by the cgroup CPU quota -- a GPU box shows
+    256 logical cores under a quota of 16, and torch's own choice (128 threads) ran the fp64 oracle 8 x slower"""
+    import builtins
+    import io
+    import os
+
+    from oracle import host_threads
+
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            return io.StringIO(fake["cpu.max"])
+        return real_open(path, *a, **k)
+
+    fake = {"cpu.max": "1600000 100000\n"}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)))
+    monkeypatch.setattr(builtins, "open", fake_open)
+    assert host_threads.cpu_budget() == 16
+    fake["cpu.max"] = "max 100000\n"
+    assert host_threads.cpu_budget() == 256
+    fake["cpu.max"] = "150000 100000\n"      # a quota of one and a half cores
+    assert host_threads.cpu_budget() == 2
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(4)))
+    fake["cpu.max"] = "1600000 100000\n"
+    assert host_threads.cpu_budget() == 4
